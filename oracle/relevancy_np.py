@@ -1,0 +1,308 @@
+"""CPU oracle (numpy, fp32) for the gradient x attention relevancy-propagation hot path.
+
+TEST INFRASTRUCTURE ONLY.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module; the product package
+(``transformer-mm-explainability_amd/``) never does and has no CPU fallback.
+
+Every function restates one reference function and cites it (paths relative to
+the reference checkout).  Parity pinning: the reference has no tests / golden
+vectors for this path, so the oracle is pinned against outputs of the
+reference's own functions executed in-process by ``tests/golden/make_golden.py``
+(fixtures committed under ``tests/golden/*.npz``; checked by
+``tests/test_oracle_golden.py``).
+
+All arithmetic is IEEE fp32 like the reference's CPU path (torch fp32); matrix
+products go through numpy's fp32 matmul, so agreement with torch is to rounding
+(different summation order), not bitwise.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+
+
+def _f32(x):
+    return np.ascontiguousarray(x, dtype=F32)
+
+
+# --------------------------------------------------------------------------- rule 5
+def avg_heads(cam, grad):
+    """``A_bar = mean_{b.h}(clamp(grad * cam, min=0))``.
+
+    Reference: DETR/modules/ExplanationGenerator.py:19-24,
+    lxmert/lxmert/src/ExplanationGenerator.py:18-23, ViT notebook cell 7:2-7.
+    ``reshape(-1, Nq, Nk)`` flattens batch AND heads (callers have B=1).
+    """
+    cam = _f32(cam)
+    grad = _f32(grad)
+    cam = cam.reshape(-1, cam.shape[-2], cam.shape[-1])
+    grad = grad.reshape(-1, grad.shape[-2], grad.shape[-1])
+    prod = grad * cam
+    # torch.clamp(min=0) propagates NaN; np.maximum does too.
+    prod = np.maximum(prod, F32(0))
+    return prod.mean(axis=0, dtype=F32)
+
+
+def avg_heads_batched(cam, grad, batch_size):
+    """CLIP notebook variant: reshape to [B, H, N, N], clamp, mean over dim 1.
+
+    Reference: CLIP_explainability.ipynb cell 6:26-31 (image) and 6:49-54 (text).
+    """
+    cam = _f32(cam)
+    grad = _f32(grad)
+    n_q, n_k = cam.shape[-2], cam.shape[-1]
+    prod = (grad.reshape(-1, n_q, n_k) * cam.reshape(-1, n_q, n_k)).reshape(batch_size, -1, n_q, n_k)
+    return np.maximum(prod, F32(0)).mean(axis=1, dtype=F32)
+
+
+# --------------------------------------------------------------------------- rules 6 / 7
+def apply_self_attention_rules(R_ss, R_sq, cam_ss):
+    """Rules 6+7: returns ``(cam_ss @ R_ss, cam_ss @ R_sq)`` (callers ``+=``).
+
+    Reference: DETR/modules/ExplanationGenerator.py:27-30,
+    lxmert/lxmert/src/ExplanationGenerator.py:26-29.
+    """
+    cam_ss = _f32(cam_ss)
+    return cam_ss @ _f32(R_ss), cam_ss @ _f32(R_sq)
+
+
+def apply_self_attention_rules_vit(R_ss, cam_ss):
+    """2-argument ViT form (rule 6 only). Reference: ViT notebook cell 7:10-12."""
+    return _f32(cam_ss) @ _f32(R_ss)
+
+
+# --------------------------------------------------------------------------- eq. 8-9
+def handle_residual(orig_self_attention):
+    """``R_hat = R - I``; assert diag >= 0; row-normalise; ``+ I``.  0/0 rows -> NaN.
+
+    Reference: DETR/modules/ExplanationGenerator.py:46-53,
+    lxmert/lxmert/src/ExplanationGenerator.py:45-54.
+    """
+    sa = _f32(orig_self_attention).copy()
+    n = sa.shape[-1]
+    eye = np.eye(n, dtype=F32)
+    sa -= eye
+    assert np.diagonal(sa).min() >= 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sa = sa / sa.sum(axis=-1, keepdims=True, dtype=F32)
+    sa += eye
+    return sa
+
+
+# --------------------------------------------------------------------------- rules 10 / 11
+def apply_mm_attention_rules_detr(R_ss, R_qq, cam_sq, apply_normalization=True,
+                                  apply_self_in_rule_10=True):
+    """Rule 10, DETR 5-argument form; NaNs in the result are zeroed.
+
+    Reference: DETR/modules/ExplanationGenerator.py:33-43.
+    """
+    R_ss_n, R_qq_n = _f32(R_ss), _f32(R_qq)
+    cam_sq = _f32(cam_sq)
+    if apply_normalization:
+        R_ss_n = handle_residual(R_ss_n)
+        R_qq_n = handle_residual(R_qq_n)
+    add = R_ss_n.T @ (cam_sq @ R_qq_n)
+    if not apply_self_in_rule_10:
+        add = cam_sq.copy()
+    add[np.isnan(add)] = 0
+    return add
+
+
+def apply_mm_attention_rules_lxmert(R_ss, R_qq, R_qs, cam_sq, apply_normalization=True,
+                                    apply_self_in_rule_10=True):
+    """Rules 10+11, LXMERT 6-argument form; NaNs propagate.
+
+    Reference: lxmert/lxmert/src/ExplanationGenerator.py:32-42.
+    Returns ``(R_sq_addition, R_ss_addition)``.
+    """
+    R_ss_n, R_qq_n = _f32(R_ss), _f32(R_qq)
+    cam_sq = _f32(cam_sq)
+    if apply_normalization:
+        R_ss_n = handle_residual(R_ss_n)
+        R_qq_n = handle_residual(R_qq_n)
+    R_sq_add = R_ss_n.T @ (cam_sq @ R_qq_n)
+    if not apply_self_in_rule_10:
+        R_sq_add = cam_sq
+    R_ss_add = cam_sq @ _f32(R_qs)
+    return R_sq_add, R_ss_add
+
+
+# --------------------------------------------------------------------------- rollout
+def compute_rollout_attention(all_layer_matrices, start_layer=0, normalize=True):
+    """``prod_i (A_i + I)[/rowsum]`` left-multiplied chain.
+
+    ``normalize=True``: DETR/modules/ExplanationGenerator.py:5-16 and
+    lxmert/lxmert/src/ExplanationGenerator.py:5-15 (matrices ``[1, N, N]`` or ``[N, N]``).
+    ``normalize=False`` with ``[B, N, N]`` inputs: the batched VisualBERT variant,
+    VisualBERT/mmf/models/transformers/backends/ExplanationGenerator.py:5-17.
+    """
+    mats = [_f32(m) for m in all_layer_matrices]
+    n = mats[0].shape[1]
+    eye = np.eye(n, dtype=F32)
+    mats = [m + eye for m in mats]
+    if normalize:
+        mats = [m / m.sum(axis=-1, keepdims=True, dtype=F32) for m in mats]
+    joint = mats[start_layer]
+    for i in range(start_layer + 1, len(mats)):
+        joint = mats[i] @ joint
+    return joint
+
+
+# --------------------------------------------------------------------------- chain drivers
+def self_chain(attn_layers, grad_layers, batch_size, start_layer=0):
+    """Batched single-stream chain: ``R <- R + A_bar_l @ R`` for ``l >= start_layer``, ``R_0 = I``.
+
+    Reference: CLIP_explainability.ipynb cell 6:19-32 (image) / 6:41-55 (text);
+    with ``batch_size=1``: ViT notebook cell 7:27-33, CLIP/example.py:20-30,
+    VisualBERT/.../ExplanationGenerator.py:84-93.
+    ``attn_layers[l]`` / ``grad_layers[l]``: ``[B*H, N, N]`` (index ``b*H + h``).
+    Returns ``R`` ``[B, N, N]``.
+    """
+    n = attn_layers[0].shape[-1]
+    R = np.broadcast_to(np.eye(n, dtype=F32), (batch_size, n, n)).copy()
+    for i, (a, g) in enumerate(zip(attn_layers, grad_layers)):
+        if i < start_layer:
+            continue
+        cam = avg_heads_batched(a, g, batch_size)
+        R = R + np.matmul(cam, R)
+    return R
+
+
+def clip_interpret_chain(img_attn, img_grad, txt_attn, txt_grad, batch_size,
+                         start_layer=-1, start_layer_text=-1):
+    """Rule part of the notebook ``interpret`` (model forward/backward excluded).
+
+    Reference: CLIP_explainability.ipynb cell 6:13-58.  ``-1`` means "last layer only".
+    Returns ``(text_relevance [B, Nt, Nt], image_relevance [B, Ni-1])``.
+    """
+    if start_layer == -1:
+        start_layer = len(img_attn) - 1
+    if start_layer_text == -1:
+        start_layer_text = len(txt_attn) - 1
+    R = self_chain(img_attn, img_grad, batch_size, start_layer)
+    image_relevance = R[:, 0, 1:]
+    R_text = self_chain(txt_attn, txt_grad, batch_size, start_layer_text)
+    return R_text, image_relevance
+
+
+def vit_generate_relevance_chain(attn_layers, grad_layers):
+    """Reference: ViT notebook cell 7:27-34 -> ``R[0, 1:]``."""
+    R = self_chain(attn_layers, grad_layers, 1, 0)[0]
+    return R[0, 1:]
+
+
+def visualbert_generate_ours_chain(attn_layers, grad_layers, cls_index):
+    """Reference: VisualBERT/.../ExplanationGenerator.py:84-98.
+
+    ``attn_layers[l]``: ``[1, H, N, N]``.  Returns ``[1, N]`` with the CLS column zeroed.
+    """
+    R = self_chain([a[0] for a in attn_layers], [g[0] for g in grad_layers], 1, 0)[0]
+    out = R[[cls_index]].copy()
+    out[:, cls_index] = 0
+    return out
+
+
+def detr_generate_ours_chain(enc_attn, enc_grad, dec_self_attn, dec_self_grad,
+                             dec_cross_attn, dec_cross_grad, target_index,
+                             normalize_self_attention=True, apply_self_in_rule_10=True):
+    """Rule schedule of ``Generator.generate_ours`` (``use_lrp=False``).
+
+    Reference: DETR/modules/ExplanationGenerator.py:110-140,169-195.
+    Layers ``[H, Nq, Nk]`` (batch 1).  Returns ``[1, 1, len(target_index), Ni]``.
+    """
+    n_i = enc_attn[0].shape[-1]
+    n_q = dec_self_attn[0].shape[-1]
+    R_i_i = np.eye(n_i, dtype=F32)
+    R_q_q = np.eye(n_q, dtype=F32)
+    R_q_i = np.zeros((n_q, n_i), dtype=F32)
+    for a, g in zip(enc_attn, enc_grad):
+        cam = avg_heads(a, g)
+        R_i_i = R_i_i + cam @ R_i_i
+    for l in range(len(dec_self_attn)):
+        cam = avg_heads(dec_self_attn[l], dec_self_grad[l])
+        qq_add, qi_add = apply_self_attention_rules(R_q_q, R_q_i, cam)
+        R_q_q = R_q_q + qq_add
+        R_q_i = R_q_i + qi_add
+        cam_q_i = avg_heads(dec_cross_attn[l], dec_cross_grad[l])
+        R_q_i = R_q_i + apply_mm_attention_rules_detr(
+            R_q_q, R_i_i, cam_q_i, apply_normalization=normalize_self_attention,
+            apply_self_in_rule_10=apply_self_in_rule_10)
+    agg = R_q_i[None]
+    return agg[:, target_index, :][None]
+
+
+def lxmert_generate_ours_chain(lang_attn, lang_grad, vis_attn, vis_grad, x_layers,
+                               normalize_self_attention=True, apply_self_in_rule_10=True):
+    """Rule schedule of ``GeneratorOurs.generate_ours`` (``use_lrp=False``).
+
+    Reference: lxmert/lxmert/src/ExplanationGenerator.py:61-211.
+    ``x_layers``: list of dicts with keys ``lang_cross`` (visual_attention, ``[1,H,T,I]``),
+    ``img_cross`` (visual_attention_copy, ``[1,H,I,T]``), ``lang_self``, ``img_self``; each a
+    ``(attn, grad)`` pair.  Returns ``(R_t_t [T,T], R_t_i [T,I])``.
+    """
+    T = lang_attn[0].shape[-1]
+    I = vis_attn[0].shape[-1]
+    R_t_t = np.eye(T, dtype=F32)
+    R_i_i = np.eye(I, dtype=F32)
+    R_t_i = np.zeros((T, I), dtype=F32)
+    R_i_t = np.zeros((I, T), dtype=F32)
+
+    def self_lang(a, g):
+        nonlocal R_t_t, R_t_i
+        cam = avg_heads(a, g)
+        tt, ti = apply_self_attention_rules(R_t_t, R_t_i, cam)
+        R_t_t = R_t_t + tt
+        R_t_i = R_t_i + ti
+
+    def self_img(a, g):
+        nonlocal R_i_i, R_i_t
+        cam = avg_heads(a, g)
+        ii, it = apply_self_attention_rules(R_i_i, R_i_t, cam)
+        R_i_i = R_i_i + ii
+        R_i_t = R_i_t + it
+
+    def co_lang(a, g):
+        cam = avg_heads(a, g)
+        return apply_mm_attention_rules_lxmert(R_t_t, R_i_i, R_i_t, cam,
+                                               normalize_self_attention, apply_self_in_rule_10)
+
+    def co_img(a, g):
+        cam = avg_heads(a, g)
+        return apply_mm_attention_rules_lxmert(R_i_i, R_t_t, R_t_i, cam,
+                                               normalize_self_attention, apply_self_in_rule_10)
+
+    for a, g in zip(lang_attn, lang_grad):
+        self_lang(a, g)
+    for a, g in zip(vis_attn, vis_grad):
+        self_img(a, g)
+    for i, blk in enumerate(x_layers):
+        if i == len(x_layers) - 1:
+            break
+        ti_add, tt_add = co_lang(*blk["lang_cross"])
+        it_add, ii_add = co_img(*blk["img_cross"])
+        R_t_i = R_t_i + ti_add
+        R_t_t = R_t_t + tt_add
+        R_i_t = R_i_t + it_add
+        R_i_i = R_i_i + ii_add
+        self_lang(*blk["lang_self"])
+        self_img(*blk["img_self"])
+    blk = x_layers[-1]
+    ti_add, tt_add = co_lang(*blk["lang_cross"])
+    R_t_i = R_t_i + ti_add
+    R_t_t = R_t_t + tt_add
+    self_lang(*blk["lang_self"])
+    R_t_t[0, 0] = 0
+    return R_t_t, R_t_i
+
+
+def gradcam(cam, grad):
+    """Reference: DETR/modules/ExplanationGenerator.py:275-280, lxmert/.../ExplanationGenerator.py:542-547.
+
+    ``cam``/``grad``: ``[1, H, Nq, Nk]``; ``grad.mean(dim=[1,2], keepdim=True)`` after reshape to
+    ``[H, Nq, Nk]``; ``(cam * grad).mean(0).clamp(min=0)``.
+    """
+    cam = _f32(cam).reshape(-1, cam.shape[-2], cam.shape[-1])
+    grad = _f32(grad).reshape(-1, grad.shape[-2], grad.shape[-1])
+    grad = grad.mean(axis=(1, 2), keepdims=True, dtype=F32)
+    return np.maximum((cam * grad).mean(axis=0, dtype=F32), F32(0))

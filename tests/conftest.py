@@ -1,0 +1,26 @@
+"""pytest config: registers the ``gpu`` marker and makes the repo root importable.
+
+``-m "not gpu"`` runs here (no GPU): oracle vs golden vectors, host logic, C-ABI symbol checks,
+gloo world_size-2 sharding tests.  ``-m gpu`` runs on an MI355X and calls the HIP path through the C-ABI.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (HIP kernels are executed)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    return load

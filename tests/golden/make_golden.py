@@ -1,0 +1,364 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by running the REFERENCE's own code in-process.
+
+Run in the build container only (needs /root/reference, which does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+Writes ``tests/golden/*.npz``.  The fixtures pin (a) the numpy oracle (``oracle/``) and (b) the
+HIP path (``-m gpu`` tests) to what the reference computes on identical seeded inputs.
+
+What is executed from the reference (nothing is copied into this repo):
+  * ``DETR/modules/ExplanationGenerator.py``           rule functions + ``Generator.generate_ours`` (+ baselines)
+  * ``lxmert/lxmert/src/ExplanationGenerator.py``      rule functions + ``GeneratorOurs.generate_ours``
+  * ``VisualBERT/.../backends/ExplanationGenerator.py`` ``compute_rollout_attention`` + ``SelfAttentionGenerator.generate_ours``
+    (imported by file path with a stub ``cv2`` module: cv2 is only used for visualisation)
+  * ``CLIP_explainability.ipynb`` cell 6 ``interpret``   exec'd from the notebook JSON
+  * ``Transformer_MM_explainability_ViT.ipynb`` cell 7   exec'd from the notebook JSON
+  * ``CLIP/clip/model.py`` + ``auxilary.py``             random-init tiny CLIP with the real hooks
+  * ``DETR/modules/layers.py`` ``MultiheadAttention``    real ``save_attn`` / ``register_hook`` capture
+``Tensor.cuda`` is patched to identity (the generators hard-code ``.cuda()``).
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = os.environ.get("MMX_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+torch.Tensor.cuda = lambda self, *a, **k: self  # CPU execution of hard-coded .cuda()
+torch.set_num_threads(4)
+
+
+def load_by_path(name, path, package=None):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+sys.path.insert(0, REF)
+from DETR.modules import ExplanationGenerator as detr_eg  # noqa: E402
+from DETR.modules import layers as detr_layers  # noqa: E402
+from lxmert.lxmert.src import ExplanationGenerator as lx_eg  # noqa: E402
+
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+vb_eg = load_by_path(
+    "vb_eg", os.path.join(REF, "VisualBERT/mmf/models/transformers/backends/ExplanationGenerator.py"))
+
+
+def softmax_attn(gen, *shape, causal=False):
+    s = torch.randn(*shape, generator=gen)
+    if causal:
+        n = shape[-1]
+        s = s + torch.full((n, n), float("-inf")).triu_(1)
+    return s.softmax(-1)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez(path, **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                      for k, v in arrays.items()})
+    print("wrote", path, {k: tuple(v.shape) if hasattr(v, "shape") else () for k, v in arrays.items()
+                           if not k.startswith("w__")})
+
+
+# ----------------------------------------------------------------------------- rule-level fixtures
+def gen_rules():
+    g = torch.Generator().manual_seed(100)
+    H, Ns, Nq = 4, 9, 13
+    out = {}
+    cam = softmax_attn(g, 1, H, Ns, Ns)
+    grad = torch.randn(1, H, Ns, Ns, generator=g) * 0.05
+    out["cam_ss"], out["grad_ss"] = cam, grad
+    out["avg_heads_detr"] = detr_eg.avg_heads(cam, grad)
+    out["avg_heads_lxmert"] = lx_eg.avg_heads(cam, grad)
+    cam_bar = out["avg_heads_detr"]
+
+    # relevancy state that satisfies handle_residual's diag >= 0 contract
+    R_ss = torch.eye(Ns)
+    R_sq = torch.rand(Ns, Nq, generator=g) * 0.1
+    for _ in range(3):
+        c = detr_eg.avg_heads(softmax_attn(g, H, Ns, Ns), torch.randn(H, Ns, Ns, generator=g) * 0.05)
+        R_ss = R_ss + c @ R_ss
+    R_qq = torch.eye(Nq)
+    for _ in range(2):
+        c = detr_eg.avg_heads(softmax_attn(g, H, Nq, Nq), torch.randn(H, Nq, Nq, generator=g) * 0.05)
+        R_qq = R_qq + c @ R_qq
+    R_qs = torch.rand(Nq, Ns, generator=g) * 0.1
+    out.update(R_ss=R_ss, R_sq=R_sq, R_qq=R_qq, R_qs=R_qs)
+
+    a, b = detr_eg.apply_self_attention_rules(R_ss, R_sq, cam_bar)
+    out["self_rules_ss_add"], out["self_rules_sq_add"] = a, b
+    out["handle_residual_ss"] = detr_eg.handle_residual(R_ss)
+    out["handle_residual_qq_lx"] = lx_eg.handle_residual(R_qq)
+
+    cam_sq = detr_eg.avg_heads(softmax_attn(g, H, Ns, Nq), torch.randn(H, Ns, Nq, generator=g) * 0.05)
+    out["cam_sq"] = cam_sq
+    out["mm_detr_norm"] = detr_eg.apply_mm_attention_rules(R_ss, R_qq, cam_sq.clone())
+    out["mm_detr_nonorm"] = detr_eg.apply_mm_attention_rules(R_ss, R_qq, cam_sq.clone(), apply_normalization=False)
+    out["mm_detr_noself"] = detr_eg.apply_mm_attention_rules(R_ss, R_qq, cam_sq.clone(), apply_self_in_rule_10=False)
+    # NaN policy: identity R (0/0 rows in handle_residual) -> DETR zeroes, LXMERT propagates
+    out["mm_detr_nan"] = detr_eg.apply_mm_attention_rules(torch.eye(Ns), torch.eye(Nq), cam_sq.clone())
+    sq, ss = lx_eg.apply_mm_attention_rules(R_ss, R_qq, R_qs, cam_sq.clone())
+    out["mm_lx_sq_add"], out["mm_lx_ss_add"] = sq, ss
+    sq, ss = lx_eg.apply_mm_attention_rules(R_ss, R_qq, R_qs, cam_sq.clone(), apply_normalization=False)
+    out["mm_lx_nonorm_sq_add"], out["mm_lx_nonorm_ss_add"] = sq, ss
+    sq, ss = lx_eg.apply_mm_attention_rules(torch.eye(Ns), torch.eye(Nq), R_qs, cam_sq.clone())
+    out["mm_lx_nan_sq_add"], out["mm_lx_nan_ss_add"] = sq, ss
+
+    # rollout: DETR/LXMERT operate on [1,N,N]/[N,N] head-averaged maps, VisualBERT on [B,N,N]
+    L = 4
+    mats = [softmax_attn(g, 1, H, Ns, Ns).mean(1) for _ in range(L)]  # [1, N, N]
+    out["rollout_in"] = torch.stack(mats)
+    out["rollout_detr"] = detr_eg.compute_rollout_attention([m.clone() for m in mats])
+    out["rollout_detr_s2"] = detr_eg.compute_rollout_attention([m.clone() for m in mats], start_layer=2)
+    out["rollout_lxmert"] = lx_eg.compute_rollout_attention([m.clone() for m in mats])
+    matsb = [softmax_attn(g, 3, H, Ns, Ns).mean(1) for _ in range(L)]  # [3, N, N]
+    out["rollout_vb_in"] = torch.stack(matsb)
+    out["rollout_vb"] = vb_eg.compute_rollout_attention([m.clone() for m in matsb])
+    out["rollout_vb_s1"] = vb_eg.compute_rollout_attention([m.clone() for m in matsb], start_layer=1)
+
+    cam4 = softmax_attn(g, 1, H, Nq, Ns)
+    grad4 = torch.randn(1, H, Nq, Ns, generator=g)
+    out["gradcam_cam"], out["gradcam_grad"] = cam4, grad4
+    out["gradcam_out"] = detr_eg.Generator.gradcam(None, cam4, grad4)
+    save("rules", **out)
+
+
+# ----------------------------------------------------------------------------- fake models for the generators
+class Slot:
+    """Stands in for a hooked attention module: fixed attn / grad tensors."""
+
+    def __init__(self, attn, grad):
+        self._a, self._g = attn, grad
+
+    def get_attn(self):
+        return self._a
+
+    def get_attn_gradients(self):
+        return self._g
+
+    def get_attn_cam(self):
+        raise AssertionError("LRP cam is not on the fixtures' path (use_lrp=False)")
+
+    # ViT naming (external ViT_new)
+    get_attention_map = get_attn
+
+
+class FakeBody(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.dummy = nn.Parameter(torch.zeros(1))
+
+
+def gen_detr_chain(tag, seed, H, Ni, Nq, Le, Ld, targets, **flags):
+    g = torch.Generator().manual_seed(seed)
+    enc = [(softmax_attn(g, H, Ni, Ni), torch.randn(H, Ni, Ni, generator=g) * 0.1) for _ in range(Le)]
+    dself = [(softmax_attn(g, H, Nq, Nq), torch.randn(H, Nq, Nq, generator=g) * 0.1) for _ in range(Ld)]
+    dcross = [(softmax_attn(g, H, Nq, Ni), torch.randn(H, Nq, Ni, generator=g) * 0.1) for _ in range(Ld)]
+    n_cls = 7
+    logits = torch.randn(1, Nq, n_cls, generator=g).requires_grad_(True)
+
+    model = FakeBody()
+    model.forward = lambda img: {"pred_logits": logits}
+    model.transformer = types.SimpleNamespace(
+        encoder=types.SimpleNamespace(layers=[types.SimpleNamespace(self_attn=Slot(a, gr)) for a, gr in enc]),
+        decoder=types.SimpleNamespace(layers=[
+            types.SimpleNamespace(self_attn=Slot(*dself[i]), multihead_attn=Slot(*dcross[i])) for i in range(Ld)]))
+    gen = detr_eg.Generator(model)
+    tgt = torch.tensor(targets)
+    out = gen.generate_ours(None, tgt, use_lrp=False, **flags)
+    arrays = dict(target_index=tgt, out=out,
+                  enc_attn=torch.stack([a for a, _ in enc]), enc_grad=torch.stack([b for _, b in enc]),
+                  dself_attn=torch.stack([a for a, _ in dself]), dself_grad=torch.stack([b for _, b in dself]),
+                  dcross_attn=torch.stack([a for a, _ in dcross]), dcross_grad=torch.stack([b for _, b in dcross]),
+                  R_i_i=gen.R_i_i, R_q_q=gen.R_q_q)
+    if not flags:
+        arrays["rollout_out"] = detr_eg.Generator(model).generate_rollout(None, tgt)
+        arrays["raw_attn_out"] = detr_eg.Generator(model).generate_raw_attn(None, tgt)
+        arrays["gradcam_out"] = detr_eg.Generator(model).generate_attn_gradcam(None, tgt)
+        abl = detr_eg.GeneratorAlbationNoAgg(model)
+        arrays["abl_out"] = abl.generate_ours_abl(None, tgt)
+    save(tag, **arrays)
+
+
+def gen_lxmert_chain(tag, seed, H, T, I, Ll, Lr, Lx, **flags):
+    g = torch.Generator().manual_seed(seed)
+
+    def pair(nq, nk):
+        return softmax_attn(g, 1, H, nq, nk), torch.randn(1, H, nq, nk, generator=g) * 0.1
+
+    lang = [pair(T, T) for _ in range(Ll)]
+    vis = [pair(I, I) for _ in range(Lr)]
+    xl = [dict(lang_cross=pair(T, I), img_cross=pair(I, T), lang_self=pair(T, T), img_self=pair(I, I))
+          for _ in range(Lx)]
+    score = torch.randn(1, 11, generator=g).requires_grad_(True)
+
+    def sa(p):
+        return types.SimpleNamespace(self=Slot(*p))
+
+    model = FakeBody()
+    model.device = torch.device("cpu")
+    model.lxmert = types.SimpleNamespace(encoder=types.SimpleNamespace(
+        layer=[types.SimpleNamespace(attention=sa(p)) for p in lang],
+        r_layers=[types.SimpleNamespace(attention=sa(p)) for p in vis],
+        x_layers=[types.SimpleNamespace(
+            visual_attention=types.SimpleNamespace(att=Slot(*b["lang_cross"])),
+            visual_attention_copy=types.SimpleNamespace(att=Slot(*b["img_cross"])),
+            lang_self_att=sa(b["lang_self"]), visn_self_att=sa(b["img_self"])) for b in xl]))
+    usage = types.SimpleNamespace(
+        model=model, text_len=T, image_boxes_len=I,
+        forward=lambda item: types.SimpleNamespace(question_answering_score=score))
+    gen = lx_eg.GeneratorOurs(usage)
+    R_t_t, R_t_i = gen.generate_ours(None, use_lrp=False, **flags)
+    arrays = dict(R_t_t=R_t_t, R_t_i=R_t_i, R_i_i=gen.R_i_i, R_i_t=gen.R_i_t,
+                  lang_attn=torch.stack([a for a, _ in lang]), lang_grad=torch.stack([b for _, b in lang]),
+                  vis_attn=torch.stack([a for a, _ in vis]), vis_grad=torch.stack([b for _, b in vis]))
+    for key in ("lang_cross", "img_cross", "lang_self", "img_self"):
+        arrays["x_%s_attn" % key] = torch.stack([b[key][0] for b in xl])
+        arrays["x_%s_grad" % key] = torch.stack([b[key][1] for b in xl])
+    if not flags:
+        abl = lx_eg.GeneratorOursAblationNoAggregation(usage)
+        # default normalize_self_attention=True trips handle_residual's diag>=0 assert on R = cam@R
+        a_tt, a_ti = abl.generate_ours_no_agg(None, use_lrp=False, normalize_self_attention=False)
+        arrays["abl_R_t_t"], arrays["abl_R_t_i"] = a_tt, a_ti
+        base = lx_eg.GeneratorBaselines(usage)
+        r_tt, r_ti = base.generate_rollout(None)
+        arrays["rollout_R_t_t"], arrays["rollout_R_t_i"] = r_tt, r_ti
+        r_tt, r_ti = base.generate_raw_attn(None)
+        arrays["raw_R_t_t"], arrays["raw_R_t_i"] = r_tt, r_ti
+        r_tt, r_ti = base.generate_attn_gradcam(None)
+        arrays["gradcam_R_t_t"], arrays["gradcam_R_t_i"] = r_tt, r_ti
+    save(tag, **arrays)
+
+
+def notebook_cell(nb_path, idx):
+    nb = json.load(open(os.path.join(REF, nb_path)))
+    return "".join(nb["cells"][idx]["source"])
+
+
+def gen_vit_chain():
+    g = torch.Generator().manual_seed(300)
+    H, N, L = 3, 17, 4
+    layers = [(softmax_attn(g, 1, H, N, N), torch.randn(1, H, N, N, generator=g) * 0.1) for _ in range(L)]
+    logits = torch.randn(1, 10, generator=g).requires_grad_(True)
+    model = FakeBody()
+    model.forward = lambda x, register_hook=False: logits
+    model.blocks = [types.SimpleNamespace(attn=Slot(a, gr)) for a, gr in layers]
+    ns = {"torch": torch, "np": np}
+    exec(notebook_cell("Transformer_MM_explainability_ViT.ipynb", 7), ns)
+    out = ns["generate_relevance"](model, torch.zeros(1, 3, 8, 8), index=3)
+    save("vit_chain", attn=torch.stack([a for a, _ in layers]), grad=torch.stack([b for _, b in layers]), out=out)
+
+
+def gen_visualbert_chain():
+    g = torch.Generator().manual_seed(400)
+    H, N, L = 4, 21, 5
+    layers = [(softmax_attn(g, 1, H, N, N), torch.randn(1, H, N, N, generator=g) * 0.1) for _ in range(L)]
+    scores = torch.randn(1, 9, generator=g).requires_grad_(True)
+    model = FakeBody()
+    model.forward = lambda inp: {"scores": scores}
+    model.model = types.SimpleNamespace(bert=types.SimpleNamespace(encoder=types.SimpleNamespace(
+        layer=[types.SimpleNamespace(attention=types.SimpleNamespace(self=Slot(a, gr))) for a, gr in layers])))
+    input_mask = torch.zeros(1, N, dtype=torch.long)
+    input_mask[0, :8] = 1
+    gen = vb_eg.SelfAttentionGenerator(model)
+    out = gen.generate_ours({"input_mask": input_mask})
+    roll = vb_eg.SelfAttentionGenerator(model).generate_rollout({"input_mask": input_mask})
+    save("visualbert_chain", attn=torch.stack([a for a, _ in layers]), grad=torch.stack([b for _, b in layers]),
+         input_mask=input_mask, out=out, rollout_out=roll)
+
+
+# ----------------------------------------------------------------------------- real hooked modules
+def gen_clip_tiny():
+    aux = load_by_path("clip_ref_pkg.auxilary", os.path.join(REF, "CLIP/clip/auxilary.py"))
+    pkg = types.ModuleType("clip_ref_pkg")
+    pkg.__path__ = [os.path.join(REF, "CLIP/clip")]
+    sys.modules["clip_ref_pkg"] = pkg
+    spec = importlib.util.spec_from_file_location("clip_ref_pkg.model", os.path.join(REF, "CLIP/clip/model.py"))
+    model_mod = importlib.util.module_from_spec(spec)
+    model_mod.__package__ = "clip_ref_pkg"
+    sys.modules["clip_ref_pkg.model"] = model_mod
+    spec.loader.exec_module(model_mod)
+
+    torch.manual_seed(0)
+    cfg = dict(embed_dim=32, image_resolution=32, vision_layers=3, vision_width=128, vision_patch_size=8,
+               context_length=12, vocab_size=64, transformer_width=64, transformer_heads=2, transformer_layers=3)
+    model = model_mod.CLIP(**cfg).float().eval()
+    B = 3
+    g = torch.Generator().manual_seed(1)
+    image = torch.randn(1, 3, 32, 32, generator=g)
+    texts = torch.zeros(B, cfg["context_length"], dtype=torch.long)
+    g2 = torch.Generator().manual_seed(2)
+    for b in range(B):
+        n = 3 + b * 2
+        texts[b, 0] = cfg["vocab_size"] - 2
+        texts[b, 1:1 + n] = torch.randint(1, cfg["vocab_size"] - 2, (n,), generator=g2)
+        texts[b, 1 + n] = cfg["vocab_size"] - 1  # EOT = arg-max id
+
+    ns = {"torch": torch, "np": np, "start_layer": -1, "start_layer_text": -1}
+    exec(notebook_cell("CLIP_explainability.ipynb", 6), ns)
+    interpret = ns["interpret"]
+    arrays = {"image": image, "texts": texts, "cfg_json": json.dumps(cfg)}
+    for k, v in model.state_dict().items():
+        arrays["w__" + k] = v
+    for tag, sl, slt in (("last", -1, -1), ("all", 0, 0), ("mid", 1, 2)):
+        R_text, R_image = interpret(image, texts, model, "cpu", start_layer=sl, start_layer_text=slt)
+        arrays["R_text_" + tag], arrays["R_image_" + tag] = R_text, R_image
+    # captured buffers of the last forward + ONE backward through every hook
+    logits_per_image, _ = model(image.repeat(B, 1, 1, 1), texts)
+    arrays["logits_per_image"] = logits_per_image
+    one_hot = torch.sum(torch.eye(B) * logits_per_image)
+    model.zero_grad()
+    one_hot.backward()
+    vis_blocks = list(model.visual.transformer.resblocks.children())
+    txt_blocks = list(model.transformer.resblocks.children())
+    arrays["img_attn"] = torch.stack([b.attn_probs for b in vis_blocks])
+    arrays["img_grad"] = torch.stack([b.attn_grad for b in vis_blocks])
+    arrays["txt_attn"] = torch.stack([b.attn_probs for b in txt_blocks])
+    arrays["txt_grad"] = torch.stack([b.attn_grad for b in txt_blocks])
+    save("clip_tiny", **arrays)
+
+
+def gen_detr_mha():
+    torch.manual_seed(5)
+    E, H, T, S, B = 64, 4, 6, 15, 2
+    mha = detr_layers.MultiheadAttention(E, H, dropout=0.0).eval()
+    g = torch.Generator().manual_seed(6)
+    q = torch.randn(T, B, E, generator=g, requires_grad=True)
+    k = torch.randn(S, B, E, generator=g, requires_grad=True)
+    v = torch.randn(S, B, E, generator=g, requires_grad=True)
+    out = mha(q, k, v)
+    up = torch.randn(T, B, E, generator=g)
+    (out * up).sum().backward()
+    arrays = dict(query=q, key=k, value=v, upstream=up, out=out, attn=mha.get_attn(),
+                  attn_grad=mha.get_attn_gradients(), dquery=q.grad, dkey=k.grad, dvalue=v.grad,
+                  num_heads=np.int64(H))
+    for name, p in mha.state_dict().items():
+        arrays["w__" + name] = p
+    save("detr_mha", **arrays)
+
+
+if __name__ == "__main__":
+    gen_rules()
+    gen_detr_chain("detr_chain", 200, H=4, Ni=35, Nq=10, Le=3, Ld=3, targets=[2, 7])
+    gen_detr_chain("detr_chain_nonorm", 201, H=2, Ni=20, Nq=6, Le=2, Ld=2, targets=[0],
+                   normalize_self_attention=False)
+    gen_detr_chain("detr_chain_noself", 202, H=2, Ni=20, Nq=6, Le=2, Ld=2, targets=[1],
+                   apply_self_in_rule_10=False)
+    gen_lxmert_chain("lxmert_chain", 250, H=4, T=7, I=12, Ll=3, Lr=2, Lx=3)
+    gen_lxmert_chain("lxmert_chain_full", 251, H=12, T=14, I=36, Ll=9, Lr=5, Lx=5)
+    gen_lxmert_chain("lxmert_chain_nonorm", 252, H=2, T=5, I=6, Ll=2, Lr=1, Lx=2,
+                     normalize_self_attention=False)
+    gen_vit_chain()
+    gen_visualbert_chain()
+    gen_clip_tiny()
+    gen_detr_mha()

@@ -1,0 +1,113 @@
+"""Pins the numpy oracle (``oracle/relevancy_np.py``) to outputs of the reference's own code.
+
+The fixtures were produced by ``tests/golden/make_golden.py`` (reference imported in-process).
+Tolerance: the oracle and torch both do fp32 arithmetic but sum in different orders -> 1e-6 abs
+(values are O(1)); NaN positions must match exactly.
+"""
+import numpy as np
+import pytest
+
+from oracle import relevancy_np as onp
+
+ATOL = 2e-6
+
+
+def close(a, b, atol=ATOL):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=atol, equal_nan=True)
+
+
+def test_rules(golden):
+    g = golden("rules")
+    close(onp.avg_heads(g["cam_ss"], g["grad_ss"]), g["avg_heads_detr"])
+    close(onp.avg_heads(g["cam_ss"], g["grad_ss"]), g["avg_heads_lxmert"])
+    cam = g["avg_heads_detr"]
+    ss, sq = onp.apply_self_attention_rules(g["R_ss"], g["R_sq"], cam)
+    close(ss, g["self_rules_ss_add"])
+    close(sq, g["self_rules_sq_add"])
+    close(onp.apply_self_attention_rules_vit(g["R_ss"], cam), g["self_rules_ss_add"])
+    close(onp.handle_residual(g["R_ss"]), g["handle_residual_ss"])
+    close(onp.handle_residual(g["R_qq"]), g["handle_residual_qq_lx"])
+    close(onp.apply_mm_attention_rules_detr(g["R_ss"], g["R_qq"], g["cam_sq"]), g["mm_detr_norm"])
+    close(onp.apply_mm_attention_rules_detr(g["R_ss"], g["R_qq"], g["cam_sq"], apply_normalization=False),
+          g["mm_detr_nonorm"])
+    close(onp.apply_mm_attention_rules_detr(g["R_ss"], g["R_qq"], g["cam_sq"], apply_self_in_rule_10=False),
+          g["mm_detr_noself"])
+    eye_s, eye_q = np.eye(g["R_ss"].shape[0]), np.eye(g["R_qq"].shape[0])
+    nan_out = onp.apply_mm_attention_rules_detr(eye_s, eye_q, g["cam_sq"])
+    assert not np.isnan(nan_out).any()
+    close(nan_out, g["mm_detr_nan"])
+    sq, ss = onp.apply_mm_attention_rules_lxmert(g["R_ss"], g["R_qq"], g["R_qs"], g["cam_sq"])
+    close(sq, g["mm_lx_sq_add"])
+    close(ss, g["mm_lx_ss_add"])
+    sq, ss = onp.apply_mm_attention_rules_lxmert(g["R_ss"], g["R_qq"], g["R_qs"], g["cam_sq"],
+                                                 apply_normalization=False)
+    close(sq, g["mm_lx_nonorm_sq_add"])
+    close(ss, g["mm_lx_nonorm_ss_add"])
+    sq, ss = onp.apply_mm_attention_rules_lxmert(eye_s, eye_q, g["R_qs"], g["cam_sq"])
+    assert np.isnan(g["mm_lx_nan_sq_add"]).all() and np.isnan(sq).all()  # LXMERT propagates NaN
+    close(ss, g["mm_lx_nan_ss_add"])
+    close(onp.gradcam(g["gradcam_cam"], g["gradcam_grad"]), g["gradcam_out"])
+
+
+def test_rollout(golden):
+    g = golden("rules")
+    mats = list(g["rollout_in"])
+    close(onp.compute_rollout_attention(mats), g["rollout_detr"])
+    close(onp.compute_rollout_attention(mats, start_layer=2), g["rollout_detr_s2"])
+    close(onp.compute_rollout_attention(mats), g["rollout_lxmert"])
+    matsb = list(g["rollout_vb_in"])
+    close(onp.compute_rollout_attention(matsb, normalize=False), g["rollout_vb"])
+    close(onp.compute_rollout_attention(matsb, start_layer=1, normalize=False), g["rollout_vb_s1"])
+
+
+@pytest.mark.parametrize("name,flags", [
+    ("detr_chain", {}),
+    ("detr_chain_nonorm", {"normalize_self_attention": False}),
+    ("detr_chain_noself", {"apply_self_in_rule_10": False}),
+])
+def test_detr_chain(golden, name, flags):
+    g = golden(name)
+    out = onp.detr_generate_ours_chain(list(g["enc_attn"]), list(g["enc_grad"]), list(g["dself_attn"]),
+                                       list(g["dself_grad"]), list(g["dcross_attn"]), list(g["dcross_grad"]),
+                                       g["target_index"], **flags)
+    close(out, g["out"])
+
+
+@pytest.mark.parametrize("name,flags", [
+    ("lxmert_chain", {}),
+    ("lxmert_chain_full", {}),
+    ("lxmert_chain_nonorm", {"normalize_self_attention": False}),
+])
+def test_lxmert_chain(golden, name, flags):
+    g = golden(name)
+    n_x = g["x_lang_cross_attn"].shape[0]
+    x_layers = [{k: (g["x_%s_attn" % k][i], g["x_%s_grad" % k][i])
+                 for k in ("lang_cross", "img_cross", "lang_self", "img_self")} for i in range(n_x)]
+    R_t_t, R_t_i = onp.lxmert_generate_ours_chain(list(g["lang_attn"]), list(g["lang_grad"]),
+                                                  list(g["vis_attn"]), list(g["vis_grad"]), x_layers, **flags)
+    close(R_t_t, g["R_t_t"], atol=1e-5)
+    close(R_t_i, g["R_t_i"], atol=1e-5)
+
+
+def test_vit_chain(golden):
+    g = golden("vit_chain")
+    close(onp.vit_generate_relevance_chain([a[0] for a in g["attn"]], [x[0] for x in g["grad"]]), g["out"])
+
+
+def test_visualbert_chain(golden):
+    g = golden("visualbert_chain")
+    cls_index = int(g["input_mask"].sum(1)[0]) - 2
+    close(onp.visualbert_generate_ours_chain(list(g["attn"]), list(g["grad"]), cls_index), g["out"])
+
+
+@pytest.mark.parametrize("tag,sl,slt", [("last", -1, -1), ("all", 0, 0), ("mid", 1, 2)])
+def test_clip_interpret_chain(golden, tag, sl, slt):
+    g = golden("clip_tiny")
+    B = g["texts"].shape[0]
+    R_text, R_image = onp.clip_interpret_chain(list(g["img_attn"]), list(g["img_grad"]), list(g["txt_attn"]),
+                                               list(g["txt_grad"]), B, sl, slt)
+    close(R_text, g["R_text_" + tag])
+    close(R_image, g["R_image_" + tag])
