@@ -1,0 +1,180 @@
+/*
+ * mmx_relevancy.h -- C-ABI of libmmx_hip.so, the MI355X (gfx950) relevancy-propagation engine.
+ *
+ * The reference (hila-chefer/Transformer-MM-Explainability) has NO FFI boundary: its hot path is
+ * Python calling stock ATen kernels.  The entry points below are what a ctypes binding of that path
+ * binds instead of those ATen call sequences; each cites the reference site it replaces
+ * (paths relative to the reference checkout).  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every pointer named *_dev / documented "device" is a HIP device pointer owned by the caller;
+ *     pointer TABLES (const void* const*) are HOST arrays of device pointers
+ *   - plain C types only: no torch / hip types in the signatures; `stream` is a hipStream_t passed
+ *     as void* (NULL = default stream)
+ *   - all launches are stream-ordered, never synchronise, never allocate (scratch is caller-provided;
+ *     sizes from the *_workspace_bytes queries)
+ *   - return value: 0 = ok, MMX_E* < 0 on error (no exceptions cross the boundary);
+ *     mmx_last_error() gives a thread-local message
+ *   - relevancy matrices R are always fp32 row-major; captured attention / gradient buffers are
+ *     `dtype` (MMX_F32 / MMX_F16 / MMX_BF16), row-major [B, H, Nq, Nk] with index b*H + h
+ *     (== CLIP's [B*H, N, N], CLIP/clip/auxilary.py:194)
+ */
+#ifndef MMX_RELEVANCY_H
+#define MMX_RELEVANCY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMX_ABI_VERSION 1
+#define MMX_MAX_LAYERS 48
+
+enum mmx_dtype { MMX_F32 = 0, MMX_F16 = 1, MMX_BF16 = 2 };
+
+enum mmx_status {
+    MMX_OK = 0,
+    MMX_EINVAL = -22,       /* bad argument (null pointer, non-positive size, unsupported dtype) */
+    MMX_ENOTSUP = -95,      /* shape outside what the kernels support (message says which limit) */
+    MMX_EWORKSPACE = -105,  /* workspace too small */
+    MMX_EHIP = -1000        /* -1000 - hipError_t */
+};
+
+/* flags for mmx_mm_attention_rules / chain schedules */
+#define MMX_MM_NORMALIZE 1u        /* apply handle_residual to R_ss / R_qq (apply_normalization=True) */
+#define MMX_MM_SELF_IN_RULE10 2u   /* apply_self_in_rule_10=True; if clear the addition is cam_sq itself */
+#define MMX_MM_NAN_TO_ZERO 4u      /* DETR: R_sq_addition[isnan] = 0 (DETR/modules/ExplanationGenerator.py:42) */
+
+/* scale placement of the attention-capture op */
+#define MMX_SCALE_Q_FIRST 0   /* q*scale, then q.k^T  (CLIP/clip/auxilary.py:153, DETR/modules/layers.py:745) */
+#define MMX_SCALE_SCORES 1    /* (q.k^T)/sqrt(d)      (lxmert_lrp.py:399, BERT_ours.py:325) */
+
+int mmx_abi_version(void);
+const char* mmx_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Rule 5: A_bar[b] = mean_h( clamp(grad[b,h] * attn[b,h], min=0) )              out: [B, Nq, Nk] fp32
+ * replaces avg_heads (DETR/modules/ExplanationGenerator.py:19-24, lxmert/.../ExplanationGenerator.py:18-23,
+ * ViT notebook cell 7:2-7) and the inline reshape/mul/clamp/mean of CLIP_explainability.ipynb cell 6:26-31.
+ * Unbatched callers pass B=1 and H = (product of all leading dims).
+ */
+int mmx_avg_heads(const void* attn_dev, const void* grad_dev, void* out_dev,
+                  int B, int H, int Nq, int Nk, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The fused self-attention chain (rules 5+6 [+7]) -- ONE launch for all layers:
+ *     R <- R_init (identity if NULL);  for l in 0..n_layers-1:  R <- R + A_bar_l . R
+ *     optional second right-hand side (rule 7): R_sq <- R_sq + A_bar_l . R_sq      (R_sq: [B, N, M])
+ * replaces the per-layer loops of CLIP_explainability.ipynb cell 6:22-32 / 6:45-55, CLIP/example.py:22-30,
+ * ViT notebook cell 7:28-33, VisualBERT/.../ExplanationGenerator.py:86-93,
+ * DETR/modules/ExplanationGenerator.py:110-118 (encoder) -- `start_layer` is applied by the caller by
+ * passing the pointer sub-range.
+ *   attn_layers/grad_layers: HOST arrays of n_layers device pointers, each [B, H, N, N] `dtype`
+ *   R_init_dev: NULL or [B, N, N] fp32;  R_out_dev: [B, N, N] fp32
+ *   Rsq_init_dev/Rsq_out_dev: NULL or [B, N, M] fp32 (M = 0 when unused)
+ *   workspace_dev: NULL allowed when mmx_self_chain_workspace_bytes() == 0 for the shape (fused path)
+ */
+size_t mmx_self_chain_workspace_bytes(int n_layers, int B, int H, int N, int M, int dtype);
+int mmx_relevancy_self_chain(const void* const* attn_layers, const void* const* grad_layers, int n_layers,
+                             int B, int H, int N, int dtype,
+                             const void* R_init_dev, void* R_out_dev,
+                             const void* Rsq_init_dev, void* Rsq_out_dev, int M,
+                             void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Batched fp32 matmul on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32):
+ *     C[b] = (accumulate ? Cin[b] : 0) + op(A[b]) . B[b],   op = transpose if trans_a
+ * A: [batch, M, K] (or [batch, K, M] if trans_a), B: [batch, K, N], C/Cin: [batch, M, N]; a batch
+ * stride of 0 broadcasts an operand.  Cin may alias C only if it does not alias A or B.
+ * replaces torch.matmul / torch.bmm in rules 6, 7, 10, 11 (DETR/.../ExplanationGenerator.py:27-43,
+ * lxmert/.../ExplanationGenerator.py:26-42) and in compute_rollout_attention.
+ */
+int mmx_bmm_f32(const void* A_dev, const void* B_dev, const void* Cin_dev, void* C_dev,
+                int batch, int M, int N, int K, int trans_a,
+                int64_t stride_a, int64_t stride_b, int64_t stride_c,
+                int nan_to_zero, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * eq. 8-9: out = (R - I) / rowsum(R - I) + I  (0/0 rows -> NaN like the reference).
+ * replaces handle_residual (DETR/.../ExplanationGenerator.py:46-53, lxmert/.../ExplanationGenerator.py:45-54).
+ * The reference's `assert diag(R-I) >= 0` is reported through *diag_min_dev (device float, may be NULL):
+ * it receives min_i (R[i,i]-1) so the host wrapper can raise AssertionError like the reference.
+ */
+int mmx_handle_residual(const void* R_dev, void* out_dev, int batch, int N, void* diag_min_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Rules 10 (+11):  R_sq_add = Rn_ss^T . (cam_sq . Rn_qq)   [, R_ss_add = cam_sq . R_qs]
+ * replaces apply_mm_attention_rules -- DETR 5-arg form (DETR/.../ExplanationGenerator.py:33-43, flags
+ * MMX_MM_NAN_TO_ZERO) and LXMERT 6-arg form (lxmert/.../ExplanationGenerator.py:32-42, R_qs/R_ss_add given).
+ *   R_ss [Ns,Ns], R_qq [Nq,Nq], cam_sq [Ns,Nq], R_qs [Nq,Ns] or NULL, outputs R_sq_add [Ns,Nq], R_ss_add [Ns,Ns] or NULL
+ *   workspace: mmx_mm_rules_workspace_bytes(Ns, Nq) bytes
+ */
+size_t mmx_mm_rules_workspace_bytes(int Ns, int Nq);
+int mmx_mm_attention_rules(const void* R_ss_dev, const void* R_qq_dev, const void* R_qs_dev,
+                           const void* cam_sq_dev, void* R_sq_add_dev, void* R_ss_add_dev,
+                           int Ns, int Nq, unsigned flags, void* diag_min_dev,
+                           void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention rollout: prod_{i >= start}( (A_i + I) [/ rowsum] ), left-multiplied.
+ * replaces compute_rollout_attention (DETR/.../ExplanationGenerator.py:5-16, lxmert/...:5-15 with
+ * normalize=1; VisualBERT/.../ExplanationGenerator.py:5-17 batched with normalize=0).
+ *   layers: HOST array of n_layers device pointers, each [B, N, N] fp32 (caller applies start_layer)
+ *   out: [B, N, N] fp32; workspace: mmx_rollout_workspace_bytes(B, N)
+ */
+size_t mmx_rollout_workspace_bytes(int B, int N);
+int mmx_rollout_chain(const void* const* layers, int n_layers, int B, int N, int normalize,
+                      void* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention-capture op (replaces the save_attn / save_attn_gradients Python hooks):
+ * forward : P = softmax(scale.Q.K^T + mask) written straight into the caller's capture slab, O = P.V
+ * backward: dP = dO.V^T written straight into the caller's gradient slab (this IS the hooked
+ *           attn gradient), dS = P*(dP - rowsum(dP*P)), dQ, dK, dV
+ * replaces CLIP/clip/auxilary.py:225-252, DETR/modules/layers.py:753-762, lxmert_lrp.py:398-414,
+ * BERT_ours.py:323-343 (+ the autograd of those ops).
+ * Layouts (element strides, last dim contiguous): q(b,h,n,:) = q_dev + b*q_sb + h*q_sh + n*q_sn, same for
+ * k, v, o and their gradients.  probs/dprobs: [B, H, Nq, Nk] contiguous, `dtype`-typed capture slabs are
+ * fp32 in this ABI version.  mask_dev: NULL or additive fp32 mask, element (b,i,j) at
+ * mask_dev + b*mask_sb + i*mask_sq + j (mask_sb = 0 / mask_sq = 0 broadcast).
+ * `scale` is the multiplier d^-0.5 in MMX_SCALE_Q_FIRST mode and the divisor sqrt(d) in MMX_SCALE_SCORES mode
+ * (the reference multiplies resp. divides; keeping the operation keeps the rounding).
+ * need_dqkv = 0 skips dS/dQ/dK/dV (lowest layer: only the captured gradient is wanted).
+ */
+int mmx_attn_capture_fwd(const void* q_dev, const void* k_dev, const void* v_dev,
+                         int64_t q_sb, int64_t q_sh, int64_t q_sn,
+                         int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                         int64_t v_sb, int64_t v_sh, int64_t v_sn,
+                         const void* mask_dev, int64_t mask_sb, int64_t mask_sq,
+                         void* probs_dev, void* o_dev, int64_t o_sb, int64_t o_sh, int64_t o_sn,
+                         int B, int H, int Nq, int Nk, int D, float scale, int scale_mode, void* stream);
+
+size_t mmx_attn_capture_bwd_workspace_bytes(int B, int H, int Nq);   /* rowsum(dP*P): [B, H, Nq] fp32 */
+int mmx_attn_capture_bwd(const void* q_dev, const void* k_dev, const void* v_dev,
+                         int64_t q_sb, int64_t q_sh, int64_t q_sn,
+                         int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                         int64_t v_sb, int64_t v_sh, int64_t v_sn,
+                         const void* probs_dev, const void* do_dev, int64_t o_sb, int64_t o_sh, int64_t o_sn,
+                         void* dprobs_dev,
+                         void* dq_dev, void* dk_dev, void* dv_dev,
+                         int64_t dq_sb, int64_t dq_sh, int64_t dq_sn,
+                         int64_t dk_sb, int64_t dk_sh, int64_t dk_sn,
+                         int64_t dv_sb, int64_t dv_sh, int64_t dv_sn,
+                         int B, int H, int Nq, int Nk, int D, float scale, int scale_mode,
+                         int need_dqkv, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Kernel timing helper for bench.py: runs `fn`-independent HIP-event timing on `stream` is done in
+ * Python via these thin wrappers so that events live on the SAME stream the kernels are launched on.
+ */
+int mmx_event_create(void** event_out);
+int mmx_event_destroy(void* event);
+int mmx_event_record(void* event, void* stream);
+int mmx_event_elapsed_ms(void* start, void* stop, float* ms_out); /* synchronises on `stop` */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMX_RELEVANCY_H */

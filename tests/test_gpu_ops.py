@@ -1,0 +1,208 @@
+"""-m gpu: the HIP kernels (through the C-ABI) against the numpy oracle on seeded inputs.
+
+Tolerance: 1e-5 absolute on relevancy values (BASELINE.json north_star: "within 1e-5 (fp32)"); both sides
+are fp32 and differ only in summation order.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import relevancy_np as onp
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from transformer_mm_explainability_amd import ops as _ops
+    return _ops
+
+
+def dev(x):
+    return torch.as_tensor(np.asarray(x)).cuda()
+
+
+def make_layers(seed, L, B, H, N, causal=False, gscale=0.05):
+    g = torch.Generator().manual_seed(seed)
+    attn, grad = [], []
+    for _ in range(L):
+        s = torch.randn(B * H, N, N, generator=g)
+        if causal:
+            s = s + torch.full((N, N), float("-inf")).triu_(1)
+        attn.append(s.softmax(-1))
+        grad.append(torch.randn(B * H, N, N, generator=g) * gscale)
+    return attn, grad
+
+
+def close(a, b, atol=ATOL):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=atol, equal_nan=True)
+
+
+def test_mfma_matmul_asymmetric(ops):
+    """A = I check with an asymmetric B, then random rectangular shapes incl. transposed A and accumulate."""
+    B = torch.arange(16 * 24, dtype=torch.float32).reshape(16, 24) * 0.01
+    close(ops.matmul(torch.eye(16).cuda(), B.cuda()), B.numpy())
+    g = torch.Generator().manual_seed(0)
+    for (m, n, k) in [(5, 7, 3), (64, 64, 64), (100, 950, 100), (77, 77, 77), (130, 65, 200)]:
+        a = torch.randn(m, k, generator=g)
+        b = torch.randn(k, n, generator=g)
+        c = torch.randn(m, n, generator=g)
+        close(ops.matmul(a.cuda(), b.cuda()), a.numpy() @ b.numpy(), atol=1e-4)
+        close(ops.matmul(a.t().contiguous().cuda(), b.cuda(), trans_a=True), a.numpy() @ b.numpy(), atol=1e-4)
+        close(ops.matmul(a.cuda(), b.cuda(), add_to=c.cuda()), c.numpy() + a.numpy() @ b.numpy(), atol=1e-4)
+    a = torch.randn(3, 20, 30, generator=g)
+    b = torch.randn(3, 30, 10, generator=g)
+    close(ops.matmul(a.cuda(), b.cuda()), np.matmul(a.numpy(), b.numpy()), atol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 12, 9, 13), (4, 8, 77, 77), (2, 12, 50, 50), (1, 3, 1, 5), (3, 1, 33, 2)])
+def test_avg_heads(ops, B, H, Nq, Nk):
+    g = torch.Generator().manual_seed(B * 1000 + Nq)
+    cam = torch.randn(B * H, Nq, Nk, generator=g).softmax(-1)
+    grad = torch.randn(B * H, Nq, Nk, generator=g)
+    want = onp.avg_heads_batched(cam.numpy(), grad.numpy(), B)
+    close(ops.avg_heads(cam.cuda(), grad.cuda(), batch_size=B), want, atol=1e-6)
+
+
+def test_avg_heads_nan_and_lowp(ops):
+    cam = torch.rand(4, 6, 6)
+    grad = torch.randn(4, 6, 6)
+    grad[1, 2, 3] = float("nan")
+    close(ops.avg_heads(cam.cuda(), grad.cuda()), onp.avg_heads(cam.numpy(), grad.numpy())[None], atol=1e-6)
+    for dt in (torch.bfloat16, torch.float16):
+        c, g = torch.rand(8, 10, 10).to(dt), torch.randn(8, 10, 10).to(dt)
+        want = onp.avg_heads(c.float().numpy(), g.float().numpy())[None]
+        close(ops.avg_heads(c.cuda(), g.cuda()), want, atol=1e-6)
+
+
+@pytest.mark.parametrize("L,B,H,N,causal", [
+    (12, 4, 12, 50, False),   # CLIP ViT-B/32 image tower shape
+    (12, 3, 8, 77, True),     # CLIP text tower shape (causal)
+    (3, 2, 2, 5, False), (1, 1, 1, 1, False), (2, 5, 3, 16, False), (4, 2, 4, 17, False),
+    (6, 2, 8, 100, False), (2, 1, 4, 128, False), (5, 3, 12, 36, False), (0, 2, 1, 7, False),
+])
+def test_self_chain_fused(ops, L, B, H, N, causal):
+    attn, grad = make_layers(L * 100 + N, max(L, 1), B, H, N, causal)
+    attn, grad = attn[:L], grad[:L]
+    want = onp.self_chain([a.numpy() for a in attn], [g.numpy() for g in grad], B) if L else \
+        np.broadcast_to(np.eye(N, dtype=np.float32), (B, N, N))
+    if L == 0:
+        got = ops.relevancy_self_chain([], [], B, R_init=torch.eye(N).cuda())
+    else:
+        got = ops.relevancy_self_chain([a.cuda() for a in attn], [g.cuda() for g in grad], B)
+    close(got, want)
+
+
+@pytest.mark.parametrize("N,M", [(197, 0), (130, 0), (20, 36), (100, 300)])
+def test_self_chain_split_and_rule7(ops, N, M):
+    L, B, H = 3, 2, 4
+    attn, grad = make_layers(N + M, L, B, H, N)
+    g = torch.Generator().manual_seed(7)
+    R0 = torch.eye(N).expand(B, N, N).contiguous()
+    sq0 = torch.rand(B, N, M, generator=g) * 0.1 if M else None
+    R, SQ = R0.numpy().copy(), (sq0.numpy().copy() if M else None)
+    for a, gr in zip(attn, grad):
+        cam = onp.avg_heads_batched(a.numpy(), gr.numpy(), B)
+        if M:
+            SQ = SQ + np.matmul(cam, SQ)
+        R = R + np.matmul(cam, R)
+    got = ops.relevancy_self_chain([a.cuda() for a in attn], [x.cuda() for x in grad], B,
+                                   R_sq_init=sq0.cuda() if M else None)
+    if M:
+        close(got[0], R)
+        close(got[1], SQ)
+    else:
+        close(got, R)
+
+
+def test_self_chain_bf16_capture(ops):
+    L, B, H, N = 4, 2, 4, 50
+    attn, grad = make_layers(5, L, B, H, N)
+    a16 = [a.bfloat16() for a in attn]
+    g16 = [g.bfloat16() for g in grad]
+    want = onp.self_chain([a.float().numpy() for a in a16], [g.float().numpy() for g in g16], B)
+    close(ops.relevancy_self_chain([a.cuda() for a in a16], [g.cuda() for g in g16], B), want)
+
+
+def test_rules_golden(ops, golden):
+    g = golden("rules")
+    close(ops.handle_residual(dev(g["R_ss"])), g["handle_residual_ss"])
+    with pytest.raises(AssertionError):
+        ops.handle_residual(dev(g["R_ss"] - 2 * np.eye(g["R_ss"].shape[0], dtype=np.float32)))
+    close(ops.mm_attention_rules(dev(g["R_ss"]), dev(g["R_qq"]), dev(g["cam_sq"]), nan_to_zero=True), g["mm_detr_norm"])
+    close(ops.mm_attention_rules(dev(g["R_ss"]), dev(g["R_qq"]), dev(g["cam_sq"]), apply_normalization=False,
+                                 nan_to_zero=True), g["mm_detr_nonorm"])
+    close(ops.mm_attention_rules(dev(g["R_ss"]), dev(g["R_qq"]), dev(g["cam_sq"]), apply_self_in_rule_10=False,
+                                 nan_to_zero=True), g["mm_detr_noself"])
+    ns, nq = g["cam_sq"].shape
+    eye_s, eye_q = torch.eye(ns).cuda(), torch.eye(nq).cuda()
+    close(ops.mm_attention_rules(eye_s, eye_q, dev(g["cam_sq"]), nan_to_zero=True), g["mm_detr_nan"])
+    sq, ss = ops.mm_attention_rules(dev(g["R_ss"]), dev(g["R_qq"]), dev(g["cam_sq"]), R_qs=dev(g["R_qs"]))
+    close(sq, g["mm_lx_sq_add"])
+    close(ss, g["mm_lx_ss_add"])
+    sq, ss = ops.mm_attention_rules(eye_s, eye_q, dev(g["cam_sq"]), R_qs=dev(g["R_qs"]))
+    close(sq, g["mm_lx_nan_sq_add"])
+    close(ss, g["mm_lx_nan_ss_add"])
+
+
+def test_rollout_golden(ops, golden):
+    g = golden("rules")
+    mats = [dev(m) for m in g["rollout_in"]]
+    close(ops.rollout_chain(mats, True), g["rollout_detr"])
+    close(ops.rollout_chain(mats[2:], True), g["rollout_detr_s2"])
+    matsb = [dev(m) for m in g["rollout_vb_in"]]
+    close(ops.rollout_chain(matsb, False), g["rollout_vb"])
+    close(ops.rollout_chain(matsb[1:], False), g["rollout_vb_s1"])
+
+
+def torch_attention(q, k, v, scale, mode, mask):
+    """Reference of the op in float64: q,k,v [B,H,N,D]."""
+    q, k, v = q.double(), k.double(), v.double()
+    s = (q * scale) @ k.transpose(-1, -2) if mode == 0 else (q @ k.transpose(-1, -2)) / scale
+    if mask is not None:
+        s = s + mask.double()
+    p = s.softmax(-1)
+    return p, p @ v
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D,mode,masked", [
+    (2, 12, 50, 50, 64, 0, False), (2, 8, 77, 77, 64, 0, True), (1, 8, 100, 180, 32, 0, False),
+    (2, 12, 14, 36, 64, 1, False), (1, 2, 1, 3, 16, 1, False), (1, 4, 197, 197, 64, 0, False),
+    (1, 2, 33, 130, 48, 1, True),
+])
+def test_attn_capture_fwd_bwd(ops, B, H, Nq, Nk, D, mode, masked):
+    g = torch.Generator().manual_seed(Nq * 7 + Nk)
+    q = torch.randn(B, Nq, H, D, generator=g)
+    k = torch.randn(B, Nk, H, D, generator=g)
+    v = torch.randn(B, Nk, H, D, generator=g)
+    d_o = torch.randn(B, Nq, H, D, generator=g)
+    scale = D ** -0.5 if mode == 0 else D ** 0.5
+    mask = None
+    if masked:
+        mask = torch.full((Nq, Nk), float("-inf")).triu_(1) if Nq == Nk else \
+            (torch.randn(B, 1, Nk, generator=g) > 1.0).float() * -10000.0
+    qr, kr, vr = (t.permute(0, 2, 1, 3).clone().requires_grad_(True) for t in (q, k, v))
+    mref = mask if mask is None or mask.dim() == 2 else mask[:, None]
+    p_ref, o_ref = torch_attention(qr, kr, vr, scale, mode, mref)
+    p_ref.retain_grad()
+    (o_ref * d_o.permute(0, 2, 1, 3).double()).sum().backward()
+
+    probs = torch.empty(B, H, Nq, Nk, device="cuda")
+    dprobs = torch.empty(B, H, Nq, Nk, device="cuda")
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    o = ops.attn_capture_fwd(qc, kc, vc, probs, scale, mode, mask.cuda() if mask is not None else None)
+    close(probs, p_ref.detach().float().numpy(), atol=2e-6)
+    close(o.permute(0, 2, 1, 3), o_ref.detach().float().numpy(), atol=1e-5)
+    dq, dk, dv = ops.attn_capture_bwd(qc, kc, vc, probs, d_o.cuda(), dprobs, scale, mode)
+    close(dprobs, p_ref.grad.float().numpy(), atol=2e-5)
+    close(dq.permute(0, 2, 1, 3), qr.grad.float().numpy(), atol=2e-5)
+    close(dk.permute(0, 2, 1, 3), kr.grad.float().numpy(), atol=2e-5)
+    close(dv.permute(0, 2, 1, 3), vr.grad.float().numpy(), atol=2e-5)
+    dprobs2 = torch.empty_like(dprobs)
+    assert ops.attn_capture_bwd(qc, kc, vc, probs, d_o.cuda(), dprobs2, scale, mode, need_dqkv=False) == (None, None, None)
+    assert torch.equal(dprobs, dprobs2)

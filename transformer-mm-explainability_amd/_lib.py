@@ -1,0 +1,88 @@
+"""ctypes binding of ``libmmx_hip.so`` (C-ABI declared in ``include/mmx_relevancy.h``).
+
+There is NO fallback: if the library is missing or a kernel cannot run, callers get an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmmx_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mmx_relevancy.h")
+
+MMX_F32, MMX_F16, MMX_BF16 = 0, 1, 2
+MM_NORMALIZE, MM_SELF_IN_RULE10, MM_NAN_TO_ZERO = 1, 2, 4
+SCALE_Q_FIRST, SCALE_SCORES = 0, 1
+MAX_LAYERS = 48
+
+_vp, _i, _i64, _sz, _f, _u = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float, C.c_uint
+_vpp = C.POINTER(C.c_void_p)
+
+_PROTOTYPES = {
+    "mmx_abi_version": (_i, []),
+    "mmx_last_error": (C.c_char_p, []),
+    "mmx_avg_heads": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mmx_self_chain_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "mmx_relevancy_self_chain": (_i, [_vpp, _vpp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "mmx_bmm_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i, _vp]),
+    "mmx_handle_residual": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "mmx_mm_rules_workspace_bytes": (_sz, [_i, _i]),
+    "mmx_mm_attention_rules": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _u, _vp, _vp, _sz, _vp]),
+    "mmx_rollout_workspace_bytes": (_sz, [_i, _i]),
+    "mmx_rollout_chain": (_i, [_vpp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "mmx_attn_capture_fwd": (_i, [_vp, _vp, _vp] + [_i64] * 9 + [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64,
+                                  _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "mmx_attn_capture_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mmx_attn_capture_bwd": (_i, [_vp, _vp, _vp] + [_i64] * 9 + [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]
+                             + [_i64] * 9 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
+    "mmx_event_create": (_i, [_vpp]),
+    "mmx_event_destroy": (_i, [_vp]),
+    "mmx_event_record": (_i, [_vp, _vp]),
+    "mmx_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
+}
+
+
+class MMXError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def header_symbols():
+    """Function names declared in include/mmx_relevancy.h."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(mmx_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises MMXError if the HIP library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MMXError(
+                "libmmx_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C transformer-mm-explainability_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.mmx_abi_version() != 1:
+            raise MMXError("libmmx_hip.so ABI version %d != 1" % handle.mmx_abi_version())
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().mmx_last_error().decode("utf-8", "replace")
+        raise MMXError("%s failed (rc=%d): %s" % (what, rc, msg))
+
+
+def ptr_table(ptrs):
+    """HOST array of device pointers for the `const void* const*` parameters."""
+    arr = (C.c_void_p * len(ptrs))(*ptrs)
+    return C.cast(arr, _vpp), arr  # keep `arr` alive while the call runs

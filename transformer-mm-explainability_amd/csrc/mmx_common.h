@@ -1,0 +1,97 @@
+// Shared device/host helpers for libmmx_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mmx_relevancy.h"
+
+namespace mmx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// 16-byte global load that only assumes 4-byte alignment: head slabs of odd N (77^2 floats) start on
+// 4/8/12-byte offsets.  gfx950 global_load_dwordx4 needs dword alignment only.
+struct __attribute__((packed, aligned(4))) f32x4_u { f32x4 v; };
+__device__ __forceinline__ f32x4 ldg4_u(const float* p) { return reinterpret_cast<const f32x4_u*>(p)->v; }
+
+struct __attribute__((packed, aligned(2))) u16x4_u { unsigned short v[4]; };
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+    return __uint_as_float(static_cast<unsigned int>(b) << 16);
+}
+__device__ __forceinline__ float f16_bits_to_f32(unsigned short b) {
+    return __half2float(__ushort_as_half(b));
+}
+
+// load 4 consecutive captured values (any alignment >= element size) as fp32
+template <int DT>
+__device__ __forceinline__ f32x4 load4_as_f32(const void* base, int64_t idx);
+template <>
+__device__ __forceinline__ f32x4 load4_as_f32<MMX_F32>(const void* base, int64_t idx) {
+    return ldg4_u(static_cast<const float*>(base) + idx);
+}
+template <>
+__device__ __forceinline__ f32x4 load4_as_f32<MMX_BF16>(const void* base, int64_t idx) {
+    u16x4_u r = *reinterpret_cast<const u16x4_u*>(static_cast<const unsigned short*>(base) + idx);
+    f32x4 o;
+    o[0] = bf16_bits_to_f32(r.v[0]); o[1] = bf16_bits_to_f32(r.v[1]);
+    o[2] = bf16_bits_to_f32(r.v[2]); o[3] = bf16_bits_to_f32(r.v[3]);
+    return o;
+}
+template <>
+__device__ __forceinline__ f32x4 load4_as_f32<MMX_F16>(const void* base, int64_t idx) {
+    u16x4_u r = *reinterpret_cast<const u16x4_u*>(static_cast<const unsigned short*>(base) + idx);
+    f32x4 o;
+    o[0] = f16_bits_to_f32(r.v[0]); o[1] = f16_bits_to_f32(r.v[1]);
+    o[2] = f16_bits_to_f32(r.v[2]); o[3] = f16_bits_to_f32(r.v[3]);
+    return o;
+}
+template <int DT>
+__device__ __forceinline__ float load1_as_f32(const void* base, int64_t idx);
+template <>
+__device__ __forceinline__ float load1_as_f32<MMX_F32>(const void* base, int64_t idx) {
+    return static_cast<const float*>(base)[idx];
+}
+template <>
+__device__ __forceinline__ float load1_as_f32<MMX_BF16>(const void* base, int64_t idx) {
+    return bf16_bits_to_f32(static_cast<const unsigned short*>(base)[idx]);
+}
+template <>
+__device__ __forceinline__ float load1_as_f32<MMX_F16>(const void* base, int64_t idx) {
+    return f16_bits_to_f32(static_cast<const unsigned short*>(base)[idx]);
+}
+
+// clamp(x, min=0) with torch semantics: NaN propagates (fmaxf would drop it)
+__device__ __forceinline__ float relu_nan(float x) { return (x < 0.0f) ? 0.0f : x; }
+
+// exact-fp32 MFMA: D(16x16) += A(16x4) . B(4x16).
+// lane l: a = A[l & 15][l >> 4], b = B[l >> 4][l & 15]; acc[r] = D[(l >> 4) * 4 + r][l & 15].
+__device__ __forceinline__ f32x4 mfma16x16x4(float a, float b, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+}
+
+inline size_t dtype_size(int dt) { return dt == MMX_F32 ? 4 : 2; }
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+}  // namespace mmx
+
+#define MMX_CHECK_ARG(cond, ...)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            mmx::set_error(__VA_ARGS__);    \
+            return MMX_EINVAL;              \
+        }                                   \
+    } while (0)
+
+#define MMX_LAUNCH_CHECK(what)                                  \
+    do {                                                        \
+        hipError_t e__ = hipGetLastError();                     \
+        if (e__ != hipSuccess) return mmx::hip_fail(e__, what); \
+    } while (0)

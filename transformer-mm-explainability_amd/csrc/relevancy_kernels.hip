@@ -1,0 +1,540 @@
+// Relevancy-propagation kernels for gfx950 (MI355X): rule 5 head reduction, the fused all-layer
+// self-attention chain (rules 5+6), exact-fp32 MFMA batched matmul, eq. 8-9 normalisation, rollout prep.
+//
+// Reference sites replaced by each kernel are cited in include/mmx_relevancy.h; DESIGN.md has the
+// layouts, the algorithmic-byte model and the roofline each kernel is bound by.
+#include "mmx_common.h"
+
+namespace mmx {
+
+// =====================================================================================================
+// K_avg_heads: A_bar[b] = (1/H) sum_h clamp(G[b,h] * A[b,h], 0).   Pure HBM stream: A and G read once.
+// grid = (ceil(NN/4 / 256), B), block 256; thread owns 4 consecutive positions and walks the heads in
+// order (deterministic, same summation order as a sequential mean over dim h).
+// =====================================================================================================
+template <int DT>
+__global__ __launch_bounds__(256) void avg_heads_kernel(const void* __restrict__ attn,
+                                                        const void* __restrict__ grad,
+                                                        float* __restrict__ out, int H, int64_t NN) {
+    const int b = blockIdx.y;
+    const int64_t p = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
+    if (p >= NN) return;
+    const int64_t base = static_cast<int64_t>(b) * H * NN + p;
+    const float fH = static_cast<float>(H);
+    if (p + 3 < NN) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int h = 0; h < H; ++h) {
+            const f32x4 a = load4_as_f32<DT>(attn, base + h * NN);
+            const f32x4 g = load4_as_f32<DT>(grad, base + h * NN);
+            const f32x4 x = g * a;
+            s[0] += relu_nan(x[0]); s[1] += relu_nan(x[1]);
+            s[2] += relu_nan(x[2]); s[3] += relu_nan(x[3]);
+        }
+        float* o = out + static_cast<int64_t>(b) * NN + p;
+        o[0] = s[0] / fH; o[1] = s[1] / fH; o[2] = s[2] / fH; o[3] = s[3] / fH;
+    } else {
+        for (int e = 0; p + e < NN; ++e) {
+            float s = 0.f;
+            for (int h = 0; h < H; ++h)
+                s += relu_nan(load1_as_f32<DT>(grad, base + h * NN + e) * load1_as_f32<DT>(attn, base + h * NN + e));
+            out[static_cast<int64_t>(b) * NN + p + e] = s / fH;
+        }
+    }
+}
+
+// =====================================================================================================
+// K_self_chain_fused: one workgroup (16 waves) per sample runs the WHOLE chain
+//     R <- I;  for every layer l:  A_bar_l = mean_h clamp(G_l*A_l, 0);  R <- R + A_bar_l . R
+// in one launch.  Roles (wave-uniform):
+//   waves [NT, 16)  "stream" waves: read A_l / G_l head slabs with 16-B loads, reduce over heads in
+//                    registers, write A_bar_l into one of two LDS buffers (row stride NP+4 floats).
+//   waves [0, NT)   "matrix" waves: wave w owns the 16-column slab w of R in REGISTERS in the MFMA
+//                    C/D layout (row = 16t + 4*(lane>>4) + r, col = 16w + (lane&15)).  Because the
+//                    k-order of a dot product is free, k is visited as (t, r, lane>>4): the B operand
+//                    of v_mfma_f32_16x16x4_f32 is then exactly the register R[t][r] the lane already
+//                    holds -- R never moves; the A operand (A_bar) is one ds_read_b128 per 4 MFMAs.
+// One s_barrier per layer: stream waves publish A_bar_l, then immediately start streaming layer l+1
+// into the other buffer while the matrix waves multiply.  HBM traffic = A and G once + R out.
+// NT = ceil(N/16) <= 8 (N <= 128); larger N takes the split path (avg_heads + bmm).
+// =====================================================================================================
+struct ChainArgs {
+    const void* attn[MMX_MAX_LAYERS];
+    const void* grad[MMX_MAX_LAYERS];
+    int n_layers, B, H, N;
+    const float* R_init;
+    float* R_out;
+};
+
+constexpr int kChainThreads = 1024;
+
+template <int NT, int DT>
+__global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const ChainArgs a) {
+    constexpr int NP = NT * 16;
+    constexpr int S = NP + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * NP * S floats
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int b = blockIdx.x;
+    const int N = a.N, H = a.H, L = a.n_layers;
+    const int64_t NN = static_cast<int64_t>(N) * N;
+
+    for (int i = tid; i < 2 * NP * S; i += kChainThreads) smem[i] = 0.f;  // pads must read as 0
+    __syncthreads();
+
+    if (wave < NT) {
+        // ------------------------------------------------------------------ matrix waves
+        const int col = wave * 16 + (lane & 15);
+        const int rq = (lane >> 4) * 4;
+        f32x4 Rold[NT], Rnew[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = t * 16 + rq + r;
+                float v = 0.f;
+                if (row < N && col < N)
+                    v = a.R_init ? a.R_init[b * NN + static_cast<int64_t>(row) * N + col] : (row == col ? 1.f : 0.f);
+                Rold[t][r] = v;
+            }
+        for (int l = 0; l < L; ++l) {
+            __syncthreads();  // A_bar_l is in buffer l&1
+            const float* Ab = smem + (l & 1) * NP * S + (lane & 15) * S + rq;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(Ab + ti * 16 * S + t * 16);
+                    acc = mfma16x16x4(av[0], Rold[t][0], acc);
+                    acc = mfma16x16x4(av[1], Rold[t][1], acc);
+                    acc = mfma16x16x4(av[2], Rold[t][2], acc);
+                    acc = mfma16x16x4(av[3], Rold[t][3], acc);
+                }
+                Rnew[ti] = Rold[ti] + acc;  // R + (A_bar . R): same association as the reference
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) Rold[t] = Rnew[t];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = t * 16 + rq + r;
+                if (row < N && col < N) a.R_out[b * NN + static_cast<int64_t>(row) * N + col] = Rold[t][r];
+            }
+    } else {
+        // ------------------------------------------------------------------ stream waves
+        constexpr int LT = kChainThreads - NT * 64;
+        const int lt = tid - NT * 64;
+        const float fH = static_cast<float>(H);
+        const int64_t sample = static_cast<int64_t>(b) * H * NN;
+        const int nchunks = static_cast<int>((NN + 3) >> 2);
+        for (int l = 0; l < L; ++l) {
+            float* Ab = smem + (l & 1) * NP * S;
+            const void* A = a.attn[l];
+            const void* G = a.grad[l];
+            for (int c = lt; c < nchunks; c += LT) {
+                const int64_t p = static_cast<int64_t>(c) * 4;
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                if (p + 3 < NN) {
+#pragma unroll 4
+                    for (int h = 0; h < H; ++h) {
+                        const f32x4 av = load4_as_f32<DT>(A, sample + h * NN + p);
+                        const f32x4 gv = load4_as_f32<DT>(G, sample + h * NN + p);
+                        const f32x4 x = gv * av;
+                        s[0] += relu_nan(x[0]); s[1] += relu_nan(x[1]);
+                        s[2] += relu_nan(x[2]); s[3] += relu_nan(x[3]);
+                    }
+                } else {
+                    for (int e = 0; p + e < NN; ++e)
+                        for (int h = 0; h < H; ++h)
+                            s[e] += relu_nan(load1_as_f32<DT>(G, sample + h * NN + p + e) *
+                                             load1_as_f32<DT>(A, sample + h * NN + p + e));
+                }
+                int row = static_cast<int>(p / N);
+                int cc = static_cast<int>(p - static_cast<int64_t>(row) * N);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (p + e < NN) Ab[row * S + cc] = s[e] / fH;
+                    if (++cc == N) { cc = 0; ++row; }
+                }
+            }
+            __syncthreads();  // publish A_bar_l (pairs with the matrix waves' barrier of layer l)
+        }
+    }
+}
+
+// =====================================================================================================
+// K_bmm_f32: C[b] = (Cin ? Cin[b] : 0) + op(A[b]) . B[b] on v_mfma_f32_16x16x4_f32 (exact fp32).
+// 64x64 output tile per 256-thread workgroup (4 waves as 2x2, 32x32 each = 2x2 MFMA tiles), BK = 16.
+// LDS tiles are k-major with row stride 80 floats: a wave's ds_read_b32 of [k = lane>>4][m = lane&15]
+// hits 32 distinct banks per half-wave.  Guarded scalar global loads: any M, N, K, any alignment.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                      const float* Cin, float* C, int M, int N, int K,
+                                                      int trans_a, int64_t sa, int64_t sb, int64_t sc,
+                                                      int nan_to_zero) {
+    __shared__ float As[16][80];
+    __shared__ float Bs[16][80];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const float* Ab = A + static_cast<int64_t>(blockIdx.z) * sa;
+    const float* Bb = B + static_cast<int64_t>(blockIdx.z) * sb;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
+            int m, k;
+            if (trans_a) { k = idx >> 6; m = idx & 63; } else { m = idx >> 4; k = idx & 15; }
+            const int gm = m0 + m, gk = k0 + k;
+            float v = 0.f;
+            if (gm < M && gk < K)
+                v = trans_a ? Ab[static_cast<int64_t>(gk) * M + gm] : Ab[static_cast<int64_t>(gm) * K + gk];
+            As[k][m] = v;
+            const int kb = idx >> 6, nb = idx & 63;
+            const int gkb = k0 + kb, gn = n0 + nb;
+            Bs[kb][nb] = (gkb < K && gn < N) ? Bb[static_cast<int64_t>(gkb) * N + gn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kk = ks * 4 + (lane >> 4);
+            const float a0 = As[kk][wr * 32 + (lane & 15)];
+            const float a1 = As[kk][wr * 32 + 16 + (lane & 15)];
+            const float b0 = Bs[kk][wc * 32 + (lane & 15)];
+            const float b1 = Bs[kk][wc * 32 + 16 + (lane & 15)];
+            acc[0][0] = mfma16x16x4(a0, b0, acc[0][0]);
+            acc[0][1] = mfma16x16x4(a0, b1, acc[0][1]);
+            acc[1][0] = mfma16x16x4(a1, b0, acc[1][0]);
+            acc[1][1] = mfma16x16x4(a1, b1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+    const int64_t cbase = static_cast<int64_t>(blockIdx.z) * sc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wr * 32 + i * 16 + (lane >> 4) * 4 + r;
+                const int gn = n0 + wc * 32 + j * 16 + (lane & 15);
+                if (gm < M && gn < N) {
+                    const int64_t off = cbase + static_cast<int64_t>(gm) * N + gn;
+                    float v = acc[i][j][r];
+                    if (Cin) v = Cin[off] + v;
+                    if (nan_to_zero && v != v) v = 0.f;
+                    C[off] = v;
+                }
+            }
+}
+
+// =====================================================================================================
+// Row kernels: one wave per row.
+//   mode 0  handle_residual (eq. 8-9): out = (R - I)/rowsum(R - I) + I ; also min_i(R[i,i] - 1)
+//   mode 1  rollout prep, normalised : out = (A + I)/rowsum(A + I)
+//   mode 2  rollout prep, plain      : out = A + I
+// =====================================================================================================
+__device__ __forceinline__ void atomic_min_float(float* addr, float v) {
+    if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+__global__ void fill_scalar_kernel(float* p, float v) { *p = v; }
+
+__global__ __launch_bounds__(256) void row_normalise_kernel(const float* __restrict__ R, float* __restrict__ out,
+                                                            int rows_total, int N, int mode, float* diag_min) {
+    const int row_g = blockIdx.x * 4 + (threadIdx.x >> 6);  // global row over batch*N
+    const int lane = threadIdx.x & 63;
+    if (row_g >= rows_total) return;
+    const int i = row_g % N;
+    const float* r = R + static_cast<int64_t>(row_g) * N;
+    float* o = out + static_cast<int64_t>(row_g) * N;
+    const float dsub = (mode == 0) ? -1.f : 1.f;
+    float s = 0.f;
+    for (int j = lane; j < N; j += 64) s += r[j] + (j == i ? dsub : 0.f);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (mode == 0 && diag_min && lane == 0) atomic_min_float(diag_min, r[i] - 1.f);
+    for (int j = lane; j < N; j += 64) {
+        float v = r[j] + (j == i ? dsub : 0.f);
+        if (mode != 2) v = v / s;
+        if (mode == 0 && j == i) v += 1.f;
+        o[j] = v;
+    }
+}
+
+}  // namespace mmx
+
+// =====================================================================================================
+// C-ABI entry points (see include/mmx_relevancy.h)
+// =====================================================================================================
+using namespace mmx;
+
+extern "C" int mmx_avg_heads(const void* attn_dev, const void* grad_dev, void* out_dev, int B, int H, int Nq,
+                             int Nk, int dtype, void* stream) {
+    MMX_CHECK_ARG(attn_dev && grad_dev && out_dev, "mmx_avg_heads: null pointer");
+    MMX_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0, "mmx_avg_heads: non-positive size B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
+    const int64_t NN = static_cast<int64_t>(Nq) * Nk;
+    dim3 grid(static_cast<unsigned>((((NN + 3) >> 2) + 255) / 256), B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* out = static_cast<float*>(out_dev);
+    switch (dtype) {
+        case MMX_F32: avg_heads_kernel<MMX_F32><<<grid, 256, 0, s>>>(attn_dev, grad_dev, out, H, NN); break;
+        case MMX_F16: avg_heads_kernel<MMX_F16><<<grid, 256, 0, s>>>(attn_dev, grad_dev, out, H, NN); break;
+        case MMX_BF16: avg_heads_kernel<MMX_BF16><<<grid, 256, 0, s>>>(attn_dev, grad_dev, out, H, NN); break;
+        default: set_error("mmx_avg_heads: unsupported dtype %d", dtype); return MMX_EINVAL;
+    }
+    MMX_LAUNCH_CHECK("avg_heads_kernel");
+    return MMX_OK;
+}
+
+extern "C" int mmx_bmm_f32(const void* A_dev, const void* B_dev, const void* Cin_dev, void* C_dev, int batch, int M,
+                           int N, int K, int trans_a, int64_t stride_a, int64_t stride_b, int64_t stride_c,
+                           int nan_to_zero, void* stream) {
+    MMX_CHECK_ARG(A_dev && B_dev && C_dev, "mmx_bmm_f32: null pointer");
+    MMX_CHECK_ARG(batch > 0 && M > 0 && N > 0 && K > 0, "mmx_bmm_f32: non-positive size");
+    MMX_CHECK_ARG(batch <= 65535, "mmx_bmm_f32: batch %d > 65535", batch);
+    dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
+    bmm_f32_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const float*>(A_dev), static_cast<const float*>(B_dev), static_cast<const float*>(Cin_dev),
+        static_cast<float*>(C_dev), M, N, K, trans_a, stride_a, stride_b, stride_c, nan_to_zero);
+    MMX_LAUNCH_CHECK("bmm_f32_kernel");
+    return MMX_OK;
+}
+
+static int launch_rows(const void* R, void* out, int batch, int N, int mode, float* diag_min, hipStream_t s) {
+    const int rows = batch * N;
+    if (diag_min) fill_scalar_kernel<<<1, 1, 0, s>>>(diag_min, __builtin_inff());
+    row_normalise_kernel<<<(rows + 3) / 4, 256, 0, s>>>(static_cast<const float*>(R), static_cast<float*>(out), rows,
+                                                        N, mode, diag_min);
+    MMX_LAUNCH_CHECK("row_normalise_kernel");
+    return MMX_OK;
+}
+
+extern "C" int mmx_handle_residual(const void* R_dev, void* out_dev, int batch, int N, void* diag_min_dev,
+                                   void* stream) {
+    MMX_CHECK_ARG(R_dev && out_dev, "mmx_handle_residual: null pointer");
+    MMX_CHECK_ARG(batch > 0 && N > 0, "mmx_handle_residual: non-positive size");
+    return launch_rows(R_dev, out_dev, batch, N, 0, static_cast<float*>(diag_min_dev),
+                       static_cast<hipStream_t>(stream));
+}
+
+// ----------------------------------------------------------------------------------------- rules 10/11
+static size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+
+extern "C" size_t mmx_mm_rules_workspace_bytes(int Ns, int Nq) {
+    // Rn_ss [Ns,Ns] + Rn_qq [Nq,Nq] + tmp [Ns,Nq]
+    return align256(sizeof(float) * Ns * Ns) + align256(sizeof(float) * Nq * Nq) + align256(sizeof(float) * Ns * Nq);
+}
+
+extern "C" int mmx_mm_attention_rules(const void* R_ss_dev, const void* R_qq_dev, const void* R_qs_dev,
+                                      const void* cam_sq_dev, void* R_sq_add_dev, void* R_ss_add_dev, int Ns, int Nq,
+                                      unsigned flags, void* diag_min_dev, void* workspace_dev,
+                                      size_t workspace_bytes, void* stream) {
+    MMX_CHECK_ARG(R_ss_dev && R_qq_dev && cam_sq_dev && R_sq_add_dev, "mmx_mm_attention_rules: null pointer");
+    MMX_CHECK_ARG(Ns > 0 && Nq > 0, "mmx_mm_attention_rules: non-positive size");
+    MMX_CHECK_ARG((R_qs_dev == nullptr) == (R_ss_add_dev == nullptr),
+                  "mmx_mm_attention_rules: R_qs and R_ss_add must be given together (rule 11)");
+    if (workspace_bytes < mmx_mm_rules_workspace_bytes(Ns, Nq) || !workspace_dev) {
+        set_error("mmx_mm_attention_rules: workspace %zu < %zu", workspace_bytes, mmx_mm_rules_workspace_bytes(Ns, Nq));
+        return MMX_EWORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace_dev);
+    float* Rn_ss = reinterpret_cast<float*>(ws);
+    float* Rn_qq = reinterpret_cast<float*>(ws + align256(sizeof(float) * Ns * Ns));
+    float* tmp = reinterpret_cast<float*>(ws + align256(sizeof(float) * Ns * Ns) + align256(sizeof(float) * Nq * Nq));
+    const int nan0 = (flags & MMX_MM_NAN_TO_ZERO) ? 1 : 0;
+    int rc;
+    if (flags & MMX_MM_SELF_IN_RULE10) {
+        const float* ss = static_cast<const float*>(R_ss_dev);
+        const float* qq = static_cast<const float*>(R_qq_dev);
+        if (flags & MMX_MM_NORMALIZE) {
+            // both residual normalisations share diag_min (min over both diagonals)
+            float* dm = static_cast<float*>(diag_min_dev);
+            if (dm) fill_scalar_kernel<<<1, 1, 0, s>>>(dm, __builtin_inff());
+            row_normalise_kernel<<<(Ns + 3) / 4, 256, 0, s>>>(ss, Rn_ss, Ns, Ns, 0, dm);
+            row_normalise_kernel<<<(Nq + 3) / 4, 256, 0, s>>>(qq, Rn_qq, Nq, Nq, 0, dm);
+            MMX_LAUNCH_CHECK("row_normalise_kernel");
+            ss = Rn_ss;
+            qq = Rn_qq;
+        }
+        // tmp = cam_sq . Rn_qq ; R_sq_add = Rn_ss^T . tmp
+        rc = mmx_bmm_f32(cam_sq_dev, qq, nullptr, tmp, 1, Ns, Nq, Nq, 0, 0, 0, 0, 0, stream);
+        if (rc) return rc;
+        rc = mmx_bmm_f32(ss, tmp, nullptr, R_sq_add_dev, 1, Ns, Nq, Ns, 1, 0, 0, 0, nan0, stream);
+        if (rc) return rc;
+    } else {
+        // reference returns cam_sq itself (DETR additionally scrubs NaN in place)
+        hipError_t e = hipMemcpyAsync(R_sq_add_dev, cam_sq_dev, sizeof(float) * Ns * Nq, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(cam_sq)");
+    }
+    if (R_qs_dev) {
+        rc = mmx_bmm_f32(cam_sq_dev, R_qs_dev, nullptr, R_ss_add_dev, 1, Ns, Ns, Nq, 0, 0, 0, 0, 0, stream);
+        if (rc) return rc;
+    }
+    return MMX_OK;
+}
+
+// ----------------------------------------------------------------------------------------- rollout
+extern "C" size_t mmx_rollout_workspace_bytes(int B, int N) {
+    return 2 * align256(sizeof(float) * static_cast<size_t>(B) * N * N);
+}
+
+extern "C" int mmx_rollout_chain(const void* const* layers, int n_layers, int B, int N, int normalize, void* out_dev,
+                                 void* workspace_dev, size_t workspace_bytes, void* stream) {
+    MMX_CHECK_ARG(layers && out_dev, "mmx_rollout_chain: null pointer");
+    MMX_CHECK_ARG(n_layers > 0 && B > 0 && N > 0, "mmx_rollout_chain: non-positive size");
+    if (workspace_bytes < mmx_rollout_workspace_bytes(B, N) || !workspace_dev) {
+        set_error("mmx_rollout_chain: workspace %zu < %zu", workspace_bytes, mmx_rollout_workspace_bytes(B, N));
+        return MMX_EWORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t mat = align256(sizeof(float) * static_cast<size_t>(B) * N * N);
+    float* aug = static_cast<float*>(workspace_dev);
+    float* pong = reinterpret_cast<float*>(static_cast<char*>(workspace_dev) + mat);
+    float* out = static_cast<float*>(out_dev);
+    const int mode = normalize ? 1 : 2;
+    const int64_t nn = static_cast<int64_t>(N) * N;
+    // joint = aug_0; joint = aug_i . joint.  Ping-pong so that the last product lands in `out`.
+    float* cur = ((n_layers - 1) % 2 == 0) ? out : pong;
+    int rc = launch_rows(layers[0], cur, B, N, mode, nullptr, s);
+    if (rc) return rc;
+    for (int i = 1; i < n_layers; ++i) {
+        float* nxt = (cur == out) ? pong : out;
+        rc = launch_rows(layers[i], aug, B, N, mode, nullptr, s);
+        if (rc) return rc;
+        rc = mmx_bmm_f32(aug, cur, nullptr, nxt, B, N, N, N, 0, nn, nn, nn, 0, stream);
+        if (rc) return rc;
+        cur = nxt;
+    }
+    return MMX_OK;
+}
+
+// ----------------------------------------------------------------------------------------- self chain
+static int nt_for(int N) { return (N + 15) / 16; }
+
+extern "C" size_t mmx_self_chain_workspace_bytes(int n_layers, int B, int H, int N, int M, int dtype) {
+    (void)n_layers; (void)H; (void)dtype;
+    if (nt_for(N) <= 8 && M == 0) return 0;  // fused single-launch path
+    const size_t mat = align256(sizeof(float) * static_cast<size_t>(B) * N * N);
+    const size_t sq = M > 0 ? align256(sizeof(float) * static_cast<size_t>(B) * N * M) : 0;
+    return 2 * mat + sq;  // A_bar + R ping-pong [+ R_sq ping-pong]
+}
+
+template <int NT>
+static int launch_fused(const ChainArgs& args, int dtype, hipStream_t s) {
+    constexpr int NP = NT * 16;
+    const size_t lds = sizeof(float) * 2 * NP * (NP + 4);
+    void (*kern)(const ChainArgs) = nullptr;
+    switch (dtype) {
+        case MMX_F32: kern = self_chain_fused_kernel<NT, MMX_F32>; break;
+        case MMX_F16: kern = self_chain_fused_kernel<NT, MMX_F16>; break;
+        case MMX_BF16: kern = self_chain_fused_kernel<NT, MMX_BF16>; break;
+        default: set_error("self_chain: unsupported dtype %d", dtype); return MMX_EINVAL;
+    }
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    kern<<<args.B, kChainThreads, lds, s>>>(args);
+    MMX_LAUNCH_CHECK("self_chain_fused_kernel");
+    return MMX_OK;
+}
+
+extern "C" int mmx_relevancy_self_chain(const void* const* attn_layers, const void* const* grad_layers, int n_layers,
+                                        int B, int H, int N, int dtype, const void* R_init_dev, void* R_out_dev,
+                                        const void* Rsq_init_dev, void* Rsq_out_dev, int M, void* workspace_dev,
+                                        size_t workspace_bytes, void* stream) {
+    MMX_CHECK_ARG(attn_layers && grad_layers && R_out_dev, "mmx_relevancy_self_chain: null pointer");
+    MMX_CHECK_ARG(n_layers >= 0 && n_layers <= MMX_MAX_LAYERS, "mmx_relevancy_self_chain: n_layers %d not in [0, %d]",
+                  n_layers, MMX_MAX_LAYERS);
+    MMX_CHECK_ARG(B > 0 && H > 0 && N > 0 && M >= 0, "mmx_relevancy_self_chain: non-positive size");
+    MMX_CHECK_ARG((M > 0) == (Rsq_out_dev != nullptr), "mmx_relevancy_self_chain: R_sq output and M must agree");
+    MMX_CHECK_ARG(dtype == MMX_F32 || dtype == MMX_F16 || dtype == MMX_BF16, "mmx_relevancy_self_chain: dtype %d", dtype);
+    for (int l = 0; l < n_layers; ++l)
+        MMX_CHECK_ARG(attn_layers[l] && grad_layers[l], "mmx_relevancy_self_chain: null layer pointer %d", l);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nt = nt_for(N);
+
+    if (nt <= 8 && M == 0) {
+        ChainArgs args;
+        memset(&args, 0, sizeof(args));
+        for (int l = 0; l < n_layers; ++l) { args.attn[l] = attn_layers[l]; args.grad[l] = grad_layers[l]; }
+        args.n_layers = n_layers; args.B = B; args.H = H; args.N = N;
+        args.R_init = static_cast<const float*>(R_init_dev);
+        args.R_out = static_cast<float*>(R_out_dev);
+        switch (nt) {
+            case 1: return launch_fused<1>(args, dtype, s);
+            case 2: return launch_fused<2>(args, dtype, s);
+            case 3: return launch_fused<3>(args, dtype, s);
+            case 4: return launch_fused<4>(args, dtype, s);
+            case 5: return launch_fused<5>(args, dtype, s);
+            case 6: return launch_fused<6>(args, dtype, s);
+            case 7: return launch_fused<7>(args, dtype, s);
+            default: return launch_fused<8>(args, dtype, s);
+        }
+    }
+
+    // ---- split path: per layer  A_bar = avg_heads(A_l, G_l);  R' = R + A_bar . R  [; R_sq' = R_sq + A_bar . R_sq]
+    const size_t need = mmx_self_chain_workspace_bytes(n_layers, B, H, N, M, dtype);
+    if (workspace_bytes < need || !workspace_dev) {
+        set_error("mmx_relevancy_self_chain: workspace %zu < %zu", workspace_bytes, need);
+        return MMX_EWORKSPACE;
+    }
+    const int64_t nn = static_cast<int64_t>(N) * N, nm = static_cast<int64_t>(N) * M;
+    const size_t mat = align256(sizeof(float) * static_cast<size_t>(B) * N * N);
+    char* ws = static_cast<char*>(workspace_dev);
+    float* abar = reinterpret_cast<float*>(ws);
+    float* Rpong = reinterpret_cast<float*>(ws + mat);
+    float* SQpong = reinterpret_cast<float*>(ws + 2 * mat);
+    float* Rout = static_cast<float*>(R_out_dev);
+    float* SQout = static_cast<float*>(Rsq_out_dev);
+
+    // state starts in the buffer that makes the LAST product land in the caller's output
+    float* Rcur = (n_layers % 2 == 0) ? Rout : Rpong;
+    float* SQcur = (n_layers % 2 == 0) ? SQout : SQpong;
+    hipError_t e;
+    if (R_init_dev) {
+        e = hipMemcpyAsync(Rcur, R_init_dev, sizeof(float) * B * nn, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(R_init)");
+    } else {
+        // identity: (0 + I) via the rollout-prep row kernel on a zeroed buffer
+        e = hipMemsetAsync(Rcur, 0, sizeof(float) * B * nn, s);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(R)");
+        int rc = launch_rows(Rcur, Rcur, B, N, 2, nullptr, s);
+        if (rc) return rc;
+    }
+    if (M > 0) {
+        if (Rsq_init_dev) e = hipMemcpyAsync(SQcur, Rsq_init_dev, sizeof(float) * B * nm, hipMemcpyDeviceToDevice, s);
+        else e = hipMemsetAsync(SQcur, 0, sizeof(float) * B * nm, s);
+        if (e != hipSuccess) return hip_fail(e, "init R_sq");
+    }
+    for (int l = 0; l < n_layers; ++l) {
+        int rc = mmx_avg_heads(attn_layers[l], grad_layers[l], abar, B, H, N, N, dtype, stream);
+        if (rc) return rc;
+        float* Rnxt = (Rcur == Rout) ? Rpong : Rout;
+        rc = mmx_bmm_f32(abar, Rcur, Rcur, Rnxt, B, N, N, N, 0, nn, nn, nn, 0, stream);
+        if (rc) return rc;
+        Rcur = Rnxt;
+        if (M > 0) {
+            float* SQnxt = (SQcur == SQout) ? SQpong : SQout;
+            rc = mmx_bmm_f32(abar, SQcur, SQcur, SQnxt, B, N, M, N, 0, nn, nm, nm, 0, stream);
+            if (rc) return rc;
+            SQcur = SQnxt;
+        }
+    }
+    return MMX_OK;
+}

@@ -1,0 +1,283 @@
+"""Thin torch-tensor front end over the C-ABI (``_lib``): pointer/stride plumbing only.
+
+Every function requires HIP-device tensors and launches on torch's current stream.  There is no CPU
+path and no PyTorch-op fallback: a CPU tensor or a missing ``libmmx_hip.so`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import MMXError, check, lib
+
+_DTYPES = {torch.float32: _lib.MMX_F32, torch.float16: _lib.MMX_F16, torch.bfloat16: _lib.MMX_BF16}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MMXError("mmx ops need HIP-device tensors (got %s); there is no CPU path" % t.device)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _f32c(t):
+    """fp32 + contiguous (no copy when already so)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _capture(t):
+    if t.dtype not in _DTYPES:
+        raise MMXError("captured buffers must be fp32/fp16/bf16, got %s" % t.dtype)
+    return t.contiguous()
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device, tag="default"):
+    """Grow-only scratch per (device, tag); stream-ordered reuse on the current stream."""
+    if nbytes == 0:
+        return None
+    key = (device, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------------------- rule 5
+def avg_heads(cam, grad, batch_size=1):
+    """``mean_h(clamp(grad*cam, 0))`` -> ``[batch_size, Nq, Nk]`` fp32 (leading dims flattened into B*H)."""
+    _dev(cam, grad)
+    cam, grad = _capture(cam), _capture(grad)
+    if cam.shape != grad.shape or cam.dtype != grad.dtype:
+        raise MMXError("avg_heads: cam %s/%s vs grad %s/%s" % (tuple(cam.shape), cam.dtype, tuple(grad.shape), grad.dtype))
+    nq, nk = cam.shape[-2], cam.shape[-1]
+    bh = cam.numel() // (nq * nk)
+    if bh % batch_size:
+        raise MMXError("avg_heads: %d matrices not divisible by batch %d" % (bh, batch_size))
+    out = torch.empty(batch_size, nq, nk, dtype=torch.float32, device=cam.device)
+    check(lib().mmx_avg_heads(_p(cam), _p(grad), _p(out), batch_size, bh // batch_size, nq, nk,
+                              _DTYPES[cam.dtype], _stream()), "mmx_avg_heads")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- fused chain
+def relevancy_self_chain(attn_layers, grad_layers, batch_size, R_init=None, R_sq_init=None):
+    """All-layer chain ``R <- R + A_bar_l @ R`` (``R_0 = I`` or ``R_init``) [and ``R_sq`` likewise] in one call.
+
+    ``attn_layers[l]`` / ``grad_layers[l]``: ``[B*H, N, N]`` or ``[B, H, N, N]`` (fp32/fp16/bf16).
+    Returns ``R [B, N, N]`` (and ``R_sq [B, N, M]`` when ``R_sq_init`` is given).
+    """
+    if len(attn_layers) != len(grad_layers):
+        raise MMXError("self_chain: %d attn layers vs %d grad layers" % (len(attn_layers), len(grad_layers)))
+    if len(attn_layers) > _lib.MAX_LAYERS:
+        raise MMXError("self_chain: more than %d layers" % _lib.MAX_LAYERS)
+    _dev(*attn_layers, *grad_layers, R_init, R_sq_init)
+    attn = [_capture(a) for a in attn_layers]
+    grad = [_capture(g) for g in grad_layers]
+    ref = attn[0] if attn else R_init
+    if ref is None:
+        raise MMXError("self_chain: no layers and no R_init")
+    n = ref.shape[-1]
+    device = ref.device
+    dt = _DTYPES[attn[0].dtype] if attn else _lib.MMX_F32
+    heads = 1
+    for a, g in zip(attn, grad):
+        if a.shape != g.shape or a.dtype != attn[0].dtype or g.dtype != attn[0].dtype or a.shape[-1] != n or a.shape[-2] != n:
+            raise MMXError("self_chain: inconsistent layer shapes/dtypes")
+    if attn:
+        bh = attn[0].numel() // (n * n)
+        if bh % batch_size:
+            raise MMXError("self_chain: %d matrices not divisible by batch %d" % (bh, batch_size))
+        heads = bh // batch_size
+    R_out = torch.empty(batch_size, n, n, dtype=torch.float32, device=device)
+    if R_init is not None:
+        R_init = _f32c(R_init).expand(batch_size, n, n).contiguous()
+    m = 0
+    sq_out = None
+    if R_sq_init is not None:
+        R_sq_init = _f32c(R_sq_init)
+        m = R_sq_init.shape[-1]
+        R_sq_init = R_sq_init.expand(batch_size, n, m).contiguous()
+        sq_out = torch.empty(batch_size, n, m, dtype=torch.float32, device=device)
+    need = lib().mmx_self_chain_workspace_bytes(len(attn), batch_size, heads, n, m, dt)
+    ws = _workspace(need, device)
+    at, _k1 = _lib.ptr_table([a.data_ptr() for a in attn])
+    gt, _k2 = _lib.ptr_table([g.data_ptr() for g in grad])
+    check(lib().mmx_relevancy_self_chain(at, gt, len(attn), batch_size, heads, n, dt, _p(R_init), _p(R_out),
+                                         _p(R_sq_init), _p(sq_out), m, _p(ws), need, _stream()),
+          "mmx_relevancy_self_chain")
+    return (R_out, sq_out) if sq_out is not None else R_out
+
+
+# ------------------------------------------------------------------------------------------- matmul
+def matmul(a, b, add_to=None, trans_a=False, nan_to_zero=False):
+    """fp32 ``op(a) @ b (+ add_to)`` on the exact-fp32 MFMA; 2-D or batched 3-D (2-D operands broadcast)."""
+    _dev(a, b, add_to)
+    a, b = _f32c(a), _f32c(b)
+    batch = 1
+    for t in (a, b):
+        if t.dim() == 3:
+            batch = max(batch, t.shape[0])
+    am, ak = (a.shape[-1], a.shape[-2]) if trans_a else (a.shape[-2], a.shape[-1])
+    if b.shape[-2] != ak:
+        raise MMXError("matmul: inner dims %d vs %d" % (ak, b.shape[-2]))
+    n = b.shape[-1]
+    sa = a.shape[-2] * a.shape[-1] if (a.dim() == 3 and a.shape[0] > 1) else 0
+    sb = ak * n if (b.dim() == 3 and b.shape[0] > 1) else 0
+    squeeze = a.dim() == 2 and b.dim() == 2
+    out = torch.empty(batch, am, n, dtype=torch.float32, device=a.device)
+    cin = None
+    if add_to is not None:
+        cin = _f32c(add_to).expand(batch, am, n).contiguous() if add_to.dim() == 2 or add_to.shape[0] != batch \
+            else _f32c(add_to)
+    check(lib().mmx_bmm_f32(_p(a), _p(b), _p(cin), _p(out), batch, am, n, ak, int(trans_a), sa, sb, am * n,
+                            int(nan_to_zero), _stream()), "mmx_bmm_f32")
+    return out[0] if squeeze else out
+
+
+# ------------------------------------------------------------------------------------------- eq. 8-9
+def handle_residual(R, check_diag=True):
+    _dev(R)
+    R = _f32c(R)
+    n = R.shape[-1]
+    batch = R.numel() // (n * n)
+    out = torch.empty_like(R)
+    dmin = torch.empty(1, dtype=torch.float32, device=R.device) if check_diag else None
+    check(lib().mmx_handle_residual(_p(R), _p(out), batch, n, _p(dmin), _stream()), "mmx_handle_residual")
+    if check_diag:
+        assert dmin.item() >= 0  # same contract as the reference's assert (it also syncs)
+    return out
+
+
+# ------------------------------------------------------------------------------------------- rules 10/11
+def mm_attention_rules(R_ss, R_qq, cam_sq, R_qs=None, apply_normalization=True, apply_self_in_rule_10=True,
+                       nan_to_zero=False, check_diag=True):
+    """Returns ``R_sq_addition`` (and ``R_ss_addition`` when ``R_qs`` is given)."""
+    _dev(R_ss, R_qq, cam_sq, R_qs)
+    R_ss, R_qq, cam_sq = _f32c(R_ss), _f32c(R_qq), _f32c(cam_sq)
+    ns, nq = cam_sq.shape[-2], cam_sq.shape[-1]
+    if R_ss.shape[-1] != ns or R_qq.shape[-1] != nq:
+        raise MMXError("mm_attention_rules: R_ss %s, R_qq %s, cam_sq %s" % (tuple(R_ss.shape), tuple(R_qq.shape), tuple(cam_sq.shape)))
+    flags = (_lib.MM_NORMALIZE if apply_normalization else 0) | (_lib.MM_SELF_IN_RULE10 if apply_self_in_rule_10 else 0) \
+        | (_lib.MM_NAN_TO_ZERO if nan_to_zero else 0)
+    sq_add = torch.empty(ns, nq, dtype=torch.float32, device=cam_sq.device)
+    ss_add = None
+    if R_qs is not None:
+        R_qs = _f32c(R_qs)
+        ss_add = torch.empty(ns, ns, dtype=torch.float32, device=cam_sq.device)
+    want_diag = check_diag and apply_normalization and apply_self_in_rule_10
+    dmin = torch.empty(1, dtype=torch.float32, device=cam_sq.device) if want_diag else None
+    need = lib().mmx_mm_rules_workspace_bytes(ns, nq)
+    ws = _workspace(need, cam_sq.device)
+    check(lib().mmx_mm_attention_rules(_p(R_ss), _p(R_qq), _p(R_qs), _p(cam_sq), _p(sq_add), _p(ss_add), ns, nq,
+                                       flags, _p(dmin), _p(ws), need, _stream()), "mmx_mm_attention_rules")
+    if want_diag:
+        assert dmin.item() >= 0
+    return (sq_add, ss_add) if R_qs is not None else sq_add
+
+
+# ------------------------------------------------------------------------------------------- rollout
+def rollout_chain(layers, normalize):
+    """``layers``: list of ``[B, N, N]`` (or ``[N, N]``) fp32 maps, already sliced to ``start_layer:``."""
+    _dev(*layers)
+    mats = [_f32c(m) for m in layers]
+    n = mats[0].shape[-1]
+    batch = mats[0].numel() // (n * n)
+    out = torch.empty(batch, n, n, dtype=torch.float32, device=mats[0].device)
+    need = lib().mmx_rollout_workspace_bytes(batch, n)
+    ws = _workspace(need, mats[0].device)
+    tbl, _k = _lib.ptr_table([m.data_ptr() for m in mats])
+    check(lib().mmx_rollout_chain(tbl, len(mats), batch, n, int(normalize), _p(out), _p(ws), need, _stream()),
+          "mmx_rollout_chain")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- attention capture
+def _bhnd_strides(t, layout):
+    """Element strides (batch, head, token) of a ``[B, N, H, D]``-viewable tensor with contiguous D."""
+    if t.stride(-1) != 1:
+        raise MMXError("attention operands need a contiguous head_dim")
+    if layout == "bnhd":
+        return t.stride(0), t.stride(2), t.stride(1)
+    if layout == "bhnd":
+        return t.stride(0), t.stride(1), t.stride(2)
+    raise MMXError("layout %r" % layout)
+
+
+def attn_capture_fwd(q, k, v, probs_out, scale, scale_mode=_lib.SCALE_Q_FIRST, mask=None, layout="bnhd"):
+    """``q``: ``[B, Nq, H, D]`` view (``layout='bnhd'``) or ``[B, H, Nq, D]``; writes P into ``probs_out``
+    (``[B, H, Nq, Nk]`` fp32 contiguous, caller-owned slab) and returns O in the same layout as q."""
+    _dev(q, k, v, probs_out, mask)
+    if q.dtype != torch.float32 or k.dtype != torch.float32 or v.dtype != torch.float32:
+        raise MMXError("attention capture op is fp32 in this ABI version")
+    if layout == "bnhd":
+        B, Nq, H, D = q.shape
+        Nk = k.shape[1]
+    else:
+        B, H, Nq, D = q.shape
+        Nk = k.shape[2]
+    if probs_out.dtype != torch.float32 or not probs_out.is_contiguous() or probs_out.numel() != B * H * Nq * Nk:
+        raise MMXError("probs_out must be a contiguous fp32 [B,H,Nq,Nk] slab")
+    o = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    msb = msq = 0
+    if mask is not None:
+        mask = _f32c(mask)
+        if mask.dim() == 2:          # [Nq, Nk]
+            msb, msq = 0, Nk
+        elif mask.dim() == 3:        # [B, Nq or 1, Nk]
+            msb = mask.shape[1] * Nk if mask.shape[0] > 1 else 0
+            msq = Nk if mask.shape[1] > 1 else 0
+        else:
+            raise MMXError("mask must be [Nq,Nk] or [B,Nq|1,Nk]")
+    check(lib().mmx_attn_capture_fwd(_p(q), _p(k), _p(v), *_bhnd_strides(q, layout), *_bhnd_strides(k, layout),
+                                     *_bhnd_strides(v, layout), _p(mask), msb, msq, _p(probs_out), _p(o),
+                                     *_bhnd_strides(o, layout), B, H, Nq, Nk, D, float(scale), scale_mode, _stream()),
+          "mmx_attn_capture_fwd")
+    return o
+
+
+def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCALE_Q_FIRST, need_dqkv=True,
+                     layout="bnhd", out=None):
+    """Writes dP into ``dprobs_out`` and returns ``(dq, dk, dv)`` (``None`` when ``need_dqkv`` is False).
+    ``out=(dq, dk, dv)`` lets the caller hand in (strided) views, e.g. of one packed dqkv tensor."""
+    _dev(q, k, v, probs, d_o, dprobs_out)
+    if layout == "bnhd":
+        B, Nq, H, D = q.shape
+        Nk = k.shape[1]
+    else:
+        B, H, Nq, D = q.shape
+        Nk = k.shape[2]
+    if d_o.stride(-1) != 1:
+        d_o = d_o.contiguous()
+    dq = dk = dv = None
+    ws = None
+    need = 0
+    if need_dqkv:
+        if out is not None:
+            dq, dk, dv = out
+        else:
+            dq, dk, dv = (torch.empty(t.shape, dtype=torch.float32, device=t.device) for t in (q, k, v))
+        need = lib().mmx_attn_capture_bwd_workspace_bytes(B, H, Nq)
+        ws = _workspace(need, q.device, "attn_bwd")
+    zero3 = (0, 0, 0)
+    check(lib().mmx_attn_capture_bwd(
+        _p(q), _p(k), _p(v), *_bhnd_strides(q, layout), *_bhnd_strides(k, layout), *_bhnd_strides(v, layout),
+        _p(probs), _p(d_o), *_bhnd_strides(d_o, layout), _p(dprobs_out), _p(dq), _p(dk), _p(dv),
+        *(_bhnd_strides(dq, layout) if need_dqkv else zero3), *(_bhnd_strides(dk, layout) if need_dqkv else zero3),
+        *(_bhnd_strides(dv, layout) if need_dqkv else zero3),
+        B, H, Nq, Nk, D, float(scale), scale_mode, int(need_dqkv), _p(ws), need, _stream()), "mmx_attn_capture_bwd")
+    return dq, dk, dv
