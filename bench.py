@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- relevancy maps/s (forward + ONE backward + fused chain), CLIP ViT-B/32, batch 64 fp32.
+
+Contract (see the task statement): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 the driver
+launches one rank per GPU through ``torch.distributed.run``.  One "step" = one pass of the hot path over one
+batch of 64 synthetic image<->text pairs per rank: CLIP forward with the HIP attention-capture op, one backward
+that fills every layer's gradient slab, the fused relevancy chain for both towers (all 12+12 layers,
+``start_layer=0``).  Rank 0 prints ONE JSON line.  Inputs are resident in HBM before the timed region.
+
+Extra objects in the line:
+  roofline     -- the chain kernel (text-tower instantiation, the longer one): algorithmic bytes / HIP-event time
+                  measured on the stream the kernel runs on, against the 8 TB/s HBM peak
+  cpu_baseline -- the reference algorithm (oracle/clip_torch.py: per-layer autograd.grad like the notebook) on this
+                  box's host cores, rank 0 / N=1 only, on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
+BATCH = 64
+MODEL = "ViT-B/32"
+
+
+def synthetic_inputs(batch, device, seed):
+    g = torch.Generator().manual_seed(1 + seed)
+    image = torch.randn(1, 3, 224, 224, generator=g)
+    texts = torch.zeros(batch, 77, dtype=torch.long)
+    g2 = torch.Generator().manual_seed(2 + seed)
+    for b in range(batch):
+        n = int(torch.randint(3, 11, (1,), generator=g2))
+        texts[b, 0] = 49406
+        texts[b, 1:1 + n] = torch.randint(1, 49405, (n,), generator=g2)
+        texts[b, 1 + n] = 49407                      # EOT must be the arg-max id (model.py:360)
+    return image.to(device), texts.to(device)
+
+
+def kernel_time_us(fn, iters, stream):
+    """Average duration of the launches issued by ``fn`` with HIP events recorded on ``stream`` itself."""
+    from transformer_mm_explainability_amd import _lib
+    lib = _lib.lib()
+    ev = [C.c_void_p(), C.c_void_p()]
+    for e in ev:
+        _lib.check(lib.mmx_event_create(C.byref(e)), "event_create")
+    sp = C.c_void_p(stream.cuda_stream)
+    fn()
+    stream.synchronize()
+    _lib.check(lib.mmx_event_record(ev[0], sp), "event_record")
+    for _ in range(iters):
+        fn()
+    _lib.check(lib.mmx_event_record(ev[1], sp), "event_record")
+    ms = C.c_float()
+    _lib.check(lib.mmx_event_elapsed_ms(ev[0], ev[1], C.byref(ms)), "event_elapsed")
+    for e in ev:
+        lib.mmx_event_destroy(e)
+    return ms.value * 1e3 / iters
+
+
+def cpu_baseline(state_dict, sample_b, reps):
+    from oracle import clip_torch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    image, texts = synthetic_inputs(sample_b, "cpu", 0)
+    sd = clip_torch.prepare_state_dict(state_dict, 8)
+    clip_torch.interpret(sd, image, texts, 0, 0)  # warm-up
+    best = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        clip_torch.interpret(sd, image, texts, 0, 0)
+        best.append(time.perf_counter() - t0)
+    best.sort()
+    med = best[len(best) // 2]
+    return {"value": round(sample_b / med, 3), "unit": "maps/s", "cores": cores, "kind": "port",
+            "sample": "reference algorithm (hooked CLIP ViT-B/32 fwd + per-layer autograd.grad + rule chain, "
+                      "all 12+12 layers) restated in oracle/clip_torch.py, torch fp32 CPU, batch %d of the same "
+                      "synthetic workload, median of %d" % (sample_b, reps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    from transformer_mm_explainability_amd import clip_model, ops
+
+    model = clip_model.random_init(MODEL, seed=0)
+    state_dict_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    model = model.to(device)
+    image, texts = synthetic_inputs(BATCH, device, seed=rank)
+    gathered = torch.empty(world * BATCH, 49, device=device) if world > 1 else None
+
+    def step():
+        R_text, R_image = ce.interpret(image, texts, model, device, start_layer=0, start_layer_text=0)
+        if world > 1:   # the evaluators' exchange step: per-sample maps gathered on every rank (KB-scale)
+            dist.all_gather_into_tensor(gathered, R_image.contiguous())
+        return R_text, R_image
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * BATCH / (elapsed / args.steps)
+
+    # ---- notebook default (last layer only), reported beside the headline
+    for _ in range(2):
+        ce.interpret(image, texts, model, device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ce.interpret(image, texts, model, device)
+    torch.cuda.synchronize()
+    last_only = BATCH / ((time.perf_counter() - t0) / args.steps)
+
+    # ---- roofline of the chain kernel, HIP events on the launch stream, buffers as the last step left them
+    vis, txt = model.visual.transformer, model.transformer
+    stream = torch.cuda.current_stream()
+
+    def chain(tr):
+        b = tr.buffers
+        return lambda: ops.relevancy_self_chain([b.probs[l] for l in range(tr.layers)],
+                                                [b.grads[l] for l in range(tr.layers)], BATCH)
+
+    def chain_bytes(tr, n):
+        return 2 * tr.layers * BATCH * tr.heads * n * n * 4 + BATCH * n * n * 4
+
+    us_txt = kernel_time_us(chain(txt), 20, stream)
+    us_img = kernel_time_us(chain(vis), 20, stream)
+    by_txt, by_img = chain_bytes(txt, 77), chain_bytes(vis, 50)
+    ach = by_txt / us_txt / 1e3  # GB/s
+    roofline = {"bound": "hbm", "kernel": "self_chain_fused_kernel<NT=5,f32> (text tower)",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": None, "bytes_per_launch": by_txt, "us_per_launch": round(us_txt, 2),
+                "image_tower": {"kernel": "self_chain_fused_kernel<NT=4,f32>", "bytes_per_launch": by_img,
+                                "us_per_launch": round(us_img, 2), "achieved": round(by_img / us_img / 1e3, 1)},
+                "kernel_only_maps_per_s": round(BATCH / ((us_txt + us_img) * 1e-6), 1)}
+
+    if rank == 0:
+        line = {
+            "metric": "relevancy maps/sec (fwd+bwd+rollout), CLIP ViT-B/32", "value": round(value, 2),
+            "unit": "maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CLIP ViT-B/32 image<->text relevancy, batch=64 fp32 per GPU, all 12+12 layers "
+                                   "(start_layer=0); random-init weights, synthetic image + token ids",
+                       "global_batch": world * BATCH, "parallelism": "dp%d (independent batches, all-gather of maps)" % world,
+                       "last_layer_only_maps_per_s": round(last_only, 2)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(state_dict_cpu, 16, 3)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

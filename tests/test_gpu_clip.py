@@ -1,0 +1,107 @@
+"""-m gpu: end-to-end CLIP path (HIP attention-capture op inside the PyTorch body + fused chain kernel)
+against (a) the reference's own outputs on a tiny CLIP (golden fixture) and (b) the torch CPU oracle at
+ViT-B/32 shapes.  Tolerance 1e-5 abs on relevancy maps (north_star), fp32."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, atol=1e-5, rtol=1e-4):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def load_tiny(golden):
+    from transformer_mm_explainability_amd import clip_model
+    g = golden("clip_tiny")
+    cfg = json.loads(str(g["cfg_json"]))
+    model = clip_model.CLIP(**cfg).float().eval()
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w__")}
+    model.load_state_dict(sd)      # the reference's own parameter names load unchanged
+    return g, model.cuda()
+
+
+@pytest.mark.parametrize("tag,sl,slt", [("last", -1, -1), ("all", 0, 0), ("mid", 1, 2)])
+def test_interpret_matches_reference_outputs(golden, tag, sl, slt):
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    g, model = load_tiny(golden)
+    image, texts = torch.from_numpy(g["image"]).cuda(), torch.from_numpy(g["texts"]).cuda()
+    R_text, R_image = ce.interpret(image, texts, model, "cuda", start_layer=sl, start_layer_text=slt)
+    close(R_text, g["R_text_" + tag])
+    close(R_image, g["R_image_" + tag])
+    assert all(p.requires_grad for p in model.parameters())          # _Frozen restored
+    assert all(p.grad is None for p in model.parameters())           # no weight gradients were computed
+
+
+def test_capture_slabs_match_reference_hooks(golden):
+    """probs/grads slabs == what the reference's set_attn_probs / set_attn_grad hooks saw."""
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    g, model = load_tiny(golden)
+    image, texts = torch.from_numpy(g["image"]).cuda(), torch.from_numpy(g["texts"]).cuda()
+    ce.interpret(image, texts, model, "cuda", 0, 0)
+    vis = list(model.visual.transformer.resblocks.children())
+    txt = list(model.transformer.resblocks.children())
+    for l, blk in enumerate(vis):
+        close(blk.attn_probs, g["img_attn"][l], atol=1e-6)
+        close(blk.attn_grad, g["img_grad"][l], atol=1e-6)
+    for l, blk in enumerate(txt):
+        close(blk.attn_probs, g["txt_attn"][l], atol=1e-6)
+        close(blk.attn_grad, g["txt_grad"][l], atol=1e-6)
+    with torch.no_grad():
+        pass
+    logits, _ = model(image.repeat(texts.shape[0], 1, 1, 1), texts)
+    close(logits, g["logits_per_image"], atol=2e-5)
+
+
+def test_full_backward_param_grads_match_oracle(golden):
+    """With capture_only off the op is a normal differentiable attention: parameter grads == torch CPU oracle."""
+    from oracle import clip_torch
+    g, model = load_tiny(golden)
+    cfg = json.loads(str(g["cfg_json"]))
+    image, texts = torch.from_numpy(g["image"]), torch.from_numpy(g["texts"])
+    B = texts.shape[0]
+    logits, _ = model(image.cuda().repeat(B, 1, 1, 1), texts.cuda())
+    model.zero_grad()
+    logits.diagonal().sum().backward()
+    sd = clip_torch.prepare_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, cfg["transformer_heads"])
+    ref_logits, _, _ = clip_torch.forward(sd, image.repeat(B, 1, 1, 1), texts)
+    ref_logits.diagonal().sum().backward()
+    for name, p in model.named_parameters():
+        if name == "logit_scale":
+            continue
+        close(p.grad, sd[name].grad, atol=2e-5, rtol=1e-3)
+
+
+def test_vit_b32_shapes_vs_oracle():
+    """CLIP ViT-B/32 architecture (random init), B=2: maps within 1e-5 of the reference-style CPU path."""
+    from oracle import clip_torch
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    from transformer_mm_explainability_amd import clip_model
+    model = clip_model.random_init("ViT-B/32", seed=0)
+    g = torch.Generator().manual_seed(1)
+    image = torch.randn(1, 3, 224, 224, generator=g)
+    texts = torch.zeros(2, 77, dtype=torch.long)
+    g2 = torch.Generator().manual_seed(2)
+    for b in range(2):
+        n = 4 + 3 * b
+        texts[b, 0] = 49406
+        texts[b, 1:1 + n] = torch.randint(1, 49405, (n,), generator=g2)
+        texts[b, 1 + n] = 49407
+    sd = clip_torch.prepare_state_dict(model.state_dict(), 8)
+    want_text, want_img = clip_torch.interpret(sd, image, texts, 0, 0)
+    model = model.cuda()
+    R_text, R_image = ce.interpret(image.cuda(), texts.cuda(), model, "cuda", 0, 0)
+    close(R_text, want_text.numpy())
+    close(R_image, want_img.numpy())
+    want_text, want_img = clip_torch.interpret(sd, image, texts)         # notebook default: last layer only
+    R_text, R_image = ce.interpret(image.cuda(), texts.cuda(), model, "cuda")
+    close(R_text, want_text.numpy())
+    close(R_image, want_img.numpy())
+    single = ce.interpret_single(image.cuda(), texts.cuda(), model, "cuda", index=1)
+    assert single.shape == (49,)

@@ -111,3 +111,61 @@ def test_clip_interpret_chain(golden, tag, sl, slt):
                                                list(g["txt_grad"]), B, sl, slt)
     close(R_text, g["R_text_" + tag])
     close(R_image, g["R_image_" + tag])
+
+
+def _clip_tiny_sd(g):
+    import json
+    import torch
+    from oracle import clip_torch
+    cfg = json.loads(str(g["cfg_json"]))
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w__")}
+    return clip_torch.prepare_state_dict(sd, cfg["transformer_heads"]), cfg
+
+
+@pytest.mark.parametrize("tag,sl,slt", [("last", -1, -1), ("all", 0, 0), ("mid", 1, 2)])
+def test_clip_torch_oracle(golden, tag, sl, slt):
+    """The torch restatement of the hooked CLIP path reproduces the reference model + notebook interpret."""
+    import torch
+    from oracle import clip_torch
+    g = golden("clip_tiny")
+    sd, _ = _clip_tiny_sd(g)
+    image, texts = torch.from_numpy(g["image"]), torch.from_numpy(g["texts"])
+    R_text, R_image = clip_torch.interpret(sd, image, texts, sl, slt)
+    close(R_text.numpy(), g["R_text_" + tag])
+    close(R_image.numpy(), g["R_image_" + tag])
+
+
+def test_clip_torch_oracle_capture(golden):
+    import torch
+    from oracle import clip_torch
+    g = golden("clip_tiny")
+    sd, _ = _clip_tiny_sd(g)
+    logits, ip, ig, tp, tg = clip_torch.capture_all(sd, torch.from_numpy(g["image"]), torch.from_numpy(g["texts"]))
+    close(logits.numpy(), g["logits_per_image"], atol=1e-5)
+    close(torch.stack(ip).numpy(), g["img_attn"])
+    close(torch.stack(ig).numpy(), g["img_grad"], atol=1e-6)
+    close(torch.stack(tp).numpy(), g["txt_attn"])
+    close(torch.stack(tg).numpy(), g["txt_grad"], atol=1e-6)
+
+
+def test_c_chain_matches_numpy_and_golden(golden):
+    """oracle/relevancy_chain.c (plain C, sequential order) == numpy oracle == reference (clip_tiny image tower)."""
+    import ctypes as C
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.run(["make", "-C", here], check=True, capture_output=True)
+    lib = C.CDLL(os.path.join(here, "liboracle_chain.so"))
+    g = golden("clip_tiny")
+    B = g["texts"].shape[0]
+    attn = [np.ascontiguousarray(a) for a in g["img_attn"]]
+    grad = [np.ascontiguousarray(a) for a in g["img_grad"]]
+    L, N = len(attn), attn[0].shape[-1]
+    H = attn[0].shape[0] // B
+    fp = C.POINTER(C.c_float)
+    at = (fp * L)(*[a.ctypes.data_as(fp) for a in attn])
+    gt = (fp * L)(*[a.ctypes.data_as(fp) for a in grad])
+    out = np.empty((B, N, N), dtype=np.float32)
+    assert lib.oracle_self_chain_f32(at, gt, L, B, H, N, out.ctypes.data_as(fp)) == 0
+    close(out, onp.self_chain(attn, grad, B, 0))
+    close(out[:, 0, 1:], g["R_image_all"])

@@ -1,0 +1,122 @@
+"""Drop-in ``interpret`` for CLIP -- same signatures as the reference, relevancy chain on the fused HIP kernel.
+
+Reference entry points mirrored here:
+  * ``interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1)``
+    -- CLIP_explainability.ipynb cell 6 (batched: one image, B texts) -> ``(text_relevance [B,Nt,Nt], image_relevance [B,Ni-1])``
+  * ``interpret_single(image, text, model, device, index=None)``
+    -- CLIP/example.py:8-32 (one image, K texts, explains ``logits_per_image[0, index]``) -> ``image_relevance [Ni-1]``
+  * ``text_scores(text_encoding, R_text)`` -- notebook cell 8:5-7 post-processing (on device)
+
+What is different under the hood (results agree to fp32 rounding, see tests/test_gpu_clip.py):
+  * the reference issues one ``torch.autograd.grad`` per layer (24 partial backward passes); here ONE backward
+    fills every layer's gradient slab (``capture_only`` also drops weight/input gradients);
+  * the per-layer reshape/mul/clamp/mean/bmm/add launches are one ``relevancy_self_chain`` launch per tower,
+    the two towers on two HIP streams.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+class _Frozen:
+    """Temporarily mark parameters as not requiring grad: the explainability pass needs d(logit)/d(probs) only."""
+
+    def __init__(self, model):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+
+    def __enter__(self):
+        for p in self.params:
+            p.requires_grad_(False)
+
+    def __exit__(self, *exc):
+        for p in self.params:
+            p.requires_grad_(True)
+
+
+def _chains(model, batch_size, start_layer, start_layer_text):
+    vis, txt = model.visual.transformer, model.transformer
+    if start_layer == -1:
+        start_layer = vis.layers - 1
+    if start_layer_text == -1:
+        start_layer_text = txt.layers - 1
+    vb, tb = vis.buffers, txt.buffers
+    cur = torch.cuda.current_stream()
+    side = _side_stream(vb.probs.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        R_text = ops.relevancy_self_chain([tb.probs[l] for l in range(start_layer_text, txt.layers)],
+                                          [tb.grads[l] for l in range(start_layer_text, txt.layers)], batch_size)
+    R = ops.relevancy_self_chain([vb.probs[l] for l in range(start_layer, vis.layers)],
+                                 [vb.grads[l] for l in range(start_layer, vis.layers)], batch_size)
+    cur.wait_stream(side)
+    R_text.record_stream(cur)
+    return R_text, R
+
+
+def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1):
+    """CLIP_explainability.ipynb cell 6.  ``image``: ``[1,3,R,R]``, ``texts``: ``[B, context]`` token ids."""
+    batch_size = texts.shape[0]
+    images = image.repeat(batch_size, 1, 1, 1)
+    prev = model.capture_only
+    model.capture_only = True
+    try:
+        with _Frozen(model), torch.enable_grad():
+            logits_per_image, _ = model(images, texts)
+            # one_hot = sum_i logits_per_image[i, i]  (cell 6:6-10)  ->  d one_hot / d logits = I
+            eye = torch.eye(batch_size, dtype=logits_per_image.dtype, device=logits_per_image.device)
+            torch.autograd.backward(logits_per_image, grad_tensors=eye)
+    finally:
+        model.capture_only = prev
+    R_text, R = _chains(model, batch_size, start_layer, start_layer_text)
+    image_relevance = R[:, 0, 1:]
+    return R_text, image_relevance
+
+
+def interpret_single(image, text, model, device, index=None):
+    """CLIP/example.py:8-32 without the plotting: returns ``image_relevance [Ni-1]`` (``R[0,0]`` zeroed first)."""
+    prev = model.capture_only
+    model.capture_only = True
+    try:
+        with _Frozen(model), torch.enable_grad():
+            logits_per_image, _ = model(image, text)
+            if index is None:
+                index = int(np.argmax(logits_per_image.detach().cpu().numpy(), axis=-1).reshape(-1)[0])
+            one_hot = torch.zeros_like(logits_per_image)
+            one_hot[0, index] = 1
+            torch.autograd.backward(logits_per_image, grad_tensors=one_hot)
+    finally:
+        model.capture_only = prev
+    vis = model.visual.transformer
+    vb = vis.buffers
+    # example.py flattens batch*heads into one head axis (cam.reshape(-1, N, N).mean(0)): batch_size = 1 here
+    R = ops.relevancy_self_chain([vb.probs[l] for l in range(vis.layers)],
+                                 [vb.grads[l] for l in range(vis.layers)], 1)[0]
+    R[0, 0] = 0
+    return R[0, 1:]
+
+
+def text_scores(text_encoding, R_text):
+    """Notebook cell 8:5-7 for one sample: row of the EOT token, columns ``1:EOT``, normalised by their sum."""
+    cls_idx = int(text_encoding.argmax(dim=-1))
+    row = R_text[cls_idx, 1:cls_idx]
+    return (row / row.sum()).flatten()
+
+
+def image_heatmap(image_relevance, size=224):
+    """Notebook cell 7:14-18: reshape to the patch grid, bilinear upsample, min-max normalise -> ``[size,size]``."""
+    dim = int(image_relevance.numel() ** 0.5)
+    rel = image_relevance.reshape(1, 1, dim, dim)
+    rel = torch.nn.functional.interpolate(rel, size=size, mode="bilinear").reshape(size, size)
+    return (rel - rel.min()) / (rel.max() - rel.min())

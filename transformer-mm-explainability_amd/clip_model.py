@@ -1,0 +1,248 @@
+"""CLIP (ViT image tower + causal text tower) whose attention runs on the HIP capture op.
+
+Role in this repo: the transformer body that FEEDS the relevancy engine.  Per BASELINE.json's north_star the
+body's GEMMs / LayerNorms stay on PyTorch-ROCm; only the attention core is ours, writing P and dP into
+preallocated slabs (``capture.CaptureBuffers``).  Parameter names and shapes are those of the reference's
+``CLIP/clip/model.py`` (``visual.transformer.resblocks.{i}.attn.in_proj_weight`` ...), so a reference /
+OpenAI ViT state dict loads with ``load_state_dict`` unchanged; the surface the explainability code touches
+is kept too (reference file:line in the docstrings):
+
+  * ``model.visual.transformer.resblocks`` / ``model.transformer.resblocks`` iterable of blocks
+  * ``blk.attn_probs`` / ``blk.attn_grad`` -> ``[B*H, N, N]`` (CLIP/clip/model.py:181-193), here views of the slabs
+  * ``model(image, text) -> (logits_per_image, logits_per_text)`` (model.py:364-378)
+
+Design differences (MI355X-first, not a port): activations are batch-first ``[B, N, E]`` end to end (the
+reference permutes to LND and back), q/k/v are strided views of the packed in-projection output consumed
+in place by the kernel, the head-concatenated output is written by the kernel in the layout ``out_proj`` reads,
+and ``capture_only`` mode cuts the autograd graph below the first block so ONE backward yields every layer's
+dP without weight or input gradients.  ModifiedResNet towers (RN50 etc.) have no attention stack to explain
+(reference notebooks use ViT-B/32) and are not built.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .capture import CaptureBuffers, attention_capture_packed
+
+
+class QuickGELU(nn.Module):
+    def forward(self, x):
+        return x * torch.sigmoid(1.702 * x)
+
+
+class _OutProj(nn.Linear):
+    """``attn.out_proj`` (name kept for state-dict compatibility)."""
+
+
+class CapturedSelfAttention(nn.Module):
+    """Packed-projection multi-head self-attention.  Parameters: ``in_proj_weight [3E, E]``, ``in_proj_bias``,
+    ``out_proj`` -- the ``nn.MultiheadAttention`` naming the reference's ``MultiheadAttention`` uses
+    (CLIP/clip/auxilary.py:265-356)."""
+
+    def __init__(self, embed_dim, num_heads):
+        super().__init__()
+        if embed_dim % num_heads:
+            raise ValueError("embed_dim must be divisible by num_heads")
+        self.embed_dim, self.num_heads, self.head_dim = embed_dim, num_heads, embed_dim // num_heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = _OutProj(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+    def forward(self, x, probs_slab, grads_slab, mask=None, need_dqkv=True, grad_hook=None):
+        B, N, E = x.shape
+        qkv = F.linear(x, self.in_proj_weight, self.in_proj_bias).view(B, N, 3, self.num_heads, self.head_dim)
+        o = attention_capture_packed(qkv, probs_slab, grads_slab, self.head_dim ** -0.5, mask=mask,
+                                     scale_mode=_lib.SCALE_Q_FIRST, need_dqkv=need_dqkv, grad_hook=grad_hook)
+        return self.out_proj(o.view(B, N, E))
+
+
+class ResidualAttentionBlock(nn.Module):
+    """Pre-LN block (CLIP/clip/model.py:167-198).  ``attn_probs`` / ``attn_grad`` are slab views."""
+
+    def __init__(self, d_model, n_head, attn_mask=None):
+        super().__init__()
+        self.attn = CapturedSelfAttention(d_model, n_head)
+        self.ln_1 = nn.LayerNorm(d_model)
+        self.mlp = nn.Sequential(OrderedDict([
+            ("c_fc", nn.Linear(d_model, d_model * 4)),
+            ("gelu", QuickGELU()),
+            ("c_proj", nn.Linear(d_model * 4, d_model)),
+        ]))
+        self.ln_2 = nn.LayerNorm(d_model)
+        self.attn_mask = attn_mask
+        self.attn_probs = None
+        self.attn_grad = None
+
+    # kept for API parity with the reference block (model.py:184-188)
+    def set_attn_probs(self, attn_probs):
+        self.attn_probs = attn_probs
+
+    def set_attn_grad(self, attn_grad):
+        self.attn_grad = attn_grad
+
+    def forward(self, x, buffers, layer, need_dqkv=True):
+        if self.attn_mask is not None and (self.attn_mask.device != x.device):
+            self.attn_mask = self.attn_mask.to(device=x.device, dtype=torch.float32)
+        probs, grads = buffers.probs[layer], buffers.grads[layer]
+        self.attn_probs = buffers.layer_probs(layer)
+        self.attn_grad = buffers.layer_grads(layer)  # valid once backward has run
+        x = x + self.attn(self.ln_1(x), probs, grads, mask=self.attn_mask, need_dqkv=need_dqkv)
+        x = x + self.mlp(self.ln_2(x))
+        return x
+
+
+class Transformer(nn.Module):
+    def __init__(self, width, layers, heads, attn_mask=None):
+        super().__init__()
+        self.width, self.layers, self.heads = width, layers, heads
+        self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask) for _ in range(layers)])
+        self.buffers = None
+
+    def _ensure_buffers(self, batch, n_tokens, device):
+        if self.buffers is None or not self.buffers.matches(self.layers, batch, self.heads, n_tokens, n_tokens, device):
+            self.buffers = CaptureBuffers(self.layers, batch, self.heads, n_tokens, n_tokens, device=device)
+        return self.buffers
+
+    def forward(self, x, capture_only=False):
+        """``x``: ``[B, N, E]``.  ``capture_only``: cut the graph below block 0 and skip block 0's dq/dk/dv."""
+        if not x.is_cuda:
+            raise _lib.MMXError("the CLIP body runs its attention on the HIP capture op: move the model and "
+                                "inputs to the MI355X (there is no CPU attention path)")
+        buffers = self._ensure_buffers(x.shape[0], x.shape[1], x.device)
+        if capture_only:
+            x = x.detach().requires_grad_(True)
+        for l, blk in enumerate(self.resblocks):
+            x = blk(x, buffers, l, need_dqkv=not (capture_only and l == 0))
+        return x
+
+
+class VisualTransformer(nn.Module):
+    """ViT image tower (CLIP/clip/model.py:211-246)."""
+
+    def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim):
+        super().__init__()
+        self.input_resolution, self.output_dim = input_resolution, output_dim
+        self.conv1 = nn.Conv2d(3, width, kernel_size=patch_size, stride=patch_size, bias=False)
+        scale = width ** -0.5
+        self.class_embedding = nn.Parameter(scale * torch.randn(width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn((input_resolution // patch_size) ** 2 + 1, width))
+        self.ln_pre = nn.LayerNorm(width)
+        self.transformer = Transformer(width, layers, heads)
+        self.ln_post = nn.LayerNorm(width)
+        self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
+
+    def forward(self, x, capture_only=False):
+        x = self.conv1(x).flatten(2).transpose(1, 2)                       # [B, grid^2, width]
+        cls = self.class_embedding.to(x.dtype).expand(x.shape[0], 1, -1)
+        x = torch.cat([cls, x], dim=1) + self.positional_embedding.to(x.dtype)
+        x = self.transformer(self.ln_pre(x), capture_only=capture_only)
+        x = self.ln_post(x[:, 0, :])
+        return x @ self.proj if self.proj is not None else x
+
+
+class CLIP(nn.Module):
+    """Same constructor signature as the reference ``CLIP`` (CLIP/clip/model.py:249-262); ViT towers only."""
+
+    def __init__(self, embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size,
+                 context_length, vocab_size, transformer_width, transformer_heads, transformer_layers):
+        super().__init__()
+        if isinstance(vision_layers, (tuple, list)):
+            raise NotImplementedError("ModifiedResNet towers have no attention stack; use a ViT config")
+        self.context_length = context_length
+        self.visual = VisualTransformer(image_resolution, vision_patch_size, vision_width, vision_layers,
+                                        vision_width // 64, embed_dim)
+        self.transformer = Transformer(transformer_width, transformer_layers, transformer_heads,
+                                       attn_mask=self.build_attention_mask())
+        self.vocab_size = vocab_size
+        self.token_embedding = nn.Embedding(vocab_size, transformer_width)
+        self.positional_embedding = nn.Parameter(torch.empty(context_length, transformer_width))
+        self.ln_final = nn.LayerNorm(transformer_width)
+        self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        self.capture_only = False
+        self.initialize_parameters()
+
+    def initialize_parameters(self):
+        """Same distributions as the reference (model.py:305-332)."""
+        nn.init.normal_(self.token_embedding.weight, std=0.02)
+        nn.init.normal_(self.positional_embedding, std=0.01)
+        w, n = self.transformer.width, self.transformer.layers
+        proj_std, attn_std, fc_std = (w ** -0.5) * ((2 * n) ** -0.5), w ** -0.5, (2 * w) ** -0.5
+        for blk in self.transformer.resblocks:
+            nn.init.normal_(blk.attn.in_proj_weight, std=attn_std)
+            nn.init.normal_(blk.attn.out_proj.weight, std=proj_std)
+            nn.init.normal_(blk.mlp.c_fc.weight, std=fc_std)
+            nn.init.normal_(blk.mlp.c_proj.weight, std=proj_std)
+        nn.init.normal_(self.text_projection, std=w ** -0.5)
+
+    def build_attention_mask(self):
+        """Additive causal mask, -inf above the diagonal (model.py:334-340)."""
+        return torch.full((self.context_length, self.context_length), float("-inf")).triu_(1)
+
+    @property
+    def dtype(self):
+        return self.visual.conv1.weight.dtype
+
+    def encode_image(self, image):
+        return self.visual(image.type(self.dtype), capture_only=self.capture_only)
+
+    def encode_text(self, text):
+        x = self.token_embedding(text).type(self.dtype) + self.positional_embedding.type(self.dtype)
+        x = self.transformer(x, capture_only=self.capture_only)
+        x = self.ln_final(x)
+        # features at the EOT token = highest token id in each sequence (model.py:360)
+        return x[torch.arange(x.shape[0], device=x.device), text.argmax(dim=-1)] @ self.text_projection
+
+    def forward(self, image, text):
+        image_features = self.encode_image(image)
+        text_features = self.encode_text(text)
+        image_features = image_features / image_features.norm(dim=-1, keepdim=True)
+        text_features = text_features / text_features.norm(dim=-1, keepdim=True)
+        logit_scale = self.logit_scale.exp()
+        logits_per_image = logit_scale * image_features @ text_features.t()
+        logits_per_text = logit_scale * text_features @ image_features.t()
+        return logits_per_image, logits_per_text
+
+
+def build_model(state_dict):
+    """Infer the ViT config from a state dict like the reference's ``build_model`` (model.py:405-442), fp32."""
+    if "visual.proj" not in state_dict:
+        raise NotImplementedError("only ViT CLIP checkpoints carry an attention stack to explain")
+    vision_width = state_dict["visual.conv1.weight"].shape[0]
+    vision_layers = len([k for k in state_dict if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+    vision_patch_size = state_dict["visual.conv1.weight"].shape[-1]
+    grid_size = round((state_dict["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    embed_dim = state_dict["text_projection"].shape[1]
+    context_length = state_dict["positional_embedding"].shape[0]
+    vocab_size = state_dict["token_embedding.weight"].shape[0]
+    transformer_width = state_dict["ln_final.weight"].shape[0]
+    transformer_layers = len({k.split(".")[2] for k in state_dict if k.startswith("transformer.resblocks")})
+    model = CLIP(embed_dim, vision_patch_size * grid_size, vision_layers, vision_width, vision_patch_size,
+                 context_length, vocab_size, transformer_width, transformer_width // 64, transformer_layers)
+    sd = {k: v.float() for k, v in state_dict.items() if k not in ("input_resolution", "context_length", "vocab_size")}
+    model.load_state_dict(sd)
+    return model.eval()
+
+
+CONFIGS = {
+    # (embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size,
+    #  context_length, vocab_size, transformer_width, transformer_heads, transformer_layers)
+    "ViT-B/32": (512, 224, 12, 768, 32, 77, 49408, 512, 8, 12),
+    "ViT-B/16": (512, 224, 12, 768, 16, 77, 49408, 512, 8, 12),
+    "ViT-L/14@336": (768, 336, 24, 1024, 14, 77, 49408, 768, 12, 12),
+}
+
+
+def random_init(name="ViT-B/32", seed=0):
+    """Random-init model of a named architecture (no pretrained weights are available offline)."""
+    torch.manual_seed(seed)
+    return CLIP(*CONFIGS[name]).float().eval()
