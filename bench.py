@@ -66,24 +66,51 @@ def kernel_time_us(fn, iters, stream):
     return ms.value * 1e3 / iters
 
 
-def cpu_baseline(state_dict, sample_b, reps):
+CPU_THREADS_CAP = 32   # torch CPU autograd on >64 threads gets slower, not faster (256-thread box: 128 threads = 0.9 maps/s)
+
+
+def cpu_baseline_worker(sample_b, reps):
+    """Runs in a child process (bounded by a timeout in the parent): the reference algorithm on host cores."""
     from oracle import clip_torch
-    cores = os.cpu_count() or 1
+    from transformer_mm_explainability_amd import clip_model
+    cores = min(os.cpu_count() or 1, CPU_THREADS_CAP)
     torch.set_num_threads(cores)
+    model = clip_model.random_init(MODEL, seed=0)       # parameters only; the CPU path never calls the HIP op
+    sd = clip_torch.prepare_state_dict(model.state_dict(), 8)
     image, texts = synthetic_inputs(sample_b, "cpu", 0)
-    sd = clip_torch.prepare_state_dict(state_dict, 8)
     clip_torch.interpret(sd, image, texts, 0, 0)  # warm-up
-    best = []
+    times = []
     for _ in range(reps):
         t0 = time.perf_counter()
         clip_torch.interpret(sd, image, texts, 0, 0)
-        best.append(time.perf_counter() - t0)
-    best.sort()
-    med = best[len(best) // 2]
-    return {"value": round(sample_b / med, 3), "unit": "maps/s", "cores": cores, "kind": "port",
-            "sample": "reference algorithm (hooked CLIP ViT-B/32 fwd + per-layer autograd.grad + rule chain, "
-                      "all 12+12 layers) restated in oracle/clip_torch.py, torch fp32 CPU, batch %d of the same "
-                      "synthetic workload, median of %d" % (sample_b, reps)}
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    print(json.dumps({"value": round(sample_b / med, 3), "unit": "maps/s", "cores": cores, "kind": "port",
+                      "sample": "reference algorithm (hooked CLIP ViT-B/32 fwd + one autograd.grad per layer + rule "
+                                "chain, all 12+12 layers) restated in oracle/clip_torch.py, torch fp32 CPU, %d threads "
+                                "of %d host cores, batch %d of the same synthetic workload, median of %d"
+                                % (cores, os.cpu_count() or 1, sample_b, reps)}), flush=True)
+
+
+def cpu_baseline(sample_b=16, reps=3, timeout_s=240):
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(sample_b), str(reps)],
+                             capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        for ln in reversed(out.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"value": None, "unit": "maps/s", "cores": 0, "kind": "port", "sample": "worker failed: " + out.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "maps/s", "cores": 0, "kind": "port", "sample": "timed out after %ds" % timeout_s}
+
+
+def log(msg):
+    print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
 
 
 def main():
@@ -92,7 +119,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", nargs=2, type=int, metavar=("BATCH", "REPS"), help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        cpu_baseline_worker(*args.cpu_baseline_worker)
+        return
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -112,8 +143,8 @@ def main():
     from transformer_mm_explainability_amd import clip_explainability as ce
     from transformer_mm_explainability_amd import clip_model, ops
 
+    log("imports done; building %s" % MODEL)
     model = clip_model.random_init(MODEL, seed=0)
-    state_dict_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model = model.to(device)
     image, texts = synthetic_inputs(BATCH, device, seed=rank)
     gathered = torch.empty(world * BATCH, 49, device=device) if world > 1 else None
@@ -129,9 +160,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log("model on device; warmup")
     for _ in range(args.warmup):
         step()
     sync()
+    log("timed region")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -144,6 +177,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * BATCH / (elapsed / args.steps)
 
+    log("timed region done: %.3f ms/step" % ms_per_step)
     # ---- notebook default (last layer only), reported beside the headline
     for _ in range(2):
         ce.interpret(image, texts, model, device)
@@ -166,13 +200,21 @@ def main():
     def chain_bytes(tr, n):
         return 2 * tr.layers * BATCH * tr.heads * n * n * 4 + BATCH * n * n * 4
 
+    log("kernel-only timing")
     us_txt = kernel_time_us(chain(txt), 20, stream)
     us_img = kernel_time_us(chain(vis), 20, stream)
     by_txt, by_img = chain_bytes(txt, 77), chain_bytes(vis, 50)
     ach = by_txt / us_txt / 1e3  # GB/s
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_chain.json")   # PMC passes cannot run inside this process
+    if os.path.exists(pmc_file):
+        pmc = json.load(open(pmc_file)).get("self_chain_fused_kernel<5, 0>")
+        if pmc:
+            traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
     roofline = {"bound": "hbm", "kernel": "self_chain_fused_kernel<NT=5,f32> (text tower)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": None, "bytes_per_launch": by_txt, "us_per_launch": round(us_txt, 2),
+                "traffic": traffic, "traffic_source": "profiles/r01_pmc_chain.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, "
+                "FETCH_SIZE x2 per the gfx950 correction), bytes per launch", "bytes_per_launch": by_txt, "us_per_launch": round(us_txt, 2),
                 "image_tower": {"kernel": "self_chain_fused_kernel<NT=4,f32>", "bytes_per_launch": by_img,
                                 "us_per_launch": round(us_img, 2), "achieved": round(by_img / us_img / 1e3, 1)},
                 "kernel_only_maps_per_s": round(BATCH / ((us_txt + us_img) * 1e-6), 1)}
@@ -190,7 +232,9 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(state_dict_cpu, 16, 3)
+            log("cpu baseline (child process, <= 240 s)")
+            line["cpu_baseline"] = cpu_baseline()
+            log("cpu baseline done")
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -53,6 +53,9 @@ enum mmx_status {
 
 int mmx_abi_version(void);
 const char* mmx_last_error(void);
+/* tuning knobs (process-wide): "self_chain_algo" = 0 auto | 1 one workgroup per sample (no scratch) |
+ * 2 one workgroup per (sample, layer) + last-arriver chain.  Both give bit-identical results. */
+int mmx_set_option(const char* key, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * Rule 5: A_bar[b] = mean_h( clamp(grad[b,h] * attn[b,h], min=0) )              out: [B, Nq, Nk] fp32

@@ -86,7 +86,9 @@ def test_avg_heads_nan_and_lowp(ops):
     (3, 2, 2, 5, False), (1, 1, 1, 1, False), (2, 5, 3, 16, False), (4, 2, 4, 17, False),
     (6, 2, 8, 100, False), (2, 1, 4, 128, False), (5, 3, 12, 36, False), (0, 2, 1, 7, False),
 ])
-def test_self_chain_fused(ops, L, B, H, N, causal):
+@pytest.mark.parametrize("algo", [1, 2])
+def test_self_chain_fused(ops, L, B, H, N, causal, algo):
+    ops.set_option("self_chain_algo", algo)
     attn, grad = make_layers(L * 100 + N, max(L, 1), B, H, N, causal)
     attn, grad = attn[:L], grad[:L]
     want = onp.self_chain([a.numpy() for a in attn], [g.numpy() for g in grad], B) if L else \
@@ -95,7 +97,25 @@ def test_self_chain_fused(ops, L, B, H, N, causal):
         got = ops.relevancy_self_chain([], [], B, R_init=torch.eye(N).cuda())
     else:
         got = ops.relevancy_self_chain([a.cuda() for a in attn], [g.cuda() for g in grad], B)
+    ops.set_option("self_chain_algo", 0)
     close(got, want)
+
+
+def test_self_chain_algorithms_bit_identical(ops):
+    """Per-sample fused kernel and reduce + last-arriver kernel sum in the same order -> identical bits;
+    repeated launches (scratch + counters reused) stay identical too."""
+    L, B, H, N = 12, 64, 8, 77
+    attn, grad = make_layers(77, L, B, H, N, causal=True)
+    attn, grad = [a.cuda() for a in attn], [g.cuda() for g in grad]
+    R0 = torch.rand(B, N, N).cuda()
+    outs = []
+    for algo in (1, 2, 2, 2):
+        ops.set_option("self_chain_algo", algo)
+        outs.append(ops.relevancy_self_chain(attn, grad, B, R_init=R0).clone())
+    ops.set_option("self_chain_algo", 0)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
 
 
 @pytest.mark.parametrize("N,M", [(197, 0), (130, 0), (20, 36), (100, 300)])

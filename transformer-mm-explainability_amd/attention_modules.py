@@ -1,0 +1,135 @@
+"""Reference-style hooked attention modules backed by the HIP capture op.
+
+The reference patches every model family's attention class with the same six accessors
+(``save_attn / get_attn / save_attn_gradients / get_attn_gradients / save_attn_cam / get_attn_cam``) fed by a Python
+forward hook and a tensor backward hook.  These classes keep that surface but the tensors behind ``get_attn()`` /
+``get_attn_gradients()`` are the slabs the HIP kernels write (no hook, no copy):
+
+  * ``MultiheadAttention``  -- DETR/modules/layers.py:666-768: separate q/k/v projections, ``q*d^-0.5`` first,
+    inputs ``[T, B, E]``, masks accepted and ignored (exactly like the reference, layers.py:728-756),
+    ``get_attn()`` -> ``[B*H, T, S]``.  Loads the reference's state dict (incl. packed ``in_proj_*`` checkpoints).
+  * ``BertStyleAttention``  -- lxmert/lxmert/src/lxmert_lrp.py:322-420 (``LxmertAttention``) and
+    VisualBERT/.../BERT_ours.py:234-343 (``BertSelfAttention``): ``query/key/value`` Linear, ``scores/sqrt(d) + mask``,
+    inputs ``[B, N, E]``, ``get_attn()`` -> ``[B, H, Nq, Nk]`` (captured before dropout; eval mode => identical).
+
+LRP (``relprop`` / ``get_attn_cam``) is out of scope: ``get_attn_cam`` raises.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .capture import attention_capture
+
+
+class _SlabOwner(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self._probs = None
+        self._grads = None
+        self.attn = None
+        self.attn_gradients = None
+
+    def _slabs(self, B, H, Nq, Nk, device):
+        shape = (B, H, Nq, Nk)
+        if self._probs is None or tuple(self._probs.shape) != shape or self._probs.device != device:
+            self._probs = torch.empty(shape, dtype=torch.float32, device=device)
+            self._grads = torch.empty(shape, dtype=torch.float32, device=device)
+        return self._probs, self._grads
+
+    # the reference's accessor surface (DETR/modules/layers.py:693-709, lxmert_lrp.py:356-372, BERT_ours.py:266-282)
+    def save_attn(self, attn):
+        self.attn = attn
+
+    def get_attn(self):
+        return self.attn
+
+    def save_attn_gradients(self, attn_gradients):
+        self.attn_gradients = attn_gradients
+
+    def get_attn_gradients(self):
+        return self.attn_gradients
+
+    def save_attn_cam(self, cam):
+        raise NotImplementedError("LRP attention cams (relprop) are out of scope; use the *_no_lrp methods")
+
+    def get_attn_cam(self):
+        raise NotImplementedError("LRP attention cams (relprop) are out of scope; use the *_no_lrp methods")
+
+
+class MultiheadAttention(_SlabOwner):
+    """DETR-style hooked MHA on the HIP capture op (see module docstring)."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.head_dim = embed_dim, num_heads, embed_dim // num_heads
+        self.q_proj = nn.Linear(embed_dim, embed_dim)
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=True)
+        self.dropout_p = dropout
+        self._register_load_state_dict_pre_hook(self._split_packed_in_proj)
+
+    @staticmethod
+    def _split_packed_in_proj(state_dict, prefix, *args):
+        """Accept ``nn.MultiheadAttention`` checkpoints (packed ``in_proj_weight``), like layers.py:711-726."""
+        if prefix + "in_proj_weight" in state_dict:
+            w, b = state_dict.pop(prefix + "in_proj_weight"), state_dict.pop(prefix + "in_proj_bias")
+            e = w.shape[1]
+            for i, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                state_dict[prefix + n + ".weight"] = w[i * e:(i + 1) * e]
+                state_dict[prefix + n + ".bias"] = b[i * e:(i + 1) * e]
+
+    def forward(self, query, key, value, key_padding_mask=None, need_weights=True, attn_mask=None):
+        if self.training and self.dropout_p > 0:
+            raise _lib.MMXError("the capture op implements eval-mode attention (the reference generators call .eval())")
+        T, B, E = query.shape
+        S = key.shape[0]
+        H, D = self.num_heads, self.head_dim
+        # [T, B, E] -> [B, T, H, D] strided views; the kernel takes (batch, head, token) strides
+        q = self.q_proj(query).view(T, B, H, D).permute(1, 0, 2, 3)
+        k = self.k_proj(key).view(S, B, H, D).permute(1, 0, 2, 3)
+        v = self.v_proj(value).view(S, B, H, D).permute(1, 0, 2, 3)
+        probs, grads = self._slabs(B, H, T, S, query.device)
+        o = attention_capture(q, k, v, probs, grads, float(D) ** -0.5, mask=None, scale_mode=_lib.SCALE_Q_FIRST)
+        self.save_attn(probs.view(B * H, T, S))
+        self.save_attn_gradients(grads.view(B * H, T, S))   # filled by the backward kernel
+        o = o.permute(1, 0, 2, 3).reshape(T, B, E)
+        return self.out_proj(o)
+
+
+class BertStyleAttention(_SlabOwner):
+    """LXMERT ``LxmertAttention`` / BERT ``BertSelfAttention`` on the HIP capture op (see module docstring)."""
+
+    def __init__(self, hidden_size, num_attention_heads, ctx_dim=None):
+        super().__init__()
+        if hidden_size % num_attention_heads:
+            raise ValueError("hidden size must be a multiple of the number of heads")
+        self.num_attention_heads = num_attention_heads
+        self.attention_head_size = hidden_size // num_attention_heads
+        self.head_size = hidden_size
+        ctx_dim = hidden_size if ctx_dim is None else ctx_dim
+        self.query = nn.Linear(hidden_size, hidden_size)
+        self.key = nn.Linear(ctx_dim, hidden_size)
+        self.value = nn.Linear(ctx_dim, hidden_size)
+
+    def forward(self, hidden_states, context=None, attention_mask=None, output_attentions=False):
+        context = hidden_states if context is None else context
+        B, Nq, _ = hidden_states.shape
+        Nk = context.shape[1]
+        H, D = self.num_attention_heads, self.attention_head_size
+        q = self.query(hidden_states).view(B, Nq, H, D)
+        k = self.key(context).view(B, Nk, H, D)
+        v = self.value(context).view(B, Nk, H, D)
+        mask = None
+        if attention_mask is not None:   # HF extended mask [B, 1, 1, Nk] (additive, -10000 on padding)
+            mask = attention_mask.reshape(B, 1, Nk).float()
+        probs, grads = self._slabs(B, H, Nq, Nk, hidden_states.device)
+        o = attention_capture(q, k, v, probs, grads, math.sqrt(D), mask=mask, scale_mode=_lib.SCALE_SCORES)
+        self.save_attn(probs)
+        self.save_attn_gradients(grads)
+        context_layer = o.reshape(B, Nq, H * D)
+        return (context_layer, probs) if output_attentions else (context_layer,)

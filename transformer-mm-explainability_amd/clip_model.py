@@ -140,8 +140,17 @@ class VisualTransformer(nn.Module):
         self.ln_post = nn.LayerNorm(width)
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
 
+    def _patchify(self, x):
+        """``conv1`` has kernel == stride == patch, i.e. it is a GEMM over flattened patches.  Doing it as one keeps
+        MIOpen (solver search, and its naive fp32 fallback kernel: 24 ms per call here) off the path."""
+        B, C, Hh, Ww = x.shape
+        p = self.conv1.kernel_size[0]
+        gh, gw = Hh // p, Ww // p
+        patches = x.reshape(B, C, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * p * p)
+        return F.linear(patches, self.conv1.weight.reshape(self.conv1.out_channels, -1))
+
     def forward(self, x, capture_only=False):
-        x = self.conv1(x).flatten(2).transpose(1, 2)                       # [B, grid^2, width]
+        x = self._patchify(x)                                               # [B, grid^2, width]
         cls = self.class_embedding.to(x.dtype).expand(x.shape[0], 1, -1)
         x = torch.cat([cls, x], dim=1) + self.positional_embedding.to(x.dtype)
         x = self.transformer(self.ln_pre(x), capture_only=capture_only)

@@ -75,6 +75,10 @@ __device__ __forceinline__ f32x4 mfma16x16x4(float a, float b, f32x4 acc) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (its workgroup fence covers
+// global memory), which would serialise every in-flight global prefetch behind the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 inline size_t dtype_size(int dt) { return dt == MMX_F32 ? 4 : 2; }
 
 void set_error(const char* fmt, ...);

@@ -45,11 +45,16 @@ def _capture(t):
 _ws_cache = {}
 
 
+def set_option(key, value):
+    """Process-wide tuning knob of the C library (see ``mmx_set_option`` in include/mmx_relevancy.h)."""
+    check(lib().mmx_set_option(key.encode(), int(value)), "mmx_set_option")
+
+
 def _workspace(nbytes, device, tag="default"):
-    """Grow-only scratch per (device, tag); stream-ordered reuse on the current stream."""
+    """Grow-only scratch per (device, stream, tag): reuse is stream-ordered, so every stream owns its own."""
     if nbytes == 0:
         return None
-    key = (device, tag)
+    key = (device, torch.cuda.current_stream(device).cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
