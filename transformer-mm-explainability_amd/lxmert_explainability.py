@@ -1,0 +1,238 @@
+"""LXMERT relevancy generators -- the reference's ``lxmert/lxmert/src/ExplanationGenerator.py`` surface on the HIP kernels.
+
+``GeneratorOurs(model_usage).generate_ours(input, index=None, use_lrp=True, normalize_self_attention=True,
+apply_self_in_rule_10=True, method_name="ours")`` keeps the reference signature and duck-typed ``model_usage``
+(``.forward(item) -> obj.question_answering_score``, ``.model``, ``.text_len``, ``.image_boxes_len``;
+lxmert/lxmert/perturbation.py:45-83).  Attention modules are reached through the same attribute paths
+(``model.lxmert.encoder.{layer, r_layers, x_layers}`` ...) and must expose ``get_attn()`` / ``get_attn_gradients()``
+``[1, H, Nq, Nk]`` device tensors (``attention_modules.BertStyleAttention`` serves them from the capture slabs).
+
+Underneath: the 9 language and 5 vision self-attention layers are one chain launch each (rules 6+7 carry the
+cross matrices as second right-hand side), the cross layers use the rule-10/11 kernels; both cross directions are
+computed from the pre-update state and added afterwards, exactly like the reference (:176-196).
+LRP methods need the LRP layer library: out of scope.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops, rules
+from .rules import avg_heads, compute_rollout_attention, handle_residual  # noqa: F401
+
+apply_self_attention_rules = rules.apply_self_attention_rules
+apply_mm_attention_rules = rules.apply_mm_attention_rules_lxmert
+
+
+def _pair(module):
+    return module.get_attn().detach(), module.get_attn_gradients().detach()
+
+
+def _backward_on_answer(model_usage, input, index):
+    """lxmert/.../ExplanationGenerator.py:136,153-163."""
+    output = model_usage.forward(input).question_answering_score
+    model = model_usage.model
+    if index is None:
+        index = np.argmax(output.cpu().data.numpy(), axis=-1)
+    one_hot = torch.zeros_like(output)
+    one_hot[0, index] = 1
+    loss = torch.sum(one_hot * output)
+    model.zero_grad()
+    loss.backward(retain_graph=True)
+    return model
+
+
+class GeneratorOurs:
+    def __init__(self, model_usage, save_visualization=False):
+        self.model_usage = model_usage
+        self.save_visualization = save_visualization
+
+    # ---- single-stream pieces: rules 6+7 for a list of blocks in one chain launch
+    def _self_chain(self, pairs, R_ss, R_sq):
+        attn = [a for a, _ in pairs]
+        grad = [g for _, g in pairs]
+        R_ss, R_sq = ops.relevancy_self_chain(attn, grad, 1, R_init=R_ss, R_sq_init=R_sq)
+        return R_ss[0], R_sq[0]
+
+    def handle_self_attention_lang(self, blocks):
+        self.R_t_t, self.R_t_i = self._self_chain([_pair(b.attention.self) for b in blocks], self.R_t_t, self.R_t_i)
+
+    def handle_self_attention_image(self, blocks):
+        self.R_i_i, self.R_i_t = self._self_chain([_pair(b.attention.self) for b in blocks], self.R_i_i, self.R_i_t)
+
+    def handle_co_attn_self_lang(self, block):
+        self.R_t_t, self.R_t_i = self._self_chain([_pair(block.lang_self_att.self)], self.R_t_t, self.R_t_i)
+
+    def handle_co_attn_self_image(self, block):
+        self.R_i_i, self.R_i_t = self._self_chain([_pair(block.visn_self_att.self)], self.R_i_i, self.R_i_t)
+
+    def handle_co_attn_lang(self, block):
+        cam_t_i = avg_heads(*_pair(block.visual_attention.att))
+        return apply_mm_attention_rules(self.R_t_t, self.R_i_i, self.R_i_t, cam_t_i,
+                                        apply_normalization=self.normalize_self_attention,
+                                        apply_self_in_rule_10=self.apply_self_in_rule_10)
+
+    def handle_co_attn_image(self, block):
+        cam_i_t = avg_heads(*_pair(block.visual_attention_copy.att))
+        return apply_mm_attention_rules(self.R_i_i, self.R_t_t, self.R_t_i, cam_i_t,
+                                        apply_normalization=self.normalize_self_attention,
+                                        apply_self_in_rule_10=self.apply_self_in_rule_10)
+
+    def generate_ours(self, input, index=None, use_lrp=True, normalize_self_attention=True, apply_self_in_rule_10=True,
+                      method_name="ours"):
+        if use_lrp:
+            raise NotImplementedError("use_lrp=True needs model.relprop (LRP layer library); call with use_lrp=False "
+                                      "(the evaluator's 'ours_no_lrp')")
+        self.use_lrp = use_lrp
+        self.normalize_self_attention = normalize_self_attention
+        self.apply_self_in_rule_10 = apply_self_in_rule_10
+        model = _backward_on_answer(self.model_usage, input, index)
+        text_tokens = self.model_usage.text_len
+        image_bboxes = self.model_usage.image_boxes_len
+        dev = model.device
+        self.R_t_t = torch.eye(text_tokens, text_tokens, device=dev)
+        self.R_i_i = torch.eye(image_bboxes, image_bboxes, device=dev)
+        self.R_t_i = torch.zeros(text_tokens, image_bboxes, device=dev)
+        self.R_i_t = torch.zeros(image_bboxes, text_tokens, device=dev)
+
+        self.handle_self_attention_lang(model.lxmert.encoder.layer)
+        self.handle_self_attention_image(model.lxmert.encoder.r_layers)
+        blocks = model.lxmert.encoder.x_layers
+        for i, blk in enumerate(blocks):
+            if i == len(blocks) - 1:
+                break
+            R_t_i_addition, R_t_t_addition = self.handle_co_attn_lang(blk)
+            R_i_t_addition, R_i_i_addition = self.handle_co_attn_image(blk)
+            self.R_t_i = self.R_t_i + R_t_i_addition
+            self.R_t_t = self.R_t_t + R_t_t_addition
+            self.R_i_t = self.R_i_t + R_i_t_addition
+            self.R_i_i = self.R_i_i + R_i_i_addition
+            self.handle_co_attn_self_lang(blk)
+            self.handle_co_attn_self_image(blk)
+        blk = blocks[-1]
+        R_t_i_addition, R_t_t_addition = self.handle_co_attn_lang(blk)
+        self.R_t_i = self.R_t_i + R_t_i_addition
+        self.R_t_t = self.R_t_t + R_t_t_addition
+        self.handle_co_attn_self_lang(blk)
+        self.R_t_t[0, 0] = 0   # disregard the [CLS] token itself (:210)
+        return self.R_t_t, self.R_t_i
+
+
+class GeneratorOursAblationNoAggregation:
+    """Reference :215-365: every accumulation replaced by assignment."""
+
+    def __init__(self, model_usage, save_visualization=False):
+        self.model_usage = model_usage
+        self.save_visualization = save_visualization
+
+    def _self(self, module, R_ss, R_sq):
+        cam = avg_heads(*_pair(module))
+        return apply_self_attention_rules(R_ss, R_sq, cam)
+
+    def generate_ours_no_agg(self, input, index=None, use_lrp=False, normalize_self_attention=True,
+                             method_name="ours_no_agg"):
+        if use_lrp:
+            raise NotImplementedError("use_lrp=True needs model.relprop: out of scope")
+        self.use_lrp = use_lrp
+        self.normalize_self_attention = normalize_self_attention
+        model = _backward_on_answer(self.model_usage, input, index)
+        T, I = self.model_usage.text_len, self.model_usage.image_boxes_len
+        dev = model.device
+        self.R_t_t, self.R_i_i = torch.eye(T, T, device=dev), torch.eye(I, I, device=dev)
+        self.R_t_i, self.R_i_t = torch.zeros(T, I, device=dev), torch.zeros(I, T, device=dev)
+        for blk in model.lxmert.encoder.layer:
+            self.R_t_t, self.R_t_i = self._self(blk.attention.self, self.R_t_t, self.R_t_i)
+        for blk in model.lxmert.encoder.r_layers:
+            self.R_i_i, self.R_i_t = self._self(blk.attention.self, self.R_i_i, self.R_i_t)
+
+        def co_lang(blk):
+            cam = avg_heads(*_pair(blk.visual_attention.att))
+            return apply_mm_attention_rules(self.R_t_t, self.R_i_i, self.R_i_t, cam,
+                                            apply_normalization=self.normalize_self_attention)
+
+        def co_img(blk):
+            cam = avg_heads(*_pair(blk.visual_attention_copy.att))
+            return apply_mm_attention_rules(self.R_i_i, self.R_t_t, self.R_t_i, cam,
+                                            apply_normalization=self.normalize_self_attention)
+
+        blocks = model.lxmert.encoder.x_layers
+        for i, blk in enumerate(blocks):
+            if i == len(blocks) - 1:
+                break
+            t_i, t_t = co_lang(blk)
+            i_t, i_i = co_img(blk)
+            self.R_t_i, self.R_t_t, self.R_i_t, self.R_i_i = t_i, t_t, i_t, i_i
+            self.R_t_t, self.R_t_i = self._self(blk.lang_self_att.self, self.R_t_t, self.R_t_i)
+            self.R_i_i, self.R_i_t = self._self(blk.visn_self_att.self, self.R_i_i, self.R_i_t)
+        blk = blocks[-1]
+        self.R_t_i, self.R_t_t = co_lang(blk)
+        self.R_t_t, self.R_t_i = self._self(blk.lang_self_att.self, self.R_t_t, self.R_t_i)
+        self.R_t_t[0, 0] = 0
+        return self.R_t_t, self.R_t_i
+
+
+class GeneratorBaselines:
+    """Attention-only baselines of the reference (:368-665): raw attention, attention GradCAM, rollout.
+    ``generate_transformer_attr`` / ``generate_partial_lrp`` need LRP and raise."""
+
+    def __init__(self, model_usage, save_visualization=False):
+        self.model_usage = model_usage
+        self.save_visualization = save_visualization
+
+    @staticmethod
+    def _head_mean(module):
+        cam = module.get_attn().detach()
+        return cam.reshape(-1, cam.shape[-2], cam.shape[-1]).mean(dim=0)
+
+    def generate_raw_attn(self, input, method_name="raw_attention"):
+        """Reference :508-540: head-means of the last cross-attention (``R_t_i``) and last language self-attention."""
+        self.model_usage.forward(input)
+        model = self.model_usage.model
+        blk = model.lxmert.encoder.x_layers[-1]
+        self.R_t_i = self._head_mean(blk.visual_attention.att)
+        self.R_t_t = self._head_mean(blk.lang_self_att.self)
+        self.R_t_t[0, 0] = 0
+        return self.R_t_t, self.R_t_i
+
+    def gradcam(self, cam, grad):
+        return rules.gradcam(cam, grad)
+
+    def generate_attn_gradcam(self, input, index=None, method_name="gradcam"):
+        """Reference :549-592: GradCAM of the last cross-attention and the last language self-attention."""
+        model = _backward_on_answer(self.model_usage, input, index)
+        blk = model.lxmert.encoder.x_layers[-1]
+        att = blk.visual_attention.att
+        self.R_t_i = self.gradcam(att.get_attn().detach(), att.get_attn_gradients().detach())
+        sa = blk.lang_self_att.self
+        self.R_t_t = self.gradcam(sa.get_attn().detach(), sa.get_attn_gradients().detach())
+        self.R_t_t[0, 0] = 0
+        return self.R_t_t, self.R_t_i
+
+    def generate_rollout(self, input, method_name="rollout"):
+        """Reference :594-665.  ``R_t_i = R_t_t^T . (cam_t_i . R_i_i)`` uses the text rollout WITHOUT the last language
+        self-attention block; the returned ``R_t_t`` includes it."""
+        self.model_usage.forward(input)
+        model = self.model_usage.model
+        enc = model.lxmert.encoder
+        cams_text = [self._head_mean(b.attention.self) for b in enc.layer]
+        cams_image = [self._head_mean(b.attention.self) for b in enc.r_layers]
+        for i, blk in enumerate(enc.x_layers):
+            if i == len(enc.x_layers) - 1:
+                break
+            cams_text.append(self._head_mean(blk.lang_self_att.self))
+            cams_image.append(self._head_mean(blk.visn_self_att.self))
+        blk = enc.x_layers[-1]
+        cam_t_i = self._head_mean(blk.visual_attention.att)
+        self.R_t_t = compute_rollout_attention(cams_text)
+        self.R_i_i = compute_rollout_attention(cams_image)
+        self.R_t_i = ops.matmul(self.R_t_t, ops.matmul(cam_t_i, self.R_i_i), trans_a=True)
+        cams_text.append(self._head_mean(blk.lang_self_att.self))
+        self.R_t_t = compute_rollout_attention(cams_text)
+        self.R_t_t[0, 0] = 0
+        return self.R_t_t, self.R_t_i
+
+    def generate_transformer_attr(self, input, index=None, method_name="transformer_attr"):
+        raise NotImplementedError("transformer_attr needs model.relprop (LRP layer library): out of scope")
+
+    def generate_partial_lrp(self, input, index=None, method_name="partial_lrp"):
+        raise NotImplementedError("partial_lrp needs model.relprop (LRP layer library): out of scope")

@@ -1,0 +1,65 @@
+"""Sample sharding + result gathering for the perturbation / segmentation evaluators.
+
+Every relevancy map depends on one sample only, so the evaluators shard the sample list across ranks (one process
+per GPU) and exchange per-sample results ONCE with a fixed-shape all-gather (RCCL on the GPUs, gloo in the CPU tests).
+Nothing here is on the per-sample data path.
+
+Reference call sites this serves: ``lxmert/lxmert/perturbation.py:205-210`` (seeded shuffle, first ``num_samples``
+items, single process), ``VisualBERT/mmf/trainers/core/evaluation_loop.py:104-168`` (running per-step accuracy),
+``DETR/main.py:151-153`` (``DistributedSampler(shuffle=False)``).
+"""
+from __future__ import annotations
+
+import random
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def perturbation_sample_indices(dataset_len, num_samples, seed=1234):
+    """The reference's sample selection (perturbation.py:205-210): ``random.seed(1234)``, shuffle ``range(len)``,
+    keep the first ``num_samples``.  Identical on every rank."""
+    rng = random.Random(seed)
+    idx = list(range(dataset_len))
+    rng.shuffle(idx)
+    return idx[:num_samples]
+
+
+def shard_indices(indices, rank=None, world_size=None):
+    """Rank-strided slice: rank r owns ``indices[r::world_size]`` (deterministic, balanced to within one sample)."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    return list(indices[rank::world_size])
+
+
+def gather_per_sample(local, total, fill=float("nan")):
+    """All-gather per-sample rows back into the ORIGINAL (unsharded) order.
+
+    ``local``: ``[n_local, ...]`` results of this rank's ``shard_indices`` slice, in that order.  ``total``: number of
+    samples over all ranks.  Returns ``[total, ...]`` on every rank.  One fixed-shape collective: shards are padded to
+    ``ceil(total / world)`` rows with ``fill`` and the padding is dropped after the gather.
+    """
+    rank, world_size = world()
+    if world_size == 1:
+        return local
+    per = (total + world_size - 1) // world_size
+    pad = torch.full((per,) + tuple(local.shape[1:]), fill, dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((world_size * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad.contiguous())
+    out = out.view((world_size, per) + tuple(local.shape[1:]))
+    # sample k of the original order lives on rank k % world at row k // world
+    return out.transpose(0, 1).reshape((per * world_size,) + tuple(local.shape[1:]))[:total]
+
+
+def mean_step_accuracy(per_sample_scores):
+    """``[total, n_steps]`` per-sample scores -> the evaluators' printed metric: mean over samples x 100
+    (perturbation.py:250-251).  NaN padding rows are never present after ``gather_per_sample``."""
+    return per_sample_scores.double().mean(dim=0) * 100.0

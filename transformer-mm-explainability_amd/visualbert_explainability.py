@@ -1,0 +1,88 @@
+"""VisualBERT (single-stream) relevancy -- ``VisualBERT/mmf/models/transformers/backends/ExplanationGenerator.py``
+surface (``SelfAttentionGenerator``) on the HIP kernels.
+
+``model`` is duck-typed as in the reference: ``model(input)['scores']``, ``model.model.bert.encoder.layer[i].attention.self``
+with ``get_attn()`` / ``get_attn_gradients()`` -> ``[1, H, N, N]``; ``input['input_mask']`` gives the ``[CLS]``-row index
+``input_mask.sum(1) - 2`` (reference :94-95).  Visualisation flags are accepted and ignored (cv2 drawing is not part of
+the path).  LRP methods (``generate_transformer_att``, ``generate_partial_lrp``) need ``model.relprop``: out of scope.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops, rules
+
+compute_rollout_attention = rules.compute_rollout_attention_batched
+
+
+def _backward_on_answer(model, input, index):
+    output = model(input)["scores"]
+    if index is None:
+        index = np.argmax(output.cpu().data.numpy(), axis=-1)
+    one_hot = torch.zeros_like(output)
+    one_hot[0, index] = 1
+    loss = torch.sum(one_hot * output)
+    model.zero_grad()
+    loss.backward(retain_graph=True)
+
+
+class SelfAttentionGenerator:
+    def __init__(self, model):
+        self.model = model
+        self.model.eval()
+
+    def _blocks(self):
+        return self.model.model.bert.encoder.layer
+
+    def generate_ours(self, input, index=None, save_visualization=False, save_visualization_per_token=False):
+        """Reference :68-107 -> ``[1, N]`` row of the answer token with its own column zeroed."""
+        _backward_on_answer(self.model, input, index)
+        blocks = self._blocks()
+        attn = [blk.attention.self.get_attn()[0] for blk in blocks]            # cam[0] -> [H, N, N]
+        grad = [blk.attention.self.get_attn_gradients()[0] for blk in blocks]
+        R = ops.relevancy_self_chain(attn, grad, 1)[0]
+        cls_index = input["input_mask"].sum(1) - 2
+        cls_per_token_score = R[cls_index]
+        cls_per_token_score[:, cls_index] = 0
+        return cls_per_token_score
+
+    def generate_rollout(self, input, start_layer=0, save_visualization=False):
+        """Reference :158-174: head-mean maps (``sum/H``), batched rollout WITHOUT row normalisation."""
+        self.model(input)
+        cams = []
+        for blk in self._blocks():
+            attn_heads = blk.attention.self.get_attn()
+            cams.append((attn_heads.sum(dim=1) / attn_heads.shape[1]).detach())        # [1, N, N]
+        rollout = compute_rollout_attention(cams, start_layer=start_layer)
+        cls_index = input["input_mask"].sum(1) - 2
+        cls_per_token_score = rollout[0, cls_index]
+        cls_per_token_score[:, cls_index] = 0
+        return cls_per_token_score
+
+    def generate_raw_attn(self, input, save_visualization=False):
+        """Reference :145-156: head-mean of the last layer."""
+        self.model(input)
+        cam = self._blocks()[-1].attention.self.get_attn()[0].mean(dim=0).unsqueeze(0)
+        cls_index = input["input_mask"].sum(1) - 2
+        cls_per_token_score = cam[0, cls_index]
+        cls_per_token_score[:, cls_index] = 0
+        return cls_per_token_score
+
+    def generate_attn_gradcam(self, input, index=None, save_visualization=False):
+        """Reference :176-215: GradCAM of the last layer, min-max normalised."""
+        _backward_on_answer(self.model, input, index)
+        sa = self._blocks()[-1].attention.self
+        cam = rules.gradcam(sa.get_attn()[0], sa.get_attn_gradients()[0]).unsqueeze(0)
+        cam = (cam - cam.min()) / (cam.max() - cam.min())
+        cls_index = input["input_mask"].sum(1) - 2
+        cls_per_token_score = cam[0, cls_index]
+        cls_per_token_score[:, cls_index] = 0
+        return cls_per_token_score
+
+    def generate_transformer_att(self, input, index=None, start_layer=0, save_visualization=False,
+                                 save_visualization_per_token=False):
+        raise NotImplementedError("transformer_att needs model.relprop (LRP layer library): out of scope")
+
+    def generate_partial_lrp(self, input, index=None, save_visualization=False):
+        raise NotImplementedError("partial_lrp needs model.relprop (LRP layer library): out of scope")
