@@ -101,6 +101,31 @@ def test_self_chain_fused(ops, L, B, H, N, causal, algo):
     close(got, want)
 
 
+@pytest.mark.parametrize("groups", [2, 3, 4])
+@pytest.mark.parametrize("L,B,H,N,causal,with_init", [
+    (12, 4, 12, 50, False, False), (12, 3, 8, 77, True, True), (5, 2, 4, 33, False, True), (2, 2, 2, 128, False, False),
+])
+def test_self_chain_layer_groups(ops, groups, L, B, H, N, causal, with_init):
+    """Layer-group split: partial products re-associated at the group boundaries, combined by the last arriver.
+    Same 1e-5 bar against the sequential oracle; repeated launches reuse scratch and counters."""
+    attn, grad = make_layers(L * 10 + N, L, B, H, N, causal)
+    R0 = (torch.eye(N) + torch.rand(B, N, N) * 0.1) if with_init else None
+    want = np.broadcast_to(np.eye(N, dtype=np.float32), (B, N, N)).copy() if R0 is None else R0.numpy().copy()
+    for a, g in zip(attn, grad):
+        cam = onp.avg_heads_batched(a.numpy(), g.numpy(), B)
+        want = want + np.matmul(cam, want)
+    ops.set_option("self_chain_algo", 1)
+    ops.set_option("self_chain_groups", groups)
+    try:
+        ca, cg = [a.cuda() for a in attn], [g.cuda() for g in grad]
+        for _ in range(3):
+            got = ops.relevancy_self_chain(ca, cg, B, R_init=R0.cuda() if with_init else None)
+            close(got, want)
+    finally:
+        ops.set_option("self_chain_groups", 0)
+        ops.set_option("self_chain_algo", 0)
+
+
 def test_self_chain_algorithms_bit_identical(ops):
     """Per-sample fused kernel and reduce + last-arriver kernel sum in the same order -> identical bits;
     repeated launches (scratch + counters reused) stay identical too."""
@@ -109,10 +134,12 @@ def test_self_chain_algorithms_bit_identical(ops):
     attn, grad = [a.cuda() for a in attn], [g.cuda() for g in grad]
     R0 = torch.rand(B, N, N).cuda()
     outs = []
+    ops.set_option("self_chain_groups", 1)   # strict sequential order (auto would split this shape into 4 groups)
     for algo in (1, 2, 2, 2):
         ops.set_option("self_chain_algo", algo)
         outs.append(ops.relevancy_self_chain(attn, grad, B, R_init=R0).clone())
     ops.set_option("self_chain_algo", 0)
+    ops.set_option("self_chain_groups", 0)
     torch.cuda.synchronize()
     for o in outs[1:]:
         assert torch.equal(outs[0], o)

@@ -10,8 +10,7 @@ Reference entry points mirrored here:
 What is different under the hood (results agree to fp32 rounding, see tests/test_gpu_clip.py):
   * the reference issues one ``torch.autograd.grad`` per layer (24 partial backward passes); here ONE backward
     fills every layer's gradient slab (``capture_only`` also drops weight/input gradients);
-  * the per-layer reshape/mul/clamp/mean/bmm/add launches are one ``relevancy_self_chain`` launch per tower,
-    the two towers on two HIP streams.
+  * the per-layer reshape/mul/clamp/mean/bmm/add launches are one ``relevancy_self_chain`` launch per tower.
 """
 from __future__ import annotations
 
@@ -19,16 +18,6 @@ import numpy as np
 import torch
 
 from . import ops
-
-_side_streams = {}
-
-
-def _side_stream(device):
-    key = torch.device(device).index
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
-    return _side_streams[key]
-
 
 class _Frozen:
     """Temporarily mark parameters as not requiring grad: the explainability pass needs d(logit)/d(probs) only."""
@@ -52,16 +41,12 @@ def _chains(model, batch_size, start_layer, start_layer_text):
     if start_layer_text == -1:
         start_layer_text = txt.layers - 1
     vb, tb = vis.buffers, txt.buffers
-    cur = torch.cuda.current_stream()
-    side = _side_stream(vb.probs.device)
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        R_text = ops.relevancy_self_chain([tb.probs[l] for l in range(start_layer_text, txt.layers)],
-                                          [tb.grads[l] for l in range(start_layer_text, txt.layers)], batch_size)
+    # Same stream, back to back: each launch already fills the chip (layer-group split), and measured on MI355X two
+    # concurrent chain kernels on two streams are slower than the two in sequence (profiles/r01_chain_probe.txt).
+    R_text = ops.relevancy_self_chain([tb.probs[l] for l in range(start_layer_text, txt.layers)],
+                                      [tb.grads[l] for l in range(start_layer_text, txt.layers)], batch_size)
     R = ops.relevancy_self_chain([vb.probs[l] for l in range(start_layer, vis.layers)],
                                  [vb.grads[l] for l in range(start_layer, vis.layers)], batch_size)
-    cur.wait_stream(side)
-    R_text.record_stream(cur)
     return R_text, R
 
 

@@ -64,6 +64,12 @@ struct ChainArgs {
     int n_layers, B, H, N;
     const float* R_init;
     float* R_out;
+    // layer-group split (G > 1): workgroup (b, g) multiplies only its contiguous layer group; the partial products
+    // P_g go to `parts` [B][G][N*N] and the last arriver of a sample (ticket on counters[b]) combines them.
+    int G;
+    float* parts;
+    unsigned* counters;
+    int debug;  // profiling only: bit0 = return before the hand-off/combine, bit2 = matrix waves skip the MFMAs
 };
 
 constexpr int kChainThreads = 1024;
@@ -77,18 +83,23 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int b = blockIdx.x;
-    const int N = a.N, H = a.H, L = a.n_layers;
+    const int G = a.G;
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int N = a.N, H = a.H;
+    const int per = (a.n_layers + G - 1) / G;
+    const int l0 = min(a.n_layers, g * per), l1 = min(a.n_layers, l0 + per);
+    const int L = l1 - l0;
     const int64_t NN = static_cast<int64_t>(N) * N;
 
     for (int i = tid; i < 2 * NP * S; i += kChainThreads) smem[i] = 0.f;  // pads must read as 0
     __syncthreads();
 
+    const int col = wave * 16 + (lane & 15);
+    const int rq = (lane >> 4) * 4;
+    f32x4 Rold[NT], Rnew[NT];
+
     if (wave < NT) {
         // ------------------------------------------------------------------ matrix waves
-        const int col = wave * 16 + (lane & 15);
-        const int rq = (lane >> 4) * 4;
-        f32x4 Rold[NT], Rnew[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -96,11 +107,13 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
                 const int row = t * 16 + rq + r;
                 float v = 0.f;
                 if (row < N && col < N)
-                    v = a.R_init ? a.R_init[b * NN + static_cast<int64_t>(row) * N + col] : (row == col ? 1.f : 0.f);
+                    v = (a.R_init && g == 0) ? a.R_init[b * NN + static_cast<int64_t>(row) * N + col]
+                                             : (row == col ? 1.f : 0.f);
                 Rold[t][r] = v;
             }
         for (int l = 0; l < L; ++l) {
             __syncthreads();  // A_bar_l is in buffer l&1
+            if (a.debug & 4) continue;
             const float* Ab = smem + (l & 1) * NP * S + (lane & 15) * S + rq;
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti) {
@@ -118,12 +131,18 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
 #pragma unroll
             for (int t = 0; t < NT; ++t) Rold[t] = Rnew[t];
         }
+        float* dst = (G == 1) ? a.R_out + b * NN : a.parts + (static_cast<int64_t>(b) * G + g) * NN;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = t * 16 + rq + r;
-                if (row < N && col < N) a.R_out[b * NN + static_cast<int64_t>(row) * N + col] = Rold[t][r];
+                if (row < N && col < N) {
+                    if (G == 1) dst[static_cast<int64_t>(row) * N + col] = Rold[t][r];
+                    else  // write-through: the hand-off below needs no L2 write-back fence
+                        __hip_atomic_store(dst + static_cast<int64_t>(row) * N + col, Rold[t][r], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
     } else {
         // ------------------------------------------------------------------ stream waves
@@ -134,8 +153,8 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
         const int nchunks = static_cast<int>((NN + 3) >> 2);
         for (int l = 0; l < L; ++l) {
             float* Ab = smem + (l & 1) * NP * S;
-            const void* A = a.attn[l];
-            const void* G = a.grad[l];
+            const void* A = a.attn[l0 + l];
+            const void* Gr = a.grad[l0 + l];
             for (int c = lt; c < nchunks; c += LT) {
                 const int64_t p = static_cast<int64_t>(c) * 4;
                 f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -143,7 +162,7 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
 #pragma unroll 4
                     for (int h = 0; h < H; ++h) {
                         const f32x4 av = load4_as_f32<DT>(A, sample + h * NN + p);
-                        const f32x4 gv = load4_as_f32<DT>(G, sample + h * NN + p);
+                        const f32x4 gv = load4_as_f32<DT>(Gr, sample + h * NN + p);
                         const f32x4 x = gv * av;
                         s[0] += relu_nan(x[0]); s[1] += relu_nan(x[1]);
                         s[2] += relu_nan(x[2]); s[3] += relu_nan(x[3]);
@@ -151,7 +170,7 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
                 } else {
                     for (int e = 0; p + e < NN; ++e)
                         for (int h = 0; h < H; ++h)
-                            s[e] += relu_nan(load1_as_f32<DT>(G, sample + h * NN + p + e) *
+                            s[e] += relu_nan(load1_as_f32<DT>(Gr, sample + h * NN + p + e) *
                                              load1_as_f32<DT>(A, sample + h * NN + p + e));
                 }
                 int row = static_cast<int>(p / N);
@@ -164,6 +183,85 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
             }
             __syncthreads();  // publish A_bar_l (pairs with the matrix waves' barrier of layer l)
         }
+    }
+    if (G == 1 || (a.debug & 1)) return;
+
+    // ------------------------------------------------------------------ hand-off + combine (G > 1)
+    // R = P_{G-1} . ... . P_1 . P_0 (P_0 already includes R_init).  Mathematically the sequential chain; the
+    // products are re-associated at the group boundaries (rounding-level difference, tests bound it at 1e-5).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
+    __syncthreads();
+    unsigned* ticket_lds = reinterpret_cast<unsigned*>(smem + 2 * NP * S - 4);  // inside the (zero) row padding
+    if (tid == 0)
+        *ticket_lds = __hip_atomic_fetch_add(a.counters + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = *ticket_lds;
+    if (ticket != static_cast<unsigned>(G - 1)) return;
+    if (tid == 0) {
+        *ticket_lds = 0u;  // restore the zero padding
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    const float* part = a.parts + static_cast<int64_t>(b) * G * NN;
+    if (wave < NT) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = t * 16 + rq + r;
+                Rold[t][r] = (row < N && col < N) ? part[static_cast<int64_t>(row) * N + col] : 0.f;
+            }
+    }
+    constexpr int CE = (NP * NP + kChainThreads - 1) / kChainThreads;  // elements of a partial product per thread
+    float pre[CE];
+    auto prefetch = [&](int gg) {
+        const float* P = part + gg * NN;
+#pragma unroll
+        for (int i = 0; i < CE; ++i) {
+            const int idx = tid + i * kChainThreads;
+            pre[i] = (idx < N * N) ? P[idx] : 0.f;
+        }
+    };
+    prefetch(1);
+    for (int gg = 1; gg < G; ++gg) {
+#pragma unroll
+        for (int i = 0; i < CE; ++i) {
+            const int idx = tid + i * kChainThreads;
+            if (idx < N * N) {
+                const int row = idx / N, cc = idx - row * N;
+                smem[row * S + cc] = pre[i];
+            }
+        }
+        lds_barrier();
+        if (gg + 1 < G) prefetch(gg + 1);  // in flight while the MFMAs run
+        if (wave < NT) {
+            const float* Ab = smem + (lane & 15) * S + rq;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(Ab + ti * 16 * S + t * 16);
+                    acc = mfma16x16x4(av[0], Rold[t][0], acc);
+                    acc = mfma16x16x4(av[1], Rold[t][1], acc);
+                    acc = mfma16x16x4(av[2], Rold[t][2], acc);
+                    acc = mfma16x16x4(av[3], Rold[t][3], acc);
+                }
+                Rnew[ti] = acc;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) Rold[t] = Rnew[t];
+        }
+        lds_barrier();
+    }
+    if (wave < NT) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = t * 16 + rq + r;
+                if (row < N && col < N) a.R_out[b * NN + static_cast<int64_t>(row) * N + col] = Rold[t][r];
+            }
     }
 }
 
@@ -615,11 +713,16 @@ extern "C" int mmx_rollout_chain(const void* const* layers, int n_layers, int B,
 // ----------------------------------------------------------------------------------------- self chain
 static int nt_for(int N) { return (N + 15) / 16; }
 static int g_debug_flags = 0;
+static int g_chain_groups = 0;  // layer groups per sample of the per-sample kernel: 0 auto, 1 = strict sequential order
 static int g_chain_algo = 0;  // 0 auto, 1 per-sample wave-specialised, 2 reduce + last-arriver chain
 
 extern "C" int mmx_set_option(const char* key, int value) {
     if (key && strcmp(key, "self_chain_algo") == 0 && value >= 0 && value <= 2) {
         g_chain_algo = value;
+        return MMX_OK;
+    }
+    if (key && strcmp(key, "self_chain_groups") == 0 && value >= 0 && value <= 8) {
+        g_chain_groups = value;
         return MMX_OK;
     }
     if (key && strcmp(key, "debug_flags") == 0) {
@@ -637,12 +740,28 @@ static bool use_v2(int n_layers, int B, int N, int M) {
     return g_chain_algo == 2;
 }
 
+static int fused_groups(int n_layers, int B, int H, int N) {
+    if (n_layers < 2) return 1;
+    int G = g_chain_groups;
+    if (G == 0) {
+        // auto: split only when a sample streams enough bytes to pay for the hand-off (>= 1 MB) and there are idle
+        // CUs to fill (256 on MI355X); 4 groups measured best at CLIP ViT-B/32 shapes (profiles/r01_chain_probe.txt)
+        const double sample_bytes = 8.0 * n_layers * H * N * N;
+        G = (sample_bytes >= 1e6 && B <= 128) ? 4 : 1;
+    }
+    return G < n_layers ? G : n_layers;
+}
+
 static size_t v2_counter_bytes(int B) { return align256(sizeof(unsigned) * static_cast<size_t>(B)); }
 
 extern "C" size_t mmx_self_chain_workspace_bytes(int n_layers, int B, int H, int N, int M, int dtype) {
-    (void)H; (void)dtype;
+    (void)dtype;
     if (nt_for(N) <= 8 && M == 0) {
-        if (!use_v2(n_layers, B, N, M)) return 0;  // per-sample fused kernel needs no scratch
+        if (!use_v2(n_layers, B, N, M)) {
+            const int G = fused_groups(n_layers, B, H, N);
+            if (G == 1) return 0;  // strict-order per-sample kernel needs no scratch
+            return v2_counter_bytes(B) + align256(sizeof(float) * static_cast<size_t>(B) * G * N * N);
+        }
         return v2_counter_bytes(B) + align256(sizeof(float) * static_cast<size_t>(n_layers) * B * N * (16 * nt_for(N) + 4));
     }
     const size_t mat = align256(sizeof(float) * static_cast<size_t>(B) * N * N);
@@ -692,7 +811,11 @@ static int launch_fused(const ChainArgs& args, int dtype, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
-    kern<<<args.B, kChainThreads, lds, s>>>(args);
+    if (args.G > 1) {
+        hipError_t e = hipMemsetAsync(args.counters, 0, sizeof(unsigned) * args.B, s);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(counters)");
+    }
+    kern<<<args.B * args.G, kChainThreads, lds, s>>>(args);
     MMX_LAUNCH_CHECK("self_chain_fused_kernel");
     return MMX_OK;
 }
@@ -743,6 +866,17 @@ extern "C" int mmx_relevancy_self_chain(const void* const* attn_layers, const vo
         args.n_layers = n_layers; args.B = B; args.H = H; args.N = N;
         args.R_init = static_cast<const float*>(R_init_dev);
         args.R_out = static_cast<float*>(R_out_dev);
+        args.G = fused_groups(n_layers, B, H, N);
+        args.debug = g_debug_flags;
+        if (args.G > 1) {
+            const size_t need = mmx_self_chain_workspace_bytes(n_layers, B, H, N, M, dtype);
+            if (workspace_bytes < need || !workspace_dev) {
+                set_error("mmx_relevancy_self_chain: workspace %zu < %zu", workspace_bytes, need);
+                return MMX_EWORKSPACE;
+            }
+            args.counters = static_cast<unsigned*>(workspace_dev);
+            args.parts = reinterpret_cast<float*>(static_cast<char*>(workspace_dev) + v2_counter_bytes(B));
+        }
         switch (nt) {
             case 1: return launch_fused<1>(args, dtype, s);
             case 2: return launch_fused<2>(args, dtype, s);
