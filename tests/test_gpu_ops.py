@@ -222,7 +222,10 @@ def torch_attention(q, k, v, scale, mode, mask):
     (2, 12, 14, 36, 64, 1, False), (1, 2, 1, 3, 16, 1, False), (1, 4, 197, 197, 64, 0, False),
     (1, 2, 33, 130, 48, 1, True),
 ])
-def test_attn_capture_fwd_bwd(ops, B, H, Nq, Nk, D, mode, masked):
+@pytest.mark.parametrize("small", [1, 0])
+def test_attn_capture_fwd_bwd(ops, B, H, Nq, Nk, D, mode, masked, small):
+    """small=1: whole-head-in-LDS kernels where eligible; small=0: the tiled kernels for every shape."""
+    ops.set_option("attn_small", small)
     g = torch.Generator().manual_seed(Nq * 7 + Nk)
     q = torch.randn(B, Nq, H, D, generator=g)
     k = torch.randn(B, Nk, H, D, generator=g)
@@ -252,4 +255,5 @@ def test_attn_capture_fwd_bwd(ops, B, H, Nq, Nk, D, mode, masked):
     close(dv.permute(0, 2, 1, 3), vr.grad.float().numpy(), atol=2e-5)
     dprobs2 = torch.empty_like(dprobs)
     assert ops.attn_capture_bwd(qc, kc, vc, probs, d_o.cuda(), dprobs2, scale, mode, need_dqkv=False) == (None, None, None)
+    ops.set_option("attn_small", 1)
     assert torch.equal(dprobs, dprobs2)

@@ -1,0 +1,33 @@
+// Argument blocks shared by the tiled (attention_kernels.hip) and whole-head (attention_small.hip) kernels.
+#pragma once
+#include "mmx_common.h"
+
+namespace mmx {
+
+struct Strides { int64_t sb, sh, sn; };
+
+struct AttnFwdArgs {
+    const float *q, *k, *v;
+    Strides qs, ks, vs;
+    const float* mask; int64_t mask_sb, mask_sq;
+    float* probs; float* o; Strides os;
+    int B, H, Nq, Nk, D;
+    float scale; int scale_mode;
+};
+
+struct AttnBwdArgs {
+    const float *q, *k, *v;
+    Strides qs, ks, vs;
+    const float* probs; const float* dout; Strides os;
+    float* dprobs;
+    float *dq, *dk, *dv;
+    Strides dqs, dks, dvs;
+    float* delta;  // [B, H, Nq] workspace: rowsum(dP * P)
+    int B, H, Nq, Nk, D;
+    float scale; int scale_mode; int need_dqkv;
+};
+
+int attn_fwd_small_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out);
+int attn_bwd_small_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);
+
+}  // namespace mmx

@@ -7,19 +7,9 @@
 // backward, per (batch, head, 16-key tile) for the dK/dV half.  All matrix products run on the exact-fp32
 // MFMA v_mfma_f32_16x16x4_f32; the full score row block [16 x Nk] lives in LDS so softmax is one pass.
 #include "mmx_common.h"
+#include "attention_args.h"
 
 namespace mmx {
-
-struct Strides { int64_t sb, sh, sn; };
-
-struct AttnFwdArgs {
-    const float *q, *k, *v;
-    Strides qs, ks, vs;
-    const float* mask; int64_t mask_sb, mask_sq;
-    float* probs; float* o; Strides os;
-    int B, H, Nq, Nk, D;
-    float scale; int scale_mode;
-};
 
 constexpr int kTQ = 16;   // query rows per workgroup
 constexpr int kTK = 64;   // keys staged per step
@@ -137,18 +127,6 @@ __global__ __launch_bounds__(256) void attn_capture_fwd_kernel(const AttnFwdArgs
 }
 
 // ---------------------------------------------------------------------------------------------- backward
-struct AttnBwdArgs {
-    const float *q, *k, *v;
-    Strides qs, ks, vs;
-    const float* probs; const float* dout; Strides os;
-    float* dprobs;
-    float *dq, *dk, *dv;
-    Strides dqs, dks, dvs;
-    float* delta;  // [B, H, Nq] workspace: rowsum(dP * P)
-    int B, H, Nq, Nk, D;
-    float scale; int scale_mode; int need_dqkv;
-};
-
 // Kernel A, per 16-query tile: dP = dO.V^T -> capture slab; delta; dS = P*(dP - delta); dQ = dS.K
 template <int DP>
 __global__ __launch_bounds__(256) void attn_capture_bwd_q_kernel(const AttnBwdArgs a) {
@@ -352,6 +330,7 @@ extern "C" int mmx_attn_capture_fwd(const void* q_dev, const void* k_dev, const 
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale; a.scale_mode = scale_mode;
     dim3 grid((Nq + kTQ - 1) / kTQ, H, B);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (attn_fwd_small_try(a, s, &rc)) return rc;   // whole head resident in LDS (short sequences)
     if (D <= 32) return launch_dyn(attn_capture_fwd_kernel<32>, a, grid, attn_lds_bytes(32, Nk), s, "attn_capture_fwd_kernel<32>");
     return launch_dyn(attn_capture_fwd_kernel<64>, a, grid, attn_lds_bytes(64, Nk), s, "attn_capture_fwd_kernel<64>");
 }
@@ -389,6 +368,7 @@ extern "C" int mmx_attn_capture_bwd(const void* q_dev, const void* k_dev, const 
     a.delta = static_cast<float*>(workspace_dev);
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale; a.scale_mode = scale_mode; a.need_dqkv = need_dqkv;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (attn_bwd_small_try(a, s, &rc)) return rc;   // whole head resident in LDS (short sequences)
     dim3 gq((Nq + kTQ - 1) / kTQ, H, B), gk((Nk + 15) / 16, H, B);
     if (D <= 32) {
         rc = launch_dyn(attn_capture_bwd_q_kernel<32>, a, gq, attn_lds_bytes(32, Nk), s, "attn_capture_bwd_q_kernel<32>");

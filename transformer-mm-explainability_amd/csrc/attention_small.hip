@@ -1,0 +1,349 @@
+// Whole-head-resident attention-capture kernels for short sequences (CLIP 50/77 tokens, LXMERT, BERT-sized N).
+//
+// The tiled kernels in attention_kernels.hip re-read K/V once per 16-query tile (rocprofv3 FETCH_SIZE: 3.7x the
+// algorithmic bytes at N = 77) and run latency-bound 16-row tiles.  Here ONE workgroup owns a (batch, head):
+// Q, K, V (and dO, P, dP for backward) are staged into LDS exactly once with 16-B loads, every matrix product is a
+// loop of v_mfma_f32_16x16x4_f32 tiles dealt round-robin to the waves, and P / dP leave the chip once, straight
+// into the capture slabs.  MFMA operands are read as ds_read_b128 along the contraction index wherever that index
+// is contiguous in LDS (the k-order inside a dot product is free: k is visited as (t, r, lane>>4)).
+//
+// Eligibility (checked on the host, otherwise the tiled kernels run): head_dim % 4 == 0, 16-B aligned rows,
+// LDS footprint <= 160 KiB (forward: N <= ~112; backward: N <= 80 at d = 64).
+#include "mmx_common.h"
+#include "attention_args.h"
+
+namespace mmx {
+
+__device__ __forceinline__ int ceil16(int x) { return (x + 15) & ~15; }
+
+// stage rows [0, rows) x [0, D) of a strided global matrix into LDS [rows_cap][LS], zero padded, times `mul`
+template <int DP>
+__device__ __forceinline__ void stage_rows_vec(float* lds, const float* base, int64_t sn, int rows, int rows_cap,
+                                               int D, float mul, int tid, int nthreads) {
+    constexpr int LS = DP + 4;
+    constexpr int C4 = DP / 4;
+    for (int idx = tid; idx < rows_cap * C4; idx += nthreads) {
+        const int r = idx / C4, c = (idx - r * C4) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows && c < D) {
+            v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(r) * sn + c);
+            v = v * mul;
+        }
+        *reinterpret_cast<f32x4*>(lds + r * LS + c) = v;
+    }
+}
+
+// D(16x16) += A.B^T-style product where BOTH operands are contiguous along the contraction index in LDS:
+// A[i][k] at pa + i*lda + k, B[j][k] at pb + j*ldb + k, k in [0, K16*16).
+__device__ __forceinline__ f32x4 tile_kk(const float* pa, int lda, const float* pb, int ldb, int K16, int i_a, int kq) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* a = pa + i_a * lda + kq;
+    const float* b = pb + i_a * ldb + kq;
+    for (int t = 0; t < K16; ++t) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + t * 16);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b + t * 16);
+        acc = mfma16x16x4(av[0], bv[0], acc);
+        acc = mfma16x16x4(av[1], bv[1], acc);
+        acc = mfma16x16x4(av[2], bv[2], acc);
+        acc = mfma16x16x4(av[3], bv[3], acc);
+    }
+    return acc;
+}
+
+// A contiguous along k (A[i][k] at pa + i*lda + k), B row-major over k (B[k][j] at pb + k*ldb + j)
+__device__ __forceinline__ f32x4 tile_kn(const float* pa, int lda, const float* pb, int ldb, int K16, int i_a, int kq) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* a = pa + i_a * lda + kq;
+    const float* b = pb + kq * ldb + i_a;
+    for (int t = 0; t < K16; ++t) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + t * 16);
+        const float* bt = b + t * 16 * ldb;
+        acc = mfma16x16x4(av[0], bt[0], acc);
+        acc = mfma16x16x4(av[1], bt[ldb], acc);
+        acc = mfma16x16x4(av[2], bt[2 * ldb], acc);
+        acc = mfma16x16x4(av[3], bt[3 * ldb], acc);
+    }
+    return acc;
+}
+
+// both operands row-major over k: A^T stored as At[k][i] at pa + k*lda + i, B[k][j] at pb + k*ldb + j
+__device__ __forceinline__ f32x4 tile_nn(const float* pa, int lda, const float* pb, int ldb, int K16, int i_a, int kq) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* a = pa + kq * lda + i_a;
+    const float* b = pb + kq * ldb + i_a;
+    for (int t = 0; t < K16; ++t) {
+        const float* at = a + t * 16 * lda;
+        const float* bt = b + t * 16 * ldb;
+        acc = mfma16x16x4(at[0], bt[0], acc);
+        acc = mfma16x16x4(at[lda], bt[ldb], acc);
+        acc = mfma16x16x4(at[2 * lda], bt[2 * ldb], acc);
+        acc = mfma16x16x4(at[3 * lda], bt[3 * ldb], acc);
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+template <int DP>
+__global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnFwdArgs a) {
+    constexpr int LS = DP + 4;
+    constexpr int NW = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int NPq = ceil16(a.Nq), NPk = ceil16(a.Nk), SS = NPk + 4;
+    float* Qs = smem;
+    float* Ks = Qs + NPq * LS;
+    float* Vs = Ks + NPk * LS;
+    float* Ss = Vs + NPk * LS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int i_a = lane & 15, kq = (lane >> 4) * 4;
+    const bool q_first = (a.scale_mode == MMX_SCALE_Q_FIRST);
+    const float* qb = a.q + b * a.qs.sb + h * a.qs.sh;
+    const float* kb = a.k + b * a.ks.sb + h * a.ks.sh;
+    const float* vb = a.v + b * a.vs.sb + h * a.vs.sh;
+
+    stage_rows_vec<DP>(Qs, qb, a.qs.sn, a.Nq, NPq, a.D, q_first ? a.scale : 1.f, tid, 256);
+    stage_rows_vec<DP>(Ks, kb, a.ks.sn, a.Nk, NPk, a.D, 1.f, tid, 256);
+    stage_rows_vec<DP>(Vs, vb, a.vs.sn, a.Nk, NPk, a.D, 1.f, tid, 256);
+    __syncthreads();
+
+    // S = Q.K^T (+ mask)
+    const int ntq = NPq >> 4, ntk = NPk >> 4;
+    for (int tile = wave; tile < ntq * ntk; tile += NW) {
+        const int ti = tile / ntk, tj = tile - ti * ntk;
+        const f32x4 acc = tile_kk(Qs + ti * 16 * LS, LS, Ks + tj * 16 * LS, LS, DP / 16, i_a, kq);
+        const int key = tj * 16 + i_a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = ti * 16 + kq + r;
+            float s = acc[r];
+            if (!q_first) s = s / a.scale;
+            if (a.mask && key < a.Nk && row < a.Nq)
+                s += a.mask[b * a.mask_sb + static_cast<int64_t>(row) * a.mask_sq + key];
+            Ss[row * SS + key] = s;
+        }
+    }
+    __syncthreads();
+
+    // row softmax; P -> LDS (zero padded) and -> the capture slab
+    float* pbase = a.probs + (static_cast<int64_t>(b) * a.H + h) * a.Nq * a.Nk;
+    for (int row = wave; row < NPq; row += NW) {
+        float* srow = Ss + row * SS;
+        if (row >= a.Nq) {
+            for (int j = lane; j < NPk; j += 64) srow[j] = 0.f;
+            continue;
+        }
+        float m = -__builtin_inff();
+        for (int j = lane; j < a.Nk; j += 64) m = fmaxf(m, srow[j]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        float sum = 0.f;
+        for (int j = lane; j < a.Nk; j += 64) {
+            const float e = expf(srow[j] - m);
+            srow[j] = e;
+            sum += e;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        float* prow = pbase + static_cast<int64_t>(row) * a.Nk;
+        for (int j = lane; j < NPk; j += 64) {
+            float p = 0.f;
+            if (j < a.Nk) {
+                p = srow[j] / sum;
+                prow[j] = p;
+            }
+            srow[j] = p;
+        }
+    }
+    __syncthreads();
+
+    // O = P.V
+    float* ob = a.o + b * a.os.sb + h * a.os.sh;
+    constexpr int ntd = DP / 16;
+    for (int tile = wave; tile < ntq * ntd; tile += NW) {
+        const int ti = tile / ntd, td = tile - ti * ntd;
+        const f32x4 acc = tile_kn(Ss + ti * 16 * SS, SS, Vs + td * 16, LS, ntk, i_a, kq);
+        const int d = td * 16 + i_a;
+        if (d < a.D) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = ti * 16 + kq + r;
+                if (row < a.Nq) ob[static_cast<int64_t>(row) * a.os.sn + d] = acc[r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+template <int DP>
+__global__ __launch_bounds__(512) void attn_bwd_small_kernel(const AttnBwdArgs a) {
+    constexpr int LS = DP + 4;
+    constexpr int NW = 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int NPq = ceil16(a.Nq), NPk = ceil16(a.Nk), SS = NPk + 4;
+    float* Qs = smem;
+    float* dOs = Qs + NPq * LS;
+    float* Ks = dOs + NPq * LS;
+    float* Vs = Ks + NPk * LS;
+    float* Ps = Vs + NPk * LS;      // [NPq][SS]
+    float* dSs = Ps + NPq * SS;     // [NPq][SS]  dP, then dS
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int i_a = lane & 15, kq = (lane >> 4) * 4;
+    const bool q_first = (a.scale_mode == MMX_SCALE_Q_FIRST);
+    const int64_t head = static_cast<int64_t>(b) * a.H + h;
+    const float* pg = a.probs + head * a.Nq * a.Nk;
+    float* dpg = a.dprobs + head * a.Nq * a.Nk;
+
+    stage_rows_vec<DP>(dOs, a.dout + b * a.os.sb + h * a.os.sh, a.os.sn, a.Nq, NPq, a.D, 1.f, tid, 512);
+    stage_rows_vec<DP>(Vs, a.v + b * a.vs.sb + h * a.vs.sh, a.vs.sn, a.Nk, NPk, a.D, 1.f, tid, 512);
+    if (a.need_dqkv) {
+        stage_rows_vec<DP>(Qs, a.q + b * a.qs.sb + h * a.qs.sh, a.qs.sn, a.Nq, NPq, a.D, q_first ? a.scale : 1.f, tid, 512);
+        stage_rows_vec<DP>(Ks, a.k + b * a.ks.sb + h * a.ks.sh, a.ks.sn, a.Nk, NPk, a.D, 1.f, tid, 512);
+    }
+    for (int idx = tid; idx < NPq * NPk; idx += 512) {
+        const int r = idx / NPk, j = idx - r * NPk;
+        Ps[r * SS + j] = (r < a.Nq && j < a.Nk) ? pg[static_cast<int64_t>(r) * a.Nk + j] : 0.f;
+    }
+    __syncthreads();
+
+    // dP = dO.V^T
+    const int ntq = NPq >> 4, ntk = NPk >> 4;
+    for (int tile = wave; tile < ntq * ntk; tile += NW) {
+        const int ti = tile / ntk, tj = tile - ti * ntk;
+        const f32x4 acc = tile_kk(dOs + ti * 16 * LS, LS, Vs + tj * 16 * LS, LS, DP / 16, i_a, kq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dSs[(ti * 16 + kq + r) * SS + tj * 16 + i_a] = acc[r];
+    }
+    __syncthreads();
+
+    // rows: dP -> capture slab; delta = rowsum(dP*P); dS = P*(dP - delta)
+    for (int row = wave; row < NPq; row += NW) {
+        float* drow = dSs + row * SS;
+        if (row >= a.Nq) {
+            for (int j = lane; j < NPk; j += 64) drow[j] = 0.f;
+            continue;
+        }
+        const float* prow = Ps + row * SS;
+        float dot = 0.f;
+        for (int j = lane; j < a.Nk; j += 64) {
+            const float dp = drow[j];
+            dpg[static_cast<int64_t>(row) * a.Nk + j] = dp;  // the captured attention gradient
+            dot += dp * prow[j];
+        }
+        if (!a.need_dqkv) continue;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+        for (int j = lane; j < NPk; j += 64) {
+            float ds = 0.f;
+            if (j < a.Nk) {
+                ds = prow[j] * (drow[j] - dot);
+                if (!q_first) ds = ds / a.scale;
+            }
+            drow[j] = ds;
+        }
+    }
+    if (!a.need_dqkv) return;
+    __syncthreads();
+
+    // dQ = dS.K (x scale) | dK = dS^T.Q | dV = P^T.dO  -- one pool of independent MFMA tiles
+    constexpr int ntd = DP / 16;
+    const int n_dq = ntq * ntd, n_dkv = ntk * ntd;
+    float* dqb = a.dq + b * a.dqs.sb + h * a.dqs.sh;
+    float* dkb = a.dk + b * a.dks.sb + h * a.dks.sh;
+    float* dvb = a.dv + b * a.dvs.sb + h * a.dvs.sh;
+    for (int tile = wave; tile < n_dq + 2 * n_dkv; tile += NW) {
+        if (tile < n_dq) {
+            const int ti = tile / ntd, td = tile - ti * ntd;
+            const f32x4 acc = tile_kn(dSs + ti * 16 * SS, SS, Ks + td * 16, LS, ntk, i_a, kq);
+            const int d = td * 16 + i_a;
+            const float mul = q_first ? a.scale : 1.f;
+            if (d < a.D) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = ti * 16 + kq + r;
+                    if (row < a.Nq) dqb[static_cast<int64_t>(row) * a.dqs.sn + d] = acc[r] * mul;
+                }
+            }
+        } else {
+            const int t2 = tile - n_dq;
+            const bool is_k = t2 < n_dkv;
+            const int t3 = is_k ? t2 : t2 - n_dkv;
+            const int tj = t3 / ntd, td = t3 - tj * ntd;
+            const f32x4 acc = is_k ? tile_nn(dSs + tj * 16, SS, Qs + td * 16, LS, ntq, i_a, kq)
+                                   : tile_nn(Ps + tj * 16, SS, dOs + td * 16, LS, ntq, i_a, kq);
+            const int d = td * 16 + i_a;
+            float* dst = is_k ? dkb : dvb;
+            const int64_t sn = is_k ? a.dks.sn : a.dvs.sn;
+            if (d < a.D) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = tj * 16 + kq + r;
+                    if (j < a.Nk) dst[static_cast<int64_t>(j) * sn + d] = acc[r];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+static bool aligned16(const void* p, int64_t s0, int64_t s1, int64_t s2) {
+    return ((reinterpret_cast<uintptr_t>(p) | static_cast<uintptr_t>(s0 * 4) | static_cast<uintptr_t>(s1 * 4) |
+             static_cast<uintptr_t>(s2 * 4)) & 15u) == 0;
+}
+
+static size_t fwd_small_lds(int DP, int Nq, int Nk) {
+    const int NPq = (Nq + 15) & ~15, NPk = (Nk + 15) & ~15;
+    return sizeof(float) * (static_cast<size_t>(NPq + 2 * NPk) * (DP + 4) + static_cast<size_t>(NPq) * (NPk + 4));
+}
+
+static size_t bwd_small_lds(int DP, int Nq, int Nk) {
+    const int NPq = (Nq + 15) & ~15, NPk = (Nk + 15) & ~15;
+    return sizeof(float) * (static_cast<size_t>(2 * NPq + 2 * NPk) * (DP + 4) + 2 * static_cast<size_t>(NPq) * (NPk + 4));
+}
+
+static int g_attn_small = 1;  // 0 forces the tiled kernels (tests / A-B profiling)
+void attn_small_enable(int on) { g_attn_small = on; }
+
+template <typename K, typename A>
+static int launch_small(K kern, const A& args, int threads, size_t lds, hipStream_t s, const char* name) {
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    kern<<<dim3(args.H, args.B), threads, lds, s>>>(args);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, name);
+    return MMX_OK;
+}
+
+// returns 1 if the small kernel was launched (rc in *rc_out), 0 if the shape is not eligible
+int attn_fwd_small_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out) {
+    if (!g_attn_small || a.D % 4 || a.D > 64) return 0;
+    const int DP = a.D <= 32 ? 32 : 64;
+    const size_t lds = fwd_small_lds(DP, a.Nq, a.Nk);
+    if (lds > 160 * 1024) return 0;
+    if (!aligned16(a.q, a.qs.sb, a.qs.sh, a.qs.sn) || !aligned16(a.k, a.ks.sb, a.ks.sh, a.ks.sn) ||
+        !aligned16(a.v, a.vs.sb, a.vs.sh, a.vs.sn))
+        return 0;
+    *rc_out = DP == 32 ? launch_small(attn_fwd_small_kernel<32>, a, 256, lds, s, "attn_fwd_small_kernel<32>")
+                       : launch_small(attn_fwd_small_kernel<64>, a, 256, lds, s, "attn_fwd_small_kernel<64>");
+    return 1;
+}
+
+int attn_bwd_small_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out) {
+    if (!g_attn_small || a.D % 4 || a.D > 64) return 0;
+    const int DP = a.D <= 32 ? 32 : 64;
+    const size_t lds = bwd_small_lds(DP, a.Nq, a.Nk);
+    if (lds > 160 * 1024) return 0;
+    if (!aligned16(a.v, a.vs.sb, a.vs.sh, a.vs.sn) || !aligned16(a.dout, a.os.sb, a.os.sh, a.os.sn)) return 0;
+    if (a.need_dqkv && (!aligned16(a.q, a.qs.sb, a.qs.sh, a.qs.sn) || !aligned16(a.k, a.ks.sb, a.ks.sh, a.ks.sn)))
+        return 0;
+    *rc_out = DP == 32 ? launch_small(attn_bwd_small_kernel<32>, a, 512, lds, s, "attn_bwd_small_kernel<32>")
+                       : launch_small(attn_bwd_small_kernel<64>, a, 512, lds, s, "attn_bwd_small_kernel<64>");
+    return 1;
+}
+
+}  // namespace mmx

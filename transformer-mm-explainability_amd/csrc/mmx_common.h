@@ -82,6 +82,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 inline size_t dtype_size(int dt) { return dt == MMX_F32 ? 4 : 2; }
 
 void set_error(const char* fmt, ...);
+void attn_small_enable(int on);
 int hip_fail(hipError_t e, const char* what);
 
 }  // namespace mmx

@@ -725,6 +725,10 @@ extern "C" int mmx_set_option(const char* key, int value) {
         g_chain_groups = value;
         return MMX_OK;
     }
+    if (key && strcmp(key, "attn_small") == 0) {
+        attn_small_enable(value);
+        return MMX_OK;
+    }
     if (key && strcmp(key, "debug_flags") == 0) {
         g_debug_flags = value;
         return MMX_OK;
