@@ -13,6 +13,7 @@ struct AttnFwdArgs {
     float* probs; float* o; Strides os;
     int B, H, Nq, Nk, D;
     float scale; int scale_mode;
+    int debug;  // profiling only (attention_small.hip)
 };
 
 struct AttnBwdArgs {
@@ -27,7 +28,7 @@ struct AttnBwdArgs {
     float scale; int scale_mode; int need_dqkv;
 };
 
-int attn_fwd_small_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out);
+int attn_fwd_small_try(AttnFwdArgs& a, hipStream_t s, int* rc_out);
 int attn_bwd_small_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);
 
 }  // namespace mmx

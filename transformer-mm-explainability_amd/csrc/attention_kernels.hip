@@ -327,7 +327,7 @@ extern "C" int mmx_attn_capture_fwd(const void* q_dev, const void* k_dev, const 
     a.qs = {q_sb, q_sh, q_sn}; a.ks = {k_sb, k_sh, k_sn}; a.vs = {v_sb, v_sh, v_sn};
     a.mask = static_cast<const float*>(mask_dev); a.mask_sb = mask_sb; a.mask_sq = mask_sq;
     a.probs = static_cast<float*>(probs_dev); a.o = static_cast<float*>(o_dev); a.os = {o_sb, o_sh, o_sn};
-    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale; a.scale_mode = scale_mode;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale; a.scale_mode = scale_mode; a.debug = 0;
     dim3 grid((Nq + kTQ - 1) / kTQ, H, B);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (attn_fwd_small_try(a, s, &rc)) return rc;   // whole head resident in LDS (short sequences)

@@ -16,21 +16,72 @@ namespace mmx {
 
 __device__ __forceinline__ int ceil16(int x) { return (x + 15) & ~15; }
 
-// stage rows [0, rows) x [0, D) of a strided global matrix into LDS [rows_cap][LS], zero padded, times `mul`
-template <int DP>
-__device__ __forceinline__ void stage_rows_vec(float* lds, const float* base, int64_t sn, int rows, int rows_cap,
-                                               int D, float mul, int tid, int nthreads) {
+// One staging job: rows [0, rows) x [0, D) of a strided global matrix -> LDS [rows_cap][DP+4], zero padded, x mul.
+struct StageJob {
+    float* lds;
+    const float* base;
+    int64_t sn;
+    int rows, rows_cap;
+    float mul;
+};
+
+// Stage up to NJ matrices in ONE pass: the flattened 16-B chunk list of all jobs is walked with UNR loads in
+// flight per lane before the first ds_write (a plain per-matrix loop serialises ~15 global round trips per
+// workgroup, which was 80 % of the first version's run time).
+template <int DP, int NJ, int UNR>
+__device__ __forceinline__ void stage_jobs(const StageJob (&jobs)[NJ], int D, int tid, int nthreads) {
     constexpr int LS = DP + 4;
     constexpr int C4 = DP / 4;
-    for (int idx = tid; idx < rows_cap * C4; idx += nthreads) {
-        const int r = idx / C4, c = (idx - r * C4) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < rows && c < D) {
-            v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(r) * sn + c);
-            v = v * mul;
+    int start[NJ + 1];
+    start[0] = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) start[j + 1] = start[j] + jobs[j].rows_cap * C4;
+    const int total = start[NJ];
+    for (int base_idx = tid; base_idx < total; base_idx += nthreads * UNR) {
+        f32x4 v[UNR];
+        float* dst[UNR];
+        float mul[UNR];
+        // Every load is UNCONDITIONAL (invalid chunks read a clamped, always-valid address and are zeroed by `mul`):
+        // a load guarded by a divergent branch makes hipcc wait vmcnt(0) per element (cdna guide, trap (c)).
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int idx = min(base_idx + u * nthreads, total - 1);
+            // select the job with compile-time indices only: a runtime-indexed jobs[j] would live in scratch memory
+            float* lds = jobs[0].lds;
+            const float* gbase = jobs[0].base;
+            int64_t sn = jobs[0].sn;
+            int rows = jobs[0].rows, first = 0;
+            float jmul = jobs[0].mul;
+#pragma unroll
+            for (int k = 1; k < NJ; ++k)
+                if (idx >= start[k]) {
+                    lds = jobs[k].lds; gbase = jobs[k].base; sn = jobs[k].sn; rows = jobs[k].rows; jmul = jobs[k].mul;
+                    first = start[k];
+                }
+            const int local = idx - first;
+            const int r = local / C4, c = (local - r * C4) * 4;
+            const bool live = (base_idx + u * nthreads < total);
+            const bool real = live && r < rows && c < D;
+            dst[u] = live ? lds + r * LS + c : nullptr;
+            mul[u] = real ? jmul : 0.f;
+            const float* src = gbase + (real ? static_cast<int64_t>(r) * sn + c : 0);
+            v[u] = *reinterpret_cast<const f32x4*>(src);
         }
-        *reinterpret_cast<f32x4*>(lds + r * LS + c) = v;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (dst[u]) *reinterpret_cast<f32x4*>(dst[u]) = mul[u] == 0.f ? f32x4{0.f, 0.f, 0.f, 0.f} : v[u] * mul[u];
     }
+}
+
+// 16-lane butterfly reductions: a wave works on 4 rows at once (lane>>4 selects the row)
+__device__ __forceinline__ float group16_max(float x) {
+    x = fmaxf(x, __shfl_xor(x, 8)); x = fmaxf(x, __shfl_xor(x, 4));
+    x = fmaxf(x, __shfl_xor(x, 2)); x = fmaxf(x, __shfl_xor(x, 1));
+    return x;
+}
+__device__ __forceinline__ float group16_sum(float x) {
+    x += __shfl_xor(x, 8); x += __shfl_xor(x, 4); x += __shfl_xor(x, 2); x += __shfl_xor(x, 1);
+    return x;
 }
 
 // D(16x16) += A.B^T-style product where BOTH operands are contiguous along the contraction index in LDS:
@@ -102,14 +153,17 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnFwdArgs a
     const float* kb = a.k + b * a.ks.sb + h * a.ks.sh;
     const float* vb = a.v + b * a.vs.sb + h * a.vs.sh;
 
-    stage_rows_vec<DP>(Qs, qb, a.qs.sn, a.Nq, NPq, a.D, q_first ? a.scale : 1.f, tid, 256);
-    stage_rows_vec<DP>(Ks, kb, a.ks.sn, a.Nk, NPk, a.D, 1.f, tid, 256);
-    stage_rows_vec<DP>(Vs, vb, a.vs.sn, a.Nk, NPk, a.D, 1.f, tid, 256);
+    {
+        const StageJob jobs[3] = {{Qs, qb, a.qs.sn, a.Nq, NPq, q_first ? a.scale : 1.f},
+                                  {Ks, kb, a.ks.sn, a.Nk, NPk, 1.f},
+                                  {Vs, vb, a.vs.sn, a.Nk, NPk, 1.f}};
+        if (!(a.debug & 8)) stage_jobs<DP, 3, 8>(jobs, a.D, tid, 256);
+    }
     __syncthreads();
 
     // S = Q.K^T (+ mask)
     const int ntq = NPq >> 4, ntk = NPk >> 4;
-    for (int tile = wave; tile < ntq * ntk; tile += NW) {
+    for (int tile = wave; tile < ntq * ntk && !(a.debug & 1); tile += NW) {
         const int ti = tile / ntk, tj = tile - ti * ntk;
         const f32x4 acc = tile_kk(Qs + ti * 16 * LS, LS, Ks + tj * 16 * LS, LS, DP / 16, i_a, kq);
         const int key = tj * 16 + i_a;
@@ -125,28 +179,26 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnFwdArgs a
     }
     __syncthreads();
 
-    // row softmax; P -> LDS (zero padded) and -> the capture slab
+    // row softmax, 4 rows per wave at a time (16 lanes per row); P -> LDS (zero padded) and -> the capture slab
     float* pbase = a.probs + (static_cast<int64_t>(b) * a.H + h) * a.Nq * a.Nk;
-    for (int row = wave; row < NPq; row += NW) {
+    for (int row = wave * 4 + (lane >> 4); row < NPq && !(a.debug & 2); row += NW * 4) {
         float* srow = Ss + row * SS;
         if (row >= a.Nq) {
-            for (int j = lane; j < NPk; j += 64) srow[j] = 0.f;
+            for (int j = i_a; j < NPk; j += 16) srow[j] = 0.f;
             continue;
         }
         float m = -__builtin_inff();
-        for (int j = lane; j < a.Nk; j += 64) m = fmaxf(m, srow[j]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        for (int j = i_a; j < a.Nk; j += 16) m = fmaxf(m, srow[j]);
+        m = group16_max(m);
         float sum = 0.f;
-        for (int j = lane; j < a.Nk; j += 64) {
+        for (int j = i_a; j < a.Nk; j += 16) {
             const float e = expf(srow[j] - m);
             srow[j] = e;
             sum += e;
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        sum = group16_sum(sum);
         float* prow = pbase + static_cast<int64_t>(row) * a.Nk;
-        for (int j = lane; j < NPk; j += 64) {
+        for (int j = i_a; j < NPk; j += 16) {
             float p = 0.f;
             if (j < a.Nk) {
                 p = srow[j] / sum;
@@ -160,7 +212,7 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnFwdArgs a
     // O = P.V
     float* ob = a.o + b * a.os.sb + h * a.os.sh;
     constexpr int ntd = DP / 16;
-    for (int tile = wave; tile < ntq * ntd; tile += NW) {
+    for (int tile = wave; tile < ntq * ntd && !(a.debug & 4); tile += NW) {
         const int ti = tile / ntd, td = tile - ti * ntd;
         const f32x4 acc = tile_kn(Ss + ti * 16 * SS, SS, Vs + td * 16, LS, ntk, i_a, kq);
         const int d = td * 16 + i_a;
@@ -196,15 +248,37 @@ __global__ __launch_bounds__(512) void attn_bwd_small_kernel(const AttnBwdArgs a
     const float* pg = a.probs + head * a.Nq * a.Nk;
     float* dpg = a.dprobs + head * a.Nq * a.Nk;
 
-    stage_rows_vec<DP>(dOs, a.dout + b * a.os.sb + h * a.os.sh, a.os.sn, a.Nq, NPq, a.D, 1.f, tid, 512);
-    stage_rows_vec<DP>(Vs, a.v + b * a.vs.sb + h * a.vs.sh, a.vs.sn, a.Nk, NPk, a.D, 1.f, tid, 512);
-    if (a.need_dqkv) {
-        stage_rows_vec<DP>(Qs, a.q + b * a.qs.sb + h * a.qs.sh, a.qs.sn, a.Nq, NPq, a.D, q_first ? a.scale : 1.f, tid, 512);
-        stage_rows_vec<DP>(Ks, a.k + b * a.ks.sb + h * a.ks.sh, a.ks.sn, a.Nk, NPk, a.D, 1.f, tid, 512);
+    {
+        const float* qp = a.need_dqkv ? a.q + b * a.qs.sb + h * a.qs.sh : a.v;   // never read when rows_cap == 0
+        const float* kp = a.need_dqkv ? a.k + b * a.ks.sb + h * a.ks.sh : a.v;
+        // without dq/dk/dv the Q and K jobs stage zero rows (rows = 0 -> no loads)
+        const StageJob jobs[4] = {{dOs, a.dout + b * a.os.sb + h * a.os.sh, a.os.sn, a.Nq, NPq, 1.f},
+                                  {Vs, a.v + b * a.vs.sb + h * a.vs.sh, a.vs.sn, a.Nk, NPk, 1.f},
+                                  {Qs, qp, a.qs.sn, a.need_dqkv ? a.Nq : 0, a.need_dqkv ? NPq : 0, q_first ? a.scale : 1.f},
+                                  {Ks, kp, a.ks.sn, a.need_dqkv ? a.Nk : 0, a.need_dqkv ? NPk : 0, 1.f}};
+        stage_jobs<DP, 4, 8>(jobs, a.D, tid, 512);
     }
-    for (int idx = tid; idx < NPq * NPk; idx += 512) {
-        const int r = idx / NPk, j = idx - r * NPk;
-        Ps[r * SS + j] = (r < a.Nq && j < a.Nk) ? pg[static_cast<int64_t>(r) * a.Nk + j] : 0.f;
+    {   // P rows (Nk floats each, any alignment) with 8 loads in flight per lane
+        const int total = NPq * NPk;
+        for (int base_idx = tid; base_idx < total; base_idx += 512 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base_idx + u * 512;
+                const int r = idx / NPk, j = idx - r * NPk;
+                const bool real = idx < total && r < a.Nq && j < a.Nk;
+                const float x = pg[real ? static_cast<int64_t>(r) * a.Nk + j : 0];   // unconditional load
+                v[u] = real ? x : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base_idx + u * 512;
+                if (idx < total) {
+                    const int r = idx / NPk, j = idx - r * NPk;
+                    Ps[r * SS + j] = v[u];
+                }
+            }
+        }
     }
     __syncthreads();
 
@@ -218,24 +292,23 @@ __global__ __launch_bounds__(512) void attn_bwd_small_kernel(const AttnBwdArgs a
     }
     __syncthreads();
 
-    // rows: dP -> capture slab; delta = rowsum(dP*P); dS = P*(dP - delta)
-    for (int row = wave; row < NPq; row += NW) {
+    // rows (4 per wave at a time): dP -> capture slab; delta = rowsum(dP*P); dS = P*(dP - delta)
+    for (int row = wave * 4 + (lane >> 4); row < NPq; row += NW * 4) {
         float* drow = dSs + row * SS;
         if (row >= a.Nq) {
-            for (int j = lane; j < NPk; j += 64) drow[j] = 0.f;
+            for (int j = i_a; j < NPk; j += 16) drow[j] = 0.f;
             continue;
         }
         const float* prow = Ps + row * SS;
         float dot = 0.f;
-        for (int j = lane; j < a.Nk; j += 64) {
+        for (int j = i_a; j < a.Nk; j += 16) {
             const float dp = drow[j];
             dpg[static_cast<int64_t>(row) * a.Nk + j] = dp;  // the captured attention gradient
             dot += dp * prow[j];
         }
         if (!a.need_dqkv) continue;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
-        for (int j = lane; j < NPk; j += 64) {
+        dot = group16_sum(dot);
+        for (int j = i_a; j < NPk; j += 16) {
             float ds = 0.f;
             if (j < a.Nk) {
                 ds = prow[j] * (drow[j] - dot);
@@ -303,8 +376,9 @@ static size_t bwd_small_lds(int DP, int Nq, int Nk) {
     return sizeof(float) * (static_cast<size_t>(2 * NPq + 2 * NPk) * (DP + 4) + 2 * static_cast<size_t>(NPq) * (NPk + 4));
 }
 
-static int g_attn_small = 1;  // 0 forces the tiled kernels (tests / A-B profiling)
-void attn_small_enable(int on) { g_attn_small = on; }
+static int g_attn_small = 1;  // 0 forces the tiled kernels (tests / A-B profiling); bits 8.. = phase-skip debug flags
+static int g_attn_debug = 0;
+void attn_small_enable(int on) { g_attn_small = on & 1; g_attn_debug = on >> 8; }
 
 template <typename K, typename A>
 static int launch_small(K kern, const A& args, int threads, size_t lds, hipStream_t s, const char* name) {
@@ -320,7 +394,8 @@ static int launch_small(K kern, const A& args, int threads, size_t lds, hipStrea
 }
 
 // returns 1 if the small kernel was launched (rc in *rc_out), 0 if the shape is not eligible
-int attn_fwd_small_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out) {
+int attn_fwd_small_try(AttnFwdArgs& a, hipStream_t s, int* rc_out) {
+    a.debug = g_attn_debug;
     if (!g_attn_small || a.D % 4 || a.D > 64) return 0;
     const int DP = a.D <= 32 ? 32 : 64;
     const size_t lds = fwd_small_lds(DP, a.Nq, a.Nk);
