@@ -86,6 +86,16 @@ int mmx_relevancy_self_chain(const void* const* attn_layers, const void* const* 
                              const void* Rsq_init_dev, void* Rsq_out_dev, int M,
                              void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Same, with an explicit batch stride (in elements) of the ATTENTION slabs: H*N*N (or -1) for per-sample slabs, 0 when
+ * one forward pass is shared by the whole batch (the reference's CLIP `interpret` repeats ONE image B times,
+ * CLIP_explainability.ipynb cell 6:3, so the image tower's probabilities are identical for every sample while the
+ * gradients differ).  Gradient slabs are always per sample.  Needs N <= 128 and M == 0. */
+int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const void* const* grad_layers, int n_layers,
+                                int B, int H, int N, int dtype, int64_t attn_batch_stride,
+                                const void* R_init_dev, void* R_out_dev,
+                                const void* Rsq_init_dev, void* Rsq_out_dev, int M,
+                                void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Batched fp32 matmul on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32):
  *     C[b] = (accumulate ? Cin[b] : 0) + op(A[b]) . B[b],   op = transpose if trans_a
@@ -144,6 +154,9 @@ int mmx_rollout_chain(const void* const* layers, int n_layers, int B, int N, int
  * mask_dev + b*mask_sb + i*mask_sq + j (mask_sb = 0 / mask_sq = 0 broadcast).
  * `scale` is the multiplier d^-0.5 in MMX_SCALE_Q_FIRST mode and the divisor sqrt(d) in MMX_SCALE_SCORES mode
  * (the reference multiplies resp. divides; keeping the operation keeps the rounding).
+ * Backward takes `probs_sb`, the batch stride of P in elements: H*Nq*Nk for a per-sample slab, 0 when ONE forward's
+ * P is shared by every sample of the batch (shared-forward / batched-backward, see clip_explainability.py); q/k/v
+ * batch strides may be 0 likewise.  dprobs is always per sample.
  * need_dqkv = 0 skips dS/dQ/dK/dV (lowest layer: only the captured gradient is wanted).
  */
 int mmx_attn_capture_fwd(const void* q_dev, const void* k_dev, const void* v_dev,
@@ -159,7 +172,8 @@ int mmx_attn_capture_bwd(const void* q_dev, const void* k_dev, const void* v_dev
                          int64_t q_sb, int64_t q_sh, int64_t q_sn,
                          int64_t k_sb, int64_t k_sh, int64_t k_sn,
                          int64_t v_sb, int64_t v_sh, int64_t v_sn,
-                         const void* probs_dev, const void* do_dev, int64_t o_sb, int64_t o_sh, int64_t o_sn,
+                         const void* probs_dev, int64_t probs_sb,
+                         const void* do_dev, int64_t o_sb, int64_t o_sh, int64_t o_sn,
                          void* dprobs_dev,
                          void* dq_dev, void* dk_dev, void* dv_dev,
                          int64_t dq_sb, int64_t dq_sh, int64_t dq_sn,

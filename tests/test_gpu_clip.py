@@ -27,28 +27,34 @@ def load_tiny(golden):
     return g, model.cuda()
 
 
+@pytest.mark.parametrize("share", [True, False])
 @pytest.mark.parametrize("tag,sl,slt", [("last", -1, -1), ("all", 0, 0), ("mid", 1, 2)])
-def test_interpret_matches_reference_outputs(golden, tag, sl, slt):
+def test_interpret_matches_reference_outputs(golden, tag, sl, slt, share):
+    """share=True: image-tower forward run once + batched hand-written backward; False: B copies like the reference."""
     from transformer_mm_explainability_amd import clip_explainability as ce
     g, model = load_tiny(golden)
     image, texts = torch.from_numpy(g["image"]).cuda(), torch.from_numpy(g["texts"]).cuda()
-    R_text, R_image = ce.interpret(image, texts, model, "cuda", start_layer=sl, start_layer_text=slt)
+    R_text, R_image = ce.interpret(image, texts, model, "cuda", start_layer=sl, start_layer_text=slt,
+                                   share_image_forward=share)
     close(R_text, g["R_text_" + tag])
     close(R_image, g["R_image_" + tag])
     assert all(p.requires_grad for p in model.parameters())          # _Frozen restored
     assert all(p.grad is None for p in model.parameters())           # no weight gradients were computed
 
 
-def test_capture_slabs_match_reference_hooks(golden):
-    """probs/grads slabs == what the reference's set_attn_probs / set_attn_grad hooks saw."""
+@pytest.mark.parametrize("share", [True, False])
+def test_capture_slabs_match_reference_hooks(golden, share):
+    """probs/grads slabs == what the reference's set_attn_probs / set_attn_grad hooks saw (in shared-forward mode the
+    image tower keeps ONE copy of the identical probabilities, the gradients stay per sample)."""
     from transformer_mm_explainability_amd import clip_explainability as ce
     g, model = load_tiny(golden)
     image, texts = torch.from_numpy(g["image"]).cuda(), torch.from_numpy(g["texts"]).cuda()
-    ce.interpret(image, texts, model, "cuda", 0, 0)
+    ce.interpret(image, texts, model, "cuda", 0, 0, share_image_forward=share)
     vis = list(model.visual.transformer.resblocks.children())
     txt = list(model.transformer.resblocks.children())
     for l, blk in enumerate(vis):
-        close(blk.attn_probs, g["img_attn"][l], atol=1e-6)
+        want = g["img_attn"][l]
+        close(blk.attn_probs, want[:blk.attn_probs.shape[0]] if share else want, atol=1e-6)
         close(blk.attn_grad, g["img_grad"][l], atol=1e-6)
     for l, blk in enumerate(txt):
         close(blk.attn_probs, g["txt_attn"][l], atol=1e-6)
@@ -96,9 +102,10 @@ def test_vit_b32_shapes_vs_oracle():
     sd = clip_torch.prepare_state_dict(model.state_dict(), 8)
     want_text, want_img = clip_torch.interpret(sd, image, texts, 0, 0)
     model = model.cuda()
-    R_text, R_image = ce.interpret(image.cuda(), texts.cuda(), model, "cuda", 0, 0)
-    close(R_text, want_text.numpy())
-    close(R_image, want_img.numpy())
+    for share in (True, False):
+        R_text, R_image = ce.interpret(image.cuda(), texts.cuda(), model, "cuda", 0, 0, share_image_forward=share)
+        close(R_text, want_text.numpy())
+        close(R_image, want_img.numpy())
     want_text, want_img = clip_torch.interpret(sd, image, texts)         # notebook default: last layer only
     R_text, R_image = ce.interpret(image.cuda(), texts.cuda(), model, "cuda")
     close(R_text, want_text.numpy())

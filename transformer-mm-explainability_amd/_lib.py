@@ -27,6 +27,7 @@ _PROTOTYPES = {
     "mmx_avg_heads": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mmx_self_chain_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mmx_relevancy_self_chain": (_i, [_vpp, _vpp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "mmx_relevancy_self_chain_ex": (_i, [_vpp, _vpp, _i, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "mmx_bmm_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i, _vp]),
     "mmx_handle_residual": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "mmx_mm_rules_workspace_bytes": (_sz, [_i, _i]),
@@ -36,7 +37,7 @@ _PROTOTYPES = {
     "mmx_attn_capture_fwd": (_i, [_vp, _vp, _vp] + [_i64] * 9 + [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64,
                                   _i, _i, _i, _i, _i, _f, _i, _vp]),
     "mmx_attn_capture_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
-    "mmx_attn_capture_bwd": (_i, [_vp, _vp, _vp] + [_i64] * 9 + [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]
+    "mmx_attn_capture_bwd": (_i, [_vp, _vp, _vp] + [_i64] * 9 + [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]
                              + [_i64] * 9 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     "mmx_event_create": (_i, [_vpp]),
     "mmx_event_destroy": (_i, [_vp]),

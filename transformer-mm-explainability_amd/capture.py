@@ -20,10 +20,14 @@ from . import _lib, ops
 class CaptureBuffers:
     """Two ``[L, B, H, Nq, Nk]`` fp32 slabs (probabilities and their gradients) for one tower."""
 
-    def __init__(self, n_layers, batch, heads, n_q, n_k=None, device="cuda"):
+    def __init__(self, n_layers, batch, heads, n_q, n_k=None, device="cuda", shared_probs=False):
+        """``shared_probs``: the probabilities come from ONE forward pass shared by the whole batch (``probs`` has batch
+        1, ``grads`` has batch ``batch``) -- CLIP ``interpret`` repeats one image ``batch`` times."""
         n_k = n_q if n_k is None else n_k
         self.shape = (n_layers, batch, heads, n_q, n_k)
-        self.probs = torch.empty(self.shape, dtype=torch.float32, device=device)
+        self.shared_probs = shared_probs
+        self.probs = torch.empty((n_layers, 1 if shared_probs else batch, heads, n_q, n_k), dtype=torch.float32,
+                                 device=device)
         self.grads = torch.empty(self.shape, dtype=torch.float32, device=device)
 
     @property
@@ -34,13 +38,14 @@ class CaptureBuffers:
     def batch(self):
         return self.shape[1]
 
-    def matches(self, n_layers, batch, heads, n_q, n_k, device):
-        return self.shape == (n_layers, batch, heads, n_q, n_k) and self.probs.device == torch.device(device)
+    def matches(self, n_layers, batch, heads, n_q, n_k, device, shared_probs=False):
+        return self.shape == (n_layers, batch, heads, n_q, n_k) and self.probs.device == torch.device(device) \
+            and self.shared_probs == shared_probs
 
     def layer_probs(self, l):
         """``[B*H, Nq, Nk]`` view, the shape the reference's ``attn_probs`` / ``get_attn()`` has."""
         _, b, h, nq, nk = self.shape
-        return self.probs[l].view(b * h, nq, nk)
+        return self.probs[l].view(-1, nq, nk)      # [B*H, Nq, Nk] ([H, Nq, Nk] when the forward is shared)
 
     def layer_grads(self, l):
         _, b, h, nq, nk = self.shape

@@ -46,22 +46,36 @@ def _chains(model, batch_size, start_layer, start_layer_text):
     R_text = ops.relevancy_self_chain([tb.probs[l] for l in range(start_layer_text, txt.layers)],
                                       [tb.grads[l] for l in range(start_layer_text, txt.layers)], batch_size)
     R = ops.relevancy_self_chain([vb.probs[l] for l in range(start_layer, vis.layers)],
-                                 [vb.grads[l] for l in range(start_layer, vis.layers)], batch_size)
+                                 [vb.grads[l] for l in range(start_layer, vis.layers)], batch_size,
+                                 shared_attn=vb.shared_probs and batch_size > 1)
     return R_text, R
 
 
-def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1):
-    """CLIP_explainability.ipynb cell 6.  ``image``: ``[1,3,R,R]``, ``texts``: ``[B, context]`` token ids."""
+def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, share_image_forward=True):
+    """CLIP_explainability.ipynb cell 6.  ``image``: ``[1,3,R,R]``, ``texts``: ``[B, context]`` token ids.
+
+    ``share_image_forward`` (extra keyword, default on): the reference repeats the ONE image B times (cell 6:3) and
+    runs the image tower on B identical copies.  Here its forward runs once and only the backward -- whose upstream
+    gradients do differ per text -- runs at batch B (``clip_model.Transformer.forward_shared``); results are the
+    same to fp32 rounding (``tests/test_gpu_clip.py``).  ``False`` runs the B copies like the reference.
+    """
     batch_size = texts.shape[0]
-    images = image.repeat(batch_size, 1, 1, 1)
     prev = model.capture_only
     model.capture_only = True
     try:
         with _Frozen(model), torch.enable_grad():
-            logits_per_image, _ = model(images, texts)
-            # one_hot = sum_i logits_per_image[i, i]  (cell 6:6-10)  ->  d one_hot / d logits = I
-            eye = torch.eye(batch_size, dtype=logits_per_image.dtype, device=logits_per_image.device)
-            torch.autograd.backward(logits_per_image, grad_tensors=eye)
+            eye = torch.eye(batch_size, dtype=torch.float32, device=texts.device)
+            if share_image_forward and image.shape[0] == 1 and batch_size > 1:
+                feat1, state = model.visual.forward_shared(image.type(model.dtype), batch_size)
+                image_features = feat1.expand(batch_size, -1).contiguous().requires_grad_(True)   # per-sample leaf
+                logits_per_image, _ = model.logits(image_features, model.encode_text(texts))
+                torch.autograd.backward(logits_per_image, grad_tensors=eye)
+                model.visual.backward_shared(state, image_features.grad)
+            else:
+                images = image.repeat(batch_size, 1, 1, 1)
+                logits_per_image, _ = model(images, texts)
+                # one_hot = sum_i logits_per_image[i, i]  (cell 6:6-10)  ->  d one_hot / d logits = I
+                torch.autograd.backward(logits_per_image, grad_tensors=eye)
     finally:
         model.capture_only = prev
     R_text, R = _chains(model, batch_size, start_layer, start_layer_text)

@@ -28,7 +28,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, ops
 from .capture import CaptureBuffers, attention_capture_packed
 
 
@@ -107,10 +107,78 @@ class Transformer(nn.Module):
         self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask) for _ in range(layers)])
         self.buffers = None
 
-    def _ensure_buffers(self, batch, n_tokens, device):
-        if self.buffers is None or not self.buffers.matches(self.layers, batch, self.heads, n_tokens, n_tokens, device):
-            self.buffers = CaptureBuffers(self.layers, batch, self.heads, n_tokens, n_tokens, device=device)
+    def _ensure_buffers(self, batch, n_tokens, device, shared_probs=False):
+        if self.buffers is None or not self.buffers.matches(self.layers, batch, self.heads, n_tokens, n_tokens, device,
+                                                            shared_probs):
+            self.buffers = CaptureBuffers(self.layers, batch, self.heads, n_tokens, n_tokens, device=device,
+                                          shared_probs=shared_probs)
         return self.buffers
+
+    # ------------------------------------------------------------------------------------------------------------
+    # Shared-forward / batched-backward (CLIP ``interpret`` repeats ONE image B times, notebook cell 6:3): the B copies
+    # have identical activations, only the upstream gradients differ.  The forward runs ONCE at batch 1 and keeps a
+    # small tape; the backward is the same chain of vector-Jacobian products autograd would run -- input-gradient
+    # GEMMs at batch B, LayerNorm backward with the shared statistics, our attention backward kernel with batch-stride-0
+    # q/k/v/P -- written out by hand because autograd cannot replay one graph for B different upstream gradients
+    # through a custom op.  Weight gradients are never formed.
+    # ------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_shared(self, x, batch):
+        """``x``: ``[1, N, E]`` (already through ``ln_pre``).  Returns ``(y [1, N, E], tape)``."""
+        if x.shape[0] != 1:
+            raise ValueError("forward_shared takes the single shared sample")
+        N, E = x.shape[1], x.shape[2]
+        buffers = self._ensure_buffers(batch, N, x.device, shared_probs=True)
+        tape = []
+        for l, blk in enumerate(self.resblocks):
+            at = blk.attn
+            h1, mean1, rstd1 = torch.native_layer_norm(x, (E,), blk.ln_1.weight, blk.ln_1.bias, blk.ln_1.eps)
+            qkv = F.linear(h1, at.in_proj_weight, at.in_proj_bias).view(1, N, 3, at.num_heads, at.head_dim)
+            o = ops.attn_capture_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], buffers.probs[l], at.head_dim ** -0.5,
+                                     _lib.SCALE_Q_FIRST, blk.attn_mask, layout="bnhd")
+            x1 = x + at.out_proj(o.view(1, N, E))
+            h2, mean2, rstd2 = torch.native_layer_norm(x1, (E,), blk.ln_2.weight, blk.ln_2.bias, blk.ln_2.eps)
+            m = blk.mlp.c_fc(h2)
+            x2 = x1 + blk.mlp.c_proj(m * torch.sigmoid(1.702 * m))
+            tape.append((x, mean1, rstd1, qkv, x1, mean2, rstd2, m))
+            blk.attn_probs, blk.attn_grad = buffers.layer_probs(l), buffers.layer_grads(l)
+            x = x2
+        return x, tape
+
+    @staticmethod
+    def _ln_backward(dy, x, mean, rstd, ln):
+        B = dy.shape[0]
+        return torch.ops.aten.native_layer_norm_backward(
+            dy.contiguous(), x.expand(B, -1, -1).contiguous(), (x.shape[-1],), mean.expand(B, -1, -1).contiguous(),
+            rstd.expand(B, -1, -1).contiguous(), ln.weight, ln.bias, [True, False, False])[0]
+
+    @torch.no_grad()
+    def backward_shared(self, tape, dy):
+        """``dy``: ``[B, N, E]`` upstream gradients w.r.t. the tower output; fills ``buffers.grads`` for every layer."""
+        B, N, E = dy.shape
+        buffers = self.buffers
+        dx = dy
+        for l in range(self.layers - 1, -1, -1):
+            blk = self.resblocks[l]
+            at = blk.attn
+            x, mean1, rstd1, qkv, x1, mean2, rstd2, m = tape[l]
+            # MLP branch: x2 = x1 + c_proj(m * sigmoid(1.702 m)),  m = c_fc(ln_2(x1))
+            d_a = torch.matmul(dx, blk.mlp.c_proj.weight)
+            sg = torch.sigmoid(1.702 * m)
+            d_m = d_a * (sg + 1.702 * m * sg * (1 - sg))                      # QuickGELU'(m), shared across the batch
+            d_h2 = torch.matmul(d_m, blk.mlp.c_fc.weight)
+            d_x1 = dx + self._ln_backward(d_h2, x1, mean2, rstd2, blk.ln_2)
+            # attention branch: x1 = x + out_proj(attn(ln_1(x)))
+            d_o = torch.matmul(d_x1, at.out_proj.weight).view(B, N, at.num_heads, at.head_dim)
+            need = l > 0                                                      # nothing below block 0 needs gradients
+            dqkv = torch.empty(B, N, 3, at.num_heads, at.head_dim, dtype=torch.float32, device=dy.device) if need else None
+            out = (dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]) if need else None
+            ops.attn_capture_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], buffers.probs[l], d_o, buffers.grads[l],
+                                 at.head_dim ** -0.5, _lib.SCALE_Q_FIRST, need_dqkv=need, layout="bnhd", out=out, batch=B)
+            if not need:
+                break
+            d_h1 = torch.matmul(dqkv.view(B, N, 3 * E), at.in_proj_weight)
+            dx = d_x1 + self._ln_backward(d_h1, x, mean1, rstd1, blk.ln_1)
 
     def forward(self, x, capture_only=False):
         """``x``: ``[B, N, E]``.  ``capture_only``: cut the graph below block 0 and skip block 0's dq/dk/dv."""
@@ -149,13 +217,37 @@ class VisualTransformer(nn.Module):
         patches = x.reshape(B, C, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * p * p)
         return F.linear(patches, self.conv1.weight.reshape(self.conv1.out_channels, -1))
 
-    def forward(self, x, capture_only=False):
+    def _embed(self, x):
         x = self._patchify(x)                                               # [B, grid^2, width]
         cls = self.class_embedding.to(x.dtype).expand(x.shape[0], 1, -1)
-        x = torch.cat([cls, x], dim=1) + self.positional_embedding.to(x.dtype)
-        x = self.transformer(self.ln_pre(x), capture_only=capture_only)
+        return self.ln_pre(torch.cat([cls, x], dim=1) + self.positional_embedding.to(x.dtype))
+
+    def forward(self, x, capture_only=False):
+        x = self.transformer(self._embed(x), capture_only=capture_only)
         x = self.ln_post(x[:, 0, :])
         return x @ self.proj if self.proj is not None else x
+
+    @torch.no_grad()
+    def forward_shared(self, image, batch):
+        """Shared-forward mode: ``image [1, 3, R, R]`` -> ``(features [1, output_dim], tape)``; see ``Transformer``."""
+        y, tape = self.transformer.forward_shared(self._embed(image), batch)
+        cls = y[:, 0, :]
+        f, mean, rstd = torch.native_layer_norm(cls, (cls.shape[-1],), self.ln_post.weight, self.ln_post.bias,
+                                                self.ln_post.eps)
+        return f @ self.proj, (tape, y.shape, cls, mean, rstd)
+
+    @torch.no_grad()
+    def backward_shared(self, state, d_features):
+        """``d_features [B, output_dim]``: per-sample upstream gradients of the (shared) image features."""
+        tape, y_shape, cls, mean, rstd = state
+        B = d_features.shape[0]
+        d_f = torch.matmul(d_features, self.proj.t())
+        d_cls = torch.ops.aten.native_layer_norm_backward(
+            d_f.contiguous(), cls.expand(B, -1).contiguous(), (cls.shape[-1],), mean.expand(B, -1).contiguous(),
+            rstd.expand(B, -1).contiguous(), self.ln_post.weight, self.ln_post.bias, [True, False, False])[0]
+        dy = torch.zeros(B, y_shape[1], y_shape[2], dtype=torch.float32, device=d_features.device)
+        dy[:, 0, :] = d_cls                                                  # only the class token feeds the features
+        self.transformer.backward_shared(tape, dy)
 
 
 class CLIP(nn.Module):
@@ -212,8 +304,10 @@ class CLIP(nn.Module):
         return x[torch.arange(x.shape[0], device=x.device), text.argmax(dim=-1)] @ self.text_projection
 
     def forward(self, image, text):
-        image_features = self.encode_image(image)
-        text_features = self.encode_text(text)
+        return self.logits(self.encode_image(image), self.encode_text(text))
+
+    def logits(self, image_features, text_features):
+        """Cosine-similarity logits (model.py:369-378) from un-normalised features."""
         image_features = image_features / image_features.norm(dim=-1, keepdim=True)
         text_features = text_features / text_features.norm(dim=-1, keepdim=True)
         logit_scale = self.logit_scale.exp()

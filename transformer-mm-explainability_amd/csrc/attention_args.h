@@ -19,7 +19,8 @@ struct AttnFwdArgs {
 struct AttnBwdArgs {
     const float *q, *k, *v;
     Strides qs, ks, vs;
-    const float* probs; const float* dout; Strides os;
+    const float* probs; int64_t probs_sb;  // batch stride of P in elements (0: one P shared by the whole batch)
+    const float* dout; Strides os;
     float* dprobs;
     float *dq, *dk, *dv;
     Strides dqs, dks, dvs;

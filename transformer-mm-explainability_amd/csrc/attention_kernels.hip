@@ -171,11 +171,12 @@ __global__ __launch_bounds__(256) void attn_capture_bwd_q_kernel(const AttnBwdAr
             continue;
         }
         const int64_t goff = (head * a.Nq + q0 + row) * a.Nk;
+        const float* prow_g = a.probs + b * a.probs_sb + (static_cast<int64_t>(h) * a.Nq + q0 + row) * a.Nk;
         float dot = 0.f;
         for (int j = lane; j < a.Nk; j += 64) {
             const float dp = drow[j];
             a.dprobs[goff + j] = dp;  // the captured attention gradient
-            dot += dp * a.probs[goff + j];
+            dot += dp * prow_g[j];
         }
         if (!a.need_dqkv) continue;
 #pragma unroll
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void attn_capture_bwd_q_kernel(const AttnBwdAr
         for (int j = lane; j < NKP; j += 64) {
             float ds = 0.f;
             if (j < a.Nk) {
-                ds = a.probs[goff + j] * (drow[j] - dot);
+                ds = prow_g[j] * (drow[j] - dot);
                 if (!q_first) ds = ds / a.scale;
             }
             drow[j] = ds;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void attn_capture_bwd_kv_kernel(const AttnBwdA
             float p = 0.f, ds = 0.f;
             if (r < rows && j < jv) {
                 const int64_t g = (head * a.Nq + qt + r) * a.Nk + j0 + j;
-                p = a.probs[g];
+                p = a.probs[b * a.probs_sb + (static_cast<int64_t>(h) * a.Nq + qt + r) * a.Nk + j0 + j];
                 ds = p * (a.dprobs[g] - a.delta[head * a.Nq + qt + r]);
                 if (!q_first) ds = ds / a.scale;
             }
@@ -341,7 +342,7 @@ extern "C" size_t mmx_attn_capture_bwd_workspace_bytes(int B, int H, int Nq) {
 
 extern "C" int mmx_attn_capture_bwd(const void* q_dev, const void* k_dev, const void* v_dev, int64_t q_sb, int64_t q_sh,
                                     int64_t q_sn, int64_t k_sb, int64_t k_sh, int64_t k_sn, int64_t v_sb, int64_t v_sh,
-                                    int64_t v_sn, const void* probs_dev, const void* do_dev, int64_t o_sb, int64_t o_sh,
+                                    int64_t v_sn, const void* probs_dev, int64_t probs_sb, const void* do_dev, int64_t o_sb, int64_t o_sh,
                                     int64_t o_sn, void* dprobs_dev, void* dq_dev, void* dk_dev, void* dv_dev,
                                     int64_t dq_sb, int64_t dq_sh, int64_t dq_sn, int64_t dk_sb, int64_t dk_sh,
                                     int64_t dk_sn, int64_t dv_sb, int64_t dv_sh, int64_t dv_sn, int B, int H, int Nq,
@@ -361,7 +362,8 @@ extern "C" int mmx_attn_capture_bwd(const void* q_dev, const void* k_dev, const 
     AttnBwdArgs a;
     a.q = static_cast<const float*>(q_dev); a.k = static_cast<const float*>(k_dev); a.v = static_cast<const float*>(v_dev);
     a.qs = {q_sb, q_sh, q_sn}; a.ks = {k_sb, k_sh, k_sn}; a.vs = {v_sb, v_sh, v_sn};
-    a.probs = static_cast<const float*>(probs_dev); a.dout = static_cast<const float*>(do_dev); a.os = {o_sb, o_sh, o_sn};
+    a.probs = static_cast<const float*>(probs_dev); a.probs_sb = probs_sb;
+    a.dout = static_cast<const float*>(do_dev); a.os = {o_sb, o_sh, o_sn};
     a.dprobs = static_cast<float*>(dprobs_dev);
     a.dq = static_cast<float*>(dq_dev); a.dk = static_cast<float*>(dk_dev); a.dv = static_cast<float*>(dv_dev);
     a.dqs = {dq_sb, dq_sh, dq_sn}; a.dks = {dk_sb, dk_sh, dk_sn}; a.dvs = {dv_sb, dv_sh, dv_sn};

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(512) void attn_bwd_small_kernel(const AttnBwdArgs a
     const int i_a = lane & 15, kq = (lane >> 4) * 4;
     const bool q_first = (a.scale_mode == MMX_SCALE_Q_FIRST);
     const int64_t head = static_cast<int64_t>(b) * a.H + h;
-    const float* pg = a.probs + head * a.Nq * a.Nk;
+    const float* pg = a.probs + b * a.probs_sb + static_cast<int64_t>(h) * a.Nq * a.Nk;
     float* dpg = a.dprobs + head * a.Nq * a.Nk;
 
     {

@@ -70,6 +70,7 @@ struct ChainArgs {
     float* parts;
     unsigned* counters;
     int debug;  // profiling only: bit0 = return before the hand-off/combine, bit2 = matrix waves skip the MFMAs
+    int64_t attn_bstride;  // batch stride of the attention slabs in elements (H*N*N, or 0: one forward shared by the batch)
 };
 
 constexpr int kChainThreads = 1024;
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
         const int lt = tid - NT * 64;
         const float fH = static_cast<float>(H);
         const int64_t sample = static_cast<int64_t>(b) * H * NN;
+        const int64_t sampleA = static_cast<int64_t>(b) * a.attn_bstride;
         const int nchunks = static_cast<int>((NN + 3) >> 2);
         for (int l = 0; l < L; ++l) {
             float* Ab = smem + (l & 1) * NP * S;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
                 if (p + 3 < NN) {
 #pragma unroll 4
                     for (int h = 0; h < H; ++h) {
-                        const f32x4 av = load4_as_f32<DT>(A, sample + h * NN + p);
+                        const f32x4 av = load4_as_f32<DT>(A, sampleA + h * NN + p);
                         const f32x4 gv = load4_as_f32<DT>(Gr, sample + h * NN + p);
                         const f32x4 x = gv * av;
                         s[0] += relu_nan(x[0]); s[1] += relu_nan(x[1]);
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
                     for (int e = 0; p + e < NN; ++e)
                         for (int h = 0; h < H; ++h)
                             s[e] += relu_nan(load1_as_f32<DT>(Gr, sample + h * NN + p + e) *
-                                             load1_as_f32<DT>(A, sample + h * NN + p + e));
+                                             load1_as_f32<DT>(A, sampleA + h * NN + p + e));
                 }
                 int row = static_cast<int>(p / N);
                 int cc = static_cast<int>(p - static_cast<int64_t>(row) * N);
@@ -288,6 +290,7 @@ struct ChainV2Args {
     const float* R_init;
     float* R_out;
     int debug;           // profiling only: bit0 = skip the chain phase, bit1 = skip the streaming phase
+    int64_t attn_bstride;  // as in ChainArgs
 };
 
 constexpr int kV2Threads = 512;
@@ -314,6 +317,7 @@ __global__ __launch_bounds__(kV2Threads) void self_chain_v2_kernel(const ChainV2
         const void* A = a.attn[l0];
         const void* G = a.grad[l0];
         const int64_t sample = static_cast<int64_t>(b) * H * NN;
+        const int64_t sampleA = static_cast<int64_t>(b) * a.attn_bstride;
         const int64_t slab = static_cast<int64_t>(a.B) * H * NN;
         float* img = a.abar + (static_cast<int64_t>(l0) * a.B + b) * img_elems;
         const float fH = static_cast<float>(H);
@@ -324,10 +328,11 @@ __global__ __launch_bounds__(kV2Threads) void self_chain_v2_kernel(const ChainV2
             const int64_t p = static_cast<int64_t>(row) * N + col;
             const int valid = min(4, N - col);
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            if (sample + (H - 1) * NN + p + 3 < slab) {  // 16-B loads stay inside the layer slab
+            // 16-B loads stay inside the layer slabs (the shared-forward attention slab holds one sample only)
+            if (sample + (H - 1) * NN + p + 3 < slab && (a.attn_bstride != 0 || (H - 1) * NN + p + 3 < H * NN)) {
 #pragma unroll 4
                 for (int h = 0; h < H; ++h) {
-                    const f32x4 av = load4_as_f32<DT>(A, sample + h * NN + p);
+                    const f32x4 av = load4_as_f32<DT>(A, sampleA + h * NN + p);
                     const f32x4 gv = load4_as_f32<DT>(G, sample + h * NN + p);
                     const f32x4 x = gv * av;
                     s[0] += relu_nan(x[0]); s[1] += relu_nan(x[1]);
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(kV2Threads) void self_chain_v2_kernel(const ChainV2
                 for (int e = 0; e < valid; ++e)
                     for (int h = 0; h < H; ++h)
                         s[e] += relu_nan(load1_as_f32<DT>(G, sample + h * NN + p + e) *
-                                         load1_as_f32<DT>(A, sample + h * NN + p + e));
+                                         load1_as_f32<DT>(A, sampleA + h * NN + p + e));
             }
             f32x2 lo = {valid > 0 ? s[0] / fH : 0.f, valid > 1 ? s[1] / fH : 0.f};
             f32x2 hi = {valid > 2 ? s[2] / fH : 0.f, valid > 3 ? s[3] / fH : 0.f};
@@ -828,6 +833,19 @@ extern "C" int mmx_relevancy_self_chain(const void* const* attn_layers, const vo
                                         int B, int H, int N, int dtype, const void* R_init_dev, void* R_out_dev,
                                         const void* Rsq_init_dev, void* Rsq_out_dev, int M, void* workspace_dev,
                                         size_t workspace_bytes, void* stream) {
+    return mmx_relevancy_self_chain_ex(attn_layers, grad_layers, n_layers, B, H, N, dtype, -1, R_init_dev, R_out_dev,
+                                       Rsq_init_dev, Rsq_out_dev, M, workspace_dev, workspace_bytes, stream);
+}
+
+extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const void* const* grad_layers, int n_layers,
+                                           int B, int H, int N, int dtype, int64_t attn_batch_stride,
+                                           const void* R_init_dev, void* R_out_dev, const void* Rsq_init_dev,
+                                           void* Rsq_out_dev, int M, void* workspace_dev, size_t workspace_bytes,
+                                           void* stream) {
+    const int64_t full_stride = static_cast<int64_t>(H) * N * N;
+    if (attn_batch_stride < 0) attn_batch_stride = full_stride;
+    MMX_CHECK_ARG(attn_batch_stride == 0 || attn_batch_stride == full_stride,
+                  "mmx_relevancy_self_chain_ex: attn_batch_stride must be 0 (shared forward) or H*N*N");
     MMX_CHECK_ARG(attn_layers && grad_layers && R_out_dev, "mmx_relevancy_self_chain: null pointer");
     MMX_CHECK_ARG(n_layers >= 0 && n_layers <= MMX_MAX_LAYERS, "mmx_relevancy_self_chain: n_layers %d not in [0, %d]",
                   n_layers, MMX_MAX_LAYERS);
@@ -852,6 +870,7 @@ extern "C" int mmx_relevancy_self_chain(const void* const* attn_layers, const vo
         args.R_init = static_cast<const float*>(R_init_dev);
         args.R_out = static_cast<float*>(R_out_dev);
         args.debug = g_debug_flags;
+        args.attn_bstride = attn_batch_stride;
         switch (nt) {
             case 1: return launch_v2<1>(args, dtype, workspace_dev, s);
             case 2: return launch_v2<2>(args, dtype, workspace_dev, s);
@@ -872,6 +891,7 @@ extern "C" int mmx_relevancy_self_chain(const void* const* attn_layers, const vo
         args.R_out = static_cast<float*>(R_out_dev);
         args.G = fused_groups(n_layers, B, H, N);
         args.debug = g_debug_flags;
+        args.attn_bstride = attn_batch_stride;
         if (args.G > 1) {
             const size_t need = mmx_self_chain_workspace_bytes(n_layers, B, H, N, M, dtype);
             if (workspace_bytes < need || !workspace_dev) {
@@ -893,6 +913,10 @@ extern "C" int mmx_relevancy_self_chain(const void* const* attn_layers, const vo
         }
     }
 
+    if (attn_batch_stride != full_stride) {
+        set_error("mmx_relevancy_self_chain_ex: shared-forward attention slabs need N <= 128 and no R_sq (fused kernels)");
+        return MMX_ENOTSUP;
+    }
     // ---- split path: per layer  A_bar = avg_heads(A_l, G_l);  R' = R + A_bar . R  [; R_sq' = R_sq + A_bar . R_sq]
     const size_t need = mmx_self_chain_workspace_bytes(n_layers, B, H, N, M, dtype);
     if (workspace_bytes < need || !workspace_dev) {

@@ -80,10 +80,12 @@ def avg_heads(cam, grad, batch_size=1):
 
 
 # ------------------------------------------------------------------------------------------- fused chain
-def relevancy_self_chain(attn_layers, grad_layers, batch_size, R_init=None, R_sq_init=None):
+def relevancy_self_chain(attn_layers, grad_layers, batch_size, R_init=None, R_sq_init=None, shared_attn=False):
     """All-layer chain ``R <- R + A_bar_l @ R`` (``R_0 = I`` or ``R_init``) [and ``R_sq`` likewise] in one call.
 
     ``attn_layers[l]`` / ``grad_layers[l]``: ``[B*H, N, N]`` or ``[B, H, N, N]`` (fp32/fp16/bf16).
+    ``shared_attn=True``: ``attn_layers[l]`` holds ONE sample's heads (``[H, N, N]``) shared by all ``batch_size``
+    samples of ``grad_layers[l]`` (shared-forward mode; read with batch stride 0).
     Returns ``R [B, N, N]`` (and ``R_sq [B, N, M]`` when ``R_sq_init`` is given).
     """
     if len(attn_layers) != len(grad_layers):
@@ -101,10 +103,11 @@ def relevancy_self_chain(attn_layers, grad_layers, batch_size, R_init=None, R_sq
     dt = _DTYPES[attn[0].dtype] if attn else _lib.MMX_F32
     heads = 1
     for a, g in zip(attn, grad):
-        if a.shape != g.shape or a.dtype != attn[0].dtype or g.dtype != attn[0].dtype or a.shape[-1] != n or a.shape[-2] != n:
+        if (a.shape != g.shape and not shared_attn) or a.dtype != attn[0].dtype or g.dtype != attn[0].dtype \
+                or a.shape[-1] != n or a.shape[-2] != n or (shared_attn and a.numel() * batch_size != g.numel()):
             raise MMXError("self_chain: inconsistent layer shapes/dtypes")
     if attn:
-        bh = attn[0].numel() // (n * n)
+        bh = grad[0].numel() // (n * n)
         if bh % batch_size:
             raise MMXError("self_chain: %d matrices not divisible by batch %d" % (bh, batch_size))
         heads = bh // batch_size
@@ -122,9 +125,9 @@ def relevancy_self_chain(attn_layers, grad_layers, batch_size, R_init=None, R_sq
     ws = _workspace(need, device)
     at, _k1 = _lib.ptr_table([a.data_ptr() for a in attn])
     gt, _k2 = _lib.ptr_table([g.data_ptr() for g in grad])
-    check(lib().mmx_relevancy_self_chain(at, gt, len(attn), batch_size, heads, n, dt, _p(R_init), _p(R_out),
-                                         _p(R_sq_init), _p(sq_out), m, _p(ws), need, _stream()),
-          "mmx_relevancy_self_chain")
+    check(lib().mmx_relevancy_self_chain_ex(at, gt, len(attn), batch_size, heads, n, dt, 0 if shared_attn else -1,
+                                            _p(R_init), _p(R_out), _p(R_sq_init), _p(sq_out), m, _p(ws), need,
+                                            _stream()), "mmx_relevancy_self_chain_ex")
     return (R_out, sq_out) if sq_out is not None else R_out
 
 
@@ -256,9 +259,11 @@ def attn_capture_fwd(q, k, v, probs_out, scale, scale_mode=_lib.SCALE_Q_FIRST, m
 
 
 def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCALE_Q_FIRST, need_dqkv=True,
-                     layout="bnhd", out=None):
+                     layout="bnhd", out=None, batch=None):
     """Writes dP into ``dprobs_out`` and returns ``(dq, dk, dv)`` (``None`` when ``need_dqkv`` is False).
-    ``out=(dq, dk, dv)`` lets the caller hand in (strided) views, e.g. of one packed dqkv tensor."""
+    ``out=(dq, dk, dv)`` lets the caller hand in (strided) views, e.g. of one packed dqkv tensor.
+    ``batch``: shared-forward mode -- q/k/v/probs come from ONE forward (batch 1) and are broadcast (stride 0) over the
+    ``batch`` upstream gradients in ``d_o``; dq/dk/dv/dprobs are per sample."""
     _dev(q, k, v, probs, d_o, dprobs_out)
     if layout == "bnhd":
         B, Nq, H, D = q.shape
@@ -266,6 +271,13 @@ def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCA
     else:
         B, H, Nq, D = q.shape
         Nk = k.shape[2]
+    shared = batch is not None and batch != B
+    if shared:
+        if B != 1:
+            raise MMXError("shared-forward backward needs batch-1 q/k/v")
+        B = batch
+        q, k, v = (t.expand(B, *t.shape[1:]) for t in (q, k, v))      # stride-0 views, no copy
+    probs_sb = 0 if shared else H * Nq * Nk
     if d_o.stride(-1) != 1:
         d_o = d_o.contiguous()
     dq = dk = dv = None
@@ -275,13 +287,13 @@ def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCA
         if out is not None:
             dq, dk, dv = out
         else:
-            dq, dk, dv = (torch.empty(t.shape, dtype=torch.float32, device=t.device) for t in (q, k, v))
+            dq, dk, dv = (torch.empty(tuple(t.shape), dtype=torch.float32, device=t.device) for t in (q, k, v))
         need = lib().mmx_attn_capture_bwd_workspace_bytes(B, H, Nq)
         ws = _workspace(need, q.device, "attn_bwd")
     zero3 = (0, 0, 0)
     check(lib().mmx_attn_capture_bwd(
         _p(q), _p(k), _p(v), *_bhnd_strides(q, layout), *_bhnd_strides(k, layout), *_bhnd_strides(v, layout),
-        _p(probs), _p(d_o), *_bhnd_strides(d_o, layout), _p(dprobs_out), _p(dq), _p(dk), _p(dv),
+        _p(probs), probs_sb, _p(d_o), *_bhnd_strides(d_o, layout), _p(dprobs_out), _p(dq), _p(dk), _p(dv),
         *(_bhnd_strides(dq, layout) if need_dqkv else zero3), *(_bhnd_strides(dk, layout) if need_dqkv else zero3),
         *(_bhnd_strides(dv, layout) if need_dqkv else zero3),
         B, H, Nq, Nk, D, float(scale), scale_mode, int(need_dqkv), _p(ws), need, _stream()), "mmx_attn_capture_bwd")
