@@ -60,8 +60,10 @@ def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, 
     same to fp32 rounding (``tests/test_gpu_clip.py``).  ``False`` runs the B copies like the reference.
     """
     batch_size = texts.shape[0]
-    prev = model.capture_only
-    model.capture_only = True
+    sl = model.visual.transformer.layers - 1 if start_layer == -1 else start_layer
+    slt = model.transformer.layers - 1 if start_layer_text == -1 else start_layer_text
+    prev = (model.capture_only, model.first_grad_layers)
+    model.capture_only, model.first_grad_layers = True, (sl, slt)    # no gradient work below the start layers
     try:
         with _Frozen(model), torch.enable_grad():
             eye = torch.eye(batch_size, dtype=torch.float32, device=texts.device)
@@ -70,14 +72,14 @@ def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, 
                 image_features = feat1.expand(batch_size, -1).contiguous().requires_grad_(True)   # per-sample leaf
                 logits_per_image, _ = model.logits(image_features, model.encode_text(texts))
                 torch.autograd.backward(logits_per_image, grad_tensors=eye)
-                model.visual.backward_shared(state, image_features.grad)
+                model.visual.backward_shared(state, image_features.grad, sl)
             else:
                 images = image.repeat(batch_size, 1, 1, 1)
                 logits_per_image, _ = model(images, texts)
                 # one_hot = sum_i logits_per_image[i, i]  (cell 6:6-10)  ->  d one_hot / d logits = I
                 torch.autograd.backward(logits_per_image, grad_tensors=eye)
     finally:
-        model.capture_only = prev
+        model.capture_only, model.first_grad_layers = prev
     R_text, R = _chains(model, batch_size, start_layer, start_layer_text)
     image_relevance = R[:, 0, 1:]
     return R_text, image_relevance
@@ -85,8 +87,8 @@ def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, 
 
 def interpret_single(image, text, model, device, index=None):
     """CLIP/example.py:8-32 without the plotting: returns ``image_relevance [Ni-1]`` (``R[0,0]`` zeroed first)."""
-    prev = model.capture_only
-    model.capture_only = True
+    prev = (model.capture_only, model.first_grad_layers)
+    model.capture_only, model.first_grad_layers = True, (0, model.transformer.layers)   # text tower: no gradient work
     try:
         with _Frozen(model), torch.enable_grad():
             logits_per_image, _ = model(image, text)
@@ -96,7 +98,7 @@ def interpret_single(image, text, model, device, index=None):
             one_hot[0, index] = 1
             torch.autograd.backward(logits_per_image, grad_tensors=one_hot)
     finally:
-        model.capture_only = prev
+        model.capture_only, model.first_grad_layers = prev
     vis = model.visual.transformer
     vb = vis.buffers
     # example.py flattens batch*heads into one head axis (cam.reshape(-1, N, N).mean(0)): batch_size = 1 here

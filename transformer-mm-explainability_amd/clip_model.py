@@ -153,12 +153,13 @@ class Transformer(nn.Module):
             rstd.expand(B, -1, -1).contiguous(), ln.weight, ln.bias, [True, False, False])[0]
 
     @torch.no_grad()
-    def backward_shared(self, tape, dy):
-        """``dy``: ``[B, N, E]`` upstream gradients w.r.t. the tower output; fills ``buffers.grads`` for every layer."""
+    def backward_shared(self, tape, dy, first_grad_layer=0):
+        """``dy``: ``[B, N, E]`` upstream gradients w.r.t. the tower output; fills ``buffers.grads`` of every block
+        ``>= first_grad_layer``."""
         B, N, E = dy.shape
         buffers = self.buffers
         dx = dy
-        for l in range(self.layers - 1, -1, -1):
+        for l in range(self.layers - 1, first_grad_layer - 1, -1):
             blk = self.resblocks[l]
             at = blk.attn
             x, mean1, rstd1, qkv, x1, mean2, rstd2, m = tape[l]
@@ -170,7 +171,7 @@ class Transformer(nn.Module):
             d_x1 = dx + self._ln_backward(d_h2, x1, mean2, rstd2, blk.ln_2)
             # attention branch: x1 = x + out_proj(attn(ln_1(x)))
             d_o = torch.matmul(d_x1, at.out_proj.weight).view(B, N, at.num_heads, at.head_dim)
-            need = l > 0                                                      # nothing below block 0 needs gradients
+            need = l > first_grad_layer                                       # nothing below needs gradients
             dqkv = torch.empty(B, N, 3, at.num_heads, at.head_dim, dtype=torch.float32, device=dy.device) if need else None
             out = (dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]) if need else None
             ops.attn_capture_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], buffers.probs[l], d_o, buffers.grads[l],
@@ -180,16 +181,24 @@ class Transformer(nn.Module):
             d_h1 = torch.matmul(dqkv.view(B, N, 3 * E), at.in_proj_weight)
             dx = d_x1 + self._ln_backward(d_h1, x, mean1, rstd1, blk.ln_1)
 
-    def forward(self, x, capture_only=False):
-        """``x``: ``[B, N, E]``.  ``capture_only``: cut the graph below block 0 and skip block 0's dq/dk/dv."""
+    def forward(self, x, capture_only=False, first_grad_layer=0):
+        """``x``: ``[B, N, E]``.  ``capture_only``: only d(loss)/d(probs) of blocks ``>= first_grad_layer`` is wanted
+        (``start_layer`` of the explainability pass): blocks below run without an autograd graph, the graph is cut at
+        the input of block ``first_grad_layer`` and that block skips its dq/dk/dv."""
         if not x.is_cuda:
             raise _lib.MMXError("the CLIP body runs its attention on the HIP capture op: move the model and "
                                 "inputs to the MI355X (there is no CPU attention path)")
         buffers = self._ensure_buffers(x.shape[0], x.shape[1], x.device)
-        if capture_only:
-            x = x.detach().requires_grad_(True)
-        for l, blk in enumerate(self.resblocks):
-            x = blk(x, buffers, l, need_dqkv=not (capture_only and l == 0))
+        if not capture_only:
+            for l, blk in enumerate(self.resblocks):
+                x = blk(x, buffers, l)
+            return x
+        with torch.no_grad():
+            for l in range(first_grad_layer):
+                x = self.resblocks[l](x, buffers, l)
+        x = x.detach().requires_grad_(True)
+        for l in range(first_grad_layer, self.layers):
+            x = self.resblocks[l](x, buffers, l, need_dqkv=(l != first_grad_layer))
         return x
 
 
@@ -222,8 +231,8 @@ class VisualTransformer(nn.Module):
         cls = self.class_embedding.to(x.dtype).expand(x.shape[0], 1, -1)
         return self.ln_pre(torch.cat([cls, x], dim=1) + self.positional_embedding.to(x.dtype))
 
-    def forward(self, x, capture_only=False):
-        x = self.transformer(self._embed(x), capture_only=capture_only)
+    def forward(self, x, capture_only=False, first_grad_layer=0):
+        x = self.transformer(self._embed(x), capture_only=capture_only, first_grad_layer=first_grad_layer)
         x = self.ln_post(x[:, 0, :])
         return x @ self.proj if self.proj is not None else x
 
@@ -237,7 +246,7 @@ class VisualTransformer(nn.Module):
         return f @ self.proj, (tape, y.shape, cls, mean, rstd)
 
     @torch.no_grad()
-    def backward_shared(self, state, d_features):
+    def backward_shared(self, state, d_features, first_grad_layer=0):
         """``d_features [B, output_dim]``: per-sample upstream gradients of the (shared) image features."""
         tape, y_shape, cls, mean, rstd = state
         B = d_features.shape[0]
@@ -247,7 +256,7 @@ class VisualTransformer(nn.Module):
             rstd.expand(B, -1).contiguous(), self.ln_post.weight, self.ln_post.bias, [True, False, False])[0]
         dy = torch.zeros(B, y_shape[1], y_shape[2], dtype=torch.float32, device=d_features.device)
         dy[:, 0, :] = d_cls                                                  # only the class token feeds the features
-        self.transformer.backward_shared(tape, dy)
+        self.transformer.backward_shared(tape, dy, first_grad_layer)
 
 
 class CLIP(nn.Module):
@@ -270,6 +279,7 @@ class CLIP(nn.Module):
         self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
         self.capture_only = False
+        self.first_grad_layers = (0, 0)     # (image tower, text tower) start layers of a capture-only pass
         self.initialize_parameters()
 
     def initialize_parameters(self):
@@ -294,11 +304,12 @@ class CLIP(nn.Module):
         return self.visual.conv1.weight.dtype
 
     def encode_image(self, image):
-        return self.visual(image.type(self.dtype), capture_only=self.capture_only)
+        return self.visual(image.type(self.dtype), capture_only=self.capture_only,
+                           first_grad_layer=self.first_grad_layers[0])
 
     def encode_text(self, text):
         x = self.token_embedding(text).type(self.dtype) + self.positional_embedding.type(self.dtype)
-        x = self.transformer(x, capture_only=self.capture_only)
+        x = self.transformer(x, capture_only=self.capture_only, first_grad_layer=self.first_grad_layers[1])
         x = self.ln_final(x)
         # features at the EOT token = highest token id in each sequence (model.py:360)
         return x[torch.arange(x.shape[0], device=x.device), text.argmax(dim=-1)] @ self.text_projection
