@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
                 const int64_t p = static_cast<int64_t>(c) * 4;
                 f32x4 s = {0.f, 0.f, 0.f, 0.f};
                 if (p + 3 < NN) {
-#pragma unroll 4
+#pragma unroll 4  // measured: 2 / 6 / 8 heads per batch are slower (profiles/r01_chain_probe.txt)
                     for (int h = 0; h < H; ++h) {
                         const f32x4 av = load4_as_f32<DT>(A, sampleA + h * NN + p);
                         const f32x4 gv = load4_as_f32<DT>(Gr, sample + h * NN + p);
