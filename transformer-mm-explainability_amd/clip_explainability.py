@@ -43,12 +43,19 @@ def _chains(model, batch_size, start_layer, start_layer_text):
     vb, tb = vis.buffers, txt.buffers
     # Same stream, back to back: each launch already fills the chip (layer-group split), and measured on MI355X two
     # concurrent chain kernels on two streams are slower than the two in sequence (profiles/r01_chain_probe.txt).
-    R_text = ops.relevancy_self_chain([tb.probs[l] for l in range(start_layer_text, txt.layers)],
-                                      [tb.grads[l] for l in range(start_layer_text, txt.layers)], batch_size)
-    R = ops.relevancy_self_chain([vb.probs[l] for l in range(start_layer, vis.layers)],
-                                 [vb.grads[l] for l in range(start_layer, vis.layers)], batch_size,
-                                 shared_attn=vb.shared_probs and batch_size > 1)
+    R_text = _plan(tb, start_layer_text, txt.layers, batch_size, False).launch()
+    R = _plan(vb, start_layer, vis.layers, batch_size, vb.shared_probs and batch_size > 1).launch()
     return R_text, R
+
+
+def _plan(buffers, first, last, batch_size, shared):
+    """Prepared chain launch, cached on the slab object (the slabs keep their addresses from call to call)."""
+    cache = buffers.__dict__.setdefault("_chain_plans", {})
+    key = (first, last, batch_size, shared)
+    if key not in cache:
+        cache[key] = ops.ChainPlan([buffers.probs[l] for l in range(first, last)],
+                                   [buffers.grads[l] for l in range(first, last)], batch_size, shared_attn=shared)
+    return cache[key]
 
 
 def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, share_image_forward=True):

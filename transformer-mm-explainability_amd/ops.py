@@ -131,6 +131,43 @@ def relevancy_self_chain(attn_layers, grad_layers, batch_size, R_init=None, R_sq
     return (R_out, sq_out) if sq_out is not None else R_out
 
 
+class ChainPlan:
+    """A prepared ``relevancy_self_chain`` launch over persistent slabs: pointer tables, scratch and the output tensor are
+    built once; ``launch()`` is a single C call (no per-call Python tensor plumbing).  The captured slabs of a tower
+    keep their addresses from step to step, so the plan stays valid as long as the tensors it references are alive."""
+
+    def __init__(self, attn_layers, grad_layers, batch_size, shared_attn=False):
+        _dev(*attn_layers, *grad_layers)
+        self.attn = [_capture(a) for a in attn_layers]
+        self.grad = [_capture(g) for g in grad_layers]
+        if not self.attn or len(self.attn) != len(self.grad) or len(self.attn) > _lib.MAX_LAYERS:
+            raise MMXError("ChainPlan: need 1..%d (attn, grad) layer pairs" % _lib.MAX_LAYERS)
+        g0 = self.grad[0]
+        self.n = g0.shape[-1]
+        self.batch = batch_size
+        self.heads = g0.numel() // (self.n * self.n) // batch_size
+        self.dt = _DTYPES[g0.dtype]
+        self.shared = 0 if shared_attn else -1
+        for a, g in zip(self.attn, self.grad):
+            if g.shape != g0.shape or g.dtype != g0.dtype or a.dtype != g0.dtype or \
+                    a.numel() * (batch_size if shared_attn else 1) != g.numel():
+                raise MMXError("ChainPlan: inconsistent layer shapes/dtypes")
+        self.device = g0.device
+        self.need = lib().mmx_self_chain_workspace_bytes(len(self.attn), batch_size, self.heads, self.n, 0, self.dt)
+        self.ws = torch.empty(max(self.need, 1), dtype=torch.uint8, device=g0.device)
+        self.at, self._k1 = _lib.ptr_table([a.data_ptr() for a in self.attn])
+        self.gt, self._k2 = _lib.ptr_table([g.data_ptr() for g in self.grad])
+
+    def launch(self, out=None):
+        """Enqueue on torch's current stream; returns ``R [B, N, N]`` (a fresh tensor unless ``out`` is given)."""
+        if out is None:
+            out = torch.empty(self.batch, self.n, self.n, dtype=torch.float32, device=self.device)
+        check(lib().mmx_relevancy_self_chain_ex(self.at, self.gt, len(self.attn), self.batch, self.heads, self.n, self.dt,
+                                                self.shared, None, _p(out), None, None, 0, _p(self.ws), self.need,
+                                                _stream()), "mmx_relevancy_self_chain_ex")
+        return out
+
+
 # ------------------------------------------------------------------------------------------- matmul
 def matmul(a, b, add_to=None, trans_a=False, nan_to_zero=False):
     """fp32 ``op(a) @ b (+ add_to)`` on the exact-fp32 MFMA; 2-D or batched 3-D (2-D operands broadcast)."""
