@@ -131,6 +131,28 @@ int mmx_mm_attention_rules(const void* R_ss_dev, const void* R_qq_dev, const voi
                            void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The whole bi-modal (two-stream, LXMERT-style) schedule in ONE launch -- rules 5, 6, 7, 10, 11 and eq. 8-9:
+ *   n_lang language + n_vis vision self-attention layers, then n_x cross layers (language cross, image cross, language
+ *   self, image self; the last cross layer runs its language half only), finally R_tt[0,0] = 0.
+ * replaces the rule schedule of GeneratorOurs.generate_ours (lxmert/lxmert/src/ExplanationGenerator.py:131-211 with the
+ * helpers :18-54, 61-129).  One workgroup per sample keeps every relevancy matrix in LDS; needs T, I <= 48.
+ *   all tables: HOST arrays of device pointers to fp32 [B, H, Nq, Nk] slabs: lang/x_lang_self [.,.,T,T],
+ *   vis/x_img_self [.,.,I,I], x_lang_cross [.,.,T,I], x_img_cross [.,.,I,T]; the image tables need n_x-1 entries.
+ *   flags: MMX_MM_NORMALIZE | MMX_MM_SELF_IN_RULE10 (NaNs propagate like the reference's LXMERT variant).
+ *   outputs fp32: R_tt [B,T,T], R_ti [B,T,I], optional R_ii [B,I,I], R_it [B,I,T]; diag_min_dev as in
+ *   mmx_handle_residual (min over all normalisations), may be NULL.
+ */
+int mmx_lxmert_schedule(const void* const* lang_attn, const void* const* lang_grad, int n_lang,
+                        const void* const* vis_attn, const void* const* vis_grad, int n_vis,
+                        const void* const* x_lang_cross_attn, const void* const* x_lang_cross_grad,
+                        const void* const* x_img_cross_attn, const void* const* x_img_cross_grad,
+                        const void* const* x_lang_self_attn, const void* const* x_lang_self_grad,
+                        const void* const* x_img_self_attn, const void* const* x_img_self_grad, int n_x,
+                        int B, int H, int T, int I, unsigned flags,
+                        void* R_tt_dev, void* R_ti_dev, void* R_ii_dev, void* R_it_dev,
+                        void* diag_min_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Attention rollout: prod_{i >= start}( (A_i + I) [/ rowsum] ), left-multiplied.
  * replaces compute_rollout_attention (DETR/.../ExplanationGenerator.py:5-16, lxmert/...:5-15 with
  * normalize=1; VisualBERT/.../ExplanationGenerator.py:5-17 batched with normalize=0).

@@ -1,0 +1,54 @@
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/mmx_relevancy.h declares (no compute calls);
+argument validation that needs no GPU returns the documented error codes."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from transformer_mm_explainability_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "transformer-mm-explainability_amd", "csrc"), "-j4"], check=True,
+                       capture_output=True)
+    return _lib
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    handle = lib.lib()
+    declared = lib.header_symbols()
+    assert len(declared) >= 20
+    missing = [s for s in declared if not hasattr(handle, s)]
+    assert not missing, missing
+    assert set(lib._PROTOTYPES) == set(declared), set(lib._PROTOTYPES) ^ set(declared)
+    assert handle.mmx_abi_version() == 1
+
+
+def test_argument_validation_without_gpu(lib):
+    handle = lib.lib()
+    null = C.c_void_p(0)
+    assert handle.mmx_avg_heads(null, null, null, 1, 1, 1, 1, 0, null) == -22           # MMX_EINVAL: null pointers
+    assert b"null" in handle.mmx_last_error()
+    assert handle.mmx_set_option(b"no_such_option", 1) == -22
+    assert handle.mmx_set_option(b"self_chain_groups", 0) == 0
+    assert handle.mmx_self_chain_workspace_bytes(12, 64, 8, 300, 0, 0) > 0              # split path needs scratch
+    assert handle.mmx_mm_rules_workspace_bytes(20, 36) > 0
+
+
+def test_no_cpu_fallback():
+    """CPU tensors are refused loudly; the package never imports the oracle."""
+    import torch
+    from transformer_mm_explainability_amd import ops
+    from transformer_mm_explainability_amd._lib import MMXError
+    with pytest.raises(MMXError):
+        ops.avg_heads(torch.rand(2, 4, 4), torch.rand(2, 4, 4))
+    pkg = os.path.join(ROOT, "transformer-mm-explainability_amd")
+    for name in os.listdir(pkg):
+        if name.endswith(".py"):
+            src = open(os.path.join(pkg, name)).read()
+            assert "import oracle" not in src and "from oracle" not in src, name

@@ -119,10 +119,13 @@ def lxmert_usage(g):
     ("lxmert_chain_full", {}),
     ("lxmert_chain_nonorm", {"normalize_self_attention": False}),
 ])
-def test_lxmert_generate_ours(golden, name, flags):
+@pytest.mark.parametrize("fused", [True, False])
+def test_lxmert_generate_ours(golden, name, flags, fused):
+    """fused=True: the whole schedule in one kernel launch (mmx_lxmert_schedule); False: per-rule kernels."""
     from transformer_mm_explainability_amd import lxmert_explainability as le
     g = golden(name)
     gen = le.GeneratorOurs(lxmert_usage(g))
+    gen.fused = fused
     R_t_t, R_t_i = gen.generate_ours(None, use_lrp=False, **flags)
     close(R_t_t, g["R_t_t"])
     close(R_t_i, g["R_t_i"])

@@ -32,6 +32,8 @@ _PROTOTYPES = {
     "mmx_handle_residual": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "mmx_mm_rules_workspace_bytes": (_sz, [_i, _i]),
     "mmx_mm_attention_rules": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _u, _vp, _vp, _sz, _vp]),
+    "mmx_lxmert_schedule": (_i, [_vpp, _vpp, _i, _vpp, _vpp, _i] + [_vpp] * 8 + [_i, _i, _i, _i, _i, _u,
+                                 _vp, _vp, _vp, _vp, _vp, _vp]),
     "mmx_rollout_workspace_bytes": (_sz, [_i, _i]),
     "mmx_rollout_chain": (_i, [_vpp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "mmx_attn_capture_fwd": (_i, [_vp, _vp, _vp] + [_i64] * 9 + [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64,

@@ -46,6 +46,19 @@ class GeneratorOurs:
     def __init__(self, model_usage, save_visualization=False):
         self.model_usage = model_usage
         self.save_visualization = save_visualization
+        self.fused = True   # one-launch schedule kernel when T, I <= 48; False forces the per-rule kernels
+
+    def _generate_ours_fused(self, model):
+        """All 38 rule applications in ONE kernel launch (``mmx_lxmert_schedule``); same results as the per-rule path."""
+        enc = model.lxmert.encoder
+        xs = list(enc.x_layers)
+        R_tt, R_ti, R_ii, R_it = ops.lxmert_schedule(
+            [_pair(b.attention.self) for b in enc.layer], [_pair(b.attention.self) for b in enc.r_layers],
+            [_pair(b.visual_attention.att) for b in xs], [_pair(b.visual_attention_copy.att) for b in xs[:-1]],
+            [_pair(b.lang_self_att.self) for b in xs], [_pair(b.visn_self_att.self) for b in xs[:-1]],
+            apply_normalization=self.normalize_self_attention, apply_self_in_rule_10=self.apply_self_in_rule_10)
+        self.R_t_t, self.R_t_i, self.R_i_i, self.R_i_t = R_tt[0], R_ti[0], R_ii[0], R_it[0]
+        return self.R_t_t, self.R_t_i
 
     # ---- single-stream pieces: rules 6+7 for a list of blocks in one chain launch
     def _self_chain(self, pairs, R_ss, R_sq):
@@ -90,6 +103,8 @@ class GeneratorOurs:
         text_tokens = self.model_usage.text_len
         image_bboxes = self.model_usage.image_boxes_len
         dev = model.device
+        if max(text_tokens, image_bboxes) <= ops.LXMERT_FUSED_MAX_TOKENS and self.fused:
+            return self._generate_ours_fused(model)
         self.R_t_t = torch.eye(text_tokens, text_tokens, device=dev)
         self.R_i_i = torch.eye(image_bboxes, image_bboxes, device=dev)
         self.R_t_i = torch.zeros(text_tokens, image_bboxes, device=dev)

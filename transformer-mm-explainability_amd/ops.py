@@ -235,6 +235,48 @@ def mm_attention_rules(R_ss, R_qq, cam_sq, R_qs=None, apply_normalization=True, 
     return (sq_add, ss_add) if R_qs is not None else sq_add
 
 
+LXMERT_FUSED_MAX_TOKENS = 48
+
+
+def lxmert_schedule(lang, vis, x_lang_cross, x_img_cross, x_lang_self, x_img_self, apply_normalization=True,
+                    apply_self_in_rule_10=True, check_diag=True):
+    """The whole LXMERT rule schedule in one launch.  Every argument is a list of ``(attn, grad)`` pairs of fp32
+    ``[B, H, Nq, Nk]`` tensors (``x_img_*`` may omit the last cross layer).  Returns ``(R_tt, R_ti, R_ii, R_it)``
+    with a leading batch dim."""
+    groups = [lang, vis, x_lang_cross, x_img_cross, x_lang_self, x_img_self]
+    flat = [t for grp in groups for pair in grp for t in pair]
+    _dev(*flat)
+    if any(t.dtype != torch.float32 for t in flat):
+        raise MMXError("lxmert_schedule: fp32 capture slabs only")
+    keep = [[(a.contiguous(), g.contiguous()) for a, g in grp] for grp in groups]
+    a0 = keep[2][0][0]                                     # [B, H, T, I]
+    B, H, T, I = a0.shape
+    n_x = len(keep[2])
+    if len(keep[4]) != n_x or len(keep[3]) < n_x - 1 or len(keep[5]) < n_x - 1:
+        raise MMXError("lxmert_schedule: inconsistent cross-layer lists")
+    dev = a0.device
+    R_tt = torch.empty(B, T, T, dtype=torch.float32, device=dev)
+    R_ti = torch.empty(B, T, I, dtype=torch.float32, device=dev)
+    R_ii = torch.empty(B, I, I, dtype=torch.float32, device=dev)
+    R_it = torch.empty(B, I, T, dtype=torch.float32, device=dev)
+    want_diag = check_diag and apply_normalization and apply_self_in_rule_10
+    dmin = torch.empty(1, dtype=torch.float32, device=dev) if want_diag else None
+    tables, alive = [], []
+    for grp in keep:
+        for which in (0, 1):
+            tbl, arr = _lib.ptr_table([pair[which].data_ptr() for pair in grp])
+            tables.append(tbl)
+            alive.append(arr)
+    flags = (_lib.MM_NORMALIZE if apply_normalization else 0) | (_lib.MM_SELF_IN_RULE10 if apply_self_in_rule_10 else 0)
+    la, lg, va, vg, xlca, xlcg, xica, xicg, xlsa, xlsg, xisa, xisg = tables
+    check(lib().mmx_lxmert_schedule(la, lg, len(keep[0]), va, vg, len(keep[1]), xlca, xlcg, xica, xicg, xlsa, xlsg,
+                                    xisa, xisg, n_x, B, H, T, I, flags, _p(R_tt), _p(R_ti), _p(R_ii), _p(R_it), _p(dmin),
+                                    _stream()), "mmx_lxmert_schedule")
+    if want_diag:
+        assert dmin.item() >= 0   # the reference's handle_residual assert
+    return R_tt, R_ti, R_ii, R_it
+
+
 # ------------------------------------------------------------------------------------------- rollout
 def rollout_chain(layers, normalize):
     """``layers``: list of ``[B, N, N]`` (or ``[N, N]``) fp32 maps, already sliced to ``start_layer:``."""
