@@ -89,7 +89,7 @@ int mmx_relevancy_self_chain(const void* const* attn_layers, const void* const* 
 /* Same, with an explicit batch stride (in elements) of the ATTENTION slabs: H*N*N (or -1) for per-sample slabs, 0 when
  * one forward pass is shared by the whole batch (the reference's CLIP `interpret` repeats ONE image B times,
  * CLIP_explainability.ipynb cell 6:3, so the image tower's probabilities are identical for every sample while the
- * gradients differ).  Gradient slabs are always per sample.  Needs N <= 128 and M == 0. */
+ * gradients differ).  Gradient slabs are always per sample. */
 int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const void* const* grad_layers, int n_layers,
                                 int B, int H, int N, int dtype, int64_t attn_batch_stride,
                                 const void* R_init_dev, void* R_out_dev,

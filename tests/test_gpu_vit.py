@@ -1,0 +1,57 @@
+"""-m gpu: ViT body on the HIP capture op + generate_relevance (notebook path) + the batched-target variant
+ against the torch CPU oracle (oracle/vit_torch.py; model body parity is unpinned, see there)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, atol=1e-5, rtol=1e-4):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def build(img, patch, dim, depth, heads, classes, seed=0):
+    from transformer_mm_explainability_amd import vit_model
+    torch.manual_seed(seed)
+    model = vit_model.VisionTransformer(img_size=img, patch_size=patch, embed_dim=dim, depth=depth, num_heads=heads,
+                                        num_classes=classes).float().eval()
+    # make the (zero-initialised) biases / head non-trivial so every path carries signal
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.02)
+        model.head.weight.mul_(10)
+    return model
+
+
+@pytest.mark.parametrize("img,patch,dim,depth,heads", [(64, 16, 128, 3, 2), (224, 16, 192, 2, 3)])
+def test_generate_relevance_and_batched_targets(img, patch, dim, depth, heads):
+    """(224,16) gives N = 197 tokens: tiled attention kernels + split chain path; (64,16) N = 17: whole-head kernels."""
+    from oracle import vit_torch
+    from transformer_mm_explainability_amd import vit_explainability as ve
+    from transformer_mm_explainability_amd import vit_model
+    model = build(img, patch, dim, depth, heads, classes=11)
+    x = torch.randn(1, 3, img, img, generator=torch.Generator().manual_seed(1))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    want = {}
+    for idx in (None, 3, 7):
+        want[idx], logits_ref = vit_torch.generate_relevance(sd, x, heads, idx)
+    model = model.cuda()
+    xc = x.cuda()
+    logits = model(xc, register_hook=True)
+    close(logits, logits_ref, atol=2e-5)
+    for idx in (None, 3, 7):
+        close(ve.generate_relevance(model, xc, index=idx), want[idx])
+    blk = model.blocks[0].attn
+    assert blk.get_attention_map().shape == (1, heads, (img // patch) ** 2 + 1, (img // patch) ** 2 + 1)
+    assert blk.get_attn_gradients().shape == blk.get_attention_map().shape
+    # K targets, one forward
+    multi = vit_model.generate_relevance_multi(model, xc, [3, 7, 0])
+    close(multi[0], want[3])
+    close(multi[1], want[7])
+    single = vit_model.generate_relevance_multi(model, xc, [7])
+    close(single[0], want[7])

@@ -15,17 +15,19 @@ namespace mmx {
 template <int DT>
 __global__ __launch_bounds__(256) void avg_heads_kernel(const void* __restrict__ attn,
                                                         const void* __restrict__ grad,
-                                                        float* __restrict__ out, int H, int64_t NN) {
+                                                        float* __restrict__ out, int H, int64_t NN,
+                                                        int64_t attn_bstride) {
     const int b = blockIdx.y;
     const int64_t p = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
     if (p >= NN) return;
     const int64_t base = static_cast<int64_t>(b) * H * NN + p;
+    const int64_t base_a = static_cast<int64_t>(b) * attn_bstride + p;   // attn_bstride = 0: one forward shared by the batch
     const float fH = static_cast<float>(H);
     if (p + 3 < NN) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
         for (int h = 0; h < H; ++h) {
-            const f32x4 a = load4_as_f32<DT>(attn, base + h * NN);
+            const f32x4 a = load4_as_f32<DT>(attn, base_a + h * NN);
             const f32x4 g = load4_as_f32<DT>(grad, base + h * NN);
             const f32x4 x = g * a;
             s[0] += relu_nan(x[0]); s[1] += relu_nan(x[1]);
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(256) void avg_heads_kernel(const void* __restrict__
         for (int e = 0; p + e < NN; ++e) {
             float s = 0.f;
             for (int h = 0; h < H; ++h)
-                s += relu_nan(load1_as_f32<DT>(grad, base + h * NN + e) * load1_as_f32<DT>(attn, base + h * NN + e));
+                s += relu_nan(load1_as_f32<DT>(grad, base + h * NN + e) * load1_as_f32<DT>(attn, base_a + h * NN + e));
             out[static_cast<int64_t>(b) * NN + p + e] = s / fH;
         }
     }
@@ -574,8 +576,8 @@ __global__ __launch_bounds__(256) void row_normalise_kernel(const float* __restr
 // =====================================================================================================
 using namespace mmx;
 
-extern "C" int mmx_avg_heads(const void* attn_dev, const void* grad_dev, void* out_dev, int B, int H, int Nq,
-                             int Nk, int dtype, void* stream) {
+static int avg_heads_launch(const void* attn_dev, const void* grad_dev, void* out_dev, int B, int H, int Nq, int Nk,
+                            int dtype, int64_t attn_bstride, void* stream) {
     MMX_CHECK_ARG(attn_dev && grad_dev && out_dev, "mmx_avg_heads: null pointer");
     MMX_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0, "mmx_avg_heads: non-positive size B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
     const int64_t NN = static_cast<int64_t>(Nq) * Nk;
@@ -583,13 +585,18 @@ extern "C" int mmx_avg_heads(const void* attn_dev, const void* grad_dev, void* o
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* out = static_cast<float*>(out_dev);
     switch (dtype) {
-        case MMX_F32: avg_heads_kernel<MMX_F32><<<grid, 256, 0, s>>>(attn_dev, grad_dev, out, H, NN); break;
-        case MMX_F16: avg_heads_kernel<MMX_F16><<<grid, 256, 0, s>>>(attn_dev, grad_dev, out, H, NN); break;
-        case MMX_BF16: avg_heads_kernel<MMX_BF16><<<grid, 256, 0, s>>>(attn_dev, grad_dev, out, H, NN); break;
+        case MMX_F32: avg_heads_kernel<MMX_F32><<<grid, 256, 0, s>>>(attn_dev, grad_dev, out, H, NN, attn_bstride); break;
+        case MMX_F16: avg_heads_kernel<MMX_F16><<<grid, 256, 0, s>>>(attn_dev, grad_dev, out, H, NN, attn_bstride); break;
+        case MMX_BF16: avg_heads_kernel<MMX_BF16><<<grid, 256, 0, s>>>(attn_dev, grad_dev, out, H, NN, attn_bstride); break;
         default: set_error("mmx_avg_heads: unsupported dtype %d", dtype); return MMX_EINVAL;
     }
     MMX_LAUNCH_CHECK("avg_heads_kernel");
     return MMX_OK;
+}
+
+extern "C" int mmx_avg_heads(const void* attn_dev, const void* grad_dev, void* out_dev, int B, int H, int Nq,
+                             int Nk, int dtype, void* stream) {
+    return avg_heads_launch(attn_dev, grad_dev, out_dev, B, H, Nq, Nk, dtype, static_cast<int64_t>(H) * Nq * Nk, stream);
 }
 
 extern "C" int mmx_bmm_f32(const void* A_dev, const void* B_dev, const void* Cin_dev, void* C_dev, int batch, int M,
@@ -913,10 +920,6 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
         }
     }
 
-    if (attn_batch_stride != full_stride) {
-        set_error("mmx_relevancy_self_chain_ex: shared-forward attention slabs need N <= 128 and no R_sq (fused kernels)");
-        return MMX_ENOTSUP;
-    }
     // ---- split path: per layer  A_bar = avg_heads(A_l, G_l);  R' = R + A_bar . R  [; R_sq' = R_sq + A_bar . R_sq]
     const size_t need = mmx_self_chain_workspace_bytes(n_layers, B, H, N, M, dtype);
     if (workspace_bytes < need || !workspace_dev) {
@@ -952,7 +955,7 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
         if (e != hipSuccess) return hip_fail(e, "init R_sq");
     }
     for (int l = 0; l < n_layers; ++l) {
-        int rc = mmx_avg_heads(attn_layers[l], grad_layers[l], abar, B, H, N, N, dtype, stream);
+        int rc = avg_heads_launch(attn_layers[l], grad_layers[l], abar, B, H, N, N, dtype, attn_batch_stride, stream);
         if (rc) return rc;
         float* Rnxt = (Rcur == Rout) ? Rpong : Rout;
         rc = mmx_bmm_f32(abar, Rcur, Rcur, Rnxt, B, N, N, N, 0, nn, nn, nn, 0, stream);
