@@ -164,6 +164,18 @@ int mmx_rollout_chain(const void* const* layers, int n_layers, int B, int N, int
                       void* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * On-device post-processing of relevancy maps (one workgroup per map, no host round trip):
+ *  mmx_heatmap_bilinear_minmax: [B, g, g] patch maps -> bilinear upsample to [B, S, S] (torch interpolate semantics,
+ *    align_corners=False) + min-max normalisation; replaces CLIP_explainability.ipynb cell 7:14-18 and
+ *    Transformer_MM_explainability_ViT.ipynb cell 8:25-28.  g <= 64.
+ *  mmx_otsu_masks: [K, n] maps -> min-max to [0,255], truncate to 8 bit, Otsu threshold (OpenCV getThreshVal_Otsu_8u),
+ *    masks [K, n] fp32 in {0, 255}; thresholds_dev: optional int32 [K]; replaces DETR/mask_generator.py:116-121
+ *    (D2H copy + cv2.threshold per kept query).
+ */
+int mmx_heatmap_bilinear_minmax(const void* in_dev, void* out_dev, int B, int g, int S, void* stream);
+int mmx_otsu_masks(const void* cam_dev, void* masks_dev, void* thresholds_dev, int K, int n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Attention-capture op (replaces the save_attn / save_attn_gradients Python hooks):
  * forward : P = softmax(scale.Q.K^T + mask) written straight into the caller's capture slab, O = P.V
  * backward: dP = dO.V^T written straight into the caller's gradient slab (this IS the hooked

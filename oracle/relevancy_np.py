@@ -306,3 +306,43 @@ def gradcam(cam, grad):
     grad = _f32(grad).reshape(-1, grad.shape[-2], grad.shape[-1])
     grad = grad.mean(axis=(1, 2), keepdims=True, dtype=F32)
     return np.maximum((cam * grad).mean(axis=0, dtype=F32), F32(0))
+
+
+# --------------------------------------------------------------------------- post-processing (section 8f row 3)
+def heatmap_bilinear_minmax(image_relevance, size=224):
+    """CLIP_explainability.ipynb cell 7:14-18 executed with the SAME torch op the reference calls (CPU)."""
+    import torch
+    rel = torch.as_tensor(np.asarray(image_relevance, dtype=F32))
+    dim = int(rel.numel() ** 0.5)
+    rel = torch.nn.functional.interpolate(rel.reshape(1, 1, dim, dim), size=size, mode="bilinear").reshape(size, size)
+    rel = rel.numpy()
+    return (rel - rel.min()) / (rel.max() - rel.min())
+
+
+def otsu_mask(cam):
+    """DETR/mask_generator.py:116-121.  ``cv2`` is absent here (and its version is unpinned in the reference's
+    requirements.txt), so ``cv2.threshold(..., THRESH_BINARY + THRESH_OTSU)`` is restated from OpenCV's published
+    ``getThreshVal_Otsu_8u`` (imgproc/thresh.cpp) -- PARITY UNPINNED for this one step.  Returns ``(mask, threshold)``."""
+    cam = _f32(cam)
+    cam = (cam - cam.min()) / (cam.max() - cam.min()) * F32(255)
+    img = cam.astype(np.uint8)
+    hist = np.bincount(img.reshape(-1), minlength=256).astype(np.float64)
+    n = img.size
+    scale = 1.0 / n
+    mu = float((np.arange(256) * hist).sum()) * scale
+    mu1 = q1 = max_sigma = 0.0
+    max_val = 0
+    eps = float(np.finfo(np.float32).eps)
+    for i in range(256):
+        p_i = hist[i] * scale
+        mu1 *= q1
+        q1 += p_i
+        q2 = 1.0 - q1
+        if min(q1, q2) < eps or max(q1, q2) > 1.0 - eps:
+            continue
+        mu1 = (mu1 + i * p_i) / q1
+        mu2 = (mu - q1 * mu1) / q2
+        sigma = q1 * q2 * (mu1 - mu2) ** 2
+        if sigma > max_sigma:
+            max_sigma, max_val = sigma, i
+    return np.where(img > max_val, F32(255), F32(0)).astype(F32), max_val

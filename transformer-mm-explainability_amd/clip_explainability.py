@@ -123,8 +123,7 @@ def text_scores(text_encoding, R_text):
 
 
 def image_heatmap(image_relevance, size=224):
-    """Notebook cell 7:14-18: reshape to the patch grid, bilinear upsample, min-max normalise -> ``[size,size]``."""
-    dim = int(image_relevance.numel() ** 0.5)
-    rel = image_relevance.reshape(1, 1, dim, dim)
-    rel = torch.nn.functional.interpolate(rel, size=size, mode="bilinear").reshape(size, size)
-    return (rel - rel.min()) / (rel.max() - rel.min())
+    """Notebook cell 7:14-18: reshape to the patch grid, bilinear upsample, min-max normalise -> ``[size, size]``
+    (``postprocess.image_heatmaps`` does a whole batch in one launch)."""
+    from .postprocess import image_heatmaps
+    return image_heatmaps(image_relevance.reshape(-1), size)
