@@ -73,14 +73,20 @@ __device__ __forceinline__ void stage_jobs(const StageJob (&jobs)[NJ], int D, in
     }
 }
 
-// 16-lane butterfly reductions: a wave works on 4 rows at once (lane>>4 selects the row)
+// 16-lane all-reduce on DPP row rotations (row_ror:8/4/2/1; a DPP "row" is 16 lanes): a wave works on 4 rows of the
+// score matrix at once (lane>>4 selects the row).  VALU-only -- __shfl_xor would go through ds_bpermute (LDS pipe,
+// ~10x the latency), and these reductions sit on the softmax critical path.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float group16_max(float x) {
-    x = fmaxf(x, __shfl_xor(x, 8)); x = fmaxf(x, __shfl_xor(x, 4));
-    x = fmaxf(x, __shfl_xor(x, 2)); x = fmaxf(x, __shfl_xor(x, 1));
+    x = fmaxf(x, dpp_row<0x128>(x)); x = fmaxf(x, dpp_row<0x124>(x));
+    x = fmaxf(x, dpp_row<0x122>(x)); x = fmaxf(x, dpp_row<0x121>(x));
     return x;
 }
 __device__ __forceinline__ float group16_sum(float x) {
-    x += __shfl_xor(x, 8); x += __shfl_xor(x, 4); x += __shfl_xor(x, 2); x += __shfl_xor(x, 1);
+    x += dpp_row<0x128>(x); x += dpp_row<0x124>(x); x += dpp_row<0x122>(x); x += dpp_row<0x121>(x);
     return x;
 }
 
@@ -135,9 +141,9 @@ __device__ __forceinline__ f32x4 tile_nn(const float* pa, int lda, const float* 
 
 // ---------------------------------------------------------------------------------------------- forward
 template <int DP>
-__global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnFwdArgs a) {
+__global__ __launch_bounds__(512) void attn_fwd_small_kernel(const AttnFwdArgs a) {
     constexpr int LS = DP + 4;
-    constexpr int NW = 4;
+    constexpr int NW = 8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int NPq = ceil16(a.Nq), NPk = ceil16(a.Nk), SS = NPk + 4;
     float* Qs = smem;
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnFwdArgs a
         const StageJob jobs[3] = {{Qs, qb, a.qs.sn, a.Nq, NPq, q_first ? a.scale : 1.f},
                                   {Ks, kb, a.ks.sn, a.Nk, NPk, 1.f},
                                   {Vs, vb, a.vs.sn, a.Nk, NPk, 1.f}};
-        if (!(a.debug & 8)) stage_jobs<DP, 3, 8>(jobs, a.D, tid, 256);
+        if (!(a.debug & 8)) stage_jobs<DP, 3, 8>(jobs, a.D, tid, 512);
     }
     __syncthreads();
 
@@ -227,10 +233,12 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const AttnFwdArgs a
 }
 
 // ---------------------------------------------------------------------------------------------- backward
+constexpr int kBwdThreads = 1024;   // 16 waves: the dQ/dK/dV tile pool (48-60 tiles) is the longest phase
+
 template <int DP>
-__global__ __launch_bounds__(512) void attn_bwd_small_kernel(const AttnBwdArgs a) {
+__global__ __launch_bounds__(kBwdThreads) void attn_bwd_small_kernel(const AttnBwdArgs a) {
     constexpr int LS = DP + 4;
-    constexpr int NW = 8;
+    constexpr int NW = kBwdThreads / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int NPq = ceil16(a.Nq), NPk = ceil16(a.Nk), SS = NPk + 4;
     float* Qs = smem;
@@ -256,15 +264,15 @@ __global__ __launch_bounds__(512) void attn_bwd_small_kernel(const AttnBwdArgs a
                                   {Vs, a.v + b * a.vs.sb + h * a.vs.sh, a.vs.sn, a.Nk, NPk, 1.f},
                                   {Qs, qp, a.qs.sn, a.need_dqkv ? a.Nq : 0, a.need_dqkv ? NPq : 0, q_first ? a.scale : 1.f},
                                   {Ks, kp, a.ks.sn, a.need_dqkv ? a.Nk : 0, a.need_dqkv ? NPk : 0, 1.f}};
-        stage_jobs<DP, 4, 8>(jobs, a.D, tid, 512);
+        stage_jobs<DP, 4, 8>(jobs, a.D, tid, kBwdThreads);
     }
     {   // P rows (Nk floats each, any alignment) with 8 loads in flight per lane
         const int total = NPq * NPk;
-        for (int base_idx = tid; base_idx < total; base_idx += 512 * 8) {
+        for (int base_idx = tid; base_idx < total; base_idx += kBwdThreads * 8) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int idx = base_idx + u * 512;
+                const int idx = base_idx + u * kBwdThreads;
                 const int r = idx / NPk, j = idx - r * NPk;
                 const bool real = idx < total && r < a.Nq && j < a.Nk;
                 const float x = pg[real ? static_cast<int64_t>(r) * a.Nk + j : 0];   // unconditional load
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(512) void attn_bwd_small_kernel(const AttnBwdArgs a
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int idx = base_idx + u * 512;
+                const int idx = base_idx + u * kBwdThreads;
                 if (idx < total) {
                     const int r = idx / NPk, j = idx - r * NPk;
                     Ps[r * SS + j] = v[u];
@@ -403,8 +411,8 @@ int attn_fwd_small_try(AttnFwdArgs& a, hipStream_t s, int* rc_out) {
     if (!aligned16(a.q, a.qs.sb, a.qs.sh, a.qs.sn) || !aligned16(a.k, a.ks.sb, a.ks.sh, a.ks.sn) ||
         !aligned16(a.v, a.vs.sb, a.vs.sh, a.vs.sn))
         return 0;
-    *rc_out = DP == 32 ? launch_small(attn_fwd_small_kernel<32>, a, 256, lds, s, "attn_fwd_small_kernel<32>")
-                       : launch_small(attn_fwd_small_kernel<64>, a, 256, lds, s, "attn_fwd_small_kernel<64>");
+    *rc_out = DP == 32 ? launch_small(attn_fwd_small_kernel<32>, a, 512, lds, s, "attn_fwd_small_kernel<32>")
+                       : launch_small(attn_fwd_small_kernel<64>, a, 512, lds, s, "attn_fwd_small_kernel<64>");
     return 1;
 }
 
@@ -416,8 +424,8 @@ int attn_bwd_small_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out) {
     if (!aligned16(a.v, a.vs.sb, a.vs.sh, a.vs.sn) || !aligned16(a.dout, a.os.sb, a.os.sh, a.os.sn)) return 0;
     if (a.need_dqkv && (!aligned16(a.q, a.qs.sb, a.qs.sh, a.qs.sn) || !aligned16(a.k, a.ks.sb, a.ks.sh, a.ks.sn)))
         return 0;
-    *rc_out = DP == 32 ? launch_small(attn_bwd_small_kernel<32>, a, 512, lds, s, "attn_bwd_small_kernel<32>")
-                       : launch_small(attn_bwd_small_kernel<64>, a, 512, lds, s, "attn_bwd_small_kernel<64>");
+    *rc_out = DP == 32 ? launch_small(attn_bwd_small_kernel<32>, a, kBwdThreads, lds, s, "attn_bwd_small_kernel<32>")
+                       : launch_small(attn_bwd_small_kernel<64>, a, kBwdThreads, lds, s, "attn_bwd_small_kernel<64>");
     return 1;
 }
 
