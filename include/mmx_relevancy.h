@@ -217,6 +217,14 @@ int mmx_attn_capture_bwd(const void* q_dev, const void* k_dev, const void* v_dev
                          int need_dqkv, void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused QuickGELU of the CLIP body's MLP, y = x * sigmoid(1.702 x) (CLIP/clip/model.py:162-164): one HBM pass forward,
+ * one backward (dx from x and dy; nothing saved but x) instead of PyTorch's 3 + 5 elementwise kernels.
+ * fp32, contiguous, 16-byte aligned, n elements.
+ */
+int mmx_quick_gelu_fwd(const void* x_dev, void* y_dev, int64_t n, void* stream);
+int mmx_quick_gelu_bwd(const void* x_dev, const void* dy_dev, void* dx_dev, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Kernel timing helper for bench.py: runs `fn`-independent HIP-event timing on `stream` is done in
  * Python via these thin wrappers so that events live on the SAME stream the kernels are launched on.
  */

@@ -257,3 +257,17 @@ def test_attn_capture_fwd_bwd(ops, B, H, Nq, Nk, D, mode, masked, small):
     assert ops.attn_capture_bwd(qc, kc, vc, probs, d_o.cuda(), dprobs2, scale, mode, need_dqkv=False) == (None, None, None)
     ops.set_option("attn_small", 1)
     assert torch.equal(dprobs, dprobs2)
+
+
+@pytest.mark.parametrize("shape", [(4928, 2048), (7, 13), (1, 3), (3, 4)])
+def test_quick_gelu_fused(ops, shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(*shape, generator=g) * 3).cuda().requires_grad_(True)
+    up = torch.randn(*shape, generator=g).cuda()
+    y = ops.quick_gelu(x)
+    y.backward(up)
+    xr = x.detach().double().requires_grad_(True)
+    yr = xr * torch.sigmoid(1.702 * xr)
+    yr.backward(up.double())
+    close(y, yr.detach().float().cpu().numpy(), atol=2e-6)
+    close(x.grad, xr.grad.float().cpu().numpy(), atol=2e-6)

@@ -34,7 +34,9 @@ from .capture import CaptureBuffers, attention_capture_packed
 
 class QuickGELU(nn.Module):
     def forward(self, x):
-        return x * torch.sigmoid(1.702 * x)
+        if x.is_cuda and x.dtype == torch.float32:
+            return ops.quick_gelu(x)            # one fused HBM pass forward, one backward
+        return x * torch.sigmoid(1.702 * x)     # parameter-only / CPU use of the module (no attention can run there)
 
 
 class _OutProj(nn.Linear):

@@ -131,6 +131,32 @@ def relevancy_self_chain(attn_layers, grad_layers, batch_size, R_init=None, R_sq
     return (R_out, sq_out) if sq_out is not None else R_out
 
 
+class _QuickGELU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib().mmx_quick_gelu_fwd(_p(x), _p(y), x.numel(), _stream()), "mmx_quick_gelu_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        check(lib().mmx_quick_gelu_bwd(_p(x), _p(dy), _p(dx), x.numel(), _stream()), "mmx_quick_gelu_bwd")
+        return dx
+
+
+def quick_gelu(x):
+    """``x * sigmoid(1.702 x)`` as one fused pass forward and one backward (fp32 HIP tensors)."""
+    _dev(x)
+    if x.dtype != torch.float32:
+        raise MMXError("quick_gelu: fp32 only")
+    return _QuickGELU.apply(x)
+
+
 class ChainPlan:
     """A prepared ``relevancy_self_chain`` launch over persistent slabs: pointer tables, scratch and the output tensor are
     built once; ``launch()`` is a single C call (no per-call Python tensor plumbing).  The captured slabs of a tower
