@@ -224,6 +224,13 @@ int mmx_attn_capture_bwd(const void* q_dev, const void* k_dev, const void* v_dev
 int mmx_quick_gelu_fwd(const void* x_dev, void* y_dev, int64_t n, void* stream);
 int mmx_quick_gelu_bwd(const void* x_dev, const void* dy_dev, void* dx_dev, int64_t n, void* stream);
 
+/* LayerNorm input gradient + residual add with forward statistics shared by the batch (shared-forward backward of the
+ * CLIP image tower / ViT): dx[r] = d_res[r] + LN'(dy[r]; x[r % x_rows], mean, rstd, gamma).  dy, d_res (may be NULL),
+ * dx: [rows, E]; x: [x_rows, E]; mean, rstd: [x_rows]; gamma: [E]; fp32 contiguous, E % 4 == 0. */
+int mmx_layernorm_bwd_add(const void* dy_dev, const void* x_dev, const void* mean_dev, const void* rstd_dev,
+                          const void* gamma_dev, const void* d_res_dev, void* dx_dev, int64_t rows, int x_rows, int E,
+                          void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Kernel timing helper for bench.py: runs `fn`-independent HIP-event timing on `stream` is done in
  * Python via these thin wrappers so that events live on the SAME stream the kernels are launched on.

@@ -65,6 +65,19 @@ def test_capture_slabs_match_reference_hooks(golden, share):
     close(logits, g["logits_per_image"], atol=2e-5)
 
 
+@pytest.mark.parametrize("tag,sl,slt", [("last", -1, -1), ("all", 0, 0), ("mid", 1, 2)])
+def test_interpret_trim_text_padding(golden, tag, sl, slt):
+    """Running the text tower only up to the last EOT token gives the reference's full [B, 77, 77] result."""
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    g, model = load_tiny(golden)
+    image, texts = torch.from_numpy(g["image"]).cuda(), torch.from_numpy(g["texts"]).cuda()
+    assert int(texts.argmax(-1).max()) + 1 < texts.shape[1]          # the fixture's captions are padded
+    R_text, R_image = ce.interpret(image, texts, model, "cuda", start_layer=sl, start_layer_text=slt,
+                                   trim_text_padding=True)
+    close(R_text, g["R_text_" + tag])
+    close(R_image, g["R_image_" + tag])
+
+
 def test_full_backward_param_grads_match_oracle(golden):
     """With capture_only off the op is a normal differentiable attention: parameter grads == torch CPU oracle."""
     from oracle import clip_torch
@@ -112,3 +125,21 @@ def test_vit_b32_shapes_vs_oracle():
     close(R_image, want_img.numpy())
     single = ce.interpret_single(image.cuda(), texts.cuda(), model, "cuda", index=1)
     assert single.shape == (49,)
+
+
+@pytest.mark.parametrize("trim", [False, True])
+def test_graphed_interpret_matches_eager(golden, trim):
+    """hipGraph replay of the whole step == eager interpret, also after new inputs are copied in."""
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    g, model = load_tiny(golden)
+    image, texts = torch.from_numpy(g["image"]).cuda(), torch.from_numpy(g["texts"]).cuda()
+    run = ce.GraphedInterpret(model, image, texts, 0, 0, trim_text_padding=trim)
+    R_text, R_image = run()
+    close(R_text, g["R_text_all"])
+    close(R_image, g["R_image_all"])
+    image2 = image.flip(-1).contiguous()
+    texts2 = texts.roll(1, 0).contiguous()
+    want_t, want_i = ce.interpret(image2, texts2, model, "cuda", 0, 0)
+    got_t, got_i = run(image2, texts2)
+    close(got_t, want_t.cpu().numpy(), atol=2e-6)
+    close(got_i, want_i.cpu().numpy(), atol=2e-6)

@@ -271,3 +271,20 @@ def test_quick_gelu_fused(ops, shape):
     yr.backward(up.double())
     close(y, yr.detach().float().cpu().numpy(), atol=2e-6)
     close(x.grad, xr.grad.float().cpu().numpy(), atol=2e-6)
+
+
+@pytest.mark.parametrize("B,N,E,shared", [(64, 50, 768, True), (3, 7, 12, True), (2, 5, 64, False)])
+def test_layernorm_bwd_add(ops, B, N, E, shared):
+    g = torch.Generator().manual_seed(B + N + E)
+    xb = 1 if shared else B
+    x = torch.randn(xb, N, E, generator=g).double()
+    gamma, beta = torch.randn(E, generator=g).double(), torch.randn(E, generator=g).double()
+    dy, d_res = torch.randn(B, N, E, generator=g), torch.randn(B, N, E, generator=g)
+    xr = x.expand(B, N, E).clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (E,), gamma, beta, 1e-5).backward(dy.double())
+    want = (xr.grad + d_res.double()).float().numpy()
+    _, mean, rstd = torch.native_layer_norm(x.float().cuda(), (E,), gamma.float().cuda(), beta.float().cuda(), 1e-5)
+    got = ops.layernorm_bwd_add(dy.cuda(), x.float().cuda(), mean, rstd, gamma.float().cuda(), d_res.cuda())
+    close(got, want, atol=2e-5)
+    got2 = ops.layernorm_bwd_add(dy.cuda(), x.float().cuda(), mean, rstd, gamma.float().cuda())
+    close(got2, xr.grad.float().numpy(), atol=2e-5)

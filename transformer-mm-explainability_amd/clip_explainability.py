@@ -58,13 +58,20 @@ def _plan(buffers, first, last, batch_size, shared):
     return cache[key]
 
 
-def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, share_image_forward=True):
+def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, share_image_forward=True,
+              trim_text_padding=False, _n_text=None):
     """CLIP_explainability.ipynb cell 6.  ``image``: ``[1,3,R,R]``, ``texts``: ``[B, context]`` token ids.
 
     ``share_image_forward`` (extra keyword, default on): the reference repeats the ONE image B times (cell 6:3) and
     runs the image tower on B identical copies.  Here its forward runs once and only the backward -- whose upstream
     gradients do differ per text -- runs at batch B (``clip_model.Transformer.forward_shared``); results are the
     same to fp32 rounding (``tests/test_gpu_clip.py``).  ``False`` runs the B copies like the reference.
+
+    ``trim_text_padding`` (extra keyword, default OFF): CLIP pads every caption to 77 tokens and the reference runs the
+    text tower over all of them.  The mask is causal and the feature is read at the EOT token, so positions after the
+    last EOT of the batch influence nothing: their gradient rows are exactly zero and the returned ``R_text`` is the
+    identity there.  With the flag the text tower runs only on the first ``max(EOT)+1`` positions and the ``[B,77,77]``
+    result is assembled around that block -- identical output, 5-6x less text-tower work for caption-length inputs.
     """
     batch_size = texts.shape[0]
     sl = model.visual.transformer.layers - 1 if start_layer == -1 else start_layer
@@ -74,22 +81,72 @@ def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, 
     try:
         with _Frozen(model), torch.enable_grad():
             eye = torch.eye(batch_size, dtype=torch.float32, device=texts.device)
+            n_text = _n_text
+            if trim_text_padding and n_text is None:
+                n_text = int(texts.argmax(dim=-1).max()) + 1                              # one D2H read of the ids
             if share_image_forward and image.shape[0] == 1 and batch_size > 1:
                 feat1, state = model.visual.forward_shared(image.type(model.dtype), batch_size)
                 image_features = feat1.expand(batch_size, -1).contiguous().requires_grad_(True)   # per-sample leaf
-                logits_per_image, _ = model.logits(image_features, model.encode_text(texts))
+                logits_per_image, _ = model.logits(image_features, model.encode_text(texts, n_text))
                 torch.autograd.backward(logits_per_image, grad_tensors=eye)
                 model.visual.backward_shared(state, image_features.grad, sl)
             else:
                 images = image.repeat(batch_size, 1, 1, 1)
-                logits_per_image, _ = model(images, texts)
+                logits_per_image, _ = model.logits(model.encode_image(images), model.encode_text(texts, n_text))
                 # one_hot = sum_i logits_per_image[i, i]  (cell 6:6-10)  ->  d one_hot / d logits = I
                 torch.autograd.backward(logits_per_image, grad_tensors=eye)
     finally:
         model.capture_only, model.first_grad_layers = prev
     R_text, R = _chains(model, batch_size, start_layer, start_layer_text)
+    if R_text.shape[-1] != texts.shape[1]:       # trimmed run: the rest of the [B, 77, 77] matrix is the identity
+        n = R_text.shape[-1]
+        full = torch.eye(texts.shape[1], dtype=R_text.dtype, device=R_text.device).repeat(batch_size, 1, 1)
+        full[:, :n, :n] = R_text
+        R_text = full
     image_relevance = R[:, 0, 1:]
     return R_text, image_relevance
+
+
+class GraphedInterpret:
+    """``interpret`` captured once into a hipGraph and replayed: the step is ~600 short launches (PyTorch body ops, our
+    attention / chain kernels) and an eager step is bound by the Python + launch path on the host (~16 ms) rather than by
+    the GPU; a replay costs one ``hipGraphLaunch``.  Shapes, ``start_layer``s and flags are fixed at construction;
+    new ``image`` / ``texts`` values are copied into the captured input buffers.
+
+        run = GraphedInterpret(model, image, texts, start_layer=0, start_layer_text=0)
+        R_text, image_relevance = run(image2, texts2)      # same results as interpret(image2, texts2, model, device, 0, 0)
+
+    The returned tensors are the graph's output buffers (overwritten by the next call; ``.clone()`` to keep them).
+    """
+
+    def __init__(self, model, image, texts, start_layer=-1, start_layer_text=-1, share_image_forward=True,
+                 trim_text_padding=False, warmup=3):
+        self.model = model
+        self.image = image.clone()
+        self.texts = texts.clone()
+        kw = dict(start_layer=start_layer, start_layer_text=start_layer_text, share_image_forward=share_image_forward)
+        # a trimmed run fixes the number of text positions at capture time: it must cover every later caption
+        self.n_text = int(texts.argmax(dim=-1).max()) + 1 if trim_text_padding else None
+        self._call = lambda: interpret(self.image, self.texts, model, self.image.device, _n_text=self.n_text, **kw)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._call()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = self._call()
+
+    def __call__(self, image=None, texts=None):
+        if image is not None:
+            self.image.copy_(image)
+        if texts is not None:
+            if self.n_text is not None and int(texts.argmax(dim=-1).max()) + 1 > self.n_text:
+                raise ValueError("caption longer than the %d positions this graph was captured for" % self.n_text)
+            self.texts.copy_(texts)
+        self.graph.replay()
+        return self.outputs
 
 
 def interpret_single(image, text, model, device, index=None):

@@ -97,7 +97,10 @@ class ResidualAttentionBlock(nn.Module):
         probs, grads = buffers.probs[layer], buffers.grads[layer]
         self.attn_probs = buffers.layer_probs(layer)
         self.attn_grad = buffers.layer_grads(layer)  # valid once backward has run
-        x = x + self.attn(self.ln_1(x), probs, grads, mask=self.attn_mask, need_dqkv=need_dqkv)
+        mask = self.attn_mask
+        if mask is not None and mask.shape[-1] != x.shape[1]:
+            mask = mask[: x.shape[1], : x.shape[1]].contiguous()   # trimmed (padding-free) text batch
+        x = x + self.attn(self.ln_1(x), probs, grads, mask=mask, need_dqkv=need_dqkv)
         x = x + self.mlp(self.ln_2(x))
         return x
 
@@ -170,7 +173,7 @@ class Transformer(nn.Module):
             sg = torch.sigmoid(1.702 * m)
             d_m = d_a * (sg + 1.702 * m * sg * (1 - sg))                      # QuickGELU'(m), shared across the batch
             d_h2 = torch.matmul(d_m, blk.mlp.c_fc.weight)
-            d_x1 = dx + self._ln_backward(d_h2, x1, mean2, rstd2, blk.ln_2)
+            d_x1 = ops.layernorm_bwd_add(d_h2, x1, mean2, rstd2, blk.ln_2.weight, dx)   # dx + LN2'(d_h2), one pass
             # attention branch: x1 = x + out_proj(attn(ln_1(x)))
             d_o = torch.matmul(d_x1, at.out_proj.weight).view(B, N, at.num_heads, at.head_dim)
             need = l > first_grad_layer                                       # nothing below needs gradients
@@ -181,7 +184,7 @@ class Transformer(nn.Module):
             if not need:
                 break
             d_h1 = torch.matmul(dqkv.view(B, N, 3 * E), at.in_proj_weight)
-            dx = d_x1 + self._ln_backward(d_h1, x, mean1, rstd1, blk.ln_1)
+            dx = ops.layernorm_bwd_add(d_h1, x, mean1, rstd1, blk.ln_1.weight, d_x1)
 
     def forward(self, x, capture_only=False, first_grad_layer=0):
         """``x``: ``[B, N, E]``.  ``capture_only``: only d(loss)/d(probs) of blocks ``>= first_grad_layer`` is wanted
@@ -309,8 +312,13 @@ class CLIP(nn.Module):
         return self.visual(image.type(self.dtype), capture_only=self.capture_only,
                            first_grad_layer=self.first_grad_layers[0])
 
-    def encode_text(self, text):
-        x = self.token_embedding(text).type(self.dtype) + self.positional_embedding.type(self.dtype)
+    def encode_text(self, text, n_tokens=None):
+        """``n_tokens``: run only the first ``n_tokens`` positions (must cover every sequence's EOT token).  With the
+        causal mask nothing after a sequence's EOT can influence its feature, so this is exact, not an approximation."""
+        if n_tokens is not None and n_tokens < text.shape[1]:
+            text = text[:, :n_tokens]
+        n = text.shape[1]
+        x = self.token_embedding(text).type(self.dtype) + self.positional_embedding[:n].type(self.dtype)
         x = self.transformer(x, capture_only=self.capture_only, first_grad_layer=self.first_grad_layers[1])
         x = self.ln_final(x)
         # features at the EOT token = highest token id in each sequence (model.py:360)

@@ -76,3 +76,64 @@ extern "C" int mmx_quick_gelu_bwd(const void* x_dev, const void* dy_dev, void* d
     MMX_LAUNCH_CHECK("quick_gelu_bwd_kernel");
     return MMX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm input-gradient fused with the residual add, with the forward statistics SHARED across the batch:
+//     dx[r] = d_res[r] + rstd[m] * (g - mean(g) - xhat[m] * mean(g * xhat[m])),   g = dy[r] * gamma,  m = r % x_rows
+// Used by the hand-written batched backward of the shared image tower (clip_model.Transformer.backward_shared): the
+// forward ran once (x_rows = N rows of x / mean / rstd), the backward has B*N rows.  ATen's native_layer_norm_backward
+// wants the input replicated per sample (an expand().contiguous() copy per call) and leaves the residual add to a
+// second elementwise kernel.  One wave per row, 16-B accesses; E % 4 == 0.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace mmx {
+
+__global__ __launch_bounds__(256) void layernorm_bwd_add_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const float* d_res,
+                                                                float* __restrict__ dx, int64_t rows, int x_rows, int E) {
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int m = static_cast<int>(r % x_rows);
+    const f32x4* dyr = reinterpret_cast<const f32x4*>(dy + r * E);
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + static_cast<int64_t>(m) * E);
+    const f32x4* gm = reinterpret_cast<const f32x4*>(gamma);
+    const float mu = mean[m], rs = rstd[m];
+    const int n4 = E >> 2;
+    float a = 0.f, b = 0.f;
+    for (int i = lane; i < n4; i += 64) {
+        const f32x4 g = dyr[i] * gm[i];
+        const f32x4 xh = (xr[i] - mu) * rs;
+        a += g[0] + g[1] + g[2] + g[3];
+        b += g[0] * xh[0] + g[1] * xh[1] + g[2] * xh[2] + g[3] * xh[3];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    a /= static_cast<float>(E);
+    b /= static_cast<float>(E);
+    const f32x4* dr = d_res ? reinterpret_cast<const f32x4*>(d_res + r * E) : nullptr;
+    f32x4* out = reinterpret_cast<f32x4*>(dx + r * E);
+    for (int i = lane; i < n4; i += 64) {
+        const f32x4 g = dyr[i] * gm[i];
+        const f32x4 xh = (xr[i] - mu) * rs;
+        f32x4 o = (g - a - xh * b) * rs;
+        if (dr) o = o + dr[i];
+        out[i] = o;
+    }
+}
+
+}  // namespace mmx
+
+extern "C" int mmx_layernorm_bwd_add(const void* dy_dev, const void* x_dev, const void* mean_dev, const void* rstd_dev,
+                                     const void* gamma_dev, const void* d_res_dev, void* dx_dev, int64_t rows, int x_rows,
+                                     int E, void* stream) {
+    MMX_CHECK_ARG(dy_dev && x_dev && mean_dev && rstd_dev && gamma_dev && dx_dev, "mmx_layernorm_bwd_add: null pointer");
+    MMX_CHECK_ARG(rows > 0 && x_rows > 0 && E > 0 && E % 4 == 0, "mmx_layernorm_bwd_add: rows=%ld x_rows=%d E=%d (E %% 4 must be 0)",
+                  static_cast<long>(rows), x_rows, E);
+    mmx::layernorm_bwd_add_kernel<<<static_cast<unsigned>((rows + 3) / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const float*>(dy_dev), static_cast<const float*>(x_dev), static_cast<const float*>(mean_dev),
+        static_cast<const float*>(rstd_dev), static_cast<const float*>(gamma_dev), static_cast<const float*>(d_res_dev),
+        static_cast<float*>(dx_dev), rows, x_rows, E);
+    MMX_LAUNCH_CHECK("layernorm_bwd_add_kernel");
+    return MMX_OK;
+}

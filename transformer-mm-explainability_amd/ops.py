@@ -157,6 +157,20 @@ def quick_gelu(x):
     return _QuickGELU.apply(x)
 
 
+def layernorm_bwd_add(dy, x, mean, rstd, gamma, d_res=None):
+    """``d_res + LayerNorm'(dy)`` with forward statistics shared across the batch: ``dy``/``d_res`` ``[B, N, E]``,
+    ``x`` ``[1, N, E]`` (or ``[B, N, E]``), ``mean``/``rstd`` matching ``x``'s rows."""
+    _dev(dy, x, mean, rstd, gamma, d_res)
+    dy, x = _f32c(dy), _f32c(x)
+    E = dy.shape[-1]
+    rows, x_rows = dy.numel() // E, x.numel() // E
+    dx = torch.empty_like(dy)
+    check(lib().mmx_layernorm_bwd_add(_p(dy), _p(x), _p(_f32c(mean)), _p(_f32c(rstd)), _p(_f32c(gamma)),
+                                      _p(_f32c(d_res)) if d_res is not None else _p(None), _p(dx), rows, x_rows, E,
+                                      _stream()), "mmx_layernorm_bwd_add")
+    return dx
+
+
 class ChainPlan:
     """A prepared ``relevancy_self_chain`` launch over persistent slabs: pointer tables, scratch and the output tensor are
     built once; ``launch()`` is a single C call (no per-call Python tensor plumbing).  The captured slabs of a tower

@@ -194,7 +194,7 @@ class VisionTransformer(nn.Module):
             d_a = torch.matmul(dx, blk.mlp.fc2.weight)
             gelu_prime = 0.5 * (1 + torch.erf(m / math.sqrt(2.0))) + m * torch.exp(-0.5 * m * m) / math.sqrt(2 * math.pi)
             d_h2 = torch.matmul(d_a * gelu_prime, blk.mlp.fc1.weight)
-            d_x1 = dx + self._ln_backward(d_h2, x1, mean2, rstd2, blk.norm2)
+            d_x1 = ops.layernorm_bwd_add(d_h2, x1, mean2, rstd2, blk.norm2.weight, dx)
             d_o = torch.matmul(d_x1, at.proj.weight).view(K, N, at.num_heads, at.head_dim)
             need = l > 0
             dqkv = torch.empty(K, N, 3, at.num_heads, at.head_dim, dtype=torch.float32, device=dx.device) if need else None
@@ -204,7 +204,7 @@ class VisionTransformer(nn.Module):
             if not need:
                 break
             d_h1 = torch.matmul(dqkv.view(K, N, 3 * E), at.qkv.weight)
-            dx = d_x1 + self._ln_backward(d_h1, x, mean1, rstd1, blk.norm1)
+            dx = ops.layernorm_bwd_add(d_h1, x, mean1, rstd1, blk.norm1.weight, d_x1)
 
 
 def vit_base_patch16_224(num_classes=1000, **kw):
