@@ -347,6 +347,57 @@ def gen_detr_mha():
     save("detr_mha", **arrays)
 
 
+def gen_detr_transformer():
+    """The REAL reference transformer body (DETR/models/transformer.py, hooked MHA from DETR/modules/layers.py) with the
+    heads of DETR/models/detr.py:34-38 on a synthetic backbone feature map, driven by the reference Generator."""
+    detr_tr = load_by_path("detr_transformer_ref", os.path.join(REF, "DETR/models/transformer.py"))
+    torch.manual_seed(11)
+    d, heads, Le, Ld, ff, Q, n_cls, Cb, h, w = 32, 4, 2, 3, 64, 7, 5, 24, 3, 5
+
+    class Body(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.transformer = detr_tr.Transformer(d_model=d, nhead=heads, num_encoder_layers=Le,
+                                                   num_decoder_layers=Ld, dim_feedforward=ff, dropout=0.0,
+                                                   return_intermediate_dec=True)
+            self.class_embed = nn.Linear(d, n_cls + 1)
+            self.query_embed = nn.Embedding(Q, d)
+            self.input_proj = nn.Conv2d(Cb, d, kernel_size=1)
+
+        def forward(self, feats):
+            mask = torch.zeros(feats.shape[0], h, w, dtype=torch.bool)
+            hs, _ = self.transformer(self.input_proj(feats), mask, self.query_embed.weight, self.pos)
+            return {"pred_logits": self.class_embed(hs)[-1]}
+
+    body = Body().eval()
+    g = torch.Generator().manual_seed(12)
+    feats = torch.randn(1, Cb, h, w, generator=g)
+    body.pos = torch.randn(1, d, h, w, generator=g)
+    tgt = torch.tensor([1, 4])
+    gen = detr_eg.Generator(body)
+    out = gen.generate_ours(feats, tgt, use_lrp=False)
+    arrays = dict(features=feats, pos=body.pos, target_index=tgt, out=out, R_i_i=gen.R_i_i, R_q_q=gen.R_q_q,
+                  pred_logits=body(feats)["pred_logits"],
+                  rollout_out=detr_eg.Generator(body).generate_rollout(feats, tgt),
+                  raw_attn_out=detr_eg.Generator(body).generate_raw_attn(feats, tgt),
+                  dims=np.array([d, heads, Le, Ld, ff, Q, n_cls, Cb, h, w]))
+    for name, p in body.state_dict().items():
+        arrays["w__" + name] = p
+    # sine position embedding (DETR/models/position_encoding.py:12-48) on a mask with right/bottom padding
+    misc = types.ModuleType("DETR.util.misc")
+    misc.NestedTensor = object
+    sys.modules.setdefault("DETR.util.misc", misc)
+    pe = load_by_path("detr_pos_ref", os.path.join(REF, "DETR/models/position_encoding.py"))
+    pad = torch.zeros(2, 4, 6, dtype=torch.bool)
+    pad[1, 3:, :] = True
+    pad[1, :, 4:] = True
+    nested = types.SimpleNamespace(tensors=torch.zeros(2, 1, 4, 6), mask=pad)
+    arrays["sine_mask"] = pad
+    arrays["sine_pos"] = pe.PositionEmbeddingSine(d // 2, normalize=True)(nested)
+    arrays["sine_pos_raw"] = pe.PositionEmbeddingSine(d // 2, normalize=False)(nested)
+    save("detr_transformer", **arrays)
+
+
 if __name__ == "__main__":
     gen_rules()
     gen_detr_chain("detr_chain", 200, H=4, Ni=35, Nq=10, Le=3, Ld=3, targets=[2, 7])
@@ -362,3 +413,4 @@ if __name__ == "__main__":
     gen_visualbert_chain()
     gen_clip_tiny()
     gen_detr_mha()
+    gen_detr_transformer()

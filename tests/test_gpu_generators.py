@@ -197,6 +197,20 @@ def test_detr_mha_module(golden):
     close(v.grad, g["dvalue"])
 
 
+def test_detr_mha_constant_inputs_still_capture_gradients(golden):
+    """Frozen parameters + constant q/k/v (DETR's first decoder self-attention): dL/dP must still reach the slab."""
+    from transformer_mm_explainability_amd.attention_modules import MultiheadAttention
+    from transformer_mm_explainability_amd.rules import frozen_parameters
+    g = golden("detr_mha")
+    mha = MultiheadAttention(g["query"].shape[-1], int(g["num_heads"])).cuda().eval()
+    mha.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w__")})
+    with frozen_parameters(mha):
+        out = mha(cu(g["query"]), cu(g["key"]), cu(g["value"]))
+    (out * cu(g["upstream"])).sum().backward()
+    close(mha.get_attn_gradients(), g["attn_grad"])
+    assert all(p.grad is None for p in mha.parameters())
+
+
 def test_bert_style_attention_matches_torch():
     """LXMERT/BERT flavour (scores / sqrt(d) + additive key mask, cross-attention with a different context)."""
     from transformer_mm_explainability_amd.attention_modules import BertStyleAttention
@@ -226,3 +240,76 @@ def test_bert_style_attention_matches_torch():
     close(att.get_attn_gradients(), p.grad.cpu().numpy())
     close(hg, h.grad.cpu().numpy(), atol=2e-5)
     close(cg, ctx.grad.cpu().numpy(), atol=2e-5)
+
+
+def _detr_from_golden(g):
+    from transformer_mm_explainability_amd import detr_model
+    d, heads, Le, Ld, ff, Q, n_cls, Cb, h, w = (int(x) for x in g["dims"])
+    model = detr_model.DETRFromFeatures(
+        detr_model.Transformer(d_model=d, nhead=heads, num_encoder_layers=Le, num_decoder_layers=Ld,
+                               dim_feedforward=ff, dropout=0.0, return_intermediate_dec=True),
+        num_classes=n_cls, num_queries=Q, backbone_channels=Cb)
+    weights = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w__")}
+    missing, unexpected = model.load_state_dict(weights, strict=False)
+    assert not unexpected and all(m.startswith("bbox_embed.") for m in missing), (missing, unexpected)
+    model = model.cuda().eval()
+    class FixedPos(nn.Module):                  # the fixture used a random position tensor, not the sine one
+        def forward(self, mask):
+            return cu(g["pos"])
+
+    model.position = FixedPos()
+    return model
+
+
+def test_detr_real_transformer_body(golden):
+    """The whole DETR hot path end to end -- ``detr_model.Transformer`` (6 kinds of captured attention) + heads +
+    ``Generator`` -- against the REFERENCE's transformer body (DETR/models/transformer.py with its hooked MHA) driven
+    by the reference Generator on the same weights and inputs."""
+    from transformer_mm_explainability_amd.detr_explainability import Generator
+    g = golden("detr_transformer")
+    model = _detr_from_golden(g)
+    feats, tgt = cu(g["features"]), cu(g["target_index"])
+    close(model(feats)["pred_logits"], g["pred_logits"])
+    gen = Generator(model)
+    close(gen.generate_ours(feats, tgt, use_lrp=False), g["out"])
+    close(gen.R_i_i, g["R_i_i"])
+    close(gen.R_q_q, g["R_q_q"])
+    close(Generator(model).generate_rollout(feats, tgt), g["rollout_out"])
+    close(Generator(model).generate_raw_attn(feats, tgt), g["raw_attn_out"])
+
+
+def test_detr_r50_shape_runs():
+    """Config 3 of BASELINE.json at its real size (d=256, 8 heads, 6+6 layers, 100 queries, 25x38 = 950 image tokens):
+    the tiled attention kernels, the N > 128 chain path and rule 10 at [100 x 950].  Checked against the reference
+    algorithm restated in torch on the captured slabs of the same run."""
+    from transformer_mm_explainability_amd import detr_model
+    from transformer_mm_explainability_amd.detr_explainability import Generator
+    torch.manual_seed(0)
+    model = detr_model.detr_resnet50_head().cuda().eval()
+    feats = torch.randn(1, 2048, 25, 38, device="cuda") * 0.5
+    gen = Generator(model)
+    tgt = torch.tensor([3, 57], device="cuda")
+    out = gen.generate_ours(feats, tgt, use_lrp=False)
+    assert out.shape == (1, 1, 2, 950) and torch.isfinite(out).all()
+
+    def cam(mod):
+        a, gr = mod.get_attn(), mod.get_attn_gradients()
+        return (gr * a).clamp(min=0).mean(0).double()
+
+    def residual(R):                          # handle_residual, ExplanationGenerator.py:26-36
+        eye = torch.eye(R.shape[0], device=R.device, dtype=R.dtype)
+        R = R - eye
+        return R / R.sum(dim=-1, keepdim=True) + eye
+
+    enc, dec = model.transformer.encoder.layers, model.transformer.decoder.layers
+    Rii = torch.eye(950, device="cuda", dtype=torch.float64)
+    for blk in enc:
+        Rii = Rii + cam(blk.self_attn) @ Rii
+    Rqq = torch.eye(100, device="cuda", dtype=torch.float64)
+    Rqi = torch.zeros(100, 950, device="cuda", dtype=torch.float64)
+    for blk in dec:
+        c = cam(blk.self_attn)
+        Rqq, Rqi = Rqq + c @ Rqq, Rqi + c @ Rqi
+        Rqi = Rqi + torch.nan_to_num(residual(Rqq).t() @ cam(blk.multihead_attn) @ residual(Rii), nan=0.0)
+    torch.testing.assert_close(gen.R_i_i.double(), Rii, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(out[0, 0].double(), Rqi[tgt], rtol=1e-4, atol=1e-7)

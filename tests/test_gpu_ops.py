@@ -220,7 +220,8 @@ def torch_attention(q, k, v, scale, mode, mask):
 @pytest.mark.parametrize("B,H,Nq,Nk,D,mode,masked", [
     (2, 12, 50, 50, 64, 0, False), (2, 8, 77, 77, 64, 0, True), (1, 8, 100, 180, 32, 0, False),
     (2, 12, 14, 36, 64, 1, False), (1, 2, 1, 3, 16, 1, False), (1, 4, 197, 197, 64, 0, False),
-    (1, 2, 33, 130, 48, 1, True),
+    (1, 2, 33, 130, 48, 1, True), (1, 4, 15, 15, 8, 0, False), (1, 4, 7, 15, 8, 0, False), (2, 3, 9, 20, 4, 1, False),
+    (1, 2, 20, 20, 24, 0, False),
 ])
 @pytest.mark.parametrize("small", [1, 0])
 def test_attn_capture_fwd_bwd(ops, B, H, Nq, Nk, D, mode, masked, small):

@@ -169,3 +169,16 @@ def test_c_chain_matches_numpy_and_golden(golden):
     assert lib.oracle_self_chain_f32(at, gt, L, B, H, N, out.ctypes.data_as(fp)) == 0
     close(out, onp.self_chain(attn, grad, B, 0))
     close(out[:, 0, 1:], g["R_image_all"])
+
+
+def test_detr_sine_position_embedding(golden):
+    """Host-side piece of the DETR body: the sine position embedding equals the reference's
+    (DETR/models/position_encoding.py:12-48), padded mask included."""
+    import torch
+    from transformer_mm_explainability_amd.detr_model import PositionEmbeddingSine
+    g = golden("detr_transformer")
+    mask = torch.from_numpy(g["sine_mask"])
+    d = int(g["dims"][0])
+    np.testing.assert_allclose(PositionEmbeddingSine(d // 2, normalize=True)(mask).numpy(), g["sine_pos"], atol=1e-6)
+    np.testing.assert_allclose(PositionEmbeddingSine(d // 2, normalize=False)(mask).numpy(), g["sine_pos_raw"],
+                               atol=1e-6)

@@ -1,0 +1,40 @@
+"""DETR-R50 head (config 3): per-query latency of Generator.generate_ours at 25x38 image tokens, 100 queries."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from transformer_mm_explainability_amd import detr_model  # noqa: E402
+from transformer_mm_explainability_amd.detr_explainability import Generator  # noqa: E402
+
+torch.manual_seed(0)
+model = detr_model.detr_resnet50_head().cuda().eval()
+feats = torch.randn(1, 2048, 25, 38, device="cuda") * 0.5
+gen = Generator(model)
+
+
+def timed(fn, n=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n * 1e3
+
+
+tgt = torch.tensor([5], device="cuda")
+print("forward only        %.2f ms" % timed(lambda: model(feats)))
+print("generate_ours/query %.2f ms" % timed(lambda: gen.generate_ours(feats, tgt, use_lrp=False)))
+print("generate_rollout    %.2f ms" % timed(lambda: gen.generate_rollout(feats, tgt)))
+
+
+def fwd_bwd():
+    out = model(feats)["pred_logits"]
+    model.zero_grad()
+    out[0, 5, 3].backward()
+
+
+print("forward+backward    %.2f ms" % timed(fwd_bwd))

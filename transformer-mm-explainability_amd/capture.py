@@ -89,7 +89,7 @@ class _AttnCapture(torch.autograd.Function):
     """General (cross-)attention: separate ``q [B, Nq, H, D]``, ``k``/``v [B, Nk, H, D]`` (strided views ok)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, mask, probs_slab, grads_slab, scale, scale_mode, grad_hook):
+    def forward(ctx, q, k, v, mask, probs_slab, grads_slab, scale, scale_mode, grad_hook, anchor):
         o = ops.attn_capture_fwd(q, k, v, probs_slab, scale, scale_mode, mask, layout="bnhd")
         ctx.save_for_backward(q, k, v)
         ctx.probs, ctx.grads = probs_slab, grads_slab
@@ -105,7 +105,7 @@ class _AttnCapture(torch.autograd.Function):
                                           layout="bnhd")
         if grad_hook is not None:
             grad_hook(ctx.grads)
-        return dq, dk, dv, None, None, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None, None, None
 
 
 def attention_capture_packed(qkv, probs_slab, grads_slab, scale, mask=None, scale_mode=_lib.SCALE_Q_FIRST,
@@ -116,5 +116,14 @@ def attention_capture_packed(qkv, probs_slab, grads_slab, scale, mask=None, scal
 
 def attention_capture(q, k, v, probs_slab, grads_slab, scale, mask=None, scale_mode=_lib.SCALE_Q_FIRST,
                       grad_hook=None):
-    """``q [B, Nq, H, D]``, ``k``/``v [B, Nk, H, D]`` fp32.  Returns ``O [B, Nq, H, D]``."""
-    return _AttnCapture.apply(q, k, v, mask, probs_slab, grads_slab, scale, scale_mode, grad_hook)
+    """``q [B, Nq, H, D]``, ``k``/``v [B, Nk, H, D]`` fp32.  Returns ``O [B, Nq, H, D]``.
+
+    dL/dP is defined -- and read by the rules -- even when q, k and v are all constants of the graph (DETR's first
+    decoder self-attention under frozen parameters: ``tgt = 0`` and ``query_pos`` is a frozen embedding; the reference's
+    tensor hook fires there because its weights require grad).  Autograd would drop such a node, so it is tied to the
+    graph through a scalar anchor: the backward kernel then runs whenever the loss depends on ``O``.
+    """
+    anchor = None
+    if torch.is_grad_enabled() and not (q.requires_grad or k.requires_grad or v.requires_grad):
+        anchor = torch.zeros((), requires_grad=True)          # host scalar: no launch, its gradient is never formed
+    return _AttnCapture.apply(q, k, v, mask, probs_slab, grads_slab, scale, scale_mode, grad_hook, anchor)

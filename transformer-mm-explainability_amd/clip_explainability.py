@@ -18,21 +18,7 @@ import numpy as np
 import torch
 
 from . import ops
-
-class _Frozen:
-    """Temporarily mark parameters as not requiring grad: the explainability pass needs d(logit)/d(probs) only."""
-
-    def __init__(self, model):
-        self.params = [p for p in model.parameters() if p.requires_grad]
-
-    def __enter__(self):
-        for p in self.params:
-            p.requires_grad_(False)
-
-    def __exit__(self, *exc):
-        for p in self.params:
-            p.requires_grad_(True)
-
+from .rules import frozen_parameters as _Frozen
 
 def _chains(model, batch_size, start_layer, start_layer_text):
     vis, txt = model.visual.transformer, model.transformer

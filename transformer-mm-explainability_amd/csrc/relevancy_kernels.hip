@@ -464,16 +464,22 @@ __global__ __launch_bounds__(kV2Threads) void self_chain_v2_kernel(const ChainV2
 
 // =====================================================================================================
 // K_bmm_f32: C[b] = (Cin ? Cin[b] : 0) + op(A[b]) . B[b] on v_mfma_f32_16x16x4_f32 (exact fp32).
-// 64x64 output tile per 256-thread workgroup (4 waves as 2x2, 32x32 each = 2x2 MFMA tiles), BK = 16.
-// LDS tiles are k-major with row stride 80 floats: a wave's ds_read_b32 of [k = lane>>4][m = lane&15]
-// hits 32 distinct banks per half-wave.  Guarded scalar global loads: any M, N, K, any alignment.
+// 64x64 output tile per 256-thread workgroup (4 waves as 2x2, 32x32 each = 2x2 MFMA tiles), BK = 32.
+// The next K-slab's global loads are issued into registers before the MFMAs of the current one (the problems here
+// are small -- rule 10 at DETR size is [100 x 950] . [950 x 950] = 30 workgroups -- so the loop is latency-, not
+// bandwidth-bound, and a workgroup has to cover its own load latency).  LDS tiles are k-major with row stride 80
+// floats: a wave's ds_read_b32 of [k = lane>>4][m = lane&15] hits 32 distinct banks per half-wave.  Guarded scalar
+// global loads: any M, N, K, any alignment.
 // =====================================================================================================
+constexpr int kBmmBK = 32;
+
 __global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                       const float* Cin, float* C, int M, int N, int K,
                                                       int trans_a, int64_t sa, int64_t sb, int64_t sc,
                                                       int nan_to_zero) {
-    __shared__ float As[16][80];
-    __shared__ float Bs[16][80];
+    __shared__ float As[kBmmBK][81];   // odd stride: the k-fastest stores of a row-major A spread over the banks
+    __shared__ float Bs[kBmmBK][80];
+    constexpr int E = kBmmBK * 64 / 256;   // elements of each operand per thread and slab
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -485,24 +491,37 @@ __global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    float ra[E], rb[E];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < E; ++e) {
             const int idx = tid + e * 256;
             int m, k;
-            if (trans_a) { k = idx >> 6; m = idx & 63; } else { m = idx >> 4; k = idx & 15; }
+            if (trans_a) { k = idx >> 6; m = idx & 63; } else { m = idx / kBmmBK; k = idx % kBmmBK; }
             const int gm = m0 + m, gk = k0 + k;
-            float v = 0.f;
-            if (gm < M && gk < K)
-                v = trans_a ? Ab[static_cast<int64_t>(gk) * M + gm] : Ab[static_cast<int64_t>(gm) * K + gk];
-            As[k][m] = v;
+            const bool ok = gm < M && gk < K;
+            const int64_t off = trans_a ? static_cast<int64_t>(gk) * M + gm : static_cast<int64_t>(gm) * K + gk;
+            const float va = Ab[ok ? off : 0];            // unconditional (clamped) load: no per-element vmcnt(0)
+            ra[e] = ok ? va : 0.f;
             const int kb = idx >> 6, nb = idx & 63;
             const int gkb = k0 + kb, gn = n0 + nb;
-            Bs[kb][nb] = (gkb < K && gn < N) ? Bb[static_cast<int64_t>(gkb) * N + gn] : 0.f;
+            const bool okb = gkb < K && gn < N;
+            const float vb = Bb[okb ? static_cast<int64_t>(gkb) * N + gn : 0];
+            rb[e] = okb ? vb : 0.f;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += kBmmBK) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int idx = tid + e * 256;
+            if (trans_a) As[idx >> 6][idx & 63] = ra[e]; else As[idx % kBmmBK][idx / kBmmBK] = ra[e];
+            Bs[idx >> 6][idx & 63] = rb[e];
         }
         __syncthreads();
+        if (k0 + kBmmBK < K) fetch(k0 + kBmmBK);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < kBmmBK / 4; ++ks) {
             const int kk = ks * 4 + (lane >> 4);
             const float a0 = As[kk][wr * 32 + (lane & 15)];
             const float a1 = As[kk][wr * 32 + 16 + (lane & 15)];

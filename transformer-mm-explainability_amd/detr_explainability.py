@@ -23,6 +23,20 @@ apply_self_attention_rules = rules.apply_self_attention_rules
 apply_mm_attention_rules = rules.apply_mm_attention_rules_detr
 
 
+def _logits_for_backward(model, img):
+    """Forward pass the one-hot backward will run through.
+
+    No rule reads a weight gradient, so when the input is a float tensor it becomes the autograd leaf and the
+    parameters are frozen while the graph is built: the backward then computes activation gradients only (the
+    reference also accumulates every ``param.grad``; nothing reads them).  Any other input type (NestedTensor, None in
+    the fake-body tests) takes the reference route unchanged.
+    """
+    if isinstance(img, torch.Tensor) and img.is_floating_point() and isinstance(model, torch.nn.Module):
+        with rules.frozen_parameters(model):
+            return model(img.detach().requires_grad_(True))["pred_logits"]
+    return model(img)["pred_logits"]
+
+
 def _one_hot_backward(model, outputs, target_index, index):
     """DETR/modules/ExplanationGenerator.py:153-163: one-hot on (query, class), zero_grad, backward."""
     if index is None:
@@ -72,7 +86,7 @@ class Generator:
         self.use_lrp = use_lrp
         self.normalize_self_attention = normalize_self_attention
         self.apply_self_in_rule_10 = apply_self_in_rule_10
-        outputs = self.model(img)["pred_logits"]
+        outputs = _logits_for_backward(self.model, img)
         _one_hot_backward(self.model, outputs, target_index, index)
 
         decoder_blocks = self.model.transformer.decoder.layers
@@ -120,7 +134,7 @@ class Generator:
 
     def generate_attn_gradcam(self, img, target_index, index=None):
         """Reference :282-305."""
-        outputs = self.model(img)["pred_logits"]
+        outputs = _logits_for_backward(self.model, img)
         _one_hot_backward(self.model, outputs, target_index, index)
         last = self.model.transformer.decoder.layers[-1].multihead_attn
         self.R_q_i = self.gradcam(last.get_attn().detach(), last.get_attn_gradients().detach())
@@ -163,7 +177,7 @@ class GeneratorAlbationNoAgg:
             raise NotImplementedError("use_lrp=True needs the reference's LRP layer library: out of scope")
         self.use_lrp = use_lrp
         self.normalize_self_attention = normalize_self_attention
-        outputs = self.model(img)["pred_logits"]
+        outputs = _logits_for_backward(self.model, img)
         _one_hot_backward(self.model, outputs, target_index, index)
         decoder_blocks = self.model.transformer.decoder.layers
         encoder_blocks = self.model.transformer.encoder.layers

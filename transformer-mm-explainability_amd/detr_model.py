@@ -1,0 +1,240 @@
+"""DETR's transformer (encoder-decoder) and detection heads on the HIP capture op.
+
+This is the part of the DETR model the relevancy path runs through: six encoder
+layers of self-attention over the image tokens, six decoder layers of query self-attention + query->image
+cross-attention, post-norm by default.  Parameter names follow ``DETR/models/transformer.py`` and
+``DETR/models/detr.py:20-41`` so a DETR-R50 checkpoint's ``transformer.*``, ``class_embed.*``, ``bbox_embed.*``,
+``query_embed.*`` and ``input_proj.*`` entries load unchanged.  The CNN backbone is torchvision's ResNet and is not
+part of the hot path: ``DETRFromFeatures`` takes the backbone's last feature map.
+
+Differences from the reference that a caller can observe:
+  * every attention block is ``attention_modules.MultiheadAttention`` -- P and dL/dP land in device slabs written by
+    the HIP kernels, ``get_attn()`` / ``get_attn_gradients()`` return views of them, there are no Python hooks;
+  * padding masks are accepted and ignored, exactly like the reference's hooked MHA (``DETR/modules/layers.py:728-756``);
+  * eval mode only (dropout is the identity), no ``relprop`` (LRP is out of scope);
+  * the reference hard-codes decoder layer index 5 for ``pred_logits`` (``detr.py:64``); here it is the last layer.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .attention_modules import MultiheadAttention
+
+
+def _with_pos(x, pos):
+    return x if pos is None else x + pos
+
+
+def _activation(name):
+    try:
+        return {"relu": F.relu, "gelu": F.gelu, "glu": F.glu}[name]
+    except KeyError:
+        raise RuntimeError(f"activation should be relu/gelu/glu, not {name}") from None
+
+
+class _FeedForward:
+    """linear1 -> activation -> linear2 shared by both layer kinds (mixin; the Linear modules live on the layer)."""
+
+    def _ffn(self, x):
+        return self.linear2(self.activation(self.linear1(x)))
+
+
+class TransformerEncoderLayer(nn.Module, _FeedForward):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.activation = _activation(activation)
+        self.normalize_before = normalize_before
+
+    def forward(self, src, src_mask=None, src_key_padding_mask=None, pos=None):
+        if self.normalize_before:          # transformer.py forward_pre
+            h = self.norm1(src)
+            qk = _with_pos(h, pos)
+            src = src + self.self_attn(qk, qk, h, attn_mask=src_mask, key_padding_mask=src_key_padding_mask)
+            return src + self._ffn(self.norm2(src))
+        qk = _with_pos(src, pos)           # transformer.py:236-256 forward_post
+        src = self.norm1(src + self.self_attn(qk, qk, src, attn_mask=src_mask,
+                                              key_padding_mask=src_key_padding_mask))
+        return self.norm2(src + self._ffn(src))
+
+
+class TransformerDecoderLayer(nn.Module, _FeedForward):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.activation = _activation(activation)
+        self.normalize_before = normalize_before
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None, pos=None, query_pos=None):
+        if self.normalize_before:          # transformer.py forward_pre
+            h = self.norm1(tgt)
+            qk = _with_pos(h, query_pos)
+            tgt = tgt + self.self_attn(qk, qk, h, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)
+            h = self.norm2(tgt)
+            tgt = tgt + self.multihead_attn(_with_pos(h, query_pos), _with_pos(memory, pos), memory,
+                                            attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask)
+            return tgt + self._ffn(self.norm3(tgt))
+        qk = _with_pos(tgt, query_pos)     # transformer.py:371-407 forward_post
+        tgt = self.norm1(tgt + self.self_attn(qk, qk, tgt, attn_mask=tgt_mask,
+                                              key_padding_mask=tgt_key_padding_mask))
+        tgt = self.norm2(tgt + self.multihead_attn(_with_pos(tgt, query_pos), _with_pos(memory, pos), memory,
+                                                   attn_mask=memory_mask,
+                                                   key_padding_mask=memory_key_padding_mask))
+        return self.norm3(tgt + self._ffn(tgt))
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, make_layer, num_layers, norm=None):
+        super().__init__()
+        self.layers = nn.ModuleList([make_layer() for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.norm = norm
+
+    def forward(self, src, mask=None, src_key_padding_mask=None, pos=None):
+        for layer in self.layers:
+            src = layer(src, src_mask=mask, src_key_padding_mask=src_key_padding_mask, pos=pos)
+        return src if self.norm is None else self.norm(src)
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, make_layer, num_layers, norm=None, return_intermediate=False):
+        super().__init__()
+        self.layers = nn.ModuleList([make_layer() for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.norm = norm
+        self.return_intermediate = return_intermediate
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None, pos=None, query_pos=None):
+        out, stack = tgt, []
+        for layer in self.layers:
+            out = layer(out, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
+                        tgt_key_padding_mask=tgt_key_padding_mask,
+                        memory_key_padding_mask=memory_key_padding_mask, pos=pos, query_pos=query_pos)
+            if self.return_intermediate:
+                stack.append(self.norm(out))     # transformer.py:148-153: every level is normed by the shared LN
+        if self.return_intermediate:
+            return torch.stack(stack)
+        return (out if self.norm is None else self.norm(out)).unsqueeze(0)
+
+
+class Transformer(nn.Module):
+    """``DETR/models/transformer.py:20-64``: ``forward(src [B,C,h,w], mask [B,h,w], query_embed [Q,C], pos_embed
+    [B,C,h,w]) -> (hs [levels, B, Q, C], memory [B, C, h, w])``."""
+
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048,
+                 dropout=0.1, activation="relu", normalize_before=False, return_intermediate_dec=False):
+        super().__init__()
+        args = (d_model, nhead, dim_feedforward, dropout, activation, normalize_before)
+        self.encoder = TransformerEncoder(lambda: TransformerEncoderLayer(*args), num_encoder_layers,
+                                          nn.LayerNorm(d_model) if normalize_before else None)
+        self.decoder = TransformerDecoder(lambda: TransformerDecoderLayer(*args), num_decoder_layers,
+                                          nn.LayerNorm(d_model), return_intermediate=return_intermediate_dec)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        self.d_model, self.nhead = d_model, nhead
+
+    def forward(self, src, mask, query_embed, pos_embed):
+        bs, c, h, w = src.shape
+        tokens = src.flatten(2).permute(2, 0, 1)                       # [hw, B, C]
+        pos = pos_embed.flatten(2).permute(2, 0, 1)
+        query_pos = query_embed.unsqueeze(1).expand(-1, bs, -1)
+        key_padding = None if mask is None else mask.flatten(1)
+        memory = self.encoder(tokens, src_key_padding_mask=key_padding, pos=pos)
+        hs = self.decoder(torch.zeros_like(query_pos), memory, memory_key_padding_mask=key_padding, pos=pos,
+                          query_pos=query_pos)
+        return hs.transpose(1, 2), memory.permute(1, 2, 0).reshape(bs, c, h, w)
+
+
+class PositionEmbeddingSine(nn.Module):
+    """``DETR/models/position_encoding.py:12-48`` on a bare ``[B, h, w]`` padding mask."""
+
+    def __init__(self, num_pos_feats=64, temperature=10000, normalize=False, scale=None):
+        super().__init__()
+        if scale is not None and not normalize:
+            raise ValueError("normalize should be True if scale is passed")
+        self.num_pos_feats, self.temperature, self.normalize = num_pos_feats, temperature, normalize
+        self.scale = 2 * math.pi if scale is None else scale
+
+    def forward(self, mask):
+        valid = ~mask
+        y = valid.cumsum(1, dtype=torch.float32)
+        x = valid.cumsum(2, dtype=torch.float32)
+        if self.normalize:
+            y = y / (y[:, -1:, :] + 1e-6) * self.scale
+            x = x / (x[:, :, -1:] + 1e-6) * self.scale
+        i = torch.arange(self.num_pos_feats, dtype=torch.float32, device=mask.device)
+        freq = self.temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / self.num_pos_feats)
+
+        def interleave(t):
+            t = t[:, :, :, None] / freq
+            return torch.stack((t[..., 0::2].sin(), t[..., 1::2].cos()), dim=4).flatten(3)
+
+        return torch.cat((interleave(y), interleave(x)), dim=3).permute(0, 3, 1, 2)
+
+
+class MLP(nn.Module):
+    """``DETR/models/detr.py`` ``MLP``: ``num_layers`` Linear layers with ReLU in between (the box head)."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.num_layers = num_layers
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = layer(x) if i == self.num_layers - 1 else F.relu(layer(x))
+        return x
+
+
+class DETRFromFeatures(nn.Module):
+    """Everything of ``DETR.forward`` (``detr.py:43-70``) after the backbone.
+
+    ``model(features [B, C_backbone, h, w], mask [B, h, w] bool | None) -> {'pred_logits': [B, Q, classes+1],
+    'pred_boxes': [B, Q, 4]}`` -- the duck type ``detr_explainability.Generator`` drives.
+    """
+
+    def __init__(self, transformer, num_classes, num_queries, backbone_channels=2048, pos_normalize=True):
+        super().__init__()
+        d = transformer.d_model
+        self.num_queries = num_queries
+        self.transformer = transformer
+        self.class_embed = nn.Linear(d, num_classes + 1)
+        self.bbox_embed = MLP(d, d, 4, 3)
+        self.query_embed = nn.Embedding(num_queries, d)
+        self.input_proj = nn.Conv2d(backbone_channels, d, kernel_size=1)
+        self.position = PositionEmbeddingSine(d // 2, normalize=pos_normalize)
+
+    def forward(self, features, mask=None):
+        if mask is None:
+            mask = torch.zeros(features.shape[0], *features.shape[-2:], dtype=torch.bool, device=features.device)
+        self.spatial_dim = features.shape[-2:]
+        # 1x1 convolution == per-pixel Linear: run it as a GEMM (MIOpen's generic conv path is far slower on gfx950)
+        proj = F.linear(features.permute(0, 2, 3, 1), self.input_proj.weight.flatten(1), self.input_proj.bias)
+        hs, memory = self.transformer(proj.permute(0, 3, 1, 2), mask, self.query_embed.weight, self.position(mask))
+        self.memory_shape = memory.shape
+        return {"pred_logits": self.class_embed(hs[-1]), "pred_boxes": self.bbox_embed(hs[-1]).sigmoid()}
+
+
+def detr_resnet50_head(num_classes=91, num_queries=100):
+    """The transformer + heads of DETR-R50 (``DETR/main.py`` defaults: d=256, 8 heads, 6+6 layers, ffn 2048)."""
+    return DETRFromFeatures(Transformer(d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6,
+                                        dim_feedforward=2048, dropout=0.1, return_intermediate_dec=True),
+                            num_classes=num_classes, num_queries=num_queries)
