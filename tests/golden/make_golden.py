@@ -398,6 +398,81 @@ def gen_detr_transformer():
     save("detr_transformer", **arrays)
 
 
+def gen_lxmert_model():
+    """The REAL reference LXMERT body (lxmert/lxmert/src/lxmert_lrp.py: embeddings, encoder with hooked attention,
+    pooler, answer head) driven by the reference GeneratorOurs / GeneratorBaselines.  ``LxmertModel`` itself derives
+    from a transformers base class whose API moved, so its forward (mask extension, lxmert_lrp.py:1188-1225) is
+    restated in the wrapper; every layer that computes is the reference's own."""
+    from transformers.models.lxmert.configuration_lxmert import LxmertConfig
+    import transformers.file_utils as fu
+    fu.add_code_sample_docstrings = lambda *a, **k: (lambda f: f)
+    shim = types.ModuleType("transformers.configuration_lxmert")
+    shim.LxmertConfig = LxmertConfig
+    sys.modules["transformers.configuration_lxmert"] = shim
+    from lxmert.lxmert.src import lxmert_lrp as lrp
+
+    torch.manual_seed(21)
+    T, I = 9, 11
+    cfg = LxmertConfig(hidden_size=48, num_attention_heads=4, intermediate_size=96, l_layers=3, x_layers=3,
+                       r_layers=2, visual_feat_dim=20, visual_pos_dim=4, vocab_size=60, num_qa_labels=13,
+                       max_position_embeddings=32, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+
+    class RefModel(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embeddings = lrp.LxmertEmbeddings(cfg)
+            self.encoder = lrp.LxmertEncoder(cfg)
+            self.pooler = lrp.LxmertPooler(cfg)
+
+        def forward(self, input_ids, visual_feats, visual_pos, attention_mask, token_type_ids):
+            ext = (1.0 - attention_mask[:, None, None, :].float()) * -10000.0
+            emb = self.embeddings(input_ids, token_type_ids, None)
+            vis_out, lang_out = self.encoder(emb, ext, visual_feats=visual_feats, visual_pos=visual_pos,
+                                             visual_attention_mask=None, output_attentions=False)[:2]
+            return self.pooler(lang_out[0][-1])
+
+    class RefQA(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lxmert = RefModel()
+            self.answer_head = lrp.LxmertVisualAnswerHead(cfg, cfg.num_qa_labels)
+            self.device = torch.device("cpu")
+
+        def forward(self, **kw):
+            return types.SimpleNamespace(question_answering_score=self.answer_head(self.lxmert(**kw)))
+
+    model = RefQA().eval()
+    # LayerNorm affine / embedding rows away from their init so every parameter matters
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    weights = {k: v.clone() for k, v in model.state_dict().items()}        # before the lazy deepcopy adds keys
+    g = torch.Generator().manual_seed(22)
+    inputs = dict(input_ids=torch.randint(1, 60, (1, T), generator=g),
+                  visual_feats=torch.randn(1, I, 20, generator=g), visual_pos=torch.rand(1, I, 4, generator=g),
+                  attention_mask=torch.ones(1, T), token_type_ids=torch.zeros(1, T, dtype=torch.long))
+    # no padded text tokens: a padded query row has zero gradient, so its row of R_tt - I sums to 0 and the reference's
+    # handle_residual (no nan_to_num in the LXMERT flavour) trips its own ``assert diag.min() >= 0`` on the NaN
+    usage = types.SimpleNamespace(model=model, text_len=T, image_boxes_len=I, forward=lambda item: model(**inputs))
+    gen = lx_eg.GeneratorOurs(usage)
+    R_t_t, R_t_i = gen.generate_ours(None, use_lrp=False)
+    arrays = dict(R_t_t=R_t_t, R_t_i=R_t_i, R_i_i=gen.R_i_i, R_i_t=gen.R_i_t,
+                  score=model(**inputs).question_answering_score,
+                  dims=np.array([cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size, cfg.l_layers,
+                                 cfg.x_layers, cfg.r_layers, cfg.visual_feat_dim, cfg.vocab_size, cfg.num_qa_labels,
+                                 cfg.max_position_embeddings, T, I]))
+    base = lx_eg.GeneratorBaselines(usage)
+    arrays["rollout_R_t_t"], arrays["rollout_R_t_i"] = base.generate_rollout(None)
+    arrays["raw_R_t_t"], arrays["raw_R_t_i"] = base.generate_raw_attn(None)
+    arrays["gradcam_R_t_t"], arrays["gradcam_R_t_i"] = base.generate_attn_gradcam(None)
+    for k, v in inputs.items():
+        arrays["in__" + k] = v
+    for k, v in weights.items():
+        arrays["w__" + k] = v
+    save("lxmert_model", **arrays)
+
+
 if __name__ == "__main__":
     gen_rules()
     gen_detr_chain("detr_chain", 200, H=4, Ni=35, Nq=10, Le=3, Ld=3, targets=[2, 7])
@@ -414,3 +489,4 @@ if __name__ == "__main__":
     gen_clip_tiny()
     gen_detr_mha()
     gen_detr_transformer()
+    gen_lxmert_model()

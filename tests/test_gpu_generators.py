@@ -313,3 +313,42 @@ def test_detr_r50_shape_runs():
         Rqi = Rqi + torch.nan_to_num(residual(Rqq).t() @ cam(blk.multihead_attn) @ residual(Rii), nan=0.0)
     torch.testing.assert_close(gen.R_i_i.double(), Rii, rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(out[0, 0].double(), Rqi[tgt], rtol=1e-4, atol=1e-7)
+
+
+def _lxmert_from_golden(g):
+    from transformer_mm_explainability_amd import lxmert_model as lm
+    hidden, heads, inter, ll, xl, rl, feat, vocab, labels, max_pos, T, I = (int(x) for x in g["dims"])
+    cfg = lm.LxmertConfig(hidden_size=hidden, num_attention_heads=heads, intermediate_size=inter, l_layers=ll,
+                          x_layers=xl, r_layers=rl, visual_feat_dim=feat, vocab_size=vocab, num_qa_labels=labels,
+                          max_position_embeddings=max_pos)
+    model = lm.LxmertForQuestionAnswering(cfg)
+    model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w__")}, strict=True)
+    model = model.cuda().eval()
+    inputs = {k[4:]: cu(v) for k, v in g.items() if k.startswith("in__")}
+    return model, types.SimpleNamespace(model=model, text_len=T, image_boxes_len=I,
+                                        forward=lambda item: model(**inputs))
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_lxmert_real_body(golden, fused):
+    """``lxmert_model`` (9 kinds of captured attention incl. the weight-sharing image->text cross direction) +
+    ``GeneratorOurs`` / ``GeneratorBaselines`` against the REFERENCE's LXMERT layers (lxmert_lrp.py) driven by the
+    reference generators on the same weights and inputs."""
+    from transformer_mm_explainability_amd import lxmert_explainability as le
+    g = golden("lxmert_model")
+    model, usage = _lxmert_from_golden(g)
+    close(usage.forward(None).question_answering_score, g["score"])
+    gen = le.GeneratorOurs(usage)
+    gen.fused = fused
+    R_t_t, R_t_i = gen.generate_ours(None, use_lrp=False)
+    close(R_t_t, g["R_t_t"])
+    close(R_t_i, g["R_t_i"])
+    close(gen.R_i_i, g["R_i_i"])
+    close(gen.R_i_t, g["R_i_t"])
+    assert all(p.grad is None for p in model.parameters())          # frozen forward: no weight gradients formed
+    base = le.GeneratorBaselines(usage)
+    for name, fn in (("rollout", base.generate_rollout), ("raw", base.generate_raw_attn),
+                     ("gradcam", base.generate_attn_gradcam)):
+        a, b = fn(None)
+        close(a, g[name + "_R_t_t"])
+        close(b, g[name + "_R_t_i"])

@@ -104,7 +104,7 @@ class MultiheadAttention(_SlabOwner):
 class BertStyleAttention(_SlabOwner):
     """LXMERT ``LxmertAttention`` / BERT ``BertSelfAttention`` on the HIP capture op (see module docstring)."""
 
-    def __init__(self, hidden_size, num_attention_heads, ctx_dim=None):
+    def __init__(self, hidden_size, num_attention_heads, ctx_dim=None, share_weights_with=None):
         super().__init__()
         if hidden_size % num_attention_heads:
             raise ValueError("hidden size must be a multiple of the number of heads")
@@ -112,6 +112,13 @@ class BertStyleAttention(_SlabOwner):
         self.attention_head_size = hidden_size // num_attention_heads
         self.head_size = hidden_size
         ctx_dim = hidden_size if ctx_dim is None else ctx_dim
+        if share_weights_with is not None:
+            # LXMERT runs its cross-attention weights twice per x-layer (text->image and image->text,
+            # lxmert_lrp.py:640-656 deep-copies the module so that each direction keeps its own saved attention);
+            # here the second direction shares the projection modules and owns only its capture slabs
+            self.query, self.key, self.value = (share_weights_with.query, share_weights_with.key,
+                                                share_weights_with.value)
+            return
         self.query = nn.Linear(hidden_size, hidden_size)
         self.key = nn.Linear(ctx_dim, hidden_size)
         self.value = nn.Linear(ctx_dim, hidden_size)

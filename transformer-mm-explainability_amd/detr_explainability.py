@@ -24,17 +24,9 @@ apply_mm_attention_rules = rules.apply_mm_attention_rules_detr
 
 
 def _logits_for_backward(model, img):
-    """Forward pass the one-hot backward will run through.
-
-    No rule reads a weight gradient, so when the input is a float tensor it becomes the autograd leaf and the
-    parameters are frozen while the graph is built: the backward then computes activation gradients only (the
-    reference also accumulates every ``param.grad``; nothing reads them).  Any other input type (NestedTensor, None in
-    the fake-body tests) takes the reference route unchanged.
-    """
-    if isinstance(img, torch.Tensor) and img.is_floating_point() and isinstance(model, torch.nn.Module):
-        with rules.frozen_parameters(model):
-            return model(img.detach().requires_grad_(True))["pred_logits"]
-    return model(img)["pred_logits"]
+    """Forward pass the one-hot backward will run through; no rule reads a weight gradient, so parameters are frozen
+    while the graph is built whenever the body allows it (``rules.forward_for_backward``)."""
+    return rules.forward_for_backward(model, lambda: model(img)["pred_logits"])
 
 
 def _one_hot_backward(model, outputs, target_index, index):

@@ -30,8 +30,8 @@ def _pair(module):
 
 def _backward_on_answer(model_usage, input, index):
     """lxmert/.../ExplanationGenerator.py:136,153-163."""
-    output = model_usage.forward(input).question_answering_score
     model = model_usage.model
+    output = rules.forward_for_backward(model, lambda: model_usage.forward(input).question_answering_score)
     if index is None:
         index = np.argmax(output.cpu().data.numpy(), axis=-1)
     one_hot = torch.zeros_like(output)

@@ -1,0 +1,253 @@
+"""LXMERT (two-stream VQA transformer) on the HIP capture op -- the body ``lxmert_explainability`` drives.
+
+Module tree and parameter names follow ``lxmert/lxmert/src/lxmert_lrp.py`` (itself HuggingFace's LXMERT), so an
+``unc-nlp/lxmert-vqa-uncased`` state dict loads unchanged: ``lxmert.embeddings``, ``lxmert.encoder.{visn_fc, layer[9],
+r_layers[5], x_layers[5]}``, ``lxmert.pooler``, ``answer_head``.  Every attention core is
+``attention_modules.BertStyleAttention``: P and dL/dP are written by the HIP kernels into device slabs, and
+``get_attn()`` / ``get_attn_gradients()`` (``[B, H, Nq, Nk]``) return views of them -- no hooks.
+
+Things a caller can observe:
+  * ``x_layers[i].visual_attention_copy`` (the image->text direction of the shared cross-attention weights,
+    lxmert_lrp.py:640-656) exists from construction and SHARES the projection / output modules with
+    ``visual_attention`` instead of deep-copying them at the first forward; it is not part of the state dict;
+  * eval mode only (dropout = identity); no ``relprop`` (LRP is out of scope);
+  * the Faster R-CNN feature extractor and the tokenizer (``ModelUsage`` in the reference's perturbation script) stay
+    outside: inputs are ``input_ids``, ``visual_feats [B, I, 2048]``, ``visual_pos [B, I, 4]`` and the two masks.
+"""
+from __future__ import annotations
+
+import types
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .attention_modules import BertStyleAttention
+
+
+@dataclass
+class LxmertConfig:
+    """The fields of ``transformers``' LxmertConfig this body reads (any object with these attributes works)."""
+    vocab_size: int = 30522
+    hidden_size: int = 768
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    l_layers: int = 9
+    x_layers: int = 5
+    r_layers: int = 5
+    visual_feat_dim: int = 2048
+    visual_pos_dim: int = 4
+    max_position_embeddings: int = 512
+    type_vocab_size: int = 2
+    num_qa_labels: int = 3129
+    hidden_act: str = "gelu"
+
+
+def _act(name):
+    return {"gelu": F.gelu, "relu": F.relu, "tanh": torch.tanh}[name]
+
+
+class LxmertEmbeddings(nn.Module):                                     # lxmert_lrp.py:268-310
+    def __init__(self, c):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(c.vocab_size, c.hidden_size, padding_idx=0)
+        self.position_embeddings = nn.Embedding(c.max_position_embeddings, c.hidden_size, padding_idx=0)
+        self.token_type_embeddings = nn.Embedding(c.type_vocab_size, c.hidden_size, padding_idx=0)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=1e-12)
+
+    def forward(self, input_ids, token_type_ids=None, inputs_embeds=None):
+        if inputs_embeds is None:
+            inputs_embeds = self.word_embeddings(input_ids)
+        n = inputs_embeds.shape[1]
+        pos = torch.arange(n, device=inputs_embeds.device).unsqueeze(0).expand(inputs_embeds.shape[:2])
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(pos)
+        return self.LayerNorm(self.token_type_embeddings(token_type_ids) + self.position_embeddings(pos)
+                              + inputs_embeds)
+
+
+class LxmertAttentionOutput(nn.Module):                                # lxmert_lrp.py:464-477 (also LxmertOutput)
+    def __init__(self, c, in_features=None):
+        super().__init__()
+        self.dense = nn.Linear(c.hidden_size if in_features is None else in_features, c.hidden_size)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=1e-12)
+
+    def forward(self, hidden_states, input_tensor):
+        return self.LayerNorm(self.dense(hidden_states) + input_tensor)
+
+
+class LxmertCrossAttentionLayer(nn.Module):                            # lxmert_lrp.py:489-503
+    def __init__(self, c, share_weights_with=None):
+        super().__init__()
+        twin = share_weights_with
+        self.att = BertStyleAttention(c.hidden_size, c.num_attention_heads,
+                                      share_weights_with=None if twin is None else twin.att)
+        self.output = LxmertAttentionOutput(c) if twin is None else twin.output
+
+    def forward(self, input_tensor, ctx_tensor, ctx_att_mask=None, output_attentions=False):
+        out = self.att(input_tensor, ctx_tensor, ctx_att_mask, output_attentions=output_attentions)
+        return (self.output(out[0], input_tensor),) + out[1:]
+
+
+class LxmertSelfAttentionLayer(nn.Module):                             # lxmert_lrp.py:513-531
+    def __init__(self, c):
+        super().__init__()
+        self.self = BertStyleAttention(c.hidden_size, c.num_attention_heads)
+        self.output = LxmertAttentionOutput(c)
+
+    def forward(self, input_tensor, attention_mask, output_attentions=False):
+        out = self.self(input_tensor, input_tensor, attention_mask, output_attentions=output_attentions)
+        return (self.output(out[0], input_tensor),) + out[1:]
+
+
+class LxmertIntermediate(nn.Module):                                   # lxmert_lrp.py:543-552
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.hidden_size, c.intermediate_size)
+        self.intermediate_act_fn = _act(c.hidden_act)
+
+    def forward(self, hidden_states):
+        return self.intermediate_act_fn(self.dense(hidden_states))
+
+
+class LxmertOutput(LxmertAttentionOutput):                             # lxmert_lrp.py:560-573
+    def __init__(self, c):
+        super().__init__(c, in_features=c.intermediate_size)
+
+
+class LxmertLayer(nn.Module):                                          # lxmert_lrp.py:584-599
+    def __init__(self, c):
+        super().__init__()
+        self.attention = LxmertSelfAttentionLayer(c)
+        self.intermediate = LxmertIntermediate(c)
+        self.output = LxmertOutput(c)
+
+    def forward(self, hidden_states, attention_mask=None, output_attentions=False):
+        out = self.attention(hidden_states, attention_mask, output_attentions=output_attentions)
+        return (self.output(self.intermediate(out[0]), out[0]),) + out[1:]
+
+
+class LxmertXLayer(nn.Module):                                         # lxmert_lrp.py:609-740
+    def __init__(self, c):
+        super().__init__()
+        self.visual_attention = LxmertCrossAttentionLayer(c)
+        self.lang_self_att = LxmertSelfAttentionLayer(c)
+        self.visn_self_att = LxmertSelfAttentionLayer(c)
+        self.lang_inter = LxmertIntermediate(c)
+        self.lang_output = LxmertOutput(c)
+        self.visn_inter = LxmertIntermediate(c)
+        self.visn_output = LxmertOutput(c)
+        # second direction of the same weights; kept out of _modules so checkpoints keep the reference's key set
+        object.__setattr__(self, "visual_attention_copy",
+                           LxmertCrossAttentionLayer(c, share_weights_with=self.visual_attention))
+
+    def forward(self, lang_feats, lang_attention_mask, visual_feats, visual_attention_mask, output_attentions=False):
+        lang_att = self.visual_attention(lang_feats, visual_feats, ctx_att_mask=visual_attention_mask,
+                                         output_attentions=output_attentions)
+        visn_att = self.visual_attention_copy(visual_feats, lang_feats, ctx_att_mask=lang_attention_mask)
+        lang = self.lang_self_att(lang_att[0], lang_attention_mask)[0]
+        visn = self.visn_self_att(visn_att[0], visual_attention_mask)[0]
+        lang = self.lang_output(self.lang_inter(lang), lang)
+        visn = self.visn_output(self.visn_inter(visn), visn)
+        return (lang, visn) + lang_att[1:]
+
+
+class LxmertVisualFeatureEncoder(nn.Module):                           # lxmert_lrp.py:742-767
+    def __init__(self, c):
+        super().__init__()
+        self.visn_fc = nn.Linear(c.visual_feat_dim, c.hidden_size)
+        self.visn_layer_norm = nn.LayerNorm(c.hidden_size, eps=1e-12)
+        self.box_fc = nn.Linear(c.visual_pos_dim, c.hidden_size)
+        self.box_layer_norm = nn.LayerNorm(c.hidden_size, eps=1e-12)
+
+    def forward(self, visual_feats, visual_pos):
+        return (self.visn_layer_norm(self.visn_fc(visual_feats)) + self.box_layer_norm(self.box_fc(visual_pos))) / 2
+
+
+class LxmertEncoder(nn.Module):                                        # lxmert_lrp.py:774-866
+    def __init__(self, c):
+        super().__init__()
+        self.visn_fc = LxmertVisualFeatureEncoder(c)
+        self.config = c
+        self.num_l_layers, self.num_x_layers, self.num_r_layers = c.l_layers, c.x_layers, c.r_layers
+        self.layer = nn.ModuleList(LxmertLayer(c) for _ in range(c.l_layers))
+        self.x_layers = nn.ModuleList(LxmertXLayer(c) for _ in range(c.x_layers))
+        self.r_layers = nn.ModuleList(LxmertLayer(c) for _ in range(c.r_layers))
+
+    def forward(self, lang_feats, lang_attention_mask, visual_feats, visual_pos, visual_attention_mask=None):
+        visual_feats = self.visn_fc(visual_feats, visual_pos)
+        for blk in self.layer:
+            lang_feats = blk(lang_feats, lang_attention_mask)[0]
+        for blk in self.r_layers:
+            visual_feats = blk(visual_feats, visual_attention_mask)[0]
+        for blk in self.x_layers:
+            lang_feats, visual_feats = blk(lang_feats, lang_attention_mask, visual_feats, visual_attention_mask)[:2]
+        return lang_feats, visual_feats
+
+
+class LxmertPooler(nn.Module):                                         # lxmert_lrp.py:868-884
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.hidden_size, c.hidden_size)
+
+    def forward(self, hidden_states):
+        return torch.tanh(self.dense(hidden_states[:, 0]))
+
+
+class LxmertVisualAnswerHead(nn.Module):                               # lxmert_lrp.py:941-953
+    def __init__(self, c, num_labels):
+        super().__init__()
+        h = c.hidden_size
+        self.logit_fc = nn.Sequential(nn.Linear(h, h * 2), nn.GELU(), nn.LayerNorm(h * 2, eps=1e-12),
+                                      nn.Linear(h * 2, num_labels))
+
+    def forward(self, hidden_states):
+        return self.logit_fc(hidden_states)
+
+
+def _extended_mask(mask, dtype):
+    """``[B, N]`` 1/0 mask -> additive ``[B, 1, 1, N]`` (0 / -10000), lxmert_lrp.py:1188-1207."""
+    return None if mask is None else (1.0 - mask[:, None, None, :].to(dtype)) * -10000.0
+
+
+class LxmertModel(nn.Module):                                          # lxmert_lrp.py:1122-1262
+    def __init__(self, c):
+        super().__init__()
+        self.config = c
+        self.embeddings = LxmertEmbeddings(c)
+        self.encoder = LxmertEncoder(c)
+        self.pooler = LxmertPooler(c)
+
+    def forward(self, input_ids=None, visual_feats=None, visual_pos=None, attention_mask=None,
+                visual_attention_mask=None, token_type_ids=None, inputs_embeds=None):
+        if visual_feats is None or visual_pos is None:
+            raise ValueError("`visual_feats` and `visual_pos` cannot be None")
+        if (input_ids is None) == (inputs_embeds is None):
+            raise ValueError("specify exactly one of input_ids and inputs_embeds")
+        emb = self.embeddings(input_ids, token_type_ids, inputs_embeds)
+        if attention_mask is None:
+            attention_mask = torch.ones(emb.shape[:2], device=emb.device)
+        lang, visn = self.encoder(emb, _extended_mask(attention_mask, emb.dtype), visual_feats, visual_pos,
+                                  _extended_mask(visual_attention_mask, emb.dtype))
+        return types.SimpleNamespace(language_output=lang, vision_output=visn, pooled_output=self.pooler(lang))
+
+
+class LxmertForQuestionAnswering(nn.Module):                           # lxmert_lrp.py:1532-1692
+    def __init__(self, c):
+        super().__init__()
+        self.config = c
+        self.num_qa_labels = c.num_qa_labels
+        self.lxmert = LxmertModel(c)
+        self.answer_head = LxmertVisualAnswerHead(c, c.num_qa_labels)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def forward(self, input_ids=None, visual_feats=None, visual_pos=None, attention_mask=None,
+                visual_attention_mask=None, token_type_ids=None, inputs_embeds=None, **unused):
+        out = self.lxmert(input_ids, visual_feats, visual_pos, attention_mask, visual_attention_mask, token_type_ids,
+                          inputs_embeds)
+        out.question_answering_score = self.answer_head(out.pooled_output)
+        return out

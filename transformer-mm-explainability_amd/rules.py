@@ -44,6 +44,22 @@ class frozen_parameters:
             p.requires_grad_(True)
 
 
+def forward_for_backward(model, run):
+    """``run()`` -> the score tensor the one-hot backward starts from, computed under frozen parameters if possible.
+
+    Bodies built on the capture op stay differentiable with every parameter frozen (an attention block whose inputs
+    are graph constants ties itself to the graph, ``capture.attention_capture``), so the backward pass is activation
+    gradients only.  Any other body (the reference's hooked modules, a test double) may come out detached; then the
+    forward is simply repeated the reference's way, parameters requiring grad.
+    """
+    if isinstance(model, torch.nn.Module):
+        with frozen_parameters(model):
+            out = run()
+        if out.requires_grad:
+            return out
+    return run()
+
+
 def avg_heads(cam, grad):
     """Rule 5 (DETR/modules/ExplanationGenerator.py:19-24): ``(grad*cam).clamp(min=0).mean(dim=0)`` over all leading dims."""
     return ops.avg_heads(cam, grad, batch_size=1)[0]

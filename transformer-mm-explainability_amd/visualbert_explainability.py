@@ -17,7 +17,7 @@ compute_rollout_attention = rules.compute_rollout_attention_batched
 
 
 def _backward_on_answer(model, input, index):
-    output = model(input)["scores"]
+    output = rules.forward_for_backward(model, lambda: model(input)["scores"])
     if index is None:
         index = np.argmax(output.cpu().data.numpy(), axis=-1)
     one_hot = torch.zeros_like(output)
