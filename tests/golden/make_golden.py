@@ -473,6 +473,106 @@ def gen_lxmert_model():
     save("lxmert_model", **arrays)
 
 
+def gen_visualbert_model():
+    """The REAL reference BERT stack of VisualBERT (backends/BERT_ours.py: BertEncoder with hooked BertSelfAttention,
+    BertPredictionHeadTransform) driven by the reference SelfAttentionGenerator.  mmf's own modules (the
+    visio-linguistic embedding sum, the VisualBERT wrapper's sample_list massaging) need an installed ``mmf`` to
+    import, so those few lines -- embeddings.py:325-460, visual_bert.py:340-395 and :568-600 -- are restated in the
+    wrapper; all layers with weights in the encoder / head are the reference's classes."""
+    import importlib
+    from transformers import BertConfig
+    pkg = types.ModuleType("vb_backends")
+    pkg.__path__ = [os.path.join(REF, "VisualBERT/mmf/models/transformers/backends")]
+    sys.modules["vb_backends"] = pkg
+    bo = importlib.import_module("vb_backends.BERT_ours")
+
+    torch.manual_seed(31)
+    T, V, Tpad, vdim, labels = 8, 10, 12, 20, 9
+    cfg = BertConfig(hidden_size=48, num_attention_heads=4, intermediate_size=96, num_hidden_layers=4, vocab_size=70,
+                     max_position_embeddings=32, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+
+    class Emb(nn.Module):
+        def __init__(self):
+            super().__init__()
+            h = cfg.hidden_size
+            self.word_embeddings = nn.Embedding(cfg.vocab_size, h, padding_idx=0)
+            self.position_embeddings = nn.Embedding(cfg.max_position_embeddings, h)
+            self.token_type_embeddings = nn.Embedding(cfg.type_vocab_size, h)
+            self.LayerNorm = nn.LayerNorm(h, eps=cfg.layer_norm_eps)
+            self.token_type_embeddings_visual = nn.Embedding(cfg.type_vocab_size, h)
+            self.position_embeddings_visual = nn.Embedding(cfg.max_position_embeddings, h)
+            self.projection = nn.Linear(vdim, h)
+
+        def forward(self, ids, types_, vis, vis_types):
+            pos = torch.arange(ids.shape[1]).unsqueeze(0).expand_as(ids)
+            text = self.word_embeddings(ids) + self.position_embeddings(pos) + self.token_type_embeddings(types_)
+            v = self.projection(vis)
+            v = v + self.position_embeddings_visual(torch.zeros(v.shape[:-1], dtype=torch.long)) \
+                + self.token_type_embeddings_visual(vis_types)
+            return self.LayerNorm(torch.cat((text, v), dim=1))
+
+    class Base(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embeddings = Emb()
+            self.encoder = bo.BertEncoder(cfg)
+            self.pooler = bo.BertPooler(cfg)
+
+    class Cls(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.bert = Base()
+            self.classifier = nn.Sequential(bo.BertPredictionHeadTransform(cfg), nn.Linear(cfg.hidden_size, labels))
+
+        def forward(self, ids, input_mask, attention_mask, types_, vis, vis_types):
+            ext = (1.0 - attention_mask[:, None, None, :].float()) * -10000.0
+            seq = self.bert.encoder(self.bert.embeddings(ids, types_, vis, vis_types), ext)[0]
+            pooled = seq[torch.arange(seq.shape[0]), input_mask.sum(1) - 2]          # pooler_strategy == "vqa"
+            return {"scores": self.classifier(pooled).view(-1, labels)}
+
+    class Wrapper(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = Cls()
+
+        def forward(self, sl):
+            n = int(sl["input_mask"].sum())
+            for key in ("input_ids", "input_mask", "segment_ids"):
+                sl[key] = sl[key][:, :n]
+            image_mask = torch.ones(sl["image_feature_0"].shape[:-1], dtype=torch.long)
+            attention_mask = torch.cat((sl["input_mask"], image_mask), dim=-1)
+            return self.model(sl["input_ids"], sl["input_mask"], attention_mask, sl["segment_ids"],
+                              sl["image_feature_0"], torch.zeros_like(image_mask))
+
+    model = Wrapper().eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    g = torch.Generator().manual_seed(32)
+    ids = torch.randint(1, 70, (1, Tpad), generator=g)
+    ids[0, T:] = 0
+    mask = torch.zeros(1, Tpad, dtype=torch.long)
+    mask[0, :T] = 1
+
+    def sample():
+        return {"input_ids": ids.clone(), "input_mask": mask.clone(),
+                "segment_ids": torch.zeros(1, Tpad, dtype=torch.long), "image_feature_0": feats}
+
+    feats = torch.randn(1, V, vdim, generator=g)
+    arrays = dict(dims=np.array([cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size,
+                                 cfg.num_hidden_layers, cfg.vocab_size, cfg.max_position_embeddings, vdim, labels]),
+                  input_ids=ids, input_mask=mask, image_feature_0=feats, scores=model(sample())["scores"],
+                  out=vb_eg.SelfAttentionGenerator(model).generate_ours(sample()),
+                  rollout_out=vb_eg.SelfAttentionGenerator(model).generate_rollout(sample()),
+                  raw_attn_out=vb_eg.SelfAttentionGenerator(model).generate_raw_attn(sample()),
+                  gradcam_out=vb_eg.SelfAttentionGenerator(model).generate_attn_gradcam(sample()))
+    for k, v in model.state_dict().items():
+        if not k.endswith("position_ids"):
+            arrays["w__" + k] = v
+    save("visualbert_model", **arrays)
+
+
 if __name__ == "__main__":
     gen_rules()
     gen_detr_chain("detr_chain", 200, H=4, Ni=35, Nq=10, Le=3, Ld=3, targets=[2, 7])
@@ -490,3 +590,4 @@ if __name__ == "__main__":
     gen_detr_mha()
     gen_detr_transformer()
     gen_lxmert_model()
+    gen_visualbert_model()

@@ -352,3 +352,32 @@ def test_lxmert_real_body(golden, fused):
         a, b = fn(None)
         close(a, g[name + "_R_t_t"])
         close(b, g[name + "_R_t_i"])
+
+
+def test_visualbert_real_body(golden):
+    """``visualbert_model`` + ``SelfAttentionGenerator`` against the REFERENCE's BERT stack (BERT_ours.py, hooked
+    BertSelfAttention) driven by the reference generator: same weights, padded text (trimmed by the wrapper exactly
+    like visual_bert.py:578-588), 'vqa' pooling of the second-to-last text token."""
+    from transformer_mm_explainability_amd import visualbert_explainability as vb
+    from transformer_mm_explainability_amd import visualbert_model as vm
+    g = golden("visualbert_model")
+    hidden, heads, inter, layers, vocab, max_pos, vdim, labels = (int(x) for x in g["dims"])
+    model = vm.VisualBERT(vm.VisualBertConfig(hidden_size=hidden, num_attention_heads=heads, intermediate_size=inter,
+                                              num_hidden_layers=layers, vocab_size=vocab,
+                                              max_position_embeddings=max_pos, visual_embedding_dim=vdim,
+                                              num_labels=labels))
+    weights = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w__")}
+    missing, unexpected = model.load_state_dict(weights, strict=False)
+    assert not unexpected and all(m.startswith("model.bert.pooler.") for m in missing), (missing, unexpected)
+    model = model.cuda().eval()
+
+    def sample():
+        return {"input_ids": cu(g["input_ids"]), "input_mask": cu(g["input_mask"]),
+                "segment_ids": torch.zeros_like(cu(g["input_ids"])), "image_feature_0": cu(g["image_feature_0"])}
+
+    close(model(sample())["scores"], g["scores"])
+    close(vb.SelfAttentionGenerator(model).generate_ours(sample()), g["out"])
+    assert all(p.grad is None for p in model.parameters())
+    close(vb.SelfAttentionGenerator(model).generate_rollout(sample()), g["rollout_out"])
+    close(vb.SelfAttentionGenerator(model).generate_raw_attn(sample()), g["raw_attn_out"])
+    close(vb.SelfAttentionGenerator(model).generate_attn_gradcam(sample()), g["gradcam_out"])

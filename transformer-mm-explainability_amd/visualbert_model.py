@@ -1,0 +1,225 @@
+"""VisualBERT (single-stream BERT over text tokens + image regions) on the HIP capture op -- the body
+``visualbert_explainability.SelfAttentionGenerator`` drives.
+
+Module tree and parameter names follow ``VisualBERT/mmf/models/visual_bert.py`` and
+``.../transformers/backends/BERT_ours.py`` so an mmf VisualBERT-VQA2 checkpoint (``model.bert.*``,
+``model.classifier.*``) loads unchanged.  Every ``encoder.layer[i].attention.self`` is
+``attention_modules.BertStyleAttention``: P and dL/dP are written into device slabs by the HIP kernels and
+``get_attn()`` / ``get_attn_gradients()`` (``[B, H, N, N]``) are views of them -- no hooks.
+
+Out of scope: mmf's registry / config / dataset machinery, the pretraining and nlvr2 heads,
+TorchScript, ``relprop``.  Eval mode only.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .attention_modules import BertStyleAttention
+
+
+@dataclass
+class VisualBertConfig:
+    """BertConfig fields + the mmf additions this body reads (``configs/models/visual_bert/defaults.yaml``)."""
+    vocab_size: int = 30522
+    hidden_size: int = 768
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    max_position_embeddings: int = 512
+    type_vocab_size: int = 2
+    layer_norm_eps: float = 1e-12
+    pad_token_id: int = 0
+    hidden_act: str = "gelu"
+    visual_embedding_dim: int = 2048
+    num_labels: int = 3129
+    pooler_strategy: str = "vqa"          # "vqa": pool the second-to-last text token (visual_bert.py:376-386)
+
+
+class BertVisioLinguisticEmbeddings(nn.Module):                        # mmf/modules/embeddings.py:305-460
+    def __init__(self, c):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(c.vocab_size, c.hidden_size, padding_idx=c.pad_token_id)
+        self.position_embeddings = nn.Embedding(c.max_position_embeddings, c.hidden_size)
+        self.token_type_embeddings = nn.Embedding(c.type_vocab_size, c.hidden_size)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.token_type_embeddings_visual = nn.Embedding(c.type_vocab_size, c.hidden_size)
+        self.position_embeddings_visual = nn.Embedding(c.max_position_embeddings, c.hidden_size)
+        self.projection = nn.Linear(c.visual_embedding_dim, c.hidden_size)
+
+    def encode_text(self, input_ids, token_type_ids=None):
+        pos = torch.arange(input_ids.shape[1], device=input_ids.device).unsqueeze(0).expand_as(input_ids)
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_ids)
+        return (self.word_embeddings(input_ids) + self.position_embeddings(pos)
+                + self.token_type_embeddings(token_type_ids))
+
+    def get_position_embeddings_visual(self, visual_embeddings, image_text_alignment=None):
+        zero_ids = torch.zeros(visual_embeddings.shape[:-1], dtype=torch.long, device=visual_embeddings.device)
+        base = self.position_embeddings_visual(zero_ids)
+        if image_text_alignment is None:
+            return base
+        # mean of the aligned words' position embeddings; -1 marks padding (embeddings.py:373-408)
+        valid = (image_text_alignment != -1).long()
+        aligned = (self.position_embeddings(valid * image_text_alignment) * valid.unsqueeze(-1)).sum(2)
+        return aligned / valid.sum(2).clamp(min=1).unsqueeze(-1) + base
+
+    def encode_image(self, visual_embeddings, visual_embeddings_type, image_text_alignment=None):
+        projected = self.projection(visual_embeddings)
+        return (projected + self.get_position_embeddings_visual(projected, image_text_alignment)
+                + self.token_type_embeddings_visual(visual_embeddings_type))
+
+    def forward(self, input_ids, token_type_ids=None, visual_embeddings=None, visual_embeddings_type=None,
+                image_text_alignment=None):
+        emb = self.encode_text(input_ids, token_type_ids)
+        if visual_embeddings is not None and visual_embeddings_type is not None:
+            emb = torch.cat((emb, self.encode_image(visual_embeddings, visual_embeddings_type,
+                                                    image_text_alignment)), dim=1)
+        return self.LayerNorm(emb)
+
+
+class _DenseAddNorm(nn.Module):                                        # BertSelfOutput / BertOutput
+    def __init__(self, c, in_features):
+        super().__init__()
+        self.dense = nn.Linear(in_features, c.hidden_size)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+
+    def forward(self, hidden_states, input_tensor):
+        return self.LayerNorm(self.dense(hidden_states) + input_tensor)
+
+
+class BertAttention(nn.Module):                                        # BERT_ours.py:189-232
+    def __init__(self, c):
+        super().__init__()
+        self.self = BertStyleAttention(c.hidden_size, c.num_attention_heads)
+        self.output = _DenseAddNorm(c, c.hidden_size)
+
+    def forward(self, hidden_states, attention_mask=None):
+        return self.output(self.self(hidden_states, None, attention_mask)[0], hidden_states)
+
+
+class BertIntermediate(nn.Module):                                     # BERT_ours.py:422-442
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.hidden_size, c.intermediate_size)
+        self.intermediate_act_fn = {"gelu": F.gelu, "relu": F.relu}[c.hidden_act]
+
+    def forward(self, hidden_states):
+        return self.intermediate_act_fn(self.dense(hidden_states))
+
+
+class BertLayer(nn.Module):                                            # BERT_ours.py:475-515
+    def __init__(self, c):
+        super().__init__()
+        self.attention = BertAttention(c)
+        self.intermediate = BertIntermediate(c)
+        self.output = _DenseAddNorm(c, c.intermediate_size)
+
+    def forward(self, hidden_states, attention_mask=None):
+        attended = self.attention(hidden_states, attention_mask)
+        return self.output(self.intermediate(attended), attended)
+
+
+class BertEncoder(nn.Module):                                          # BERT_ours.py:93-157
+    def __init__(self, c):
+        super().__init__()
+        self.layer = nn.ModuleList(BertLayer(c) for _ in range(c.num_hidden_layers))
+
+    def forward(self, hidden_states, attention_mask=None):
+        for blk in self.layer:
+            hidden_states = blk(hidden_states, attention_mask)
+        return hidden_states
+
+
+class BertPooler(nn.Module):                                           # BERT_ours.py:159-187
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.hidden_size, c.hidden_size)
+
+    def forward(self, hidden_states):
+        return torch.tanh(self.dense(hidden_states[:, 0]))
+
+
+class BertPredictionHeadTransform(nn.Module):                          # BERT_ours.py:517-538
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.hidden_size, c.hidden_size)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.transform_act_fn = {"gelu": F.gelu, "relu": F.relu}[c.hidden_act]
+
+    def forward(self, hidden_states):
+        return self.LayerNorm(self.transform_act_fn(self.dense(hidden_states)))
+
+
+class VisualBERTBase(nn.Module):                                       # visual_bert.py:34-153 (no bypass_transformer)
+    def __init__(self, c):
+        super().__init__()
+        self.config = c
+        self.embeddings = BertVisioLinguisticEmbeddings(c)
+        self.encoder = BertEncoder(c)
+        self.pooler = BertPooler(c)
+
+    def forward(self, input_ids, attention_mask=None, token_type_ids=None, visual_embeddings=None,
+                visual_embeddings_type=None, image_text_alignment=None):
+        emb = self.embeddings(input_ids, token_type_ids, visual_embeddings, visual_embeddings_type,
+                              image_text_alignment)
+        if attention_mask is None:
+            attention_mask = torch.ones(emb.shape[:2], device=emb.device)
+        extended = (1.0 - attention_mask[:, None, None, :].to(emb.dtype)) * -10000.0
+        sequence_output = self.encoder(emb, extended)
+        return sequence_output, self.pooler(sequence_output), []
+
+
+class VisualBERTForClassification(nn.Module):                          # visual_bert.py:280-405
+    def __init__(self, c):
+        super().__init__()
+        self.config = c
+        self.num_labels = c.num_labels
+        self.pooler_strategy = c.pooler_strategy
+        self.bert = VisualBERTBase(c)
+        self.classifier = nn.Sequential(BertPredictionHeadTransform(c), nn.Linear(c.hidden_size, c.num_labels))
+
+    def forward(self, input_ids, input_mask, attention_mask=None, token_type_ids=None, visual_embeddings=None,
+                visual_embeddings_type=None, image_text_alignment=None, masked_lm_labels=None):
+        sequence_output, pooled_output, _ = self.bert(input_ids, attention_mask, token_type_ids, visual_embeddings,
+                                                      visual_embeddings_type, image_text_alignment)
+        if self.pooler_strategy == "vqa":
+            index = input_mask.sum(1) - 2                              # second-to-last text token
+            pooled_output = sequence_output[torch.arange(sequence_output.shape[0], device=index.device), index]
+        return {"scores": self.classifier(pooled_output).reshape(-1, self.num_labels)}
+
+
+class VisualBERT(nn.Module):
+    """``VisualBERT.forward(sample_list)`` (visual_bert.py:408-620, classification head): ``sample_list`` is a dict
+    with ``input_ids``, ``input_mask``, ``segment_ids`` (``[B, T]``), ``image_feature_0`` (``[B, V, dim]``) and
+    optionally ``image_dim`` (valid regions per sample).  Like the reference it trims the text padding (batch-1
+    evaluator assumption, visual_bert.py:578-588) and rewrites those entries of ``sample_list`` in place -- the
+    generator reads ``input['input_mask']`` afterwards."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.config = c
+        self.model = VisualBERTForClassification(c)
+
+    def forward(self, sample_list):
+        feats = sample_list["image_feature_0"]
+        image_dim = sample_list.get("image_dim")
+        if image_dim is None:
+            image_dim = torch.full((feats.shape[0], 1), feats.shape[1], device=feats.device)
+        if image_dim.dim() < 2:
+            image_dim = image_dim.unsqueeze(-1)
+        image_mask = (torch.arange(feats.shape[1], device=feats.device).expand(feats.shape[:-1]) < image_dim).long()
+        n_text = int(sample_list["input_mask"].sum())                  # one D2H read, as in the reference
+        for key in ("input_ids", "input_mask", "segment_ids"):
+            sample_list[key] = sample_list[key][:, :n_text]
+        sample_list["token_type_ids"] = sample_list["segment_ids"]
+        sample_list["visual_embeddings"] = feats
+        sample_list["image_mask"] = image_mask
+        sample_list["visual_embeddings_type"] = torch.zeros_like(image_mask)
+        sample_list["attention_mask"] = torch.cat((sample_list["input_mask"], image_mask), dim=-1)
+        return self.model(sample_list["input_ids"], sample_list["input_mask"], sample_list["attention_mask"],
+                          sample_list["token_type_ids"], feats, sample_list["visual_embeddings_type"],
+                          sample_list.get("image_text_alignment"))
