@@ -381,3 +381,46 @@ def test_visualbert_real_body(golden):
     close(vb.SelfAttentionGenerator(model).generate_rollout(sample()), g["rollout_out"])
     close(vb.SelfAttentionGenerator(model).generate_raw_attn(sample()), g["raw_attn_out"])
     close(vb.SelfAttentionGenerator(model).generate_attn_gradcam(sample()), g["gradcam_out"])
+
+
+@pytest.mark.parametrize("flags", [{}, {"normalize_self_attention": False}, {"apply_self_in_rule_10": False}])
+def test_detr_generate_ours_multi_equals_per_query_loop(golden, flags):
+    """Section 8f row 1: K kept queries in one replicated-batch pass == the reference's per-query loop."""
+    from transformer_mm_explainability_amd.detr_explainability import Generator
+    g = golden("detr_transformer")
+    model = _detr_from_golden(g)
+    feats = cu(g["features"])
+    targets = torch.tensor([4, 0, 6], device="cuda")
+    gen = Generator(model)
+    want = torch.cat([gen.generate_ours(feats, t.reshape(1), use_lrp=False, **flags) for t in targets], dim=2)
+    got = Generator(model).generate_ours_multi(feats, targets, **flags)
+    assert got.shape == want.shape == (1, 1, 3, 15)
+    close(got, want.cpu().numpy(), atol=1e-6)
+    if not flags:      # target 4 of the fixture: the reference generator's own single-target-of-two run used [1, 4]
+        two = Generator(model).generate_ours_multi(feats, torch.tensor([1], device="cuda"))
+        one = gen.generate_ours(feats, torch.tensor([1], device="cuda"), use_lrp=False)
+        close(two, one.cpu().numpy(), atol=1e-6)
+
+
+def test_detr_mask_generator_r50_shape():
+    """mask_generator.py core at config-3 size: batched relevancy + batched Otsu == per-query loop + per-map Otsu."""
+    from transformer_mm_explainability_amd import detr_model, postprocess
+    from transformer_mm_explainability_amd.detr_explainability import Generator, MaskGenerator
+    torch.manual_seed(1)
+    model = detr_model.detr_resnet50_head(num_classes=20).cuda().eval()
+    feats = torch.randn(1, 2048, 25, 38, device="cuda") * 0.5
+    mg = MaskGenerator(model, threshold=0.0)
+    with torch.no_grad():
+        mg.threshold = float(model(feats)["pred_logits"].softmax(-1)[0, :, :-1].max(-1).values.sort().values[-8])
+    masks, keep = mg.get_masks(feats, "ours_no_lrp")
+    kept = keep.nonzero().reshape(-1)
+    assert masks.shape == (1, 100, 25, 38) and 1 <= kept.numel() <= 8
+    assert (masks[0, ~keep] == -1).all()
+    gen = Generator(model)
+    for idx in kept:
+        cam = gen.generate_ours(feats, idx.reshape(1), use_lrp=False).reshape(1, -1)
+        ref = postprocess.otsu_masks(cam).reshape(25, 38)
+        # replicated-batch GEMMs round differently from batch-1 GEMMs: allow a handful of threshold-edge pixels
+        assert (masks[0, idx] != ref).float().mean() < 0.01
+    rollout_masks, _ = mg.get_masks(feats, "rollout")
+    assert set(rollout_masks[0, kept].unique().tolist()) <= {0.0, 255.0}

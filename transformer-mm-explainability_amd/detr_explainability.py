@@ -97,6 +97,64 @@ class Generator:
         aggregated = self.R_q_i.unsqueeze_(0)
         return aggregated[:, target_index, :].unsqueeze_(0).detach()
 
+    def generate_ours_multi(self, img, target_indices, index=None, normalize_self_attention=True,
+                            apply_self_in_rule_10=True):
+        """All kept queries of one image in ONE pass.
+
+        Equal to ``torch.cat([generate_ours(img, t, index, use_lrp=False, ...) for t in target_indices], dim=2)`` --
+        the loop ``DETR/mask_generator.py:90-110`` runs, one full forward + backward + rule schedule per kept query --
+        but the image is replicated into a batch of K, ONE backward carries the K one-hot seeds (sample k's logits
+        depend on sample k only, so its slabs hold exactly the single-query gradients), and every rule runs batched:
+        the encoder chain is one launch for all K, each decoder block is one rules-6+7 launch, one head-average launch
+        and two batched MFMA matmuls; ``handle_residual(R_i_i)`` is hoisted out of the decoder loop (R_i_i does not
+        change there).  ``img``: ``[1, C, h, w]`` float features.  Returns ``[1, 1, K, Ni]``.
+        """
+        self.use_lrp = False
+        self.normalize_self_attention = normalize_self_attention
+        self.apply_self_in_rule_10 = apply_self_in_rule_10
+        targets = torch.as_tensor(target_indices, device=img.device).reshape(-1)
+        K = targets.numel()
+        if img.shape[0] != 1:
+            raise ValueError("generate_ours_multi explains the queries of ONE image (got batch %d)" % img.shape[0])
+        batch = img.expand(K, *img.shape[1:])
+        outputs = rules.forward_for_backward(self.model, lambda: self.model(batch)["pred_logits"])   # [K, Q, C+1]
+        rows = torch.arange(K, device=img.device)
+        if index is None:
+            index = outputs[rows, targets, :-1].argmax(dim=-1)
+        one_hot = torch.zeros_like(outputs)
+        one_hot[rows, targets, index] = 1
+        self.model.zero_grad()
+        torch.sum(one_hot * outputs).backward(retain_graph=True)
+
+        decoder_blocks = self.model.transformer.decoder.layers
+        encoder_blocks = self.model.transformer.encoder.layers
+
+        def pair(mod):
+            return mod.get_attn().detach(), mod.get_attn_gradients().detach()
+
+        enc = [pair(blk.self_attn) for blk in encoder_blocks]
+        self.R_i_i = ops.relevancy_self_chain([a for a, _ in enc], [g for _, g in enc], K)           # [K, Ni, Ni]
+        n_img = self.R_i_i.shape[-1]
+        n_q = decoder_blocks[0].self_attn.get_attn().shape[-1]
+        self.R_q_q = torch.eye(n_q, device=img.device).repeat(K, 1, 1)
+        self.R_q_i = torch.zeros(K, n_q, n_img, device=img.device)
+        use_self = apply_self_in_rule_10
+        R_ii_hat = self.R_i_i
+        if use_self and normalize_self_attention:
+            R_ii_hat = ops.handle_residual(self.R_i_i)
+        for blk in decoder_blocks:
+            a, g = pair(blk.self_attn)
+            self.R_q_q, self.R_q_i = ops.relevancy_self_chain([a], [g], K, R_init=self.R_q_q, R_sq_init=self.R_q_i)
+            cam = ops.avg_heads(*pair(blk.multihead_attn), batch_size=K)                             # [K, Q, Ni]
+            if not use_self:                                   # ablation: the addition is the cross-attention map
+                self.R_q_i = self.R_q_i + cam
+                continue
+            R_qq_hat = ops.handle_residual(self.R_q_q) if normalize_self_attention else self.R_q_q
+            # R_q_i += nan_to_zero( R_qq_hat^T . (cam . R_ii_hat) )      (rule 10, DETR/...:33-43)
+            addition = ops.matmul(R_qq_hat, ops.matmul(cam, R_ii_hat), trans_a=True, nan_to_zero=True)
+            self.R_q_i = self.R_q_i + addition
+        return self.R_q_i[rows, targets].reshape(1, 1, K, n_img).detach()
+
     # ------------------------------------------------------------------ baselines on the same slabs
     def generate_raw_attn(self, img, target_index):
         """Reference :225-238: head-mean of the last decoder cross-attention."""
@@ -185,3 +243,51 @@ class GeneratorAlbationNoAgg:
             self.handle_co_attn_query(blk)
         aggregated = self.R_q_i.unsqueeze_(0)
         return aggregated[:, target_index, :].unsqueeze_(0).detach()
+
+
+class MaskGenerator:
+    """The per-image core of ``DETR/mask_generator.py:40-125`` (``MaskGenerator.get_panoptic``) without the COCO /
+    visualisation plumbing: keep the confident queries, explain them, binarise each relevancy map with Otsu.
+
+    ``get_masks(img, method)`` -> ``(masks [1, Q, h, w], keep [Q] bool)``; rows of queries that are not kept hold -1
+    like the reference's buffer.  For the three rule-based methods every kept query goes through
+    ``Generator.generate_ours_multi`` in one pass and all Otsu thresholds are one launch
+    (``postprocess.otsu_masks``); the remaining methods run the reference's per-query loop.
+    """
+
+    _BATCHED = {"ours_no_lrp": {}, "ablation_no_self_in_10": {"apply_self_in_rule_10": False},
+                "ours_no_lrp_no_norm": {"normalize_self_attention": False}}
+
+    def __init__(self, model, threshold=0.5):
+        self.gen = Generator(model)
+        self.abl = GeneratorAlbationNoAgg(model)
+        self.model = model
+        self.threshold = threshold
+
+    def _per_query(self, img, idx, method):
+        if method == "ablation_no_aggregation":
+            return self.abl.generate_ours_abl(img, idx, use_lrp=False, normalize_self_attention=False)
+        fn = {"raw_attn": self.gen.generate_raw_attn, "rollout": self.gen.generate_rollout,
+              "attn_gradcam": self.gen.generate_attn_gradcam}.get(method)
+        if fn is None:
+            raise ValueError("please provide a valid explainability method (got %r; LRP methods are out of scope)"
+                             % (method,))
+        return fn(img, idx)
+
+    def get_masks(self, img, method="ours_no_lrp"):
+        from . import postprocess
+        with torch.no_grad():
+            outputs = self.model(img)
+        h, w = self.model.spatial_dim
+        probas = outputs["pred_logits"].softmax(-1)[0, :, :-1]
+        keep = probas.max(-1).values > self.threshold
+        kept = keep.nonzero().reshape(-1)
+        masks = torch.full((1, probas.shape[0], h, w), -1.0, device=img.device)
+        if kept.numel() == 0:
+            return masks, keep
+        if method in self._BATCHED:
+            cams = self.gen.generate_ours_multi(img, kept, **self._BATCHED[method])[0, 0]          # [K, Ni]
+        else:
+            cams = torch.cat([self._per_query(img, idx.reshape(1), method).reshape(1, -1) for idx in kept])
+        masks[0, kept] = postprocess.otsu_masks(cams).reshape(-1, h, w)
+        return masks, keep
