@@ -221,12 +221,15 @@ def torch_attention(q, k, v, scale, mode, mask):
     (2, 12, 50, 50, 64, 0, False), (2, 8, 77, 77, 64, 0, True), (1, 8, 100, 180, 32, 0, False),
     (2, 12, 14, 36, 64, 1, False), (1, 2, 1, 3, 16, 1, False), (1, 4, 197, 197, 64, 0, False),
     (1, 2, 33, 130, 48, 1, True), (1, 4, 15, 15, 8, 0, False), (1, 4, 7, 15, 8, 0, False), (2, 3, 9, 20, 4, 1, False),
-    (1, 2, 20, 20, 24, 0, False),
+    (1, 2, 20, 20, 24, 0, False), (1, 8, 200, 330, 32, 0, False), (2, 4, 130, 70, 64, 1, True),
+    (1, 3, 65, 129, 48, 0, True),
 ])
-@pytest.mark.parametrize("small", [1, 0])
-def test_attn_capture_fwd_bwd(ops, B, H, Nq, Nk, D, mode, masked, small):
-    """small=1: whole-head-in-LDS kernels where eligible; small=0: the tiled kernels for every shape."""
-    ops.set_option("attn_small", small)
+@pytest.mark.parametrize("path", ["small", "stream", "tiled"])
+def test_attn_capture_fwd_bwd(ops, B, H, Nq, Nk, D, mode, masked, path):
+    """small: whole-head-in-LDS kernels where eligible (else the next path); stream: the long-sequence kernels
+    (K/V streamed in 64-row tiles) for every shape; tiled: the first-generation fallback for every shape."""
+    ops.set_option("attn_small", int(path == "small"))
+    ops.set_option("attn_stream", int(path != "tiled"))
     g = torch.Generator().manual_seed(Nq * 7 + Nk)
     q = torch.randn(B, Nq, H, D, generator=g)
     k = torch.randn(B, Nk, H, D, generator=g)
@@ -257,6 +260,7 @@ def test_attn_capture_fwd_bwd(ops, B, H, Nq, Nk, D, mode, masked, small):
     dprobs2 = torch.empty_like(dprobs)
     assert ops.attn_capture_bwd(qc, kc, vc, probs, d_o.cuda(), dprobs2, scale, mode, need_dqkv=False) == (None, None, None)
     ops.set_option("attn_small", 1)
+    ops.set_option("attn_stream", 1)
     assert torch.equal(dprobs, dprobs2)
 
 

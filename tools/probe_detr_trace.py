@@ -1,4 +1,4 @@
-"""Kernel trace target: 10 x Generator.generate_ours on the DETR-R50 head (run under rocprofv3 --kernel-trace)."""
+"""Kernel trace target: Generator.generate_ours[_multi] on the DETR-R50 head (run under rocprofv3 --kernel-trace)."""
 import sys
 
 import torch
@@ -11,7 +11,12 @@ torch.manual_seed(0)
 model = detr_model.detr_resnet50_head().cuda().eval()
 feats = torch.randn(1, 2048, 25, 38, device="cuda") * 0.5
 gen = Generator(model)
-tgt = torch.tensor([5], device="cuda")
-for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
-    gen.generate_ours(feats, tgt, use_lrp=False)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+tgt = torch.arange(K, device="cuda") * 3
+for _ in range(n):
+    if K == 1:
+        gen.generate_ours(feats, tgt, use_lrp=False)
+    else:
+        gen.generate_ours_multi(feats, tgt)
 torch.cuda.synchronize()

@@ -31,5 +31,7 @@ struct AttnBwdArgs {
 
 int attn_fwd_small_try(AttnFwdArgs& a, hipStream_t s, int* rc_out);
 int attn_bwd_small_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);
+int attn_fwd_stream_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out);   // attention_stream.hip
+int attn_bwd_stream_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);
 
 }  // namespace mmx

@@ -332,6 +332,7 @@ extern "C" int mmx_attn_capture_fwd(const void* q_dev, const void* k_dev, const 
     dim3 grid((Nq + kTQ - 1) / kTQ, H, B);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (attn_fwd_small_try(a, s, &rc)) return rc;   // whole head resident in LDS (short sequences)
+    if (attn_fwd_stream_try(a, s, &rc)) return rc;  // long sequences: K/V streamed, nothing of size Nk on chip
     if (D <= 32) return launch_dyn(attn_capture_fwd_kernel<32>, a, grid, attn_lds_bytes(32, Nk), s, "attn_capture_fwd_kernel<32>");
     return launch_dyn(attn_capture_fwd_kernel<64>, a, grid, attn_lds_bytes(64, Nk), s, "attn_capture_fwd_kernel<64>");
 }
@@ -371,6 +372,7 @@ extern "C" int mmx_attn_capture_bwd(const void* q_dev, const void* k_dev, const 
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale; a.scale_mode = scale_mode; a.need_dqkv = need_dqkv;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (attn_bwd_small_try(a, s, &rc)) return rc;   // whole head resident in LDS (short sequences)
+    if (attn_bwd_stream_try(a, s, &rc)) return rc;  // long sequences
     dim3 gq((Nq + kTQ - 1) / kTQ, H, B), gk((Nk + 15) / 16, H, B);
     if (D <= 32) {
         rc = launch_dyn(attn_capture_bwd_q_kernel<32>, a, gq, attn_lds_bytes(32, Nk), s, "attn_capture_bwd_q_kernel<32>");

@@ -73,23 +73,6 @@ __device__ __forceinline__ void stage_jobs(const StageJob (&jobs)[NJ], int D, in
     }
 }
 
-// 16-lane all-reduce on DPP row rotations (row_ror:8/4/2/1; a DPP "row" is 16 lanes): a wave works on 4 rows of the
-// score matrix at once (lane>>4 selects the row).  VALU-only -- __shfl_xor would go through ds_bpermute (LDS pipe,
-// ~10x the latency), and these reductions sit on the softmax critical path.
-template <int CTRL>
-__device__ __forceinline__ float dpp_row(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float group16_max(float x) {
-    x = fmaxf(x, dpp_row<0x128>(x)); x = fmaxf(x, dpp_row<0x124>(x));
-    x = fmaxf(x, dpp_row<0x122>(x)); x = fmaxf(x, dpp_row<0x121>(x));
-    return x;
-}
-__device__ __forceinline__ float group16_sum(float x) {
-    x += dpp_row<0x128>(x); x += dpp_row<0x124>(x); x += dpp_row<0x122>(x); x += dpp_row<0x121>(x);
-    return x;
-}
-
 // D(16x16) += A.B^T-style product where BOTH operands are contiguous along the contraction index in LDS:
 // A[i][k] at pa + i*lda + k, B[j][k] at pb + j*ldb + k, k in [0, K16*16).
 __device__ __forceinline__ f32x4 tile_kk(const float* pa, int lda, const float* pb, int ldb, int K16, int i_a, int kq) {

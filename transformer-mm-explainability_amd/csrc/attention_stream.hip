@@ -1,0 +1,495 @@
+// Attention-capture kernels for LONG sequences on gfx950 (DETR encoder 850-1050 image tokens, ViT-L/14@336 577):
+// the whole-head kernels of attention_small.hip need the head's score matrix in LDS, the first-generation tiled
+// kernels of attention_kernels.hip keep a [16 x Nk] score row block there and re-stage K / V for every 16 queries.
+// Here nothing of size Nk lives on chip:
+//
+//   * a workgroup owns 64 query rows (forward, dQ half of backward) or 64 keys (dK/dV half); each of its 4 waves
+//     owns 16 of them and keeps its MFMA A operand (Q, dO, or the P / dS columns) in registers;
+//   * K / V (or Q / dO) stream through LDS in 64-row tiles; the NEXT tile's global loads are issued into registers
+//     before the MFMAs of the current one and the barriers are LDS-only (s_waitcnt lgkmcnt), so loads and the
+//     capture-slab stores stay in flight across them;
+//   * forward is two sweeps over the keys: (1) running row max / row sum (lane-local online softmax, merged across
+//     the 16 lanes of a row with DPP at the end), (2) recompute S, write P = exp(S - max) / sum straight to the
+//     capture slab and accumulate O = P.V.  Recomputing S costs MFMA time the kernel has to spare: it is bound by
+//     the N^2 slab traffic (P written once; in backward P read and dP written), which is the algorithmic minimum
+//     because P and dP are the PRODUCT here (they feed the relevancy rules), unlike flash attention;
+//   * every product runs on the exact-fp32 v_mfma_f32_16x16x4_f32.  The contraction index is visited in the order
+//     (block, lane>>4, step) so that each lane's four consecutive steps read ONE ds_read_b128 / global float4.
+//
+// Operand geometry (lane l, i = l & 15, g = l >> 4):  A[m = i][k-slot g],  B[k-slot g][n = i],
+// C/D[m = 4g + r][n = i], r = 0..3.  k-slot g of step s in block blk is contraction index 16 blk + 4 g + s.
+#include "mmx_common.h"
+#include "attention_args.h"
+
+namespace mmx {
+namespace {
+
+constexpr int kRows = 64;      // query rows (or keys, in the dK/dV kernel) per workgroup = 4 waves x 16
+constexpr int kTile = 64;      // rows of the streamed operand per step
+constexpr int kThreads = 256;
+constexpr int kPS = kTile + 4; // row stride of a wave's private [16][64] P / dS tile (16-byte rows, conflict-free b128)
+
+int g_attn_stream = 1;
+
+// exp(x) on the hardware exp2 (v_exp_f32, 1 ulp) with the rounding error of x * log2(e) folded back in:
+// ~1e-7 relative, a third of libm expf's instruction count.  The forward kernel is VALU/MFMA-bound, not HBM-bound,
+// at head_dim 32, and it evaluates exp twice per score (statistics sweep + output sweep).
+__device__ __forceinline__ float exp_fast(float x) {
+    const float kLog2e = 1.4426950408889634f, kLog2eLo = 1.9259629911e-8f, kLn2 = 0.6931471805599453f;
+    const float t = x * kLog2e;
+    const float err = fmaf(x, kLog2e, -t) + x * kLog2eLo;
+    const float r = __builtin_amdgcn_exp2f(t);
+    return (x == -__builtin_inff()) ? 0.f : fmaf(r, err * kLn2, r);
+}
+
+// ---- streamed [64 x D] operand tile: global -> registers (prefetch) -> LDS, row stride DP + 4 floats
+template <int DP>
+__device__ __forceinline__ void tile_fetch(f32x4 (&reg)[DP / 16], const float* base, int64_t sn, int row0,
+                                           int rows_total, int D, int tid) {
+    constexpr int C4 = DP / 4;
+#pragma unroll
+    for (int e = 0; e < DP / 16; ++e) {
+        const int f = tid + kThreads * e;
+        const int row = row0 + f / C4, c = (f % C4) * 4;
+        const bool ok = row < rows_total && c < D;
+        // unconditional (clamped) load + select: a conditional load would serialise on vmcnt(0) per element
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (ok ? static_cast<int64_t>(row) * sn + c : 0));
+        reg[e] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+template <int DP>
+__device__ __forceinline__ void tile_store(float* lds, const f32x4 (&reg)[DP / 16], float mul, int tid) {
+    constexpr int C4 = DP / 4, LS = DP + 4;
+#pragma unroll
+    for (int e = 0; e < DP / 16; ++e) {
+        const int f = tid + kThreads * e;
+        *reinterpret_cast<f32x4*>(lds + (f / C4) * LS + (f % C4) * 4) = reg[e] * mul;
+    }
+}
+
+// A operand held in registers: rows row0 + i of a [rows x D] matrix, contraction index permuted as in the header
+template <int DP>
+__device__ __forceinline__ void load_a_rows(f32x4 (&a)[DP / 16], const float* base, int64_t sn, int row, int D,
+                                            int g, float mul) {
+#pragma unroll
+    for (int blk = 0; blk < DP / 16; ++blk) {
+        const int d0 = 16 * blk + 4 * g;
+        const bool ok = d0 < D;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(row) * sn + (ok ? d0 : 0));
+        a[blk] = ok ? v * mul : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// C[16 x 16] = A_regs[16 x D] . T^T, T = rows 16 t .. 16 t + 15 of the LDS tile ([row][d], both contiguous in d)
+template <int DP>
+__device__ __forceinline__ f32x4 tile_abt(const f32x4 (&a)[DP / 16], const float* tile, int t, int i, int g) {
+    constexpr int LS = DP + 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* p = tile + (16 * t + i) * LS + 4 * g;
+#pragma unroll
+    for (int blk = 0; blk < DP / 16; ++blk) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p + 16 * blk);
+        acc = mfma16x16x4(a[blk][0], b[0], acc);
+        acc = mfma16x16x4(a[blk][1], b[1], acc);
+        acc = mfma16x16x4(a[blk][2], b[2], acc);
+        acc = mfma16x16x4(a[blk][3], b[3], acc);
+    }
+    return acc;
+}
+
+// acc[dt] (16 x 16 each, columns d = 16 dt + i) += W[16 x 64] . T[64 x D]: W = the wave's private tile (A operand,
+// one b128 per 4 steps), T = the LDS tile read along its rows
+template <int DP>
+__device__ __forceinline__ void tile_wt(f32x4 (&acc)[DP / 16], const float* w, const float* tile, int i, int g) {
+    constexpr int LS = DP + 4;
+#pragma unroll
+    for (int kb = 0; kb < kTile / 16; ++kb) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(w + i * kPS + 16 * kb + 4 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float* row = tile + (16 * kb + 4 * g + s) * LS + i;
+#pragma unroll
+            for (int dt = 0; dt < DP / 16; ++dt) acc[dt] = mfma16x16x4(av[s], row[16 * dt], acc[dt]);
+        }
+    }
+}
+
+template <int DP>
+constexpr size_t stream_lds_bytes(int tiles) {
+    return sizeof(float) * (static_cast<size_t>(tiles) * kTile * (DP + 4) + 4 * 16 * kPS);
+}
+
+// =============================================================================================== forward
+template <int DP>
+__global__ __launch_bounds__(kThreads) void attn_fwd_stream_kernel(const AttnFwdArgs a) {
+    constexpr int LS = DP + 4, NB = DP / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    float* Ks = smem;
+    float* Vs = Ks + kTile * LS;
+    float* Pw = Vs + kTile * LS + wave * 16 * kPS;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int rw = blockIdx.x * kRows + wave * 16;          // first query row of this wave
+    const float* qb = a.q + b * a.qs.sb + h * a.qs.sh;
+    const float* kb = a.k + b * a.ks.sb + h * a.ks.sh;
+    const float* vb = a.v + b * a.vs.sb + h * a.vs.sh;
+    const bool q_first = (a.scale_mode == MMX_SCALE_Q_FIRST);
+    const float ninf = -__builtin_inff();
+
+    f32x4 qa[NB];
+    load_a_rows<DP>(qa, qb, a.qs.sn, min(rw + i, a.Nq - 1), a.D, g, q_first ? a.scale : 1.f);
+
+    int rows[4];
+    const float* mrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        rows[r] = rw + 4 * g + r;
+        mrow[r] = a.mask ? a.mask + b * a.mask_sb + static_cast<int64_t>(min(rows[r], a.Nq - 1)) * a.mask_sq : nullptr;
+    }
+    // one score of the C tile: scale, additive mask, -inf beyond the last key
+    auto score = [&](float s, int r, int key) {
+        if (!q_first) s = s / a.scale;                      // scale = sqrt(d) divisor in MMX_SCALE_SCORES mode
+        if (a.mask) s += mrow[r][min(key, a.Nk - 1)];
+        return key < a.Nk ? s : ninf;
+    };
+
+    const int ntiles = (a.Nk + kTile - 1) / kTile;
+    f32x4 kreg[NB], vreg[NB];
+
+    // ---- sweep 1: lane-local running max m and sum l of exp(s - m) over this lane's keys
+    float m[4] = {ninf, ninf, ninf, ninf}, l[4] = {0.f, 0.f, 0.f, 0.f};
+    tile_fetch<DP>(kreg, kb, a.ks.sn, 0, a.Nk, a.D, tid);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        lds_barrier();
+        tile_store<DP>(Ks, kreg, 1.f, tid);
+        lds_barrier();
+        if (kt + 1 < ntiles) tile_fetch<DP>(kreg, kb, a.ks.sn, (kt + 1) * kTile, a.Nk, a.D, tid);
+        float sv[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 acc = tile_abt<DP>(qa, Ks, t, i, g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sv[t][r] = score(acc[r], r, kt * kTile + 16 * t + i);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float mx = fmaxf(fmaxf(sv[0][r], sv[1][r]), fmaxf(sv[2][r], sv[3][r]));
+            const float mn = fmaxf(m[r], mx);
+            const float base = (mn == ninf) ? 0.f : mn;     // all keys masked so far: keep l = 0 instead of inf - inf
+            l[r] = l[r] * exp_fast(m[r] - base) + exp_fast(sv[0][r] - base) + exp_fast(sv[1][r] - base) +
+                   exp_fast(sv[2][r] - base) + exp_fast(sv[3][r] - base);
+            m[r] = mn;
+        }
+    }
+    // merge the 16 lanes of each row (a fully masked row ends as 0 / 0 = NaN like torch.softmax)
+    float linv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float mall = group16_max(m[r]);
+        const float base = (mall == ninf) ? 0.f : mall;
+        linv[r] = 1.f / group16_sum(l[r] * exp_fast(m[r] - base));
+        m[r] = base;
+    }
+
+    // ---- sweep 2: P -> capture slab, O += P.V
+    f32x4 oacc[NB];
+#pragma unroll
+    for (int dt = 0; dt < NB; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t pbase = (static_cast<int64_t>(b) * a.H + h) * a.Nq;
+    tile_fetch<DP>(kreg, kb, a.ks.sn, 0, a.Nk, a.D, tid);
+    tile_fetch<DP>(vreg, vb, a.vs.sn, 0, a.Nk, a.D, tid);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        lds_barrier();
+        tile_store<DP>(Ks, kreg, 1.f, tid);
+        tile_store<DP>(Vs, vreg, 1.f, tid);
+        lds_barrier();
+        if (kt + 1 < ntiles) {
+            tile_fetch<DP>(kreg, kb, a.ks.sn, (kt + 1) * kTile, a.Nk, a.D, tid);
+            tile_fetch<DP>(vreg, vb, a.vs.sn, (kt + 1) * kTile, a.Nk, a.D, tid);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 acc = tile_abt<DP>(qa, Ks, t, i, g);
+            const int key = kt * kTile + 16 * t + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = key < a.Nk ? exp_fast(score(acc[r], r, key) - m[r]) * linv[r] : 0.f;
+                if (rows[r] < a.Nq && key < a.Nk) a.probs[(pbase + rows[r]) * a.Nk + key] = p;
+                Pw[(4 * g + r) * kPS + 16 * t + i] = p;
+            }
+        }
+        tile_wt<DP>(oacc, Pw, Vs, i, g);                   // same-wave LDS traffic is in order: no barrier needed
+    }
+    float* ob = a.o + b * a.os.sb + h * a.os.sh;
+#pragma unroll
+    for (int dt = 0; dt < NB; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (rows[r] < a.Nq && 16 * dt + i < a.D) ob[static_cast<int64_t>(rows[r]) * a.os.sn + 16 * dt + i] = oacc[dt][r];
+}
+
+// =============================================================================================== backward, query side
+// dP = dO.V^T -> capture slab;  delta = rowsum(P * dP) -> workspace;  dS = P * (dP - delta);  dQ = dS.K
+template <int DP>
+__global__ __launch_bounds__(kThreads) void attn_bwd_q_stream_kernel(const AttnBwdArgs a) {
+    constexpr int LS = DP + 4, NB = DP / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    float* Vs = smem;
+    float* Ks = Vs + kTile * LS;
+    float* Sw = Ks + kTile * LS + wave * 16 * kPS;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int rw = blockIdx.x * kRows + wave * 16;
+    const float* kb = a.need_dqkv ? a.k + b * a.ks.sb + h * a.ks.sh : nullptr;
+    const float* vb = a.v + b * a.vs.sb + h * a.vs.sh;
+    const float* dob = a.dout + b * a.os.sb + h * a.os.sh;
+    const bool q_first = (a.scale_mode == MMX_SCALE_Q_FIRST);
+    const int64_t head = static_cast<int64_t>(b) * a.H + h;
+
+    f32x4 doa[NB];
+    load_a_rows<DP>(doa, dob, a.os.sn, min(rw + i, a.Nq - 1), a.D, g, 1.f);
+
+    int rows[4];
+    const float* prow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        rows[r] = rw + 4 * g + r;
+        prow[r] = a.probs + b * a.probs_sb + (static_cast<int64_t>(h) * a.Nq + min(rows[r], a.Nq - 1)) * a.Nk;
+    }
+    const int ntiles = (a.Nk + kTile - 1) / kTile;
+    f32x4 kreg[NB], vreg[NB];
+
+    float delta[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.need_dqkv) {
+        // ---- sweep 1: delta (dP is recomputed in sweep 2 instead of being read back)
+        tile_fetch<DP>(vreg, vb, a.vs.sn, 0, a.Nk, a.D, tid);
+        for (int kt = 0; kt < ntiles; ++kt) {
+            lds_barrier();
+            tile_store<DP>(Vs, vreg, 1.f, tid);
+            lds_barrier();
+            if (kt + 1 < ntiles) tile_fetch<DP>(vreg, vb, a.vs.sn, (kt + 1) * kTile, a.Nk, a.D, tid);
+            float p[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int key = kt * kTile + 16 * t + i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = prow[r][min(key, a.Nk - 1)];
+                    p[t][r] = key < a.Nk ? v : 0.f;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 dp = tile_abt<DP>(doa, Vs, t, i, g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) delta[r] += p[t][r] * dp[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            delta[r] = group16_sum(delta[r]);
+            if (i == 0 && rows[r] < a.Nq) a.delta[head * a.Nq + rows[r]] = delta[r];
+        }
+    }
+
+    // ---- sweep 2: dP -> capture slab; dS -> wave tile; dQ += dS.K
+    f32x4 qacc[NB];
+#pragma unroll
+    for (int dt = 0; dt < NB; ++dt) qacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    tile_fetch<DP>(vreg, vb, a.vs.sn, 0, a.Nk, a.D, tid);
+    if (a.need_dqkv) tile_fetch<DP>(kreg, kb, a.ks.sn, 0, a.Nk, a.D, tid);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        lds_barrier();
+        tile_store<DP>(Vs, vreg, 1.f, tid);
+        if (a.need_dqkv) tile_store<DP>(Ks, kreg, 1.f, tid);
+        lds_barrier();
+        if (kt + 1 < ntiles) {
+            tile_fetch<DP>(vreg, vb, a.vs.sn, (kt + 1) * kTile, a.Nk, a.D, tid);
+            if (a.need_dqkv) tile_fetch<DP>(kreg, kb, a.ks.sn, (kt + 1) * kTile, a.Nk, a.D, tid);
+        }
+        float p[4][4];
+        if (a.need_dqkv) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int key = kt * kTile + 16 * t + i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = prow[r][min(key, a.Nk - 1)];
+                    p[t][r] = key < a.Nk ? v : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 dp = tile_abt<DP>(doa, Vs, t, i, g);
+            const int key = kt * kTile + 16 * t + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (rows[r] < a.Nq && key < a.Nk) a.dprobs[(head * a.Nq + rows[r]) * a.Nk + key] = dp[r];
+                if (a.need_dqkv) {
+                    float ds = p[t][r] * (dp[r] - delta[r]);
+                    if (!q_first) ds = ds / a.scale;
+                    Sw[(4 * g + r) * kPS + 16 * t + i] = ds;
+                }
+            }
+        }
+        if (a.need_dqkv) tile_wt<DP>(qacc, Sw, Ks, i, g);
+    }
+    if (!a.need_dqkv) return;
+    float* dqb = a.dq + b * a.dqs.sb + h * a.dqs.sh;
+    const float mul = q_first ? a.scale : 1.f;
+#pragma unroll
+    for (int dt = 0; dt < NB; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (rows[r] < a.Nq && 16 * dt + i < a.D)
+                dqb[static_cast<int64_t>(rows[r]) * a.dqs.sn + 16 * dt + i] = qacc[dt][r] * mul;
+}
+
+// =============================================================================================== backward, key side
+// per 64 keys (16 per wave): dV = P^T.dO, dK = dS^T.Q with dS rebuilt from the two capture slabs and delta.
+// The A operands (columns of P / dS) come straight from the slabs in MFMA layout: lane (key i, slot g) reads rows
+// 16 rb + 4 g + s of key column j0 + i -- 16 consecutive keys per row segment, no LDS staging.
+template <int DP>
+__global__ __launch_bounds__(kThreads) void attn_bwd_kv_stream_kernel(const AttnBwdArgs a) {
+    constexpr int LS = DP + 4, NB = DP / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    float* Qs = smem;
+    float* dOs = Qs + kTile * LS;
+    float* dl = dOs + kTile * LS;                             // [64] delta of the staged query rows
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int kw = blockIdx.x * kRows + wave * 16;          // first key of this wave
+    const int key = kw + i;
+    const bool key_ok = key < a.Nk;
+    const int keyc = min(key, a.Nk - 1);
+    const float* qb = a.q + b * a.qs.sb + h * a.qs.sh;
+    const float* dob = a.dout + b * a.os.sb + h * a.os.sh;
+    const bool q_first = (a.scale_mode == MMX_SCALE_Q_FIRST);
+    const int64_t head = static_cast<int64_t>(b) * a.H + h;
+    const float* pcol = a.probs + b * a.probs_sb + static_cast<int64_t>(h) * a.Nq * a.Nk + keyc;
+    const float* dpcol = a.dprobs + head * a.Nq * a.Nk + keyc;
+
+    f32x4 kacc[NB], vacc[NB];
+#pragma unroll
+    for (int dt = 0; dt < NB; ++dt) kacc[dt] = vacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = (a.Nq + kTile - 1) / kTile;
+    f32x4 qreg[NB], doreg[NB];
+    float dlreg = 0.f;
+    auto fetch = [&](int qt) {
+        tile_fetch<DP>(qreg, qb, a.qs.sn, qt * kTile, a.Nq, a.D, tid);
+        tile_fetch<DP>(doreg, dob, a.os.sn, qt * kTile, a.Nq, a.D, tid);
+        if (tid < kTile) {
+            const int row = qt * kTile + tid;
+            const float v = a.delta[head * a.Nq + min(row, a.Nq - 1)];
+            dlreg = row < a.Nq ? v : 0.f;
+        }
+    };
+    fetch(0);
+    for (int qt = 0; qt < ntiles; ++qt) {
+        // this tile's slab columns: issued before the barriers so they overlap the LDS staging
+        float p[4][4], dp[4][4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int row = qt * kTile + 16 * rb + 4 * g + s;
+                const int64_t off = static_cast<int64_t>(min(row, a.Nq - 1)) * a.Nk;
+                const bool ok = key_ok && row < a.Nq;
+                const float pv = pcol[off], dv = dpcol[off];
+                p[rb][s] = ok ? pv : 0.f;
+                dp[rb][s] = ok ? dv : 0.f;
+            }
+        lds_barrier();
+        tile_store<DP>(Qs, qreg, q_first ? a.scale : 1.f, tid);
+        tile_store<DP>(dOs, doreg, 1.f, tid);
+        if (tid < kTile) dl[tid] = dlreg;
+        lds_barrier();
+        if (qt + 1 < ntiles) fetch(qt + 1);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const f32x4 dlv = *reinterpret_cast<const f32x4*>(dl + 16 * rb + 4 * g);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float ds = p[rb][s] * (dp[rb][s] - dlv[s]);
+                if (!q_first) ds = ds / a.scale;
+                const float* qrow = Qs + (16 * rb + 4 * g + s) * LS + i;
+                const float* drow = dOs + (16 * rb + 4 * g + s) * LS + i;
+#pragma unroll
+                for (int dt = 0; dt < NB; ++dt) {
+                    vacc[dt] = mfma16x16x4(p[rb][s], drow[16 * dt], vacc[dt]);
+                    kacc[dt] = mfma16x16x4(ds, qrow[16 * dt], kacc[dt]);
+                }
+            }
+        }
+    }
+    float* dkb = a.dk + b * a.dks.sb + h * a.dks.sh;
+    float* dvb = a.dv + b * a.dvs.sb + h * a.dvs.sh;
+#pragma unroll
+    for (int dt = 0; dt < NB; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = kw + 4 * g + r, d = 16 * dt + i;
+            if (j < a.Nk && d < a.D) {
+                dkb[static_cast<int64_t>(j) * a.dks.sn + d] = kacc[dt][r];
+                dvb[static_cast<int64_t>(j) * a.dvs.sn + d] = vacc[dt][r];
+            }
+        }
+}
+
+bool aligned16(const float* p, const Strides& s) {
+    return reinterpret_cast<uintptr_t>(p) % 16 == 0 && s.sb % 4 == 0 && s.sh % 4 == 0 && s.sn % 4 == 0;
+}
+
+template <typename K, typename A>
+int launch_stream(K kern, const A& args, dim3 grid, size_t lds, hipStream_t s, const char* name) {
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    kern<<<grid, kThreads, lds, s>>>(args);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, name);
+    return MMX_OK;
+}
+
+}  // namespace
+
+void attn_stream_enable(int on) { g_attn_stream = on & 1; }
+
+// returns 1 if the streaming kernel was launched (rc in *rc_out), 0 if the shape / layout is not eligible
+int attn_fwd_stream_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out) {
+    if (!g_attn_stream || a.D % 4 || a.D > 64) return 0;
+    if (!aligned16(a.q, a.qs) || !aligned16(a.k, a.ks) || !aligned16(a.v, a.vs)) return 0;
+    dim3 grid((a.Nq + kRows - 1) / kRows, a.H, a.B);
+    *rc_out = a.D <= 32
+        ? launch_stream(attn_fwd_stream_kernel<32>, a, grid, stream_lds_bytes<32>(2), s, "attn_fwd_stream_kernel<32>")
+        : launch_stream(attn_fwd_stream_kernel<64>, a, grid, stream_lds_bytes<64>(2), s, "attn_fwd_stream_kernel<64>");
+    return 1;
+}
+
+int attn_bwd_stream_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out) {
+    if (!g_attn_stream || a.D % 4 || a.D > 64) return 0;
+    if (!aligned16(a.v, a.vs) || !aligned16(a.dout, a.os)) return 0;
+    if (a.need_dqkv && (!aligned16(a.q, a.qs) || !aligned16(a.k, a.ks))) return 0;
+    dim3 gq((a.Nq + kRows - 1) / kRows, a.H, a.B), gk((a.Nk + kRows - 1) / kRows, a.H, a.B);
+    const bool small_d = a.D <= 32;
+    int rc = small_d ? launch_stream(attn_bwd_q_stream_kernel<32>, a, gq, stream_lds_bytes<32>(2), s,
+                                     "attn_bwd_q_stream_kernel<32>")
+                     : launch_stream(attn_bwd_q_stream_kernel<64>, a, gq, stream_lds_bytes<64>(2), s,
+                                     "attn_bwd_q_stream_kernel<64>");
+    if (rc == MMX_OK && a.need_dqkv) {
+        // the key-side kernel's LDS: two operand tiles + 64 deltas (the 4 x 16 x 68 floats of the wave tiles cover it)
+        rc = small_d ? launch_stream(attn_bwd_kv_stream_kernel<32>, a, gk, stream_lds_bytes<32>(2), s,
+                                     "attn_bwd_kv_stream_kernel<32>")
+                     : launch_stream(attn_bwd_kv_stream_kernel<64>, a, gk, stream_lds_bytes<64>(2), s,
+                                     "attn_bwd_kv_stream_kernel<64>");
+    }
+    *rc_out = rc;
+    return 1;
+}
+
+}  // namespace mmx

@@ -79,10 +79,28 @@ __device__ __forceinline__ f32x4 mfma16x16x4(float a, float b, f32x4 acc) {
 // global memory), which would serialise every in-flight global prefetch behind the barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// 16-lane all-reduce on DPP row rotations (row_ror:8/4/2/1; a DPP "row" is 16 lanes): a wave works on 4 rows of the
+// score matrix at once (lane>>4 selects the row).  VALU-only -- __shfl_xor would go through ds_bpermute (LDS pipe,
+// ~10x the latency), and these reductions sit on the softmax critical path.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float group16_max(float x) {
+    x = fmaxf(x, dpp_row<0x128>(x)); x = fmaxf(x, dpp_row<0x124>(x));
+    x = fmaxf(x, dpp_row<0x122>(x)); x = fmaxf(x, dpp_row<0x121>(x));
+    return x;
+}
+__device__ __forceinline__ float group16_sum(float x) {
+    x += dpp_row<0x128>(x); x += dpp_row<0x124>(x); x += dpp_row<0x122>(x); x += dpp_row<0x121>(x);
+    return x;
+}
+
 inline size_t dtype_size(int dt) { return dt == MMX_F32 ? 4 : 2; }
 
 void set_error(const char* fmt, ...);
 void attn_small_enable(int on);
+void attn_stream_enable(int on);
 int hip_fail(hipError_t e, const char* what);
 
 }  // namespace mmx

@@ -473,23 +473,29 @@ __global__ __launch_bounds__(kV2Threads) void self_chain_v2_kernel(const ChainV2
 // =====================================================================================================
 constexpr int kBmmBK = 32;
 
+// T x T output tile per 256-thread workgroup, 4 waves as 2 x 2, each (T/2) x (T/2) = (T/32)^2 MFMA tiles.
+// T = 64 for large problems; T = 32 when 64 x 64 tiles would leave most CUs with at most one workgroup (nothing to
+// hide the global-load latency behind): 4x the workgroups for the same work.
+template <int T>
 __global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                       const float* Cin, float* C, int M, int N, int K,
                                                       int trans_a, int64_t sa, int64_t sb, int64_t sc,
                                                       int nan_to_zero) {
-    __shared__ float As[kBmmBK][81];   // odd stride: the k-fastest stores of a row-major A spread over the banks
-    __shared__ float Bs[kBmmBK][80];
-    constexpr int E = kBmmBK * 64 / 256;   // elements of each operand per thread and slab
+    constexpr int W = T / 32;              // MFMA tiles per wave and dimension
+    constexpr int E = kBmmBK * T / 256;    // elements of each operand per thread and slab
+    constexpr int LA = T + 17, LB = T + 16;   // odd A stride: the k-fastest stores of a row-major A spread over the banks
+    __shared__ float As[kBmmBK][LA];
+    __shared__ float Bs[kBmmBK][LB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
     const float* Ab = A + static_cast<int64_t>(blockIdx.z) * sa;
     const float* Bb = B + static_cast<int64_t>(blockIdx.z) * sb;
-    f32x4 acc[2][2];
+    f32x4 acc[W][W];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < W; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < W; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     float ra[E], rb[E];
     auto fetch = [&](int k0) {
@@ -497,13 +503,13 @@ __global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ 
         for (int e = 0; e < E; ++e) {
             const int idx = tid + e * 256;
             int m, k;
-            if (trans_a) { k = idx >> 6; m = idx & 63; } else { m = idx / kBmmBK; k = idx % kBmmBK; }
+            if (trans_a) { k = idx / T; m = idx % T; } else { m = idx / kBmmBK; k = idx % kBmmBK; }
             const int gm = m0 + m, gk = k0 + k;
             const bool ok = gm < M && gk < K;
             const int64_t off = trans_a ? static_cast<int64_t>(gk) * M + gm : static_cast<int64_t>(gm) * K + gk;
             const float va = Ab[ok ? off : 0];            // unconditional (clamped) load: no per-element vmcnt(0)
             ra[e] = ok ? va : 0.f;
-            const int kb = idx >> 6, nb = idx & 63;
+            const int kb = idx / T, nb = idx % T;
             const int gkb = k0 + kb, gn = n0 + nb;
             const bool okb = gkb < K && gn < N;
             const float vb = Bb[okb ? static_cast<int64_t>(gkb) * N + gn : 0];
@@ -515,34 +521,36 @@ __global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int idx = tid + e * 256;
-            if (trans_a) As[idx >> 6][idx & 63] = ra[e]; else As[idx % kBmmBK][idx / kBmmBK] = ra[e];
-            Bs[idx >> 6][idx & 63] = rb[e];
+            if (trans_a) As[idx / T][idx % T] = ra[e]; else As[idx % kBmmBK][idx / kBmmBK] = ra[e];
+            Bs[idx / T][idx % T] = rb[e];
         }
-        __syncthreads();
-        if (k0 + kBmmBK < K) fetch(k0 + kBmmBK);
+        lds_barrier();
+        if (k0 + kBmmBK < K) fetch(k0 + kBmmBK);          // in flight across the MFMAs and the next (LDS-only) barrier
 #pragma unroll
         for (int ks = 0; ks < kBmmBK / 4; ++ks) {
             const int kk = ks * 4 + (lane >> 4);
-            const float a0 = As[kk][wr * 32 + (lane & 15)];
-            const float a1 = As[kk][wr * 32 + 16 + (lane & 15)];
-            const float b0 = Bs[kk][wc * 32 + (lane & 15)];
-            const float b1 = Bs[kk][wc * 32 + 16 + (lane & 15)];
-            acc[0][0] = mfma16x16x4(a0, b0, acc[0][0]);
-            acc[0][1] = mfma16x16x4(a0, b1, acc[0][1]);
-            acc[1][0] = mfma16x16x4(a1, b0, acc[1][0]);
-            acc[1][1] = mfma16x16x4(a1, b1, acc[1][1]);
+            float av[W], bv[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                av[i] = As[kk][wr * (T / 2) + 16 * i + (lane & 15)];
+                bv[i] = Bs[kk][wc * (T / 2) + 16 * i + (lane & 15)];
+            }
+#pragma unroll
+            for (int i = 0; i < W; ++i)
+#pragma unroll
+                for (int j = 0; j < W; ++j) acc[i][j] = mfma16x16x4(av[i], bv[j], acc[i][j]);
         }
-        __syncthreads();
+        lds_barrier();
     }
     const int64_t cbase = static_cast<int64_t>(blockIdx.z) * sc;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < W; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < W; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gm = m0 + wr * 32 + i * 16 + (lane >> 4) * 4 + r;
-                const int gn = n0 + wc * 32 + j * 16 + (lane & 15);
+                const int gm = m0 + wr * (T / 2) + i * 16 + (lane >> 4) * 4 + r;
+                const int gn = n0 + wc * (T / 2) + j * 16 + (lane & 15);
                 if (gm < M && gn < N) {
                     const int64_t off = cbase + static_cast<int64_t>(gm) * N + gn;
                     float v = acc[i][j][r];
@@ -551,6 +559,18 @@ __global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ 
                     C[off] = v;
                 }
             }
+}
+
+static void launch_bmm(const float* A, const float* B, const float* Cin, float* C, int batch, int M, int N, int K,
+                       int trans_a, int64_t sa, int64_t sb, int64_t sc, int nan_to_zero, hipStream_t s) {
+    const int64_t wgs64 = static_cast<int64_t>((N + 63) / 64) * ((M + 63) / 64) * batch;
+    if (wgs64 >= 1024) {
+        bmm_f32_kernel<64><<<dim3((N + 63) / 64, (M + 63) / 64, batch), 256, 0, s>>>(A, B, Cin, C, M, N, K, trans_a, sa,
+                                                                                    sb, sc, nan_to_zero);
+    } else {
+        bmm_f32_kernel<32><<<dim3((N + 31) / 32, (M + 31) / 32, batch), 256, 0, s>>>(A, B, Cin, C, M, N, K, trans_a, sa,
+                                                                                    sb, sc, nan_to_zero);
+    }
 }
 
 // =====================================================================================================
@@ -624,10 +644,9 @@ extern "C" int mmx_bmm_f32(const void* A_dev, const void* B_dev, const void* Cin
     MMX_CHECK_ARG(A_dev && B_dev && C_dev, "mmx_bmm_f32: null pointer");
     MMX_CHECK_ARG(batch > 0 && M > 0 && N > 0 && K > 0, "mmx_bmm_f32: non-positive size");
     MMX_CHECK_ARG(batch <= 65535, "mmx_bmm_f32: batch %d > 65535", batch);
-    dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
-    bmm_f32_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(
-        static_cast<const float*>(A_dev), static_cast<const float*>(B_dev), static_cast<const float*>(Cin_dev),
-        static_cast<float*>(C_dev), M, N, K, trans_a, stride_a, stride_b, stride_c, nan_to_zero);
+    launch_bmm(static_cast<const float*>(A_dev), static_cast<const float*>(B_dev), static_cast<const float*>(Cin_dev),
+               static_cast<float*>(C_dev), batch, M, N, K, trans_a, stride_a, stride_b, stride_c, nan_to_zero,
+               static_cast<hipStream_t>(stream));
     MMX_LAUNCH_CHECK("bmm_f32_kernel");
     return MMX_OK;
 }
@@ -758,6 +777,10 @@ extern "C" int mmx_set_option(const char* key, int value) {
     }
     if (key && strcmp(key, "attn_small") == 0) {
         attn_small_enable(value);
+        return MMX_OK;
+    }
+    if (key && strcmp(key, "attn_stream") == 0) {
+        attn_stream_enable(value);
         return MMX_OK;
     }
     if (key && strcmp(key, "debug_flags") == 0) {
