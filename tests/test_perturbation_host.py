@@ -1,0 +1,51 @@
+"""Host logic of the batched perturbation evaluator (runs on CPU): which regions / tokens each of the 9 steps keeps
+equals the reference loop's own selection (lxmert/lxmert/perturbation.py:110-117 and :158-172, restated inline)."""
+import torch
+
+from transformer_mm_explainability_amd import lxmert_perturbation as lp
+
+
+def test_image_keep_masks_match_reference_selection():
+    g = torch.Generator().manual_seed(0)
+    cam = torch.rand(36, generator=g)
+    for positive in (False, True):
+        keep = lp.image_keep_masks(cam, is_positive_pert=positive)
+        assert keep.shape == (9, 36)
+        c = -cam if positive else cam
+        for s, step in enumerate(lp.PERT_STEPS):
+            k = int((1 - step) * 36)
+            want = torch.zeros(36)
+            want[c.topk(k=k, dim=-1).indices] = 1
+            assert torch.equal(keep[s], want)
+        assert keep[0].sum() == 36 and keep[-1].sum() == 0
+
+
+def test_text_keep_batch_matches_reference_gather():
+    g = torch.Generator().manual_seed(1)
+    T = 14
+    ids = torch.randint(5, 1000, (1, T), generator=g)
+    types = torch.zeros(1, T, dtype=torch.long)
+    cam = torch.rand(T, generator=g)
+    for positive in (False, True):
+        got_ids, got_types, mask = lp.text_keep_batch(ids, types, cam, is_positive_pert=positive)
+        c = -cam if positive else cam
+        for s, step in enumerate(lp.PERT_STEPS):
+            pure = c[1:-1]
+            k = int((1 - step) * pure.shape[0])
+            top = pure.topk(k=k, dim=-1).indices.tolist()
+            kept = sorted([0, T - 1] + [i + 1 for i in top])                  # perturbation.py:166-170
+            n = len(kept)
+            assert mask[s].tolist() == [1.0] * n + [0.0] * (T - n)
+            assert got_ids[s, :n].tolist() == ids[0, kept].tolist()
+            assert got_ids[s, n:].abs().sum() == 0 and got_types[s].abs().sum() == 0
+        assert mask[-1].sum() == 2                                            # only [CLS] and [SEP] survive step 1.0
+
+
+def test_normalize_cams_and_accuracy():
+    R_t_t = torch.tensor([[1.0, 3.0, 2.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0]])
+    R_t_i = torch.tensor([[2.0, 6.0], [0.0, 0.0], [0.0, 0.0]])
+    cam_image, cam_text = lp.normalize_cams(R_t_t, R_t_i)
+    assert cam_image.tolist() == [0.0, 1.0] and cam_text.tolist() == [0.0, 1.0, 0.5]
+    scores = torch.tensor([[0.1, 0.9, 0.0], [0.7, 0.2, 0.1]])
+    labels = torch.tensor([0.3, 1.0, 0.0])
+    assert lp.LxmertPerturbation.accuracy(scores, labels).tolist() == [1.0, 0.30000001192092896]

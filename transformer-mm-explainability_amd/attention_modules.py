@@ -131,6 +131,14 @@ class BertStyleAttention(_SlabOwner):
         q = self.query(hidden_states).view(B, Nq, H, D)
         k = self.key(context).view(B, Nk, H, D)
         v = self.value(context).view(B, Nk, H, D)
+        if Nq == 0 or Nk == 0:
+            # an empty stream (the perturbation evaluator's "no region kept" step): softmax over no keys contributes
+            # nothing, exactly like torch's matmul with an empty inner dimension
+            probs = hidden_states.new_zeros(B, H, Nq, Nk)
+            self.save_attn(probs)
+            self.save_attn_gradients(torch.zeros_like(probs))
+            context_layer = hidden_states.new_zeros(B, Nq, H * D)
+            return (context_layer, probs) if output_attentions else (context_layer,)
         mask = None
         if attention_mask is not None:   # HF extended mask [B, 1, 1, Nk] (additive, -10000 on padding)
             mask = attention_mask.reshape(B, 1, Nk).float()

@@ -1,0 +1,120 @@
+"""Perturbation evaluator inner loop for LXMERT -- ``lxmert/lxmert/perturbation.py:85-194``.
+
+The reference scores an explanation by removing the least (negative test) or most (positive test) relevant image
+regions / question tokens in 9 steps and re-running the model after each removal: 9 sequential batch-1 forwards per
+sample, each preceded by a host ``topk`` -> numpy round trip (and a Faster R-CNN re-run, which is outside this path).
+Here the 9 perturbed inputs of one sample are ONE batch:
+
+  * image test: a region that is masked as an attention key everywhere (-10000 additive mask -> exp underflows to an
+    exact 0) is indistinguishable from a removed region for every other token -- LXMERT's visual stream has no
+    index-dependent position term, and the answer is read from the [CLS] text token.  So the 9 steps are 9 rows of a
+    ``visual_attention_mask``; the features are shared.  The step that keeps ZERO regions is the one exception (a
+    uniform -10000 shift is no mask at all): it runs as a second, region-free forward.
+  * text test: removing tokens re-indexes the position embeddings (``perturbation.py:170``: "text tokens must be
+    sorted for positional embedding to work"), so the kept ids are gathered, left-aligned and padded; padding is masked.
+
+Everything (``topk``, mask / gather construction, arg-max, accuracy lookup) stays on the device; one host read per
+sample at most.  Results equal the sequential loop up to fp32 summation order (tests/test_gpu_perturbation.py).
+"""
+from __future__ import annotations
+
+import torch
+
+PERT_STEPS = (0, 0.25, 0.5, 0.75, 0.8, 0.85, 0.9, 0.95, 1)
+
+
+def normalize_cams(R_t_t, R_t_i):
+    """``perturbation.py:242-245``: first rows of the text / image relevancies, min-max normalised."""
+    cam_image, cam_text = R_t_i[0], R_t_t[0]
+    cam_image = (cam_image - cam_image.min()) / (cam_image.max() - cam_image.min())
+    cam_text = (cam_text - cam_text.min()) / (cam_text.max() - cam_text.min())
+    return cam_image, cam_text
+
+
+def image_keep_masks(cam_image, steps=PERT_STEPS, is_positive_pert=False):
+    """``[S, I]`` float 0/1: row s keeps the ``int((1 - step_s) * I)`` top-scoring regions (``perturbation.py:114-117``)."""
+    cam = -cam_image if is_positive_pert else cam_image
+    n = cam.shape[-1]
+    keep = torch.zeros(len(steps), n, dtype=torch.float32, device=cam.device)
+    order = cam.topk(k=n, dim=-1).indices                     # topk(k) for every k is a prefix of topk(n)
+    for s, step in enumerate(steps):
+        keep[s, order[: int((1 - step) * n)]] = 1.0
+    return keep
+
+
+def text_keep_batch(input_ids, token_type_ids, cam_text, steps=PERT_STEPS, is_positive_pert=False):
+    """Perturbed question batch (``perturbation.py:158-176``): [CLS] and [SEP] always stay, the
+    ``int((1 - step) * (T - 2))`` top-scoring inner tokens stay in their original order, the rest is dropped.
+    Returns ``(ids [S, T], token_types [S, T], attention_mask [S, T])`` with the kept tokens left-aligned."""
+    cam = -cam_text if is_positive_pert else cam_text
+    T = cam.shape[-1]
+    inner = cam[1:-1]
+    order = inner.topk(k=T - 2, dim=-1).indices + 1
+    S = len(steps)
+    keep = torch.zeros(S, T, dtype=torch.bool, device=cam.device)
+    keep[:, 0] = keep[:, T - 1] = True
+    for s, step in enumerate(steps):
+        keep[s, order[: int((1 - step) * (T - 2))]] = True
+    # stable left-alignment: kept positions sorted by index first, dropped ones after
+    pos = torch.arange(T, device=cam.device).expand(S, T)
+    perm = torch.argsort(torch.where(keep, pos, pos + T), dim=1)
+    mask = torch.gather(keep, 1, perm)
+    ids = torch.gather(input_ids.expand(S, T), 1, perm) * mask
+    types = torch.gather(token_type_ids.expand(S, T), 1, perm) * mask
+    return ids, types, mask.to(torch.float32)
+
+
+class LxmertPerturbation:
+    """``ModelPert.perturbation_image`` / ``perturbation_text`` for one sample, the 9 steps batched.
+
+    ``model``: an ``lxmert_model.LxmertForQuestionAnswering``.  ``inputs``: the tensors the reference's ``forward``
+    hands to the model -- ``input_ids``, ``attention_mask``, ``token_type_ids`` (``[1, T]``), ``visual_feats``
+    (``[1, I, F]``), ``visual_pos`` (``[1, I, 4]``).  Both methods return the answer scores ``[S, num_answers]``;
+    ``accuracy`` turns them into the per-step VQA soft accuracies (``label_scores[argmax]``, ``perturbation.py:134-136``).
+    """
+
+    def __init__(self, model, steps=PERT_STEPS):
+        self.model = model
+        self.steps = tuple(steps)
+
+    @torch.no_grad()
+    def perturbation_image(self, inputs, cam_image, is_positive_pert=False):
+        keep = image_keep_masks(cam_image, self.steps, is_positive_pert)                 # [S, I]
+        counts = [int((1 - step) * cam_image.shape[-1]) for step in self.steps]          # host arithmetic only
+        live = [s for s, c in enumerate(counts) if c > 0]
+        S = len(self.steps)
+        scores = None
+        if live:
+            rows = torch.tensor(live, device=keep.device)
+            n = len(live)
+            out = self.model(input_ids=inputs["input_ids"].expand(n, -1),
+                             attention_mask=inputs["attention_mask"].expand(n, -1),
+                             token_type_ids=inputs["token_type_ids"].expand(n, -1),
+                             visual_feats=inputs["visual_feats"].expand(n, -1, -1),
+                             visual_pos=inputs["visual_pos"].expand(n, -1, -1),
+                             visual_attention_mask=keep[rows]).question_answering_score
+            scores = out.new_empty(S, out.shape[-1])
+            scores[rows] = out
+        if len(live) < S:                                    # steps that keep no region at all: region-free forward
+            out = self.model(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
+                             token_type_ids=inputs["token_type_ids"], visual_feats=inputs["visual_feats"][:, :0],
+                             visual_pos=inputs["visual_pos"][:, :0]).question_answering_score
+            if scores is None:
+                scores = out.new_empty(S, out.shape[-1])
+            dead = torch.tensor([s for s in range(S) if s not in live], device=keep.device)
+            scores[dead] = out
+        return scores
+
+    @torch.no_grad()
+    def perturbation_text(self, inputs, cam_text, is_positive_pert=False):
+        ids, types, mask = text_keep_batch(inputs["input_ids"], inputs["token_type_ids"], cam_text, self.steps,
+                                           is_positive_pert)
+        S = len(self.steps)
+        return self.model(input_ids=ids, attention_mask=mask, token_type_ids=types,
+                          visual_feats=inputs["visual_feats"].expand(S, -1, -1),
+                          visual_pos=inputs["visual_pos"].expand(S, -1, -1)).question_answering_score
+
+    @staticmethod
+    def accuracy(scores, label_scores):
+        """``label_scores [num_answers]``: the item's soft VQA scores per answer id (0 where absent) -> ``[S]``."""
+        return label_scores[scores.argmax(dim=-1)]
