@@ -121,7 +121,9 @@ class GraphedInterpret:
                 self._call()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: a collective backend's watchdog thread (RCCL, one rank per GPU) may poll events while this
+        # thread captures; only calls made by the capturing thread must be capture-safe
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.outputs = self._call()
 
     def __call__(self, image=None, texts=None):
