@@ -53,8 +53,14 @@ enum mmx_status {
 
 int mmx_abi_version(void);
 const char* mmx_last_error(void);
-/* tuning knobs (process-wide): "self_chain_algo" = 0 auto | 1 one workgroup per sample (no scratch) |
- * 2 one workgroup per (sample, layer) + last-arriver chain.  Both give bit-identical results. */
+/* tuning knobs (process-wide; results stay within the parity tolerance for every setting):
+ *   "self_chain_algo"    0 auto | 1 one workgroup per (sample, layer group), no scratch beyond the partial products |
+ *                        2 one workgroup per (sample, layer) + last-arriver chain (bit-identical to 1 at groups = 1)
+ *   "self_chain_groups"  0 auto | 1..8 layer groups per sample of the fused chain kernel (1 = strict sequential order)
+ *   "attn_small"         1 (default) whole-head-in-LDS attention kernels where the head fits | 0 never
+ *   "attn_stream"        1 (default) long-sequence streaming attention kernels | 0 first-generation tiled kernels
+ *   "debug_flags"        profiling only (phase skipping); 0 in production
+ * Unknown keys / out-of-range values return MMX_EINVAL. */
 int mmx_set_option(const char* key, int value);
 
 /* ---------------------------------------------------------------------------------------------

@@ -101,8 +101,55 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
     const int rq = (lane >> 4) * 4;
     f32x4 Rold[NT], Rnew[NT];
 
+    // ---- head reduction of one 4-element chunk of A_bar_l (used by the stream waves and, for the remainder pass, by
+    // the otherwise idle matrix waves)
+    constexpr int LT = kChainThreads - NT * 64;   // stream lanes
+    constexpr int ML = NT * 64;                   // matrix lanes
+    const float fH = static_cast<float>(H);
+    const int64_t sample = static_cast<int64_t>(b) * H * NN;
+    const int64_t sampleA = static_cast<int64_t>(b) * a.attn_bstride;
+    const int nchunks = static_cast<int>((NN + 3) >> 2);
+    // Work split: a chunk costs one batch of global round trips whatever the number of busy lanes, so the pass count
+    // of the stream waves is what matters.  When the chunks left over after the stream waves' full passes fit the
+    // matrix lanes (text tower: 1483 = 2 x 704 + 75), the matrix waves reduce them between their MFMAs and the stream
+    // waves save a whole, almost empty, pass per layer.
+    const int full = nchunks / LT;
+    const bool split = full >= 1 && nchunks - full * LT <= ML;
+    const int stream_end = split ? full * LT : nchunks;
+    auto reduce_chunk = [&](int c, const void* A, const void* Gr, float* Ab) {
+        const int64_t p = static_cast<int64_t>(c) * 4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (p + 3 < NN) {
+#pragma unroll 4  // measured: 2 / 6 / 8 heads per batch are slower (profiles/r01_chain_probe.txt)
+            for (int h = 0; h < H; ++h) {
+                const f32x4 av = load4_as_f32<DT>(A, sampleA + h * NN + p);
+                const f32x4 gv = load4_as_f32<DT>(Gr, sample + h * NN + p);
+                const f32x4 x = gv * av;
+                s[0] += relu_nan(x[0]); s[1] += relu_nan(x[1]);
+                s[2] += relu_nan(x[2]); s[3] += relu_nan(x[3]);
+            }
+        } else {
+            for (int e = 0; p + e < NN; ++e)
+                for (int h = 0; h < H; ++h)
+                    s[e] += relu_nan(load1_as_f32<DT>(Gr, sample + h * NN + p + e) *
+                                     load1_as_f32<DT>(A, sampleA + h * NN + p + e));
+        }
+        int row = static_cast<int>(p / N);
+        int cc = static_cast<int>(p - static_cast<int64_t>(row) * N);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (p + e < NN) Ab[row * S + cc] = s[e] / fH;
+            if (++cc == N) { cc = 0; ++row; }
+        }
+    };
+
     if (wave < NT) {
         // ------------------------------------------------------------------ matrix waves
+        auto remainder_pass = [&](int l) {   // this lane's share of A_bar_l's remainder chunks (split mode only)
+            const int c = stream_end + tid;
+            if (split && l < L && c < nchunks) reduce_chunk(c, a.attn[l0 + l], a.grad[l0 + l], smem + (l & 1) * NP * S);
+        };
+        remainder_pass(0);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -116,7 +163,7 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
             }
         for (int l = 0; l < L; ++l) {
             __syncthreads();  // A_bar_l is in buffer l&1
-            if (a.debug & 4) continue;
+            if (a.debug & 4) { remainder_pass(l + 1); continue; }
             const float* Ab = smem + (l & 1) * NP * S + (lane & 15) * S + rq;
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti) {
@@ -133,6 +180,7 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) Rold[t] = Rnew[t];
+            remainder_pass(l + 1);   // into the other buffer; published by the next barrier
         }
         float* dst = (G == 1) ? a.R_out + b * NN : a.parts + (static_cast<int64_t>(b) * G + g) * NN;
 #pragma unroll
@@ -149,42 +197,12 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
             }
     } else {
         // ------------------------------------------------------------------ stream waves
-        constexpr int LT = kChainThreads - NT * 64;
         const int lt = tid - NT * 64;
-        const float fH = static_cast<float>(H);
-        const int64_t sample = static_cast<int64_t>(b) * H * NN;
-        const int64_t sampleA = static_cast<int64_t>(b) * a.attn_bstride;
-        const int nchunks = static_cast<int>((NN + 3) >> 2);
         for (int l = 0; l < L; ++l) {
             float* Ab = smem + (l & 1) * NP * S;
             const void* A = a.attn[l0 + l];
             const void* Gr = a.grad[l0 + l];
-            for (int c = lt; c < nchunks; c += LT) {
-                const int64_t p = static_cast<int64_t>(c) * 4;
-                f32x4 s = {0.f, 0.f, 0.f, 0.f};
-                if (p + 3 < NN) {
-#pragma unroll 4  // measured: 2 / 6 / 8 heads per batch are slower (profiles/r01_chain_probe.txt)
-                    for (int h = 0; h < H; ++h) {
-                        const f32x4 av = load4_as_f32<DT>(A, sampleA + h * NN + p);
-                        const f32x4 gv = load4_as_f32<DT>(Gr, sample + h * NN + p);
-                        const f32x4 x = gv * av;
-                        s[0] += relu_nan(x[0]); s[1] += relu_nan(x[1]);
-                        s[2] += relu_nan(x[2]); s[3] += relu_nan(x[3]);
-                    }
-                } else {
-                    for (int e = 0; p + e < NN; ++e)
-                        for (int h = 0; h < H; ++h)
-                            s[e] += relu_nan(load1_as_f32<DT>(Gr, sample + h * NN + p + e) *
-                                             load1_as_f32<DT>(A, sampleA + h * NN + p + e));
-                }
-                int row = static_cast<int>(p / N);
-                int cc = static_cast<int>(p - static_cast<int64_t>(row) * N);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (p + e < NN) Ab[row * S + cc] = s[e] / fH;
-                    if (++cc == N) { cc = 0; ++row; }
-                }
-            }
+            for (int c = lt; c < stream_end; c += LT) reduce_chunk(c, A, Gr, Ab);
             __syncthreads();  // publish A_bar_l (pairs with the matrix waves' barrier of layer l)
         }
     }
