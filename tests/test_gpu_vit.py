@@ -55,3 +55,14 @@ def test_generate_relevance_and_batched_targets(img, patch, dim, depth, heads):
     close(multi[1], want[7])
     single = vit_model.generate_relevance_multi(model, xc, [7])
     close(single[0], want[7])
+    close(vit_model.generate_relevance_multi(model, xc, top_k=1)[0], want[None])       # arg-max class, picked on device
+    # hipGraph replay: same values, new inputs / targets copied into the captured buffers
+    run = vit_model.GraphedRelevance(model, xc, indices=[3, 7])
+    got = run()
+    close(got[0], want[3])
+    close(got[1], want[7])
+    x2 = torch.randn(1, 3, img, img, generator=torch.Generator().manual_seed(2)).cuda()
+    eager = vit_model.generate_relevance_multi(model, x2, [0, 5]).clone()
+    close(run(x2, [0, 5]), eager.cpu().numpy(), atol=1e-6)
+    top = vit_model.GraphedRelevance(model, xc, top_k=1)
+    close(top()[0], want[None])

@@ -212,19 +212,62 @@ def vit_base_patch16_224(num_classes=1000, **kw):
     return VisionTransformer(img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12, num_classes=num_classes, **kw)
 
 
-def generate_relevance_multi(model, input, indices):
+def generate_relevance_multi(model, input, indices=None, top_k=None):
     """Relevancy maps of ONE image for K class indices with one forward (section 8f row 1).
 
     Equivalent to ``[generate_relevance(model, input, index=k) for k in indices]`` (notebook cell 9:12-16 runs those as
-    separate full passes).  Returns ``[K, N-1]``.
+    separate full passes).  ``indices=None``: the ``top_k`` highest-scoring classes, picked on the device (the
+    notebook's default ``index=None`` is ``top_k=1``).  Returns ``[K, N-1]``.
     """
-    idx = torch.as_tensor(indices, device=input.device).reshape(-1)
-    K = idx.numel()
+    if indices is None:
+        K = 1 if top_k is None else int(top_k)
+        idx = None
+    else:
+        idx = torch.as_tensor(indices, device=input.device).reshape(-1)
+        K = idx.numel()
     logits, state = model.forward_shared(input, K)
+    if idx is None:
+        idx = logits[0].topk(K).indices
     d_logits = torch.zeros(K, logits.shape[-1], dtype=torch.float32, device=input.device)
-    d_logits[torch.arange(K, device=input.device), idx] = 1          # one one-hot per target
+    d_logits.scatter_(1, idx.reshape(K, 1), 1.0)                     # one one-hot per target (capturable: no host sync)
     model.backward_shared(state, d_logits)
     buf = model.buffers_
     R = ops.relevancy_self_chain([buf.probs[l] for l in range(model.depth)], [buf.grads[l] for l in range(model.depth)],
                                  K, shared_attn=K > 1)
     return R[:, 0, 1:]
+
+
+class GraphedRelevance:
+    """``generate_relevance_multi`` captured once into a hipGraph and replayed.  At batch 1 the pass is ~700 launches
+    of a few microseconds each, i.e. bound by the Python + launch path on the host; a replay is one ``hipGraphLaunch``.
+
+        run = GraphedRelevance(model, image, indices=[243, 282])      # or top_k=1: arg-max class, chosen on the device
+        maps = run(image2, [1, 7])                                    # [K, N-1]; same values as the eager function
+
+    K and the image shape are fixed at construction; the returned tensor is the graph's output buffer (overwritten by
+    the next call, ``.clone()`` to keep it).
+    """
+
+    def __init__(self, model, input, indices=None, top_k=None, warmup=3):
+        self.input = input.clone()
+        self.indices = None if indices is None else torch.as_tensor(indices, device=input.device).reshape(-1).clone()
+        call = lambda: generate_relevance_multi(model, self.input, self.indices, top_k)   # noqa: E731
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                call()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.output = call()
+
+    def __call__(self, input=None, indices=None):
+        if input is not None:
+            self.input.copy_(input)
+        if indices is not None:
+            if self.indices is None:
+                raise ValueError("this graph picks its classes itself (top_k mode)")
+            self.indices.copy_(torch.as_tensor(indices, device=self.indices.device).reshape(-1))
+        self.graph.replay()
+        return self.output
