@@ -77,3 +77,43 @@ def test_generator_to_perturbation_pipeline():
     pert = lp.LxmertPerturbation(model)
     for scores in (pert.perturbation_image(inputs, cam_image), pert.perturbation_text(inputs, cam_text)):
         assert scores.shape == (9, 31) and torch.isfinite(scores).all()
+
+
+def test_generate_ours_batch_equals_per_item_loop():
+    """B items of equal question length in one forward/backward/schedule launch == the evaluator's per-item calls."""
+    import types
+    from transformer_mm_explainability_amd import lxmert_explainability as le
+    model, inputs, g = _model_and_inputs()
+    B = 5
+    batch = dict(input_ids=torch.randint(1, 200, (B, 12), generator=g).cuda(), attention_mask=torch.ones(B, 12).cuda(),
+                 token_type_ids=torch.zeros(B, 12, dtype=torch.long).cuda(),
+                 visual_feats=torch.randn(B, 20, 40, generator=g).cuda(), visual_pos=torch.rand(B, 20, 4, generator=g).cuda())
+    gen = le.GeneratorOurs(types.SimpleNamespace(model=model, text_len=12, image_boxes_len=20))
+    R_tt, R_ti = gen.generate_ours_batch(batch)
+    assert R_tt.shape == (B, 12, 12) and R_ti.shape == (B, 12, 20)
+    for b in range(B):
+        one = {k: v[b:b + 1] for k, v in batch.items()}
+        usage = types.SimpleNamespace(model=model, text_len=12, image_boxes_len=20, forward=lambda item: model(**one))
+        tt, ti = le.GeneratorOurs(usage).generate_ours(None, use_lrp=False)
+        torch.testing.assert_close(R_tt[b], tt, rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(R_ti[b], ti, rtol=1e-4, atol=1e-6)
+
+
+def test_perturbation_batched_over_items():
+    from transformer_mm_explainability_amd import lxmert_perturbation as lp
+    model, inputs, g = _model_and_inputs()
+    B = 3
+    batch = dict(input_ids=torch.randint(1, 200, (B, 12), generator=g).cuda(), attention_mask=torch.ones(B, 12).cuda(),
+                 token_type_ids=torch.zeros(B, 12, dtype=torch.long).cuda(),
+                 visual_feats=torch.randn(B, 20, 40, generator=g).cuda(), visual_pos=torch.rand(B, 20, 4, generator=g).cuda())
+    cam_i, cam_t = torch.rand(B, 20, generator=g).cuda(), torch.rand(B, 12, generator=g).cuda()
+    pert = lp.LxmertPerturbation(model)
+    img, txt = pert.perturbation_image(batch, cam_i), pert.perturbation_text(batch, cam_t, True)
+    assert img.shape == txt.shape == (B, 9, 31)
+    for b in range(B):
+        one = {k: v[b:b + 1] for k, v in batch.items()}
+        torch.testing.assert_close(img[b], pert.perturbation_image(one, cam_i[b]), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(txt[b], pert.perturbation_text(one, cam_t[b], True), rtol=1e-4, atol=1e-5)
+    labels = torch.rand(B, 31, device="cuda")
+    acc = lp.LxmertPerturbation.accuracy(img, labels)
+    assert acc.shape == (B, 9) and acc[1, 0] == labels[1, img[1, 0].argmax()]

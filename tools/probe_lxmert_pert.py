@@ -42,3 +42,25 @@ def sequential_image():
 print("image test, 9 sequential forwards : %.2f ms / sample" % timed(sequential_image))
 print("image test, batched               : %.2f ms / sample" % timed(lambda: pert.perturbation_image(inputs, cam_i)))
 print("text  test, batched               : %.2f ms / sample" % timed(lambda: pert.perturbation_text(inputs, cam_t)))
+
+# relevancy generation itself (config 4 sizes: T = 14 question tokens, I = 36 regions, 9 + 5 + 5 layers)
+import types  # noqa: E402
+
+from transformer_mm_explainability_amd import lxmert_explainability as le  # noqa: E402
+
+usage = types.SimpleNamespace(model=model, text_len=T, image_boxes_len=I, forward=lambda item: model(**inputs))
+gen = le.GeneratorOurs(usage)
+print("GeneratorOurs.generate_ours (fused)   : %.2f ms / sample" % timed(lambda: gen.generate_ours(None, use_lrp=False)))
+with torch.no_grad():
+    print("forward only                          : %.2f ms / sample" % timed(lambda: model(**inputs)))
+
+for B in (8, 32):
+    gb = torch.Generator().manual_seed(2)
+    batch = dict(input_ids=torch.randint(1, 30000, (B, T), generator=gb).cuda(), attention_mask=torch.ones(B, T).cuda(),
+                 token_type_ids=torch.zeros(B, T, dtype=torch.long).cuda(),
+                 visual_feats=torch.randn(B, I, 2048, generator=gb).cuda(), visual_pos=torch.rand(B, I, 4, generator=gb).cuda())
+    ms = timed(lambda: gen.generate_ours_batch(batch), n=5)
+    cams = torch.rand(B, I, generator=gb).cuda()
+    mp = timed(lambda: pert.perturbation_image(batch, cams), n=5)
+    print("B=%-2d generate_ours_batch %.2f ms (%.2f ms/sample) | image test %.2f ms (%.2f ms/sample) -> %.0f samples/s for both"
+          % (B, ms, ms / B, mp, mp / B, B / (ms + mp) * 1e3))

@@ -60,6 +60,42 @@ class GeneratorOurs:
         self.R_t_t, self.R_t_i, self.R_i_i, self.R_i_t = R_tt[0], R_ti[0], R_ii[0], R_it[0]
         return self.R_t_t, self.R_t_i
 
+    def generate_ours_batch(self, model_inputs, index=None, normalize_self_attention=True, apply_self_in_rule_10=True):
+        """B samples with the same number of question tokens in ONE forward + ONE backward + ONE schedule launch.
+
+        The evaluator (``perturbation.py:216-250``) explains one item per call; every per-item pass is ~1000 launches on
+        a batch-1 body, i.e. bound by the host, not by the GPU.  Samples are independent (sample b's score depends on
+        sample b's inputs only), so a batch of B one-hot seeds in one backward leaves exactly the per-sample
+        gradients in the slabs, and the schedule kernel already runs one workgroup per sample.  Group the items by
+        question length (no padding: a padded query row would have zero gradient and 0/0 in ``handle_residual``, the
+        failure the reference's own assert guards against).
+
+        ``model_inputs``: the keyword tensors of the model, batch-first (``input_ids [B, T]``, ``visual_feats [B, I, F]``,
+        ...).  ``index``: ``None`` (arg-max answer per sample, chosen on the device) or ``[B]`` answer ids.
+        Returns ``(R_t_t [B, T, T], R_t_i [B, T, I])``; ``self.R_i_i`` / ``self.R_i_t`` hold the image-side matrices.
+        """
+        self.use_lrp = False
+        self.normalize_self_attention = normalize_self_attention
+        self.apply_self_in_rule_10 = apply_self_in_rule_10
+        model = self.model_usage.model
+        output = rules.forward_for_backward(model, lambda: model(**model_inputs).question_answering_score)   # [B, A]
+        idx = output.argmax(dim=-1) if index is None else torch.as_tensor(index, device=output.device).reshape(-1)
+        one_hot = torch.zeros_like(output).scatter_(1, idx.reshape(-1, 1), 1.0)
+        model.zero_grad()
+        torch.sum(one_hot * output).backward(retain_graph=True)
+        T, I = model_inputs["input_ids"].shape[1], model_inputs["visual_feats"].shape[1]
+        if max(T, I) > ops.LXMERT_FUSED_MAX_TOKENS:
+            raise NotImplementedError("generate_ours_batch runs the one-launch schedule (T, I <= %d)"
+                                      % ops.LXMERT_FUSED_MAX_TOKENS)
+        enc = model.lxmert.encoder
+        xs = list(enc.x_layers)
+        self.R_t_t, self.R_t_i, self.R_i_i, self.R_i_t = ops.lxmert_schedule(
+            [_pair(b.attention.self) for b in enc.layer], [_pair(b.attention.self) for b in enc.r_layers],
+            [_pair(b.visual_attention.att) for b in xs], [_pair(b.visual_attention_copy.att) for b in xs[:-1]],
+            [_pair(b.lang_self_att.self) for b in xs], [_pair(b.visn_self_att.self) for b in xs[:-1]],
+            apply_normalization=normalize_self_attention, apply_self_in_rule_10=apply_self_in_rule_10)
+        return self.R_t_t, self.R_t_i
+
     # ---- single-stream pieces: rules 6+7 for a list of blocks in one chain launch
     def _self_chain(self, pairs, R_ss, R_sq):
         attn = [a for a, _ in pairs]

@@ -65,56 +65,72 @@ def text_keep_batch(input_ids, token_type_ids, cam_text, steps=PERT_STEPS, is_po
 
 
 class LxmertPerturbation:
-    """``ModelPert.perturbation_image`` / ``perturbation_text`` for one sample, the 9 steps batched.
+    """``ModelPert.perturbation_image`` / ``perturbation_text``, the 9 steps (and optionally B samples) in one batch.
 
     ``model``: an ``lxmert_model.LxmertForQuestionAnswering``.  ``inputs``: the tensors the reference's ``forward``
-    hands to the model -- ``input_ids``, ``attention_mask``, ``token_type_ids`` (``[1, T]``), ``visual_feats``
-    (``[1, I, F]``), ``visual_pos`` (``[1, I, 4]``).  Both methods return the answer scores ``[S, num_answers]``;
-    ``accuracy`` turns them into the per-step VQA soft accuracies (``label_scores[argmax]``, ``perturbation.py:134-136``).
+    hands to the model -- ``input_ids``, ``attention_mask``, ``token_type_ids`` (``[B, T]``), ``visual_feats``
+    (``[B, I, F]``), ``visual_pos`` (``[B, I, 4]``); B = 1 for the reference's one-item call, B > 1 for items of equal
+    question length.  ``cam_image [I]`` / ``cam_text [T]`` (or ``[B, I]`` / ``[B, T]``).  Both methods return the answer
+    scores ``[S, num_answers]`` (``[B, S, num_answers]`` for 2-D cams); ``accuracy`` turns them into the per-step VQA
+    soft accuracies (``label_scores[argmax]``, ``perturbation.py:134-136``).
     """
 
     def __init__(self, model, steps=PERT_STEPS):
         self.model = model
         self.steps = tuple(steps)
 
+    @staticmethod
+    def _rep(x, S):
+        return x.repeat_interleave(S, dim=0)
+
     @torch.no_grad()
     def perturbation_image(self, inputs, cam_image, is_positive_pert=False):
-        keep = image_keep_masks(cam_image, self.steps, is_positive_pert)                 # [S, I]
-        counts = [int((1 - step) * cam_image.shape[-1]) for step in self.steps]          # host arithmetic only
-        live = [s for s, c in enumerate(counts) if c > 0]
+        single = cam_image.dim() == 1
+        cams = cam_image.reshape(-1, cam_image.shape[-1])
+        B, I = cams.shape
         S = len(self.steps)
+        keep = torch.stack([image_keep_masks(c, self.steps, is_positive_pert) for c in cams])      # [B, S, I]
+        counts = [int((1 - step) * I) for step in self.steps]                                       # host arithmetic only
+        live = [s for s, c in enumerate(counts) if c > 0]
         scores = None
         if live:
             rows = torch.tensor(live, device=keep.device)
             n = len(live)
-            out = self.model(input_ids=inputs["input_ids"].expand(n, -1),
-                             attention_mask=inputs["attention_mask"].expand(n, -1),
-                             token_type_ids=inputs["token_type_ids"].expand(n, -1),
-                             visual_feats=inputs["visual_feats"].expand(n, -1, -1),
-                             visual_pos=inputs["visual_pos"].expand(n, -1, -1),
-                             visual_attention_mask=keep[rows]).question_answering_score
-            scores = out.new_empty(S, out.shape[-1])
-            scores[rows] = out
+            out = self.model(input_ids=self._rep(inputs["input_ids"], n),
+                             attention_mask=self._rep(inputs["attention_mask"], n),
+                             token_type_ids=self._rep(inputs["token_type_ids"], n),
+                             visual_feats=self._rep(inputs["visual_feats"], n),
+                             visual_pos=self._rep(inputs["visual_pos"], n),
+                             visual_attention_mask=keep[:, rows].reshape(B * n, I)).question_answering_score
+            scores = out.new_empty(B, S, out.shape[-1])
+            scores[:, rows] = out.reshape(B, n, -1)
         if len(live) < S:                                    # steps that keep no region at all: region-free forward
             out = self.model(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
                              token_type_ids=inputs["token_type_ids"], visual_feats=inputs["visual_feats"][:, :0],
                              visual_pos=inputs["visual_pos"][:, :0]).question_answering_score
             if scores is None:
-                scores = out.new_empty(S, out.shape[-1])
+                scores = out.new_empty(B, S, out.shape[-1])
             dead = torch.tensor([s for s in range(S) if s not in live], device=keep.device)
-            scores[dead] = out
-        return scores
+            scores[:, dead] = out[:, None, :]
+        return scores[0] if single else scores
 
     @torch.no_grad()
     def perturbation_text(self, inputs, cam_text, is_positive_pert=False):
-        ids, types, mask = text_keep_batch(inputs["input_ids"], inputs["token_type_ids"], cam_text, self.steps,
-                                           is_positive_pert)
-        S = len(self.steps)
-        return self.model(input_ids=ids, attention_mask=mask, token_type_ids=types,
-                          visual_feats=inputs["visual_feats"].expand(S, -1, -1),
-                          visual_pos=inputs["visual_pos"].expand(S, -1, -1)).question_answering_score
+        single = cam_text.dim() == 1
+        cams = cam_text.reshape(-1, cam_text.shape[-1])
+        B, S = cams.shape[0], len(self.steps)
+        parts = [text_keep_batch(inputs["input_ids"][b:b + 1], inputs["token_type_ids"][b:b + 1], cams[b], self.steps,
+                                 is_positive_pert) for b in range(B)]
+        ids, types, mask = (torch.cat([p[k] for p in parts]) for k in range(3))                     # [B*S, T]
+        out = self.model(input_ids=ids, attention_mask=mask, token_type_ids=types,
+                         visual_feats=self._rep(inputs["visual_feats"], S),
+                         visual_pos=self._rep(inputs["visual_pos"], S)).question_answering_score
+        out = out.reshape(B, S, -1)
+        return out[0] if single else out
 
     @staticmethod
     def accuracy(scores, label_scores):
-        """``label_scores [num_answers]``: the item's soft VQA scores per answer id (0 where absent) -> ``[S]``."""
-        return label_scores[scores.argmax(dim=-1)]
+        """``label_scores [num_answers]`` (or ``[B, num_answers]`` for batched scores): the item's soft VQA scores per
+        answer id (0 where absent) -> ``[S]`` (``[B, S]``)."""
+        best = scores.argmax(dim=-1)
+        return label_scores[best] if label_scores.dim() == 1 else torch.gather(label_scores, 1, best)
