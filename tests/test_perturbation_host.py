@@ -49,3 +49,23 @@ def test_normalize_cams_and_accuracy():
     scores = torch.tensor([[0.1, 0.9, 0.0], [0.7, 0.2, 0.1]])
     labels = torch.tensor([0.3, 1.0, 0.0])
     assert lp.LxmertPerturbation.accuracy(scores, labels).tolist() == [1.0, 0.30000001192092896]
+
+
+def test_visualbert_text_keep_batch_matches_reference_gather():
+    """evaluation_loop.py:128-150 restated: keep [CLS], the inner top-k, the '?' token at cls_index and [SEP]."""
+    from transformer_mm_explainability_amd import visualbert_perturbation as vp
+    g = torch.Generator().manual_seed(3)
+    n_text = 11
+    ids = torch.randint(5, 1000, (1, n_text), generator=g)
+    seg = torch.zeros(1, n_text, dtype=torch.long)
+    cls_index = n_text - 2
+    scores = torch.rand(cls_index - 1, generator=g)                      # method_cam[0, 1:cls_index]
+    got_ids, got_seg, mask = vp.text_keep_batch(ids, seg, scores, n_text)
+    for s, step in enumerate(vp.PERT_STEPS):
+        k = int((1 - step) * len(scores))
+        top = scores.topk(k=k, dim=-1).indices.tolist()
+        kept = sorted([0, cls_index, cls_index + 1] + [i + 1 for i in top])
+        n = len(kept)
+        assert mask[s].tolist() == [1] * n + [0] * (n_text - n)
+        assert got_ids[s, :n].tolist() == ids[0, kept].tolist()
+        assert int(mask[s].sum()) - 2 == kept.index(cls_index)            # the 'vqa' pooler still reads the '?' token

@@ -20,7 +20,6 @@ dP without weight or input gradients.  ModifiedResNet towers (RN50 etc.) have no
 """
 from __future__ import annotations
 
-import math
 from collections import OrderedDict
 
 import numpy as np
@@ -149,13 +148,6 @@ class Transformer(nn.Module):
             blk.attn_probs, blk.attn_grad = buffers.layer_probs(l), buffers.layer_grads(l)
             x = x2
         return x, tape
-
-    @staticmethod
-    def _ln_backward(dy, x, mean, rstd, ln):
-        B = dy.shape[0]
-        return torch.ops.aten.native_layer_norm_backward(
-            dy.contiguous(), x.expand(B, -1, -1).contiguous(), (x.shape[-1],), mean.expand(B, -1, -1).contiguous(),
-            rstd.expand(B, -1, -1).contiguous(), ln.weight, ln.bias, [True, False, False])[0]
 
     @torch.no_grad()
     def backward_shared(self, tape, dy, first_grad_layer=0):
