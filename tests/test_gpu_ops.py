@@ -293,3 +293,22 @@ def test_layernorm_bwd_add(ops, B, N, E, shared):
     close(got, want, atol=2e-5)
     got2 = ops.layernorm_bwd_add(dy.cuda(), x.float().cuda(), mean, rstd, gamma.float().cuda())
     close(got2, xr.grad.float().numpy(), atol=2e-5)
+
+
+def test_unsupported_shapes_fail_loudly(ops):
+    """The C-ABI refuses what it does not implement (negative return code -> MMXError with the library's message);
+    nothing falls back to another implementation."""
+    from transformer_mm_explainability_amd import postprocess
+    from transformer_mm_explainability_amd._lib import MMXError
+    q = torch.randn(1, 5, 2, 80, device="cuda")                      # head_dim 80 > 64
+    probs = torch.empty(1, 2, 5, 5, device="cuda")
+    with pytest.raises(MMXError, match="head_dim"):
+        ops.attn_capture_fwd(q, q, q, probs, 80 ** -0.5, 0, None)
+    with pytest.raises(MMXError, match="64"):
+        postprocess.image_heatmaps(torch.rand(1, 65 * 65, device="cuda"), 224)   # patch grid > 64
+    big = [(torch.rand(1, 2, 60, 60, device="cuda").softmax(-1), torch.rand(1, 2, 60, 60, device="cuda"))]
+    cross = [(torch.rand(1, 2, 60, 36, device="cuda").softmax(-1), torch.rand(1, 2, 60, 36, device="cuda"))]
+    with pytest.raises(MMXError):
+        ops.lxmert_schedule(big, big[:0], cross, [], big, [])          # T = 60 > 48: the one-launch schedule is LDS-sized
+    with pytest.raises(MMXError, match="inner dims"):
+        ops.matmul(torch.rand(4, 5, device="cuda"), torch.rand(4, 4, device="cuda"))
