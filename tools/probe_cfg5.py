@@ -1,0 +1,47 @@
+"""BASELINE.json config 5 shape (CLIP ViT-L/14@336: image tower 24 x 16 heads x 577 tokens, text 12 x 12 x 77) on the
+fp32 path: self-consistency of the shared-forward route at N = 577, then maps/s at growing batch."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from transformer_mm_explainability_amd import clip_explainability as ce  # noqa: E402
+from transformer_mm_explainability_amd import clip_model  # noqa: E402
+
+dev = torch.device("cuda")
+model = clip_model.random_init("ViT-L/14@336", seed=0).to(dev)
+g = torch.Generator().manual_seed(1)
+image = torch.randn(1, 3, 336, 336, generator=g).to(dev)
+
+
+def prompts(B):
+    t = torch.zeros(B, 77, dtype=torch.long)
+    gg = torch.Generator().manual_seed(2)
+    for b in range(B):
+        n = int(torch.randint(3, 11, (1,), generator=gg))
+        t[b, 0] = 49406
+        t[b, 1:1 + n] = torch.randint(1, 49405, (n,), generator=gg)
+        t[b, 1 + n] = 49407
+    return t.to(dev)
+
+
+texts = prompts(2)
+a = ce.interpret(image, texts, model, dev, start_layer=0, start_layer_text=0, share_image_forward=True)
+b = ce.interpret(image, texts, model, dev, start_layer=0, start_layer_text=0, share_image_forward=False)
+print("shared vs replicated image tower, B=2: max |dR_image| = %.3e (max |R| = %.3e), max |dR_text| = %.3e"
+      % ((a[1] - b[1]).abs().max().item(), b[1].abs().max().item(), (a[0] - b[0]).abs().max().item()))
+for B in (16, 64, 128):
+    texts = prompts(B)
+    torch.cuda.reset_peak_memory_stats()
+    for _ in range(2):
+        ce.interpret(image, texts, model, dev, start_layer=0, start_layer_text=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        ce.interpret(image, texts, model, dev, start_layer=0, start_layer_text=0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print("ViT-L/14@336 fp32, B=%-3d all layers: %.1f ms/step = %.1f maps/s, peak memory %.1f GB"
+          % (B, dt * 1e3, B / dt, torch.cuda.max_memory_allocated() / 2**30))
