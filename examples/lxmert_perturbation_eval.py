@@ -1,0 +1,95 @@
+"""Sharded LXMERT perturbation evaluation on synthetic data -- the shape of ``lxmert/lxmert/perturbation.py``'s main
+loop (BASELINE.json config 4) on this package: one process per GPU, samples sharded rank-strided, items of equal
+question length explained and perturbed as one batch, ONE all-gather of the per-sample step accuracies at the end.
+
+    python examples/lxmert_perturbation_eval.py --num-samples 512                      # one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \\
+        examples/lxmert_perturbation_eval.py --num-samples 10000                       # one rank per GPU, RCCL
+
+Random-init LXMERT-base and random features / questions (no VQA data or checkpoint offline): the numbers that mean
+something are samples/s, not the accuracies.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from transformer_mm_explainability_amd import lxmert_explainability as le  # noqa: E402
+from transformer_mm_explainability_amd import lxmert_model as lm  # noqa: E402
+from transformer_mm_explainability_amd import lxmert_perturbation as lp  # noqa: E402
+from transformer_mm_explainability_amd import sharding  # noqa: E402
+
+
+def synthetic_item(k, regions, feat_dim, vocab, answers):
+    """Item ``k`` of the synthetic dataset (seeded by its index: any rank can materialise any item)."""
+    g = torch.Generator().manual_seed(1000 + k)
+    T = int(torch.randint(6, 21, (1,), generator=g))
+    label = torch.zeros(answers)
+    label[torch.randint(0, answers, (3,), generator=g)] = torch.tensor([1.0, 0.6, 0.3])
+    return dict(input_ids=torch.randint(1, vocab, (T,), generator=g), visual_feats=torch.randn(regions, feat_dim, generator=g),
+                visual_pos=torch.rand(regions, 4, generator=g), label=label)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num-samples", type=int, default=512)
+    ap.add_argument("--dataset-len", type=int, default=20000)
+    ap.add_argument("--max-batch", type=int, default=32)
+    ap.add_argument("--text", action="store_true", help="text perturbation test instead of the image one")
+    ap.add_argument("--positive", action="store_true")
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = lm.LxmertConfig()
+    torch.manual_seed(0)
+    model = lm.LxmertForQuestionAnswering(cfg).to(dev).eval()
+    indices = sharding.perturbation_sample_indices(args.dataset_len, args.num_samples)      # same list on every rank
+    mine = sharding.shard_indices(indices)
+    items = [synthetic_item(k, 36, cfg.visual_feat_dim, cfg.vocab_size, cfg.num_qa_labels) for k in mine]
+    gen = le.GeneratorOurs(type("Usage", (), {"model": model})())
+    pert = lp.LxmertPerturbation(model)
+    local = torch.zeros(len(mine), len(lp.PERT_STEPS), device=dev)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for T, positions in sharding.length_buckets([it["input_ids"].numel() for it in items], args.max_batch):
+        B = len(positions)
+        batch = dict(input_ids=torch.stack([items[p]["input_ids"] for p in positions]).to(dev),
+                     attention_mask=torch.ones(B, T, device=dev), token_type_ids=torch.zeros(B, T, dtype=torch.long, device=dev),
+                     visual_feats=torch.stack([items[p]["visual_feats"] for p in positions]).to(dev),
+                     visual_pos=torch.stack([items[p]["visual_pos"] for p in positions]).to(dev))
+        R_t_t, R_t_i = gen.generate_ours_batch(batch)
+        cam_image, cam_text = lp.normalize_cams_batch(R_t_t, R_t_i)
+        scores = pert.perturbation_text(batch, cam_text, args.positive) if args.text else \
+            pert.perturbation_image(batch, cam_image, args.positive)
+        labels = torch.stack([items[p]["label"] for p in positions]).to(dev)
+        local[torch.tensor(positions, device=dev)] = lp.LxmertPerturbation.accuracy(scores, labels)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    per_sample = sharding.gather_per_sample(local, len(indices))                             # the one exchange step
+    acc = sharding.mean_step_accuracy(per_sample)
+    if rank == 0:
+        print(json.dumps({"samples": len(indices), "n_gpus": world, "seconds": round(elapsed, 3),
+                          "samples_per_s": round(len(indices) / elapsed, 1), "test": "text" if args.text else "image",
+                          "step_accuracy_percent": [round(float(a), 2) for a in acc]}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,3 +69,20 @@ def test_visualbert_text_keep_batch_matches_reference_gather():
         assert mask[s].tolist() == [1] * n + [0] * (n_text - n)
         assert got_ids[s, :n].tolist() == ids[0, kept].tolist()
         assert int(mask[s].sum()) - 2 == kept.index(cls_index)            # the 'vqa' pooler still reads the '?' token
+
+
+def test_length_buckets():
+    from transformer_mm_explainability_amd import sharding
+    lengths = [7, 9, 7, 7, 12, 9, 7, 7]
+    got = sharding.length_buckets(lengths, max_batch=3)
+    assert got == [(7, [0, 2, 3]), (7, [6, 7]), (9, [1, 5]), (12, [4])]
+    assert sorted(p for _, ps in got for p in ps) == list(range(len(lengths)))
+
+
+def test_normalize_cams_batch_matches_per_item():
+    g = torch.Generator().manual_seed(4)
+    R_t_t, R_t_i = torch.rand(3, 5, 5, generator=g), torch.rand(3, 5, 8, generator=g)
+    ci, ct = lp.normalize_cams_batch(R_t_t, R_t_i)
+    for b in range(3):
+        one_i, one_t = lp.normalize_cams(R_t_t[b], R_t_i[b])
+        assert torch.allclose(ci[b], one_i) and torch.allclose(ct[b], one_t)

@@ -31,6 +31,14 @@ def normalize_cams(R_t_t, R_t_i):
     return cam_image, cam_text
 
 
+def normalize_cams_batch(R_t_t, R_t_i):
+    """``normalize_cams`` for ``[B, T, T]`` / ``[B, T, I]`` relevancies -> ``(cam_image [B, I], cam_text [B, T])``."""
+    def minmax(x):
+        lo, hi = x.min(dim=-1, keepdim=True).values, x.max(dim=-1, keepdim=True).values
+        return (x - lo) / (hi - lo)
+    return minmax(R_t_i[:, 0]), minmax(R_t_t[:, 0])
+
+
 def image_keep_masks(cam_image, steps=PERT_STEPS, is_positive_pert=False):
     """``[S, I]`` float 0/1: row s keeps the ``int((1 - step_s) * I)`` top-scoring regions (``perturbation.py:114-117``)."""
     cam = -cam_image if is_positive_pert else cam_image

@@ -39,6 +39,22 @@ def shard_indices(indices, rank=None, world_size=None):
     return list(indices[rank::world_size])
 
 
+def length_buckets(lengths, max_batch):
+    """Batches of samples with EQUAL length (the batched generators take no padding, see
+    ``lxmert_explainability.GeneratorOurs.generate_ours_batch``): ``[(length, [positions...]), ...]`` over positions
+    ``0 .. len(lengths) - 1``, each batch at most ``max_batch`` long, in a deterministic order (by length, then
+    position)."""
+    by_len = {}
+    for pos, n in enumerate(lengths):
+        by_len.setdefault(int(n), []).append(pos)
+    out = []
+    for n in sorted(by_len):
+        group = by_len[n]
+        for i in range(0, len(group), max_batch):
+            out.append((n, group[i:i + max_batch]))
+    return out
+
+
 def gather_per_sample(local, total, fill=float("nan")):
     """All-gather per-sample rows back into the ORIGINAL (unsharded) order.
 
