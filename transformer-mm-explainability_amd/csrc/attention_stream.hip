@@ -138,8 +138,12 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_ke
     float* Ks = smem;
     float* Vs = Ks + kTile * LS;
     float* Pw = Vs + kTile * LS + wave * 16 * kPS;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int rw = blockIdx.x * kRows + wave * 16;          // first query row of this wave
+    // 1-D grid, XCD-contiguous logical order (row tile fastest): the row tiles of a head share that head's K / V in
+    // one XCD's L2
+    const int nrt = (a.Nq + kRows - 1) / kRows;
+    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int h = (wg / nrt) % a.H, b = wg / (nrt * a.H);
+    const int rw = (wg % nrt) * kRows + wave * 16;          // first query row of this wave
     const float* qb = a.q + b * a.qs.sb + h * a.qs.sh;
     const float* kb = a.k + b * a.ks.sb + h * a.ks.sh;
     const float* vb = a.v + b * a.vs.sb + h * a.vs.sh;
@@ -261,8 +265,10 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
     float* Vs = smem;
     float* Ks = Vs + kTile * LS;
     float* Sw = Ks + kTile * LS + wave * 16 * kPS;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int rw = blockIdx.x * kRows + wave * 16;
+    const int nrt = (a.Nq + kRows - 1) / kRows;           // 1-D grid, XCD-contiguous logical order (see forward)
+    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int h = (wg / nrt) % a.H, b = wg / (nrt * a.H);
+    const int rw = (wg % nrt) * kRows + wave * 16;
     const float* kb = a.need_dqkv ? a.k + b * a.ks.sb + h * a.ks.sh : nullptr;
     const float* vb = a.v + b * a.vs.sb + h * a.vs.sh;
     const float* dob = a.dout + b * a.os.sb + h * a.os.sh;
@@ -385,8 +391,10 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_kv_stream_kernel(const Attn
     float* Qs = smem;
     float* dOs = Qs + kTile * LS;
     float* dl = dOs + kTile * LS;                             // [64] delta of the staged query rows
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int kw = blockIdx.x * kRows + wave * 16;          // first key of this wave
+    const int nkt = (a.Nk + kRows - 1) / kRows;           // 1-D grid, XCD-contiguous: a head's key tiles share Q / dO
+    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int h = (wg / nkt) % a.H, b = wg / (nkt * a.H);
+    const int kw = (wg % nkt) * kRows + wave * 16;          // first key of this wave
     const int key = kw + i;
     const bool key_ok = key < a.Nk;
     const int keyc = min(key, a.Nk - 1);
@@ -490,7 +498,7 @@ void attn_stream_enable(int on) { g_attn_stream = on & 1; }
 int attn_fwd_stream_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out) {
     if (!g_attn_stream || a.D % 4 || a.D > 64) return 0;
     if (!aligned16(a.q, a.qs) || !aligned16(a.k, a.ks) || !aligned16(a.v, a.vs)) return 0;
-    dim3 grid((a.Nq + kRows - 1) / kRows, a.H, a.B);
+    dim3 grid(((a.Nq + kRows - 1) / kRows) * a.H * a.B);
     *rc_out = a.D <= 32
         ? launch_stream(attn_fwd_stream_kernel<32>, a, grid, stream_lds_bytes<32>(2), s, "attn_fwd_stream_kernel<32>")
         : launch_stream(attn_fwd_stream_kernel<64>, a, grid, stream_lds_bytes<64>(2), s, "attn_fwd_stream_kernel<64>");
@@ -501,7 +509,7 @@ int attn_bwd_stream_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out) {
     if (!g_attn_stream || a.D % 4 || a.D > 64) return 0;
     if (!aligned16(a.v, a.vs) || !aligned16(a.dout, a.os)) return 0;
     if (a.need_dqkv && (!aligned16(a.q, a.qs) || !aligned16(a.k, a.ks))) return 0;
-    dim3 gq((a.Nq + kRows - 1) / kRows, a.H, a.B), gk((a.Nk + kRows - 1) / kRows, a.H, a.B);
+    dim3 gq(((a.Nq + kRows - 1) / kRows) * a.H * a.B), gk(((a.Nk + kRows - 1) / kRows) * a.H * a.B);
     const bool small_d = a.D <= 32;
     int rc = small_d ? launch_stream(attn_bwd_q_stream_kernel<32>, a, gq, stream_lds_bytes<32>(2), s,
                                      "attn_bwd_q_stream_kernel<32>")

@@ -96,6 +96,16 @@ __device__ __forceinline__ float group16_sum(float x) {
     return x;
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2 (linear workgroup id w runs on XCD w % 8).
+// Map w to a logical id such that every XCD owns ONE contiguous range of logical ids: neighbours in logical order --
+// e.g. the query tiles of one attention head, which all stream the same K / V -- then share an L2 instead of filling
+// eight.  A bijection on [0, total) for any total; placement is a performance hint only (nothing depends on it).
+__device__ __forceinline__ int xcd_contiguous_id(int w, int total) {
+    constexpr int X = 8;
+    const int xcd = w % X, local = w / X, per = total / X, rem = total % X;
+    return xcd < rem ? xcd * (per + 1) + local : rem * (per + 1) + (xcd - rem) * per + local;
+}
+
 inline size_t dtype_size(int dt) { return dt == MMX_F32 ? 4 : 2; }
 
 void set_error(const char* fmt, ...);
