@@ -77,8 +77,18 @@ struct ChainArgs {
 
 constexpr int kChainThreads = 1024;
 
-template <int NT, int DT>
-__global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const ChainArgs a) {
+// THREADS / U / EQ: workgroup width, heads per load batch and work split of the head reduction.
+//   EQ = false (1024 threads, U = 4): NT matrix waves + (16 - NT) stream waves; the matrix waves only reduce the chunks
+//        left over after the stream waves' full passes.
+//   EQ = true: every wave reduces an equal share of the chunks (the matrix waves do theirs after their MFMAs).  With
+//        fewer threads per workgroup the VGPR budget per lane grows (1024 threads: 128, 768: 170, 512: 256), which
+//        lets a lane keep U = 8..12 heads x 2 arrays = 16..24 16-byte loads in flight instead of 8 (verified in the
+//        ISA).  Measured on MI355X (profiles/r01_chain_probe.txt): every such variant is SLOWER than the default
+//        (text tower 75.7 us vs 77.8 / 84.6 / 82.3 / 90.4 us for 1024-EQ / 768-U8 / 768-U12 / 512-U8) -- a CU
+//        already streams at ~8 of its ~10 B/cycle HBM ceiling, more bytes in flight per lane do not raise it and
+//        fewer waves lose issue overlap.  Only the default is instantiated.
+template <int NT, int DT, int THREADS = kChainThreads, int U = 4, bool EQ = false>
+__global__ __launch_bounds__(THREADS) void self_chain_fused_kernel(const ChainArgs a) {
     constexpr int NP = NT * 16;
     constexpr int S = NP + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * NP * S floats
@@ -94,7 +104,7 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
     const int L = l1 - l0;
     const int64_t NN = static_cast<int64_t>(N) * N;
 
-    for (int i = tid; i < 2 * NP * S; i += kChainThreads) smem[i] = 0.f;  // pads must read as 0
+    for (int i = tid; i < 2 * NP * S; i += THREADS) smem[i] = 0.f;  // pads must read as 0
     __syncthreads();
 
     const int col = wave * 16 + (lane & 15);
@@ -103,7 +113,7 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
 
     // ---- head reduction of one 4-element chunk of A_bar_l (used by the stream waves and, for the remainder pass, by
     // the otherwise idle matrix waves)
-    constexpr int LT = kChainThreads - NT * 64;   // stream lanes
+    constexpr int LT = THREADS - NT * 64;         // stream lanes
     constexpr int ML = NT * 64;                   // matrix lanes
     const float fH = static_cast<float>(H);
     const int64_t sample = static_cast<int64_t>(b) * H * NN;
@@ -114,13 +124,14 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
     // matrix lanes (text tower: 1483 = 2 x 704 + 75), the matrix waves reduce them between their MFMAs and the stream
     // waves save a whole, almost empty, pass per layer.
     const int full = nchunks / LT;
-    const bool split = full >= 1 && nchunks - full * LT <= ML;
+    const bool split = !EQ && full >= 1 && nchunks - full * LT <= ML;
     const int stream_end = split ? full * LT : nchunks;
+    constexpr int SSTRIDE = EQ ? THREADS : LT;    // chunk stride of a stream lane
     auto reduce_chunk = [&](int c, const void* A, const void* Gr, float* Ab) {
         const int64_t p = static_cast<int64_t>(c) * 4;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         if (p + 3 < NN) {
-#pragma unroll 4  // measured: 2 / 6 / 8 heads per batch are slower (profiles/r01_chain_probe.txt)
+#pragma unroll U  // at 1024 threads (128 VGPRs per lane) U = 4 is the optimum: 6 / 8 spill (r01_chain_probe.txt)
             for (int h = 0; h < H; ++h) {
                 const f32x4 av = load4_as_f32<DT>(A, sampleA + h * NN + p);
                 const f32x4 gv = load4_as_f32<DT>(Gr, sample + h * NN + p);
@@ -145,9 +156,15 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
 
     if (wave < NT) {
         // ------------------------------------------------------------------ matrix waves
-        auto remainder_pass = [&](int l) {   // this lane's share of A_bar_l's remainder chunks (split mode only)
-            const int c = stream_end + tid;
-            if (split && l < L && c < nchunks) reduce_chunk(c, a.attn[l0 + l], a.grad[l0 + l], smem + (l & 1) * NP * S);
+        auto remainder_pass = [&](int l) {   // this lane's share of A_bar_l: the remainder chunks, or an equal share (EQ)
+            if (l >= L) return;
+            if (EQ) {
+                for (int c = LT + tid; c < nchunks; c += THREADS)
+                    reduce_chunk(c, a.attn[l0 + l], a.grad[l0 + l], smem + (l & 1) * NP * S);
+            } else {
+                const int c = stream_end + tid;
+                if (split && c < nchunks) reduce_chunk(c, a.attn[l0 + l], a.grad[l0 + l], smem + (l & 1) * NP * S);
+            }
         };
         remainder_pass(0);
 #pragma unroll
@@ -202,7 +219,7 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
             float* Ab = smem + (l & 1) * NP * S;
             const void* A = a.attn[l0 + l];
             const void* Gr = a.grad[l0 + l];
-            for (int c = lt; c < stream_end; c += LT) reduce_chunk(c, A, Gr, Ab);
+            for (int c = lt; c < stream_end; c += SSTRIDE) reduce_chunk(c, A, Gr, Ab);
             __syncthreads();  // publish A_bar_l (pairs with the matrix waves' barrier of layer l)
         }
     }
@@ -234,13 +251,13 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
                 Rold[t][r] = (row < N && col < N) ? part[static_cast<int64_t>(row) * N + col] : 0.f;
             }
     }
-    constexpr int CE = (NP * NP + kChainThreads - 1) / kChainThreads;  // elements of a partial product per thread
+    constexpr int CE = (NP * NP + THREADS - 1) / THREADS;  // elements of a partial product per thread
     float pre[CE];
     auto prefetch = [&](int gg) {
         const float* P = part + gg * NN;
 #pragma unroll
         for (int i = 0; i < CE; ++i) {
-            const int idx = tid + i * kChainThreads;
+            const int idx = tid + i * THREADS;
             pre[i] = (idx < N * N) ? P[idx] : 0.f;
         }
     };
@@ -248,7 +265,7 @@ __global__ __launch_bounds__(kChainThreads) void self_chain_fused_kernel(const C
     for (int gg = 1; gg < G; ++gg) {
 #pragma unroll
         for (int i = 0; i < CE; ++i) {
-            const int idx = tid + i * kChainThreads;
+            const int idx = tid + i * THREADS;
             if (idx < N * N) {
                 const int row = idx / N, cc = idx - row * N;
                 smem[row * S + cc] = pre[i];
