@@ -71,6 +71,10 @@ int mmx_set_option(const char* key, int value);
  */
 int mmx_avg_heads(const void* attn_dev, const void* grad_dev, void* out_dev,
                   int B, int H, int Nq, int Nk, int dtype, void* stream);
+/* Same with an explicit batch stride (in elements) for the attention slab: H*Nq*Nk (or -1) = per-sample slabs, 0 = ONE
+ * forward pass shared by all B samples of `grad` (shared-forward mode, see mmx_relevancy_self_chain_ex). */
+int mmx_avg_heads_ex(const void* attn_dev, const void* grad_dev, void* out_dev,
+                     int B, int H, int Nq, int Nk, int dtype, int64_t attn_batch_stride, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The fused self-attention chain (rules 5+6 [+7]) -- ONE launch for all layers:

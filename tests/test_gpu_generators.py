@@ -393,9 +393,13 @@ def test_detr_generate_ours_multi_equals_per_query_loop(golden, flags):
     targets = torch.tensor([4, 0, 6], device="cuda")
     gen = Generator(model)
     want = torch.cat([gen.generate_ours(feats, t.reshape(1), use_lrp=False, **flags) for t in targets], dim=2)
-    got = Generator(model).generate_ours_multi(feats, targets, **flags)
+    got = Generator(model).generate_ours_multi(feats, targets, **flags)                      # shared forward (default)
     assert got.shape == want.shape == (1, 1, 3, 15)
     close(got, want.cpu().numpy(), atol=1e-6)
+    assert model.transformer.encoder.layers[0].self_attn.get_attn().shape[0] == 4           # ONE probability slab (H heads)
+    assert model.transformer.encoder.layers[0].self_attn.get_attn_gradients().shape[0] == 12   # K x H gradient slabs
+    replicated = Generator(model).generate_ours_multi(feats, targets, share_forward=False, **flags)
+    close(replicated, want.cpu().numpy(), atol=1e-6)
     if not flags:      # target 4 of the fixture: the reference generator's own single-target-of-two run used [1, 4]
         two = Generator(model).generate_ours_multi(feats, torch.tensor([1], device="cuda"))
         one = gen.generate_ours(feats, torch.tensor([1], device="cuda"), use_lrp=False)

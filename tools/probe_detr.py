@@ -43,3 +43,8 @@ for K in (1, 5, 10, 20):
     t = torch.arange(K, device="cuda") * 3
     ms = timed(lambda: gen.generate_ours_multi(feats, t), n=5, warm=2)
     print("generate_ours_multi K=%-2d %.2f ms  (%.2f ms/query, %.0f queries/s)" % (K, ms, ms / K, K / ms * 1e3))
+
+for K in (5, 10, 20):
+    t = torch.arange(K, device="cuda") * 3
+    ms = timed(lambda: gen.generate_ours_multi(feats, t, share_forward=False), n=5, warm=2)
+    print("  replicated forward       K=%-2d %.2f ms  (%.2f ms/query)" % (K, ms, ms / K))

@@ -25,6 +25,7 @@ _PROTOTYPES = {
     "mmx_last_error": (C.c_char_p, []),
     "mmx_set_option": (_i, [C.c_char_p, _i]),
     "mmx_avg_heads": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mmx_avg_heads_ex": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _vp]),
     "mmx_self_chain_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mmx_relevancy_self_chain": (_i, [_vpp, _vpp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "mmx_relevancy_self_chain_ex": (_i, [_vpp, _vpp, _i, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),

@@ -21,7 +21,7 @@ import math
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, ops
 from .capture import attention_capture
 
 
@@ -37,7 +37,8 @@ class _SlabOwner(nn.Module):
         shape = (B, H, Nq, Nk)
         if self._probs is None or tuple(self._probs.shape) != shape or self._probs.device != device:
             self._probs = torch.empty(shape, dtype=torch.float32, device=device)
-            self._grads = torch.empty(shape, dtype=torch.float32, device=device)
+        if self._grads is None or tuple(self._grads.shape) != shape or self._grads.device != device:
+            self._grads = torch.empty(shape, dtype=torch.float32, device=device)   # (shared-forward mode sizes it by K)
         return self._probs, self._grads
 
     # the reference's accessor surface (DETR/modules/layers.py:693-709, lxmert_lrp.py:356-372, BERT_ours.py:266-282)
@@ -99,6 +100,41 @@ class MultiheadAttention(_SlabOwner):
         self.save_attn_gradients(grads.view(B * H, T, S))   # filled by the backward kernel
         o = o.permute(1, 0, 2, 3).reshape(T, B, E)
         return self.out_proj(o)
+
+
+    # ---- shared-forward mode (one forward at batch 1, K upstream gradients): batch-first tensors
+    def forward_shared(self, query, key, value, batch):
+        """``query [1, T, E]``, ``key`` / ``value [1, S, E]``.  Returns ``(out [1, T, E], tape)``; ``get_attn()`` then is
+        the ONE ``[H, T, S]`` slab and ``get_attn_gradients()`` the ``[batch*H, T, S]`` slab ``backward_shared`` fills."""
+        T, S, H, D = query.shape[1], key.shape[1], self.num_heads, self.head_dim
+        q = self.q_proj(query).view(1, T, H, D)
+        k = self.k_proj(key).view(1, S, H, D)
+        v = self.v_proj(value).view(1, S, H, D)
+        dev = query.device
+        if self._probs is None or tuple(self._probs.shape) != (1, H, T, S) or self._probs.device != dev:
+            self._probs = torch.empty(1, H, T, S, dtype=torch.float32, device=dev)
+        if self._grads is None or tuple(self._grads.shape) != (batch, H, T, S) or self._grads.device != dev:
+            self._grads = torch.empty(batch, H, T, S, dtype=torch.float32, device=dev)
+        o = ops.attn_capture_fwd(q, k, v, self._probs, float(D) ** -0.5, _lib.SCALE_Q_FIRST, None, layout="bnhd")
+        self.save_attn(self._probs.view(H, T, S))
+        self.save_attn_gradients(self._grads.view(batch * H, T, S))
+        return self.out_proj(o.reshape(1, T, self.embed_dim)), (q, k, v)
+
+    @torch.no_grad()
+    def backward_shared(self, tape, d_out, need_input_grads=True):
+        """``d_out [K, T, E]`` -> ``(d_query [K, T, E], d_key [K, S, E], d_value [K, S, E])`` (``None`` when not needed);
+        always writes dL/dP of the K samples into the gradient slab."""
+        q, k, v = tape
+        K, T = d_out.shape[0], d_out.shape[1]
+        d_o = torch.matmul(d_out, self.out_proj.weight).view(K, T, self.num_heads, self.head_dim)
+        dq, dk, dv = ops.attn_capture_bwd(q, k, v, self._probs, d_o, self._grads, float(self.head_dim) ** -0.5,
+                                          _lib.SCALE_Q_FIRST, need_dqkv=need_input_grads, layout="bnhd", batch=K)
+        if not need_input_grads:
+            return None, None, None
+        E = self.embed_dim
+        return (torch.matmul(dq.reshape(K, T, E), self.q_proj.weight),
+                torch.matmul(dk.reshape(K, -1, E), self.k_proj.weight),
+                torch.matmul(dv.reshape(K, -1, E), self.v_proj.weight))
 
 
 class BertStyleAttention(_SlabOwner):

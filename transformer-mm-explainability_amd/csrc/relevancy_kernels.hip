@@ -673,6 +673,15 @@ extern "C" int mmx_avg_heads(const void* attn_dev, const void* grad_dev, void* o
     return avg_heads_launch(attn_dev, grad_dev, out_dev, B, H, Nq, Nk, dtype, static_cast<int64_t>(H) * Nq * Nk, stream);
 }
 
+extern "C" int mmx_avg_heads_ex(const void* attn_dev, const void* grad_dev, void* out_dev, int B, int H, int Nq,
+                                int Nk, int dtype, int64_t attn_batch_stride, void* stream) {
+    const int64_t full = static_cast<int64_t>(H) * Nq * Nk;
+    if (attn_batch_stride < 0) attn_batch_stride = full;
+    MMX_CHECK_ARG(attn_batch_stride == 0 || attn_batch_stride == full,
+                  "mmx_avg_heads_ex: attn_batch_stride must be 0 (shared forward) or H*Nq*Nk");
+    return avg_heads_launch(attn_dev, grad_dev, out_dev, B, H, Nq, Nk, dtype, attn_batch_stride, stream);
+}
+
 extern "C" int mmx_bmm_f32(const void* A_dev, const void* B_dev, const void* Cin_dev, void* C_dev, int batch, int M,
                            int N, int K, int trans_a, int64_t stride_a, int64_t stride_b, int64_t stride_c,
                            int nan_to_zero, void* stream) {

@@ -98,7 +98,7 @@ class Generator:
         return aggregated[:, target_index, :].unsqueeze_(0).detach()
 
     def generate_ours_multi(self, img, target_indices, index=None, normalize_self_attention=True,
-                            apply_self_in_rule_10=True):
+                            apply_self_in_rule_10=True, share_forward=True):
         """All kept queries of one image in ONE pass.
 
         Equal to ``torch.cat([generate_ours(img, t, index, use_lrp=False, ...) for t in target_indices], dim=2)`` --
@@ -108,6 +108,12 @@ class Generator:
         the encoder chain is one launch for all K, each decoder block is one rules-6+7 launch, one head-average launch
         and two batched MFMA matmuls; ``handle_residual(R_i_i)`` is hoisted out of the decoder loop (R_i_i does not
         change there).  ``img``: ``[1, C, h, w]`` float features.  Returns ``[1, 1, K, Ni]``.
+
+        ``share_forward`` (default on, used when the body offers ``forward_shared`` / ``backward_shared``, i.e.
+        ``detr_model.DETRFromFeatures``): the K replicas of the image have identical activations and differ only in
+        their upstream gradients, so the forward runs ONCE at batch 1 and the backward -- the same chain of
+        vector-Jacobian products, written out by hand -- runs at batch K; every block then holds ONE probability slab
+        and K gradient slabs, which the rule kernels read with batch stride 0.  Same results to fp32 rounding.
         """
         self.use_lrp = False
         self.normalize_self_attention = normalize_self_attention
@@ -116,15 +122,25 @@ class Generator:
         K = targets.numel()
         if img.shape[0] != 1:
             raise ValueError("generate_ours_multi explains the queries of ONE image (got batch %d)" % img.shape[0])
-        batch = img.expand(K, *img.shape[1:])
-        outputs = rules.forward_for_backward(self.model, lambda: self.model(batch)["pred_logits"])   # [K, Q, C+1]
         rows = torch.arange(K, device=img.device)
-        if index is None:
-            index = outputs[rows, targets, :-1].argmax(dim=-1)
-        one_hot = torch.zeros_like(outputs)
-        one_hot[rows, targets, index] = 1
-        self.model.zero_grad()
-        torch.sum(one_hot * outputs).backward(retain_graph=True)
+        shared = bool(share_forward and K > 1 and hasattr(self.model, "forward_shared"))
+        if shared:
+            with torch.no_grad():
+                logits, state = self.model.forward_shared(img, K)                                     # [1, Q, C+1]
+                if index is None:
+                    index = logits[0, targets, :-1].argmax(dim=-1)
+                one_hot = torch.zeros(K, *logits.shape[1:], dtype=logits.dtype, device=img.device)
+                one_hot[rows, targets, index] = 1
+                self.model.backward_shared(state, one_hot)
+        else:
+            batch = img.expand(K, *img.shape[1:])
+            outputs = rules.forward_for_backward(self.model, lambda: self.model(batch)["pred_logits"])   # [K, Q, C+1]
+            if index is None:
+                index = outputs[rows, targets, :-1].argmax(dim=-1)
+            one_hot = torch.zeros_like(outputs)
+            one_hot[rows, targets, index] = 1
+            self.model.zero_grad()
+            torch.sum(one_hot * outputs).backward(retain_graph=True)
 
         decoder_blocks = self.model.transformer.decoder.layers
         encoder_blocks = self.model.transformer.encoder.layers
@@ -133,7 +149,7 @@ class Generator:
             return mod.get_attn().detach(), mod.get_attn_gradients().detach()
 
         enc = [pair(blk.self_attn) for blk in encoder_blocks]
-        self.R_i_i = ops.relevancy_self_chain([a for a, _ in enc], [g for _, g in enc], K)           # [K, Ni, Ni]
+        self.R_i_i = ops.relevancy_self_chain([a for a, _ in enc], [g for _, g in enc], K, shared_attn=shared)   # [K, Ni, Ni]
         n_img = self.R_i_i.shape[-1]
         n_q = decoder_blocks[0].self_attn.get_attn().shape[-1]
         self.R_q_q = torch.eye(n_q, device=img.device).repeat(K, 1, 1)
@@ -144,8 +160,9 @@ class Generator:
             R_ii_hat = ops.handle_residual(self.R_i_i)
         for blk in decoder_blocks:
             a, g = pair(blk.self_attn)
-            self.R_q_q, self.R_q_i = ops.relevancy_self_chain([a], [g], K, R_init=self.R_q_q, R_sq_init=self.R_q_i)
-            cam = ops.avg_heads(*pair(blk.multihead_attn), batch_size=K)                             # [K, Q, Ni]
+            self.R_q_q, self.R_q_i = ops.relevancy_self_chain([a], [g], K, R_init=self.R_q_q, R_sq_init=self.R_q_i,
+                                                              shared_attn=shared)
+            cam = ops.avg_heads(*pair(blk.multihead_attn), batch_size=K, shared_attn=shared)         # [K, Q, Ni]
             if not use_self:                                   # ablation: the addition is the cross-attention map
                 self.R_q_i = self.R_q_i + cam
                 continue

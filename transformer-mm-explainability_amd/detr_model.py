@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .attention_modules import MultiheadAttention
 
 
@@ -36,11 +37,34 @@ def _activation(name):
         raise RuntimeError(f"activation should be relu/gelu/glu, not {name}") from None
 
 
+def _ln_fwd(ln, x):
+    """LayerNorm forward that keeps what the hand-written backward needs: ``(y, (x, mean, rstd))``."""
+    y, mean, rstd = torch.native_layer_norm(x, (x.shape[-1],), ln.weight, ln.bias, ln.eps)
+    return y, (x, mean, rstd)
+
+
+def _ln_bwd(ln, saved, dy, d_res=None):
+    """``LN'(dy) [+ d_res]`` for K upstream gradients against ONE forward's statistics (``ops.layernorm_bwd_add``)."""
+    x, mean, rstd = saved
+    return ops.layernorm_bwd_add(dy, x, mean, rstd, ln.weight, d_res)
+
+
 class _FeedForward:
     """linear1 -> activation -> linear2 shared by both layer kinds (mixin; the Linear modules live on the layer)."""
 
     def _ffn(self, x):
         return self.linear2(self.activation(self.linear1(x)))
+
+    def _ffn_fwd_shared(self, x):
+        if self.activation is not F.relu:
+            raise NotImplementedError("the shared-forward backward is written for DETR's ReLU feed-forward")
+        h = self.linear1(x)
+        return self.linear2(F.relu(h)), h
+
+    def _ffn_bwd_shared(self, h, d_out):
+        """``d_out [K, T, E]`` -> gradient w.r.t. the feed-forward input; ``h [1, T, F]`` is the shared pre-activation."""
+        d_h = torch.matmul(d_out, self.linear2.weight) * (h > 0)
+        return torch.matmul(d_h, self.linear1.weight)
 
 
 class TransformerEncoderLayer(nn.Module, _FeedForward):
@@ -64,6 +88,24 @@ class TransformerEncoderLayer(nn.Module, _FeedForward):
         src = self.norm1(src + self.self_attn(qk, qk, src, attn_mask=src_mask,
                                               key_padding_mask=src_key_padding_mask))
         return self.norm2(src + self._ffn(src))
+
+    # ---- shared-forward mode (post-norm): tensors are batch-first, ``[1, N, E]`` forward / ``[K, N, E]`` backward
+    def forward_shared(self, src, pos, batch):
+        if self.normalize_before:
+            raise NotImplementedError("shared-forward mode covers the post-norm layers DETR ships")
+        qk = _with_pos(src, pos)
+        a, att = self.self_attn.forward_shared(qk, qk, src, batch)
+        src1, ln1 = _ln_fwd(self.norm1, src + a)
+        ff, h = self._ffn_fwd_shared(src1)
+        out, ln2 = _ln_fwd(self.norm2, src1 + ff)
+        return out, (att, ln1, h, ln2)
+
+    def backward_shared(self, tape, d_out, need_input_grad=True):
+        att, ln1, h, ln2 = tape
+        d_z2 = _ln_bwd(self.norm2, ln2, d_out)                           # w.r.t. src1 + ff
+        d_z1 = _ln_bwd(self.norm1, ln1, d_z2 + self._ffn_bwd_shared(h, d_z2))   # w.r.t. src + attention output
+        dq, dk, dv = self.self_attn.backward_shared(att, d_z1, need_input_grad)
+        return d_z1 + dq + dk + dv if need_input_grad else None          # pos is a constant: q, k and v all lead to src
 
 
 class TransformerDecoderLayer(nn.Module, _FeedForward):
@@ -96,6 +138,30 @@ class TransformerDecoderLayer(nn.Module, _FeedForward):
                                                    attn_mask=memory_mask,
                                                    key_padding_mask=memory_key_padding_mask))
         return self.norm3(tgt + self._ffn(tgt))
+
+
+    # ---- shared-forward mode (post-norm), batch-first tensors
+    def forward_shared(self, tgt, memory, pos, query_pos, batch):
+        if self.normalize_before:
+            raise NotImplementedError("shared-forward mode covers the post-norm layers DETR ships")
+        qk = _with_pos(tgt, query_pos)
+        a, t_self = self.self_attn.forward_shared(qk, qk, tgt, batch)
+        tgt1, ln1 = _ln_fwd(self.norm1, tgt + a)
+        c, t_cross = self.multihead_attn.forward_shared(_with_pos(tgt1, query_pos), _with_pos(memory, pos), memory, batch)
+        tgt2, ln2 = _ln_fwd(self.norm2, tgt1 + c)
+        ff, h = self._ffn_fwd_shared(tgt2)
+        out, ln3 = _ln_fwd(self.norm3, tgt2 + ff)
+        return out, (t_self, ln1, t_cross, ln2, h, ln3)
+
+    def backward_shared(self, tape, d_out, need_tgt_grad=True):
+        """``d_out [K, Q, E]`` -> ``(d_tgt [K, Q, E] | None, d_memory [K, N, E])``."""
+        t_self, ln1, t_cross, ln2, h, ln3 = tape
+        d_z3 = _ln_bwd(self.norm3, ln3, d_out)                             # w.r.t. tgt2 + ff
+        d_z2 = _ln_bwd(self.norm2, ln2, d_z3 + self._ffn_bwd_shared(h, d_z3))   # w.r.t. tgt1 + cross-attention output
+        dq, dk, dv = self.multihead_attn.backward_shared(t_cross, d_z2)
+        d_z1 = _ln_bwd(self.norm1, ln1, d_z2 + dq)                         # w.r.t. tgt + self-attention output
+        sq, sk, sv = self.self_attn.backward_shared(t_self, d_z1, need_tgt_grad)
+        return (d_z1 + sq + sk + sv if need_tgt_grad else None), dk + dv
 
 
 class TransformerEncoder(nn.Module):
@@ -160,6 +226,40 @@ class Transformer(nn.Module):
         hs = self.decoder(torch.zeros_like(query_pos), memory, memory_key_padding_mask=key_padding, pos=pos,
                           query_pos=query_pos)
         return hs.transpose(1, 2), memory.permute(1, 2, 0).reshape(bs, c, h, w)
+
+
+    # ---- shared-forward mode: ONE forward at batch 1, the backward at batch K (K upstream gradients)
+    def forward_shared(self, src, query_embed, pos_embed, batch):
+        """``src [1, C, h, w]`` -> ``(hs_last [1, Q, C], tape)``: the last decoder level through the shared decoder norm
+        (what ``pred_logits`` reads).  Every attention block keeps ONE probability slab and a ``batch``-sized gradient slab."""
+        tokens = src.flatten(2).transpose(1, 2)                         # [1, hw, C], batch-first
+        pos = pos_embed.flatten(2).transpose(1, 2)
+        query_pos = query_embed.unsqueeze(0)
+        enc_tapes, dec_tapes = [], []
+        memory = tokens
+        for layer in self.encoder.layers:
+            memory, t = layer.forward_shared(memory, pos, batch)
+            enc_tapes.append(t)
+        if self.encoder.norm is not None:
+            raise NotImplementedError("shared-forward mode covers the post-norm encoder (no final encoder norm)")
+        out = torch.zeros_like(query_pos)
+        for layer in self.decoder.layers:
+            out, t = layer.forward_shared(out, memory, pos, query_pos, batch)
+            dec_tapes.append(t)
+        hs, ln = _ln_fwd(self.decoder.norm, out)
+        return hs, (enc_tapes, dec_tapes, ln)
+
+    @torch.no_grad()
+    def backward_shared(self, tape, d_hs):
+        """``d_hs [K, Q, C]``: per-sample upstream gradients of ``hs_last``; fills every block's gradient slab."""
+        enc_tapes, dec_tapes, ln = tape
+        d_out = _ln_bwd(self.decoder.norm, ln, d_hs)
+        d_memory = None
+        for i in range(len(self.decoder.layers) - 1, -1, -1):
+            d_out, d_mem = self.decoder.layers[i].backward_shared(dec_tapes[i], d_out, need_tgt_grad=i > 0)
+            d_memory = d_mem if d_memory is None else d_memory + d_mem
+        for i in range(len(self.encoder.layers) - 1, -1, -1):         # the first layer's input is a constant of the pass
+            d_memory = self.encoder.layers[i].backward_shared(enc_tapes[i], d_memory, need_input_grad=i > 0)
 
 
 class PositionEmbeddingSine(nn.Module):
@@ -231,6 +331,25 @@ class DETRFromFeatures(nn.Module):
         hs, memory = self.transformer(proj.permute(0, 3, 1, 2), mask, self.query_embed.weight, self.position(mask))
         self.memory_shape = memory.shape
         return {"pred_logits": self.class_embed(hs[-1]), "pred_boxes": self.bbox_embed(hs[-1]).sigmoid()}
+
+
+    def forward_shared(self, features, batch, mask=None):
+        """Shared-forward mode for ``Generator.generate_ours_multi``: ``features [1, C, h, w]`` ->
+        ``(pred_logits [1, Q, classes+1], state)``; see ``Transformer.forward_shared``."""
+        if features.shape[0] != 1:
+            raise ValueError("forward_shared takes the single shared image")
+        if mask is None:
+            mask = torch.zeros(1, *features.shape[-2:], dtype=torch.bool, device=features.device)
+        self.spatial_dim = features.shape[-2:]
+        proj = F.linear(features.permute(0, 2, 3, 1), self.input_proj.weight.flatten(1), self.input_proj.bias)
+        hs, tape = self.transformer.forward_shared(proj.permute(0, 3, 1, 2), self.query_embed.weight,
+                                                   self.position(mask), batch)
+        return self.class_embed(hs), tape
+
+    @torch.no_grad()
+    def backward_shared(self, state, d_logits):
+        """``d_logits [K, Q, classes+1]``: one upstream gradient of ``pred_logits`` per explained target."""
+        self.transformer.backward_shared(state, torch.matmul(d_logits, self.class_embed.weight))
 
 
 def detr_resnet50_head(num_classes=91, num_queries=100):

@@ -63,19 +63,21 @@ def _workspace(nbytes, device, tag="default"):
 
 
 # ------------------------------------------------------------------------------------------- rule 5
-def avg_heads(cam, grad, batch_size=1):
-    """``mean_h(clamp(grad*cam, 0))`` -> ``[batch_size, Nq, Nk]`` fp32 (leading dims flattened into B*H)."""
+def avg_heads(cam, grad, batch_size=1, shared_attn=False):
+    """``mean_h(clamp(grad*cam, 0))`` -> ``[batch_size, Nq, Nk]`` fp32 (leading dims flattened into B*H).
+    ``shared_attn=True``: ``cam`` holds ONE sample's heads, shared by the ``batch_size`` samples of ``grad``."""
     _dev(cam, grad)
     cam, grad = _capture(cam), _capture(grad)
-    if cam.shape != grad.shape or cam.dtype != grad.dtype:
+    nq, nk = grad.shape[-2], grad.shape[-1]
+    bh = grad.numel() // (nq * nk)
+    ok = cam.numel() * batch_size == grad.numel() if shared_attn else cam.shape == grad.shape
+    if not ok or cam.shape[-2:] != grad.shape[-2:] or cam.dtype != grad.dtype:
         raise MMXError("avg_heads: cam %s/%s vs grad %s/%s" % (tuple(cam.shape), cam.dtype, tuple(grad.shape), grad.dtype))
-    nq, nk = cam.shape[-2], cam.shape[-1]
-    bh = cam.numel() // (nq * nk)
     if bh % batch_size:
         raise MMXError("avg_heads: %d matrices not divisible by batch %d" % (bh, batch_size))
     out = torch.empty(batch_size, nq, nk, dtype=torch.float32, device=cam.device)
-    check(lib().mmx_avg_heads(_p(cam), _p(grad), _p(out), batch_size, bh // batch_size, nq, nk,
-                              _DTYPES[cam.dtype], _stream()), "mmx_avg_heads")
+    check(lib().mmx_avg_heads_ex(_p(cam), _p(grad), _p(out), batch_size, bh // batch_size, nq, nk, _DTYPES[cam.dtype],
+                                 0 if shared_attn else -1, _stream()), "mmx_avg_heads_ex")
     return out
 
 
