@@ -143,3 +143,41 @@ def test_graphed_interpret_matches_eager(golden, trim):
     got_t, got_i = run(image2, texts2)
     close(got_t, want_t.cpu().numpy(), atol=2e-6)
     close(got_i, want_i.cpu().numpy(), atol=2e-6)
+
+
+def test_full_size_batch_properties():
+    """BASELINE.json's measured configuration (ViT-B/32, batch 64, all layers) through size-independent properties:
+    every sample of the full batch equals the same sample explained in a batch of 2 (samples are independent), the text
+    relevancy is causal (lower triangular), >= identity on the diagonal and exactly the identity beyond the prompt's
+    EOT token, image relevancies are non-negative, and the hipGraph replay returns the eager values."""
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    from transformer_mm_explainability_amd import clip_model
+    model = clip_model.random_init("ViT-B/32", seed=0).cuda()
+    g = torch.Generator().manual_seed(1)                                 # bench.py's synthetic workload
+    image = torch.randn(1, 3, 224, 224, generator=g).cuda()
+    texts = torch.zeros(64, 77, dtype=torch.long)
+    g2 = torch.Generator().manual_seed(2)
+    for b in range(64):
+        n = int(torch.randint(3, 11, (1,), generator=g2))
+        texts[b, 0] = 49406
+        texts[b, 1:1 + n] = torch.randint(1, 49405, (n,), generator=g2)
+        texts[b, 1 + n] = 49407
+    texts = texts.cuda()
+    R_text, R_image = (t.clone() for t in ce.interpret(image, texts, model, "cuda", 0, 0))
+    assert R_text.shape == (64, 77, 77) and R_image.shape == (64, 49)
+    assert torch.isfinite(R_text).all() and torch.isfinite(R_image).all() and (R_image >= 0).all()
+    for pick in ([0, 1], [37, 63]):
+        sub_text, sub_image = ce.interpret(image, texts[pick], model, "cuda", 0, 0)
+        torch.testing.assert_close(sub_text, R_text[pick], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(sub_image, R_image[pick], rtol=1e-4, atol=1e-5)
+    assert (R_text.triu(1) == 0).all()                                   # causal attention: no relevancy from the future
+    assert (R_text.diagonal(dim1=1, dim2=2) >= 1).all()
+    eot = texts.argmax(dim=-1)
+    eye = torch.eye(77, device="cuda")
+    for b in (0, 5, 63):
+        n = int(eot[b]) + 1
+        assert torch.equal(R_text[b, n:, :], eye[n:, :])                 # padding rows: zero gradient -> identity
+    run = ce.GraphedInterpret(model, image, texts, start_layer=0, start_layer_text=0)
+    g_text, g_image = run()
+    torch.testing.assert_close(g_text, R_text, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(g_image, R_image, rtol=1e-5, atol=1e-6)
