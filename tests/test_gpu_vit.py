@@ -66,3 +66,18 @@ def test_generate_relevance_and_batched_targets(img, patch, dim, depth, heads):
     close(run(x2, [0, 5]), eager.cpu().numpy(), atol=1e-6)
     top = vit_model.GraphedRelevance(model, xc, top_k=1)
     close(top()[0], want[None])
+
+
+def test_vit_b16_full_size_properties():
+    """BASELINE.json config 1's architecture (ViT-B/16: 12 layers x 12 heads x 197 tokens) at full size: the K-target
+    pass (shared forward, streaming attention kernels, split chain path with a shared probability slab) equals K
+    single-target notebook passes; maps are finite and non-negative."""
+    from transformer_mm_explainability_amd import vit_explainability as ve
+    from transformer_mm_explainability_amd import vit_model
+    model = build(224, 16, 768, 12, 12, classes=1000).cuda()
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(3)).cuda()
+    targets = [5, 980, 417]
+    multi = vit_model.generate_relevance_multi(model, x, targets).clone()
+    assert multi.shape == (3, 196) and torch.isfinite(multi).all() and (multi >= 0).all()
+    for k, t in enumerate(targets):
+        close(multi[k], ve.generate_relevance(model, x, index=t), atol=1e-6, rtol=1e-4)
