@@ -175,3 +175,22 @@ def test_visualbert_perturbation_equals_sequential(positive):
             sl["segment_ids"] = sl["segment_ids"][:, :sl["input_ids"].shape[1]]
             torch.testing.assert_close(got_txt[s], model(sl)["scores"][0], rtol=1e-4, atol=1e-5)
     assert torch.isfinite(got_img).all() and not torch.allclose(got_img[0], got_img[-1], atol=1e-3)
+
+
+def test_visualbert_generate_ours_batch_equals_per_item():
+    from transformer_mm_explainability_amd import visualbert_explainability as vb
+    model, sample, n_text, V, g = _visualbert_and_sample()
+    B, T = 4, 16
+    ids = torch.randint(1, 300, (B, T), generator=g)
+    ids[:, n_text:] = 0
+    mask = torch.zeros(B, T, dtype=torch.long)
+    mask[:, :n_text] = 1
+    feats = torch.randn(B, V, 40, generator=g)
+    batch = {"input_ids": ids.cuda(), "input_mask": mask.cuda(), "segment_ids": torch.zeros(B, T, dtype=torch.long).cuda(),
+             "image_feature_0": feats.cuda()}
+    got = vb.SelfAttentionGenerator(model).generate_ours_batch(batch)
+    assert got.shape == (B, n_text + V)
+    for b in range(B):
+        one = {k: v[b:b + 1].clone() for k, v in batch.items()}
+        want = vb.SelfAttentionGenerator(model).generate_ours(one)
+        torch.testing.assert_close(got[b:b + 1], want, rtol=1e-4, atol=1e-6)

@@ -47,6 +47,39 @@ class SelfAttentionGenerator:
         cls_per_token_score[:, cls_index] = 0
         return cls_per_token_score
 
+    def generate_ours_batch(self, input, index=None):
+        """B items with the same number of real text tokens in ONE forward + ONE backward + ONE chain launch.
+
+        ``input``: the ``sample_list`` dict with batch-first tensors of B items whose ``input_mask`` rows have equal sums
+        (the wrapper trims the text padding by that length, ``visual_bert.py:578-588``).  Samples are independent, so B
+        one-hot seeds in one backward leave the per-sample gradients in the slabs and the chain kernel runs one
+        (sample, layer group) per workgroup.  Returns ``[B, N]``: row ``b`` equals ``generate_ours`` of item ``b``.
+        """
+        mask = input["input_mask"]
+        lengths = mask.sum(1)
+        if int((lengths != lengths[0]).sum()) != 0:
+            raise ValueError("generate_ours_batch needs items of equal text length (bucket them: sharding.length_buckets)")
+        n_text = int(lengths[0])
+        B = mask.shape[0]
+        model = self.model.model                                     # VisualBERTForClassification
+        ids, seg = input["input_ids"][:, :n_text], input["segment_ids"][:, :n_text]
+        feats = input["image_feature_0"]
+        text_mask = torch.ones(B, n_text, dtype=torch.long, device=ids.device)
+        visual_mask = torch.ones(B, feats.shape[1], dtype=torch.long, device=ids.device)
+        output = rules.forward_for_backward(self.model, lambda: model(
+            ids, text_mask, torch.cat((text_mask, visual_mask), dim=-1), seg, feats, torch.zeros_like(visual_mask))["scores"])
+        idx = output.argmax(dim=-1) if index is None else torch.as_tensor(index, device=output.device).reshape(-1)
+        one_hot = torch.zeros_like(output).scatter_(1, idx.reshape(-1, 1), 1.0)
+        self.model.zero_grad()
+        torch.sum(one_hot * output).backward(retain_graph=True)
+        blocks = self._blocks()
+        R = ops.relevancy_self_chain([blk.attention.self.get_attn() for blk in blocks],
+                                     [blk.attention.self.get_attn_gradients() for blk in blocks], B)          # [B, N, N]
+        cls_index = n_text - 2
+        scores = R[:, cls_index, :].clone()
+        scores[:, cls_index] = 0
+        return scores
+
     def generate_rollout(self, input, start_layer=0, save_visualization=False):
         """Reference :158-174: head-mean maps (``sum/H``), batched rollout WITHOUT row normalisation."""
         self.model(input)
