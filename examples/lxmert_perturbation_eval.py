@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--max-batch", type=int, default=32)
     ap.add_argument("--text", action="store_true", help="text perturbation test instead of the image one")
     ap.add_argument("--positive", action="store_true")
+    ap.add_argument("--resume-dir", default=None, help="per-rank partial score files; finished samples are skipped on restart")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
@@ -55,10 +56,12 @@ def main():
     model = lm.LxmertForQuestionAnswering(cfg).to(dev).eval()
     indices = sharding.perturbation_sample_indices(args.dataset_len, args.num_samples)      # same list on every rank
     mine = sharding.shard_indices(indices)
-    items = [synthetic_item(k, 36, cfg.visual_feat_dim, cfg.vocab_size, cfg.num_qa_labels) for k in mine]
+    store = sharding.PartialScores(args.resume_dir, rank) if args.resume_dir else None
+    todo = [k for k in mine if store is None or k not in store.done()]
+    items = [synthetic_item(k, 36, cfg.visual_feat_dim, cfg.vocab_size, cfg.num_qa_labels) for k in todo]
     gen = le.GeneratorOurs(type("Usage", (), {"model": model})())
     pert = lp.LxmertPerturbation(model)
-    local = torch.zeros(len(mine), len(lp.PERT_STEPS), device=dev)
+    fresh = torch.zeros(len(todo), len(lp.PERT_STEPS), device=dev)
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -73,13 +76,20 @@ def main():
         scores = pert.perturbation_text(batch, cam_text, args.positive) if args.text else \
             pert.perturbation_image(batch, cam_image, args.positive)
         labels = torch.stack([items[p]["label"] for p in positions]).to(dev)
-        local[torch.tensor(positions, device=dev)] = lp.LxmertPerturbation.accuracy(scores, labels)
+        acc_rows = lp.LxmertPerturbation.accuracy(scores, labels)
+        fresh[torch.tensor(positions, device=dev)] = acc_rows
+        if store is not None:
+            store.add([todo[p] for p in positions], acc_rows)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if store is not None:
+        local = store.table(mine, device=dev)            # resumed rows + the ones computed now, in shard order
+    else:
+        local = fresh
     per_sample = sharding.gather_per_sample(local, len(indices))                             # the one exchange step
     acc = sharding.mean_step_accuracy(per_sample)
     if rank == 0:

@@ -86,3 +86,21 @@ def test_normalize_cams_batch_matches_per_item():
     for b in range(3):
         one_i, one_t = lp.normalize_cams(R_t_t[b], R_t_i[b])
         assert torch.allclose(ci[b], one_i) and torch.allclose(ct[b], one_t)
+
+
+def test_partial_scores_resume(tmp_path):
+    """Evaluator resume: rows survive a restart, a torn last line is ignored, table() follows the requested order."""
+    from transformer_mm_explainability_amd import sharding
+    store = sharding.PartialScores(str(tmp_path), rank=3)
+    store.add([11, 4], torch.tensor([[1.0, 0.5], [0.0, 0.25]]))
+    store.add([7], torch.tensor([[0.75, 0.125]]))
+    store.close()
+    with open(store.path, "a") as f:
+        f.write('{"ids": [99], "rows": [[0.')                       # killed mid-write
+    again = sharding.PartialScores(str(tmp_path), rank=3)
+    assert again.done() == {11, 4, 7}
+    assert again.table([7, 11, 4]).tolist() == [[0.75, 0.125], [1.0, 0.5], [0.0, 0.25]]
+    again.add([99], torch.tensor([[1.0, 1.0]]))
+    again.close()
+    assert sharding.PartialScores(str(tmp_path), rank=3).done() == {11, 4, 7, 99}
+    assert sharding.PartialScores(str(tmp_path), rank=0).done() == set()

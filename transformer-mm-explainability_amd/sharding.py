@@ -10,6 +10,8 @@ items, single process), ``VisualBERT/mmf/trainers/core/evaluation_loop.py:104-16
 """
 from __future__ import annotations
 
+import json
+import os
 import random
 
 import torch
@@ -79,3 +81,53 @@ def mean_step_accuracy(per_sample_scores):
     """``[total, n_steps]`` per-sample scores -> the evaluators' printed metric: mean over samples x 100
     (perturbation.py:250-251).  NaN padding rows are never present after ``gather_per_sample``."""
     return per_sample_scores.double().mean(dim=0) * 100.0
+
+
+class PartialScores:
+    """Append-only per-rank store of per-sample result rows, so that a killed evaluator resumes where it stopped.
+
+    The reference evaluators keep their running accuracies in Python lists (``perturbation.py:43``,
+    ``evaluation_loop.py:97``): a crash at sample 9 000 of 10 000 loses everything.  Here every finished batch is
+    appended as one JSON line ``{"ids": [...], "rows": [[...], ...]}`` to ``<directory>/scores_rank<r>.jsonl`` (flushed
+    and fsynced); on restart ``done()`` tells which sample ids can be skipped and ``table()`` returns the rows in the
+    order the gather expects.  A torn last line (killed mid-write) is ignored.
+    """
+
+    def __init__(self, directory, rank):
+        os.makedirs(directory, exist_ok=True)
+        self.path = os.path.join(directory, "scores_rank%d.jsonl" % rank)
+        self.rows = {}
+        if os.path.exists(self.path):
+            with open(self.path) as f:
+                for line in f:
+                    try:
+                        rec = json.loads(line)
+                    except ValueError:
+                        continue                      # torn tail of an interrupted write
+                    for k, row in zip(rec["ids"], rec["rows"]):
+                        self.rows[int(k)] = row
+        torn = os.path.exists(self.path) and os.path.getsize(self.path) > 0 and \
+            open(self.path, "rb").read()[-1:] != b"\n"
+        self._f = open(self.path, "a")
+        if torn:
+            self._f.write("\n")                  # finish the torn line so the next record starts on its own line
+
+    def done(self):
+        return set(self.rows)
+
+    def add(self, sample_ids, rows):
+        """``sample_ids``: iterable of ints; ``rows``: ``[len(ids), n_cols]`` tensor (moved to the host here)."""
+        ids = [int(k) for k in sample_ids]
+        data = rows.detach().cpu().tolist()
+        for k, row in zip(ids, data):
+            self.rows[k] = row
+        self._f.write(json.dumps({"ids": ids, "rows": data}) + "\n")
+        self._f.flush()
+        os.fsync(self._f.fileno())
+
+    def table(self, sample_ids, device="cpu"):
+        """Rows of ``sample_ids`` in that order (every id must be done) -> ``[len(ids), n_cols]`` fp32 tensor."""
+        return torch.tensor([self.rows[int(k)] for k in sample_ids], dtype=torch.float32, device=device)
+
+    def close(self):
+        self._f.close()
