@@ -226,6 +226,34 @@ int mmx_attn_capture_bwd(const void* q_dev, const void* k_dev, const void* v_dev
                          int B, int H, int Nq, int Nk, int D, float scale, int scale_mode,
                          int need_dqkv, void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* The same two entry points with an element type for the capture slabs (`probs`, `dprobs`): MMX_F32, MMX_F16 or
+ * MMX_BF16 (the GPU notebooks of the reference run the models in fp16; BASELINE config 5 asks for bf16 capture).
+ * P and dL/dP are rounded to nearest even when they are stored; the forward's O is computed from the unrounded P,
+ * the backward reads the stored (rounded) P.  q/k/v/O and their gradients stay fp32.  Half-precision slabs are written
+ * by the long-sequence streaming kernels only: head_dim % 4 == 0 and 16-byte aligned q/k/v views, else MMX_ENOTSUP.
+ * The rule kernels (mmx_avg_heads*, mmx_relevancy_self_chain*) read all three slab types and accumulate in fp32. */
+int mmx_attn_capture_fwd_ex(const void* q_dev, const void* k_dev, const void* v_dev,
+                            int64_t q_sb, int64_t q_sh, int64_t q_sn,
+                            int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                            int64_t v_sb, int64_t v_sh, int64_t v_sn,
+                            const void* mask_dev, int64_t mask_sb, int64_t mask_sq,
+                            void* probs_dev, int slab_dtype,
+                            void* o_dev, int64_t o_sb, int64_t o_sh, int64_t o_sn,
+                            int B, int H, int Nq, int Nk, int D, float scale, int scale_mode, void* stream);
+int mmx_attn_capture_bwd_ex(const void* q_dev, const void* k_dev, const void* v_dev,
+                            int64_t q_sb, int64_t q_sh, int64_t q_sn,
+                            int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                            int64_t v_sb, int64_t v_sh, int64_t v_sn,
+                            const void* probs_dev, int64_t probs_sb, int slab_dtype,
+                            const void* do_dev, int64_t o_sb, int64_t o_sh, int64_t o_sn,
+                            void* dprobs_dev,
+                            void* dq_dev, void* dk_dev, void* dv_dev,
+                            int64_t dq_sb, int64_t dq_sh, int64_t dq_sn,
+                            int64_t dk_sb, int64_t dk_sh, int64_t dk_sn,
+                            int64_t dv_sb, int64_t dv_sh, int64_t dv_sn,
+                            int B, int H, int Nq, int Nk, int D, float scale, int scale_mode,
+                            int need_dqkv, void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused QuickGELU of the CLIP body's MLP, y = x * sigmoid(1.702 x) (CLIP/clip/model.py:162-164): one HBM pass forward,
  * one backward (dx from x and dy; nothing saved but x) instead of PyTorch's 3 + 5 elementwise kernels.

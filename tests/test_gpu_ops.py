@@ -312,3 +312,37 @@ def test_unsupported_shapes_fail_loudly(ops):
         ops.lxmert_schedule(big, big[:0], cross, [], big, [])          # T = 60 > 48: the one-launch schedule is LDS-sized
     with pytest.raises(MMXError, match="inner dims"):
         ops.matmul(torch.rand(4, 5, device="cuda"), torch.rand(4, 4, device="cuda"))
+
+
+@pytest.mark.parametrize("dtype,rel", [(torch.bfloat16, 2 ** -8), (torch.float16, 2 ** -11)])
+@pytest.mark.parametrize("B,H,Nq,Nk,D,masked", [(2, 4, 130, 130, 64, True), (1, 3, 70, 200, 32, False)])
+def test_attn_capture_half_precision_slabs(ops, dtype, rel, B, H, Nq, Nk, D, masked):
+    """fp16 / bf16 capture slabs (streaming kernels): P and dP equal the fp32 results rounded to the slab type; O comes
+    from the unrounded P; dq/dk/dv are the exact gradients for the ROUNDED P (what the backward reads)."""
+    g = torch.Generator().manual_seed(Nq + Nk)
+    q, k, v, d_o = (torch.randn(B, n, H, D, generator=g).cuda() for n in (Nq, Nk, Nk, Nq))
+    mask = torch.full((Nq, Nk), float("-inf")).triu_(1).cuda() if masked else None
+    scale = D ** -0.5
+    p32 = torch.empty(B, H, Nq, Nk, device="cuda")
+    dp32 = torch.empty_like(p32)
+    ops.set_option("attn_small", 0)                                      # fp32 reference on the same (streaming) kernels
+    o32 = ops.attn_capture_fwd(q, k, v, p32, scale, 0, mask)
+    ops.attn_capture_bwd(q, k, v, p32, d_o, dp32, scale, 0)
+    ops.set_option("attn_small", 1)
+    p16 = torch.empty(B, H, Nq, Nk, device="cuda", dtype=dtype)
+    dp16 = torch.empty_like(p16)
+    o16 = ops.attn_capture_fwd(q, k, v, p16, scale, 0, mask)
+    dq, dk, dv = ops.attn_capture_bwd(q, k, v, p16, d_o, dp16, scale, 0)
+    assert torch.equal(o16, o32) or (o16 - o32).abs().max() < 1e-6
+    assert torch.equal(p16, p32.to(dtype))                               # same values, rounded to nearest even once
+    torch.testing.assert_close(dp16.float(), dp32, rtol=2 * rel, atol=1e-6)
+    # reference gradients for the rounded P: dS = P16 * (dP - rowsum(P16 * dP)), dQ = dS K scale, dK = dS^T Q scale, dV = P16^T dO
+    P = p16.double()
+    dP = torch.einsum("bqhd,bkhd->bhqk", d_o.double(), v.double())
+    dS = P * (dP - (P * dP).sum(-1, keepdim=True))
+    torch.testing.assert_close(dq.double(), torch.einsum("bhqk,bkhd->bqhd", dS, k.double()) * scale, rtol=1e-3, atol=5 * rel)
+    torch.testing.assert_close(dv.double(), torch.einsum("bhqk,bqhd->bkhd", P, d_o.double()), rtol=1e-3, atol=1e-4)
+    # the rule kernels read the half-precision slabs directly
+    abar = ops.avg_heads(p16.view(B * H, Nq, Nk), dp16.view(B * H, Nq, Nk), batch_size=B)
+    want = (p16.float() * dp16.float()).clamp(min=0).view(B, H, Nq, Nk).mean(1)
+    torch.testing.assert_close(abar, want, rtol=1e-5, atol=1e-7)

@@ -81,3 +81,19 @@ def test_vit_b16_full_size_properties():
     assert multi.shape == (3, 196) and torch.isfinite(multi).all() and (multi >= 0).all()
     for k, t in enumerate(targets):
         close(multi[k], ve.generate_relevance(model, x, index=t), atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_vit_half_precision_capture_slabs(dtype):
+    """``capture_dtype``: P and dP stored in bf16 / fp16 (N = 197: streaming kernels), rules accumulate in fp32; the maps
+    stay within the slab precision of the fp32-slab result."""
+    from transformer_mm_explainability_amd import vit_model
+    model = build(224, 16, 192, 3, 3, classes=11).cuda()
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(5)).cuda()
+    want = vit_model.generate_relevance_multi(model, x, [2, 9]).clone()
+    model.capture_dtype = dtype
+    got = vit_model.generate_relevance_multi(model, x, [2, 9])
+    assert model.buffers_.probs.dtype == dtype and model.buffers_.grads.dtype == dtype
+    rel = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+    assert (got - want).abs().max() <= rel * want.abs().max() + 1e-9
+    model.capture_dtype = torch.float32

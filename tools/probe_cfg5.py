@@ -31,7 +31,11 @@ a = ce.interpret(image, texts, model, dev, start_layer=0, start_layer_text=0, sh
 b = ce.interpret(image, texts, model, dev, start_layer=0, start_layer_text=0, share_image_forward=False)
 print("shared vs replicated image tower, B=2: max |dR_image| = %.3e (max |R| = %.3e), max |dR_text| = %.3e"
       % ((a[1] - b[1]).abs().max().item(), b[1].abs().max().item(), (a[0] - b[0]).abs().max().item()))
-for B in (16, 64, 128):
+import sys as _sys  # noqa: E402
+if len(_sys.argv) > 1 and _sys.argv[1] == "bf16":
+    model.visual.transformer.capture_dtype = torch.bfloat16      # image tower slabs in bf16 (config 5's "bf16 capture")
+    print("image-tower capture slabs: bf16")
+for B in ((128,) if len(_sys.argv) > 1 else (16, 64, 128)):
     texts = prompts(B)
     torch.cuda.reset_peak_memory_stats()
     for _ in range(2):

@@ -18,17 +18,18 @@ from . import _lib, ops
 
 
 class CaptureBuffers:
-    """Two ``[L, B, H, Nq, Nk]`` fp32 slabs (probabilities and their gradients) for one tower."""
+    """Two ``[L, B, H, Nq, Nk]`` slabs (probabilities and their gradients) for one tower; fp32, or fp16 / bf16 for the
+    long-sequence towers (half the resident bytes and half the rule kernels' traffic; the rules accumulate in fp32)."""
 
-    def __init__(self, n_layers, batch, heads, n_q, n_k=None, device="cuda", shared_probs=False):
+    def __init__(self, n_layers, batch, heads, n_q, n_k=None, device="cuda", shared_probs=False, dtype=torch.float32):
         """``shared_probs``: the probabilities come from ONE forward pass shared by the whole batch (``probs`` has batch
         1, ``grads`` has batch ``batch``) -- CLIP ``interpret`` repeats one image ``batch`` times."""
         n_k = n_q if n_k is None else n_k
         self.shape = (n_layers, batch, heads, n_q, n_k)
         self.shared_probs = shared_probs
-        self.probs = torch.empty((n_layers, 1 if shared_probs else batch, heads, n_q, n_k), dtype=torch.float32,
-                                 device=device)
-        self.grads = torch.empty(self.shape, dtype=torch.float32, device=device)
+        self.dtype = dtype
+        self.probs = torch.empty((n_layers, 1 if shared_probs else batch, heads, n_q, n_k), dtype=dtype, device=device)
+        self.grads = torch.empty(self.shape, dtype=dtype, device=device)
 
     @property
     def n_layers(self):
@@ -38,9 +39,9 @@ class CaptureBuffers:
     def batch(self):
         return self.shape[1]
 
-    def matches(self, n_layers, batch, heads, n_q, n_k, device, shared_probs=False):
+    def matches(self, n_layers, batch, heads, n_q, n_k, device, shared_probs=False, dtype=torch.float32):
         return self.shape == (n_layers, batch, heads, n_q, n_k) and self.probs.device == torch.device(device) \
-            and self.shared_probs == shared_probs
+            and self.shared_probs == shared_probs and self.dtype == dtype
 
     def layer_probs(self, l):
         """``[B*H, Nq, Nk]`` view, the shape the reference's ``attn_probs`` / ``get_attn()`` has."""
@@ -52,7 +53,7 @@ class CaptureBuffers:
         return self.grads[l].view(b * h, nq, nk)
 
     def nbytes(self):
-        return 2 * self.probs.numel() * 4
+        return (self.probs.numel() + self.grads.numel()) * self.probs.element_size()
 
 
 class _AttnCapturePacked(torch.autograd.Function):

@@ -110,12 +110,15 @@ class Transformer(nn.Module):
         self.width, self.layers, self.heads = width, layers, heads
         self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask) for _ in range(layers)])
         self.buffers = None
+        # element type of the capture slabs: torch.float16 / torch.bfloat16 halve the resident bytes of a long-sequence
+        # tower (ViT-L/14@336: 577 tokens); only the streaming attention kernels write them (capture op, ABI note)
+        self.capture_dtype = torch.float32
 
     def _ensure_buffers(self, batch, n_tokens, device, shared_probs=False):
         if self.buffers is None or not self.buffers.matches(self.layers, batch, self.heads, n_tokens, n_tokens, device,
-                                                            shared_probs):
+                                                            shared_probs, self.capture_dtype):
             self.buffers = CaptureBuffers(self.layers, batch, self.heads, n_tokens, n_tokens, device=device,
-                                          shared_probs=shared_probs)
+                                          shared_probs=shared_probs, dtype=self.capture_dtype)
         return self.buffers
 
     # ------------------------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@ struct AttnFwdArgs {
     int B, H, Nq, Nk, D;
     float scale; int scale_mode;
     int debug;  // profiling only (attention_small.hip)
+    int slab_dt;  // MMX_F32 | MMX_F16 | MMX_BF16: element type behind `probs` (non-fp32: streaming kernels only)
 };
 
 struct AttnBwdArgs {
@@ -27,6 +28,7 @@ struct AttnBwdArgs {
     float* delta;  // [B, H, Nq] workspace: rowsum(dP * P)
     int B, H, Nq, Nk, D;
     float scale; int scale_mode; int need_dqkv;
+    int slab_dt;  // element type behind `probs` and `dprobs` (see AttnFwdArgs)
 };
 
 int attn_fwd_small_try(AttnFwdArgs& a, hipStream_t s, int* rc_out);

@@ -320,7 +320,20 @@ extern "C" int mmx_attn_capture_fwd(const void* q_dev, const void* k_dev, const 
                                     int64_t v_sn, const void* mask_dev, int64_t mask_sb, int64_t mask_sq,
                                     void* probs_dev, void* o_dev, int64_t o_sb, int64_t o_sh, int64_t o_sn, int B,
                                     int H, int Nq, int Nk, int D, float scale, int scale_mode, void* stream) {
+    return mmx_attn_capture_fwd_ex(q_dev, k_dev, v_dev, q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn, mask_dev,
+                                   mask_sb, mask_sq, probs_dev, MMX_F32, o_dev, o_sb, o_sh, o_sn, B, H, Nq, Nk, D, scale,
+                                   scale_mode, stream);
+}
+
+extern "C" int mmx_attn_capture_fwd_ex(const void* q_dev, const void* k_dev, const void* v_dev, int64_t q_sb,
+                                       int64_t q_sh, int64_t q_sn, int64_t k_sb, int64_t k_sh, int64_t k_sn, int64_t v_sb,
+                                       int64_t v_sh, int64_t v_sn, const void* mask_dev, int64_t mask_sb, int64_t mask_sq,
+                                       void* probs_dev, int slab_dtype, void* o_dev, int64_t o_sb, int64_t o_sh,
+                                       int64_t o_sn, int B, int H, int Nq, int Nk, int D, float scale, int scale_mode,
+                                       void* stream) {
     MMX_CHECK_ARG(q_dev && k_dev && v_dev && probs_dev && o_dev, "mmx_attn_capture_fwd: null pointer");
+    MMX_CHECK_ARG(slab_dtype == MMX_F32 || slab_dtype == MMX_F16 || slab_dtype == MMX_BF16,
+                  "mmx_attn_capture_fwd: slab dtype %d", slab_dtype);
     int rc = check_attn_dims("mmx_attn_capture_fwd", B, H, Nq, Nk, D, scale_mode);
     if (rc) return rc;
     AttnFwdArgs a;
@@ -329,8 +342,14 @@ extern "C" int mmx_attn_capture_fwd(const void* q_dev, const void* k_dev, const 
     a.mask = static_cast<const float*>(mask_dev); a.mask_sb = mask_sb; a.mask_sq = mask_sq;
     a.probs = static_cast<float*>(probs_dev); a.o = static_cast<float*>(o_dev); a.os = {o_sb, o_sh, o_sn};
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale; a.scale_mode = scale_mode; a.debug = 0;
+    a.slab_dt = slab_dtype;
     dim3 grid((Nq + kTQ - 1) / kTQ, H, B);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (slab_dtype != MMX_F32) {   // half-precision slabs: the streaming kernels are the only writers
+        if (attn_fwd_stream_try(a, s, &rc)) return rc;
+        set_error("mmx_attn_capture_fwd: fp16 / bf16 capture slabs need head_dim %% 4 == 0 and 16-byte aligned q/k/v views");
+        return MMX_ENOTSUP;
+    }
     if (attn_fwd_small_try(a, s, &rc)) return rc;   // whole head resident in LDS (short sequences)
     if (attn_fwd_stream_try(a, s, &rc)) return rc;  // long sequences: K/V streamed, nothing of size Nk on chip
     if (D <= 32) return launch_dyn(attn_capture_fwd_kernel<32>, a, grid, attn_lds_bytes(32, Nk), s, "attn_capture_fwd_kernel<32>");
@@ -349,7 +368,24 @@ extern "C" int mmx_attn_capture_bwd(const void* q_dev, const void* k_dev, const 
                                     int64_t dk_sn, int64_t dv_sb, int64_t dv_sh, int64_t dv_sn, int B, int H, int Nq,
                                     int Nk, int D, float scale, int scale_mode, int need_dqkv, void* workspace_dev,
                                     size_t workspace_bytes, void* stream) {
+    return mmx_attn_capture_bwd_ex(q_dev, k_dev, v_dev, q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn, probs_dev,
+                                   probs_sb, MMX_F32, do_dev, o_sb, o_sh, o_sn, dprobs_dev, dq_dev, dk_dev, dv_dev, dq_sb,
+                                   dq_sh, dq_sn, dk_sb, dk_sh, dk_sn, dv_sb, dv_sh, dv_sn, B, H, Nq, Nk, D, scale,
+                                   scale_mode, need_dqkv, workspace_dev, workspace_bytes, stream);
+}
+
+extern "C" int mmx_attn_capture_bwd_ex(const void* q_dev, const void* k_dev, const void* v_dev, int64_t q_sb,
+                                       int64_t q_sh, int64_t q_sn, int64_t k_sb, int64_t k_sh, int64_t k_sn, int64_t v_sb,
+                                       int64_t v_sh, int64_t v_sn, const void* probs_dev, int64_t probs_sb, int slab_dtype,
+                                       const void* do_dev, int64_t o_sb, int64_t o_sh, int64_t o_sn, void* dprobs_dev,
+                                       void* dq_dev, void* dk_dev, void* dv_dev, int64_t dq_sb, int64_t dq_sh,
+                                       int64_t dq_sn, int64_t dk_sb, int64_t dk_sh, int64_t dk_sn, int64_t dv_sb,
+                                       int64_t dv_sh, int64_t dv_sn, int B, int H, int Nq, int Nk, int D, float scale,
+                                       int scale_mode, int need_dqkv, void* workspace_dev, size_t workspace_bytes,
+                                       void* stream) {
     MMX_CHECK_ARG(v_dev && probs_dev && do_dev && dprobs_dev, "mmx_attn_capture_bwd: null pointer");
+    MMX_CHECK_ARG(slab_dtype == MMX_F32 || slab_dtype == MMX_F16 || slab_dtype == MMX_BF16,
+                  "mmx_attn_capture_bwd: slab dtype %d", slab_dtype);
     int rc = check_attn_dims("mmx_attn_capture_bwd", B, H, Nq, Nk, D, scale_mode);
     if (rc) return rc;
     if (need_dqkv) {
@@ -370,7 +406,13 @@ extern "C" int mmx_attn_capture_bwd(const void* q_dev, const void* k_dev, const 
     a.dqs = {dq_sb, dq_sh, dq_sn}; a.dks = {dk_sb, dk_sh, dk_sn}; a.dvs = {dv_sb, dv_sh, dv_sn};
     a.delta = static_cast<float*>(workspace_dev);
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale; a.scale_mode = scale_mode; a.need_dqkv = need_dqkv;
+    a.slab_dt = slab_dtype;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (slab_dtype != MMX_F32) {
+        if (attn_bwd_stream_try(a, s, &rc)) return rc;
+        set_error("mmx_attn_capture_bwd: fp16 / bf16 capture slabs need head_dim %% 4 == 0 and 16-byte aligned views");
+        return MMX_ENOTSUP;
+    }
     if (attn_bwd_small_try(a, s, &rc)) return rc;   // whole head resident in LDS (short sequences)
     if (attn_bwd_stream_try(a, s, &rc)) return rc;  // long sequences
     dim3 gq((Nq + kTQ - 1) / kTQ, H, B), gk((Nk + 15) / 16, H, B);

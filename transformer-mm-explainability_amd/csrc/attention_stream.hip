@@ -130,8 +130,9 @@ constexpr size_t stream_lds_bytes(int tiles) {
 }
 
 // =============================================================================================== forward
-template <int DP>
+template <int DP, int DT>
 __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_kernel(const AttnFwdArgs a) {
+    typedef typename slab_elem<DT>::type slab_t;
     constexpr int LS = DP + 4, NB = DP / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
@@ -157,13 +158,13 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_ke
     // and rows beyond Nq simply have no output pointer
     int rows[4];
     const float* mrow[4];
-    float* pout[4];
+    slab_t* pout[4];
     const int64_t pbase = (static_cast<int64_t>(b) * a.H + h) * a.Nq;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         rows[r] = rw + 4 * g + r;
         mrow[r] = a.mask ? a.mask + b * a.mask_sb + static_cast<int64_t>(min(rows[r], a.Nq - 1)) * a.mask_sq : nullptr;
-        pout[r] = rows[r] < a.Nq ? a.probs + (pbase + rows[r]) * a.Nk + i : nullptr;
+        pout[r] = rows[r] < a.Nq ? reinterpret_cast<slab_t*>(a.probs) + (pbase + rows[r]) * a.Nk + i : nullptr;
     }
     // one score of the C tile: scale, additive mask, -inf beyond the last key.  EDGE = the tile may run past Nk
     // (only the last tile of a sweep); interior tiles skip every key-range test.
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_ke
             for (int r = 0; r < 4; ++r) {
                 float p = exp_fast(score(sacc[t][r], r, k0, edge) - m[r]) * linv[r];
                 if (EDGE && k0 + i >= a.Nk) p = 0.f;                        // (also keeps NaN rows out of the padding)
-                if (pout[r] && (!EDGE || k0 + i < a.Nk)) pout[r][k0] = p;
+                if (pout[r] && (!EDGE || k0 + i < a.Nk)) slab_store<DT>(pout[r] + k0, p);
                 Pw[(4 * g + r) * kPS + 16 * t + i] = p;
             }
         }
@@ -257,8 +258,9 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_ke
 
 // =============================================================================================== backward, query side
 // dP = dO.V^T -> capture slab;  delta = rowsum(P * dP) -> workspace;  dS = P * (dP - delta);  dQ = dS.K
-template <int DP>
+template <int DP, int DT>
 __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_kernel(const AttnBwdArgs a) {
+    typedef typename slab_elem<DT>::type slab_t;
     constexpr int LS = DP + 4, NB = DP / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
@@ -280,13 +282,14 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
 
     // per-lane row pointers incl. this lane's key column i; the sweeps add wave-uniform key offsets only
     int rows[4];
-    const float* prow[4];
-    float* dpout[4];
+    const slab_t* prow[4];
+    slab_t* dpout[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         rows[r] = rw + 4 * g + r;
-        prow[r] = a.probs + b * a.probs_sb + (static_cast<int64_t>(h) * a.Nq + min(rows[r], a.Nq - 1)) * a.Nk + i;
-        dpout[r] = rows[r] < a.Nq ? a.dprobs + (head * a.Nq + rows[r]) * a.Nk + i : nullptr;
+        prow[r] = reinterpret_cast<const slab_t*>(a.probs) + b * a.probs_sb +
+                  (static_cast<int64_t>(h) * a.Nq + min(rows[r], a.Nq - 1)) * a.Nk + i;
+        dpout[r] = rows[r] < a.Nq ? reinterpret_cast<slab_t*>(a.dprobs) + (head * a.Nq + rows[r]) * a.Nk + i : nullptr;
     }
     const int ntiles = (a.Nk + kTile - 1) / kTile;
     f32x4 kreg[NB], vreg[NB];
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
             const bool ok = !EDGE || k0 + i < a.Nk;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = prow[r][EDGE ? min(k0, a.Nk - 1 - i) : k0];   // clamped, unconditional
+                const float v = slab_load<DT>(prow[r] + (EDGE ? min(k0, a.Nk - 1 - i) : k0));   // clamped, unconditional
                 p[t][r] = ok ? v : 0.f;
             }
         }
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
             const int k0 = kt * kTile + 16 * t;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (dpout[r] && (!EDGE || k0 + i < a.Nk)) dpout[r][k0] = dp[t][r];
+                if (dpout[r] && (!EDGE || k0 + i < a.Nk)) slab_store<DT>(dpout[r] + k0, dp[t][r]);
                 if (a.need_dqkv) Sw[(4 * g + r) * kPS + 16 * t + i] = p[t][r] * (dp[t][r] - delta[r]) * ds_mul;
             }
         }
@@ -383,8 +386,9 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
 // per 64 keys (16 per wave): dV = P^T.dO, dK = dS^T.Q with dS rebuilt from the two capture slabs and delta.
 // The A operands (columns of P / dS) come straight from the slabs in MFMA layout: lane (key i, slot g) reads rows
 // 16 rb + 4 g + s of key column j0 + i -- 16 consecutive keys per row segment, no LDS staging.
-template <int DP>
+template <int DP, int DT>
 __global__ __launch_bounds__(kThreads) void attn_bwd_kv_stream_kernel(const AttnBwdArgs a) {
+    typedef typename slab_elem<DT>::type slab_t;
     constexpr int LS = DP + 4, NB = DP / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
@@ -402,8 +406,8 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_kv_stream_kernel(const Attn
     const float* dob = a.dout + b * a.os.sb + h * a.os.sh;
     const bool q_first = (a.scale_mode == MMX_SCALE_Q_FIRST);
     const int64_t head = static_cast<int64_t>(b) * a.H + h;
-    const float* pcol = a.probs + b * a.probs_sb + static_cast<int64_t>(h) * a.Nq * a.Nk + keyc;
-    const float* dpcol = a.dprobs + head * a.Nq * a.Nk + keyc;
+    const slab_t* pcol = reinterpret_cast<const slab_t*>(a.probs) + b * a.probs_sb + static_cast<int64_t>(h) * a.Nq * a.Nk + keyc;
+    const slab_t* dpcol = reinterpret_cast<const slab_t*>(a.dprobs) + head * a.Nq * a.Nk + keyc;
 
     f32x4 kacc[NB], vacc[NB];
 #pragma unroll
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_kv_stream_kernel(const Attn
                 const int row = qt * kTile + 16 * rb + 4 * g + s;
                 const int64_t off = static_cast<int64_t>(min(row, a.Nq - 1)) * a.Nk;
                 const bool ok = key_ok && row < a.Nq;
-                const float pv = pcol[off], dv = dpcol[off];
+                const float pv = slab_load<DT>(pcol + off), dv = slab_load<DT>(dpcol + off);
                 p[rb][s] = ok ? pv : 0.f;
                 dp[rb][s] = ok ? dv : 0.f;
             }
@@ -490,39 +494,60 @@ int launch_stream(K kern, const A& args, dim3 grid, size_t lds, hipStream_t s, c
     return MMX_OK;
 }
 
+template <int DT>
+int launch_fwd_dt(const AttnFwdArgs& a, dim3 grid, hipStream_t s) {
+    return a.D <= 32
+        ? launch_stream(attn_fwd_stream_kernel<32, DT>, a, grid, stream_lds_bytes<32>(2), s, "attn_fwd_stream_kernel<32>")
+        : launch_stream(attn_fwd_stream_kernel<64, DT>, a, grid, stream_lds_bytes<64>(2), s, "attn_fwd_stream_kernel<64>");
+}
+
+template <int DT>
+int launch_bwd_dt(const AttnBwdArgs& a, dim3 gq, dim3 gk, hipStream_t s) {
+    const bool small_d = a.D <= 32;
+    int rc = small_d ? launch_stream(attn_bwd_q_stream_kernel<32, DT>, a, gq, stream_lds_bytes<32>(2), s,
+                                     "attn_bwd_q_stream_kernel<32>")
+                     : launch_stream(attn_bwd_q_stream_kernel<64, DT>, a, gq, stream_lds_bytes<64>(2), s,
+                                     "attn_bwd_q_stream_kernel<64>");
+    if (rc == MMX_OK && a.need_dqkv) {
+        // the key-side kernel's LDS: two operand tiles + 64 deltas (the 4 x 16 x 68 floats of the wave tiles cover it)
+        rc = small_d ? launch_stream(attn_bwd_kv_stream_kernel<32, DT>, a, gk, stream_lds_bytes<32>(2), s,
+                                     "attn_bwd_kv_stream_kernel<32>")
+                     : launch_stream(attn_bwd_kv_stream_kernel<64, DT>, a, gk, stream_lds_bytes<64>(2), s,
+                                     "attn_bwd_kv_stream_kernel<64>");
+    }
+    return rc;
+}
+
 }  // namespace
 
 void attn_stream_enable(int on) { g_attn_stream = on & 1; }
 
-// returns 1 if the streaming kernel was launched (rc in *rc_out), 0 if the shape / layout is not eligible
+// returns 1 if the streaming kernel was launched (rc in *rc_out), 0 if the shape / layout is not eligible.
+// Slabs in fp16 / bf16 (slab_dt) exist on this path only: they ignore the "attn_stream" switch.
 int attn_fwd_stream_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out) {
-    if (!g_attn_stream || a.D % 4 || a.D > 64) return 0;
+    if ((!g_attn_stream && a.slab_dt == MMX_F32) || a.D % 4 || a.D > 64) return 0;
     if (!aligned16(a.q, a.qs) || !aligned16(a.k, a.ks) || !aligned16(a.v, a.vs)) return 0;
     dim3 grid(((a.Nq + kRows - 1) / kRows) * a.H * a.B);
-    *rc_out = a.D <= 32
-        ? launch_stream(attn_fwd_stream_kernel<32>, a, grid, stream_lds_bytes<32>(2), s, "attn_fwd_stream_kernel<32>")
-        : launch_stream(attn_fwd_stream_kernel<64>, a, grid, stream_lds_bytes<64>(2), s, "attn_fwd_stream_kernel<64>");
+    switch (a.slab_dt) {
+        case MMX_F32: *rc_out = launch_fwd_dt<MMX_F32>(a, grid, s); break;
+        case MMX_F16: *rc_out = launch_fwd_dt<MMX_F16>(a, grid, s); break;
+        case MMX_BF16: *rc_out = launch_fwd_dt<MMX_BF16>(a, grid, s); break;
+        default: return 0;
+    }
     return 1;
 }
 
 int attn_bwd_stream_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out) {
-    if (!g_attn_stream || a.D % 4 || a.D > 64) return 0;
+    if ((!g_attn_stream && a.slab_dt == MMX_F32) || a.D % 4 || a.D > 64) return 0;
     if (!aligned16(a.v, a.vs) || !aligned16(a.dout, a.os)) return 0;
     if (a.need_dqkv && (!aligned16(a.q, a.qs) || !aligned16(a.k, a.ks))) return 0;
     dim3 gq(((a.Nq + kRows - 1) / kRows) * a.H * a.B), gk(((a.Nk + kRows - 1) / kRows) * a.H * a.B);
-    const bool small_d = a.D <= 32;
-    int rc = small_d ? launch_stream(attn_bwd_q_stream_kernel<32>, a, gq, stream_lds_bytes<32>(2), s,
-                                     "attn_bwd_q_stream_kernel<32>")
-                     : launch_stream(attn_bwd_q_stream_kernel<64>, a, gq, stream_lds_bytes<64>(2), s,
-                                     "attn_bwd_q_stream_kernel<64>");
-    if (rc == MMX_OK && a.need_dqkv) {
-        // the key-side kernel's LDS: two operand tiles + 64 deltas (the 4 x 16 x 68 floats of the wave tiles cover it)
-        rc = small_d ? launch_stream(attn_bwd_kv_stream_kernel<32>, a, gk, stream_lds_bytes<32>(2), s,
-                                     "attn_bwd_kv_stream_kernel<32>")
-                     : launch_stream(attn_bwd_kv_stream_kernel<64>, a, gk, stream_lds_bytes<64>(2), s,
-                                     "attn_bwd_kv_stream_kernel<64>");
+    switch (a.slab_dt) {
+        case MMX_F32: *rc_out = launch_bwd_dt<MMX_F32>(a, gq, gk, s); break;
+        case MMX_F16: *rc_out = launch_bwd_dt<MMX_F16>(a, gq, gk, s); break;
+        case MMX_BF16: *rc_out = launch_bwd_dt<MMX_BF16>(a, gq, gk, s); break;
+        default: return 0;
     }
-    *rc_out = rc;
     return 1;
 }
 

@@ -66,6 +66,28 @@ __device__ __forceinline__ float load1_as_f32<MMX_F16>(const void* base, int64_t
     return f16_bits_to_f32(static_cast<const unsigned short*>(base)[idx]);
 }
 
+// Storage type of a capture slab element and its conversions (round to nearest even on store)
+template <int DT> struct slab_elem { typedef unsigned short type; };
+template <> struct slab_elem<MMX_F32> { typedef float type; };
+template <int DT>
+__device__ __forceinline__ float slab_load(const typename slab_elem<DT>::type* p) {
+    if constexpr (DT == MMX_F32) return *p;
+    else if constexpr (DT == MMX_BF16) return bf16_bits_to_f32(*p);
+    else return f16_bits_to_f32(*p);
+}
+template <int DT>
+__device__ __forceinline__ void slab_store(typename slab_elem<DT>::type* p, float v) {
+    if constexpr (DT == MMX_F32) {
+        *p = v;
+    } else if constexpr (DT == MMX_BF16) {
+        const unsigned u = __float_as_uint(v);
+        *p = (v != v) ? static_cast<unsigned short>(0x7FC0)
+                      : static_cast<unsigned short>((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    } else {
+        *p = __half_as_ushort(__float2half(v));
+    }
+}
+
 // clamp(x, min=0) with torch semantics: NaN propagates (fmaxf would drop it)
 __device__ __forceinline__ float relu_nan(float x) { return (x < 0.0f) ? 0.0f : x; }
 

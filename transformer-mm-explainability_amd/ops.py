@@ -359,8 +359,8 @@ def attn_capture_fwd(q, k, v, probs_out, scale, scale_mode=_lib.SCALE_Q_FIRST, m
     else:
         B, H, Nq, D = q.shape
         Nk = k.shape[2]
-    if probs_out.dtype != torch.float32 or not probs_out.is_contiguous() or probs_out.numel() != B * H * Nq * Nk:
-        raise MMXError("probs_out must be a contiguous fp32 [B,H,Nq,Nk] slab")
+    if probs_out.dtype not in _DTYPES or not probs_out.is_contiguous() or probs_out.numel() != B * H * Nq * Nk:
+        raise MMXError("probs_out must be a contiguous fp32 / fp16 / bf16 [B,H,Nq,Nk] slab")
     o = torch.empty(q.shape, dtype=torch.float32, device=q.device)
     msb = msq = 0
     if mask is not None:
@@ -372,10 +372,10 @@ def attn_capture_fwd(q, k, v, probs_out, scale, scale_mode=_lib.SCALE_Q_FIRST, m
             msq = Nk if mask.shape[1] > 1 else 0
         else:
             raise MMXError("mask must be [Nq,Nk] or [B,Nq|1,Nk]")
-    check(lib().mmx_attn_capture_fwd(_p(q), _p(k), _p(v), *_bhnd_strides(q, layout), *_bhnd_strides(k, layout),
-                                     *_bhnd_strides(v, layout), _p(mask), msb, msq, _p(probs_out), _p(o),
-                                     *_bhnd_strides(o, layout), B, H, Nq, Nk, D, float(scale), scale_mode, _stream()),
-          "mmx_attn_capture_fwd")
+    check(lib().mmx_attn_capture_fwd_ex(_p(q), _p(k), _p(v), *_bhnd_strides(q, layout), *_bhnd_strides(k, layout),
+                                        *_bhnd_strides(v, layout), _p(mask), msb, msq, _p(probs_out),
+                                        _DTYPES[probs_out.dtype], _p(o), *_bhnd_strides(o, layout), B, H, Nq, Nk, D,
+                                        float(scale), scale_mode, _stream()), "mmx_attn_capture_fwd")
     return o
 
 
@@ -386,6 +386,8 @@ def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCA
     ``batch``: shared-forward mode -- q/k/v/probs come from ONE forward (batch 1) and are broadcast (stride 0) over the
     ``batch`` upstream gradients in ``d_o``; dq/dk/dv/dprobs are per sample."""
     _dev(q, k, v, probs, d_o, dprobs_out)
+    if probs.dtype not in _DTYPES or probs.dtype != dprobs_out.dtype:
+        raise MMXError("attn_capture_bwd: probs / dprobs slabs must share one of fp32 / fp16 / bf16")
     if layout == "bnhd":
         B, Nq, H, D = q.shape
         Nk = k.shape[1]
@@ -412,9 +414,10 @@ def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCA
         need = lib().mmx_attn_capture_bwd_workspace_bytes(B, H, Nq)
         ws = _workspace(need, q.device, "attn_bwd")
     zero3 = (0, 0, 0)
-    check(lib().mmx_attn_capture_bwd(
+    check(lib().mmx_attn_capture_bwd_ex(
         _p(q), _p(k), _p(v), *_bhnd_strides(q, layout), *_bhnd_strides(k, layout), *_bhnd_strides(v, layout),
-        _p(probs), probs_sb, _p(d_o), *_bhnd_strides(d_o, layout), _p(dprobs_out), _p(dq), _p(dk), _p(dv),
+        _p(probs), probs_sb, _DTYPES[probs.dtype], _p(d_o), *_bhnd_strides(d_o, layout), _p(dprobs_out), _p(dq), _p(dk),
+        _p(dv),
         *(_bhnd_strides(dq, layout) if need_dqkv else zero3), *(_bhnd_strides(dk, layout) if need_dqkv else zero3),
         *(_bhnd_strides(dv, layout) if need_dqkv else zero3),
         B, H, Nq, Nk, D, float(scale), scale_mode, int(need_dqkv), _p(ws), need, _stream()), "mmx_attn_capture_bwd")

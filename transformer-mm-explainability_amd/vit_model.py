@@ -127,9 +127,10 @@ class VisionTransformer(nn.Module):
 
     def _slabs(self, batch, n_tokens, device, shared=False):
         b = self.buffers_
-        if b is None or not b.matches(self.depth, batch, self.num_heads, n_tokens, n_tokens, device, shared):
+        dtype = getattr(self, "capture_dtype", torch.float32)   # torch.float16 / bfloat16: half-size slabs (N >= ~128)
+        if b is None or not b.matches(self.depth, batch, self.num_heads, n_tokens, n_tokens, device, shared, dtype):
             self.buffers_ = b = CaptureBuffers(self.depth, batch, self.num_heads, n_tokens, n_tokens, device=device,
-                                               shared_probs=shared)
+                                               shared_probs=shared, dtype=dtype)
         return b
 
     def _embed(self, x):
