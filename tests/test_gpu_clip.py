@@ -181,3 +181,19 @@ def test_full_size_batch_properties():
     g_text, g_image = run()
     torch.testing.assert_close(g_text, R_text, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(g_image, R_image, rtol=1e-5, atol=1e-6)
+
+
+def test_bf16_backward_gemms_stay_close(golden):
+    """``backward_gemm_dtype = bfloat16`` on the image tower (config-5 style low-precision mode): only the input-gradient
+    GEMMs of the hand-written backward run on the bf16 MFMA; the maps stay within bf16 precision of the reference's."""
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    g, model = load_tiny(golden)
+    image, texts = torch.from_numpy(g["image"]).cuda(), torch.from_numpy(g["texts"]).cuda()
+    model.visual.transformer.backward_gemm_dtype = torch.bfloat16
+    R_text, R_image = ce.interpret(image, texts, model, "cuda", start_layer=0, start_layer_text=0)
+    close(R_text, g["R_text_all"])                                    # the text tower is untouched
+    want = torch.from_numpy(g["R_image_all"]).cuda()
+    assert (R_image - want).abs().max() <= 2e-2 * want.abs().max()
+    assert torch.nn.functional.cosine_similarity(R_image, want, dim=-1).min() > 0.9995
+    model.visual.transformer.backward_gemm_dtype = torch.float32
+    close(ce.interpret(image, texts, model, "cuda", start_layer=0, start_layer_text=0)[1], g["R_image_all"])

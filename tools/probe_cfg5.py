@@ -35,6 +35,13 @@ import sys as _sys  # noqa: E402
 if len(_sys.argv) > 1 and _sys.argv[1] == "bf16":
     model.visual.transformer.capture_dtype = torch.bfloat16      # image tower slabs in bf16 (config 5's "bf16 capture")
     print("image-tower capture slabs: bf16")
+if len(_sys.argv) > 2 and _sys.argv[2] == "gemm":
+    ref = ce.interpret(image, prompts(4), model, dev, start_layer=0, start_layer_text=0)[1].clone()
+    model.visual.transformer.backward_gemm_dtype = torch.bfloat16
+    got = ce.interpret(image, prompts(4), model, dev, start_layer=0, start_layer_text=0)[1]
+    cos = torch.nn.functional.cosine_similarity(got, ref, dim=-1)
+    print("backward GEMMs in bf16: min cosine similarity of the image maps vs fp32 GEMMs = %.6f, max rel err = %.3e"
+          % (cos.min().item(), ((got - ref).abs().max() / ref.abs().max()).item()))
 for B in ((128,) if len(_sys.argv) > 1 else (16, 64, 128)):
     texts = prompts(B)
     torch.cuda.reset_peak_memory_stats()

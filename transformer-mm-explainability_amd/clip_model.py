@@ -113,6 +113,21 @@ class Transformer(nn.Module):
         # element type of the capture slabs: torch.float16 / torch.bfloat16 halve the resident bytes of a long-sequence
         # tower (ViT-L/14@336: 577 tokens); only the streaming attention kernels write them (capture op, ABI note)
         self.capture_dtype = torch.float32
+        # dtype of the input-gradient GEMMs of ``backward_shared`` (the bulk of a long-sequence step: ViT-L/14@336 at
+        # batch 128 is ~45 TFLOP of them).  torch.bfloat16 runs them on the bf16 MFMA with fp32 accumulation and fp32
+        # results; everything else (forward, LayerNorm, attention, the relevancy rules) stays fp32.
+        self.backward_gemm_dtype = torch.float32
+
+    def _gemm(self, x, weight):
+        """``x @ weight`` for the hand-written backward, in ``backward_gemm_dtype`` (cached converted weights)."""
+        dt = self.backward_gemm_dtype
+        if dt == torch.float32:
+            return torch.matmul(x, weight)
+        cache = self.__dict__.setdefault("_gemm_weights", {})
+        key = (id(weight), dt)
+        if key not in cache or cache[key][0] != weight._version:
+            cache[key] = (weight._version, weight.detach().to(dt))
+        return torch.matmul(x.to(dt), cache[key][1]).float()
 
     def _ensure_buffers(self, batch, n_tokens, device, shared_probs=False):
         if self.buffers is None or not self.buffers.matches(self.layers, batch, self.heads, n_tokens, n_tokens, device,
@@ -164,13 +179,13 @@ class Transformer(nn.Module):
             at = blk.attn
             x, mean1, rstd1, qkv, x1, mean2, rstd2, m = tape[l]
             # MLP branch: x2 = x1 + c_proj(m * sigmoid(1.702 m)),  m = c_fc(ln_2(x1))
-            d_a = torch.matmul(dx, blk.mlp.c_proj.weight)
+            d_a = self._gemm(dx, blk.mlp.c_proj.weight)
             sg = torch.sigmoid(1.702 * m)
             d_m = d_a * (sg + 1.702 * m * sg * (1 - sg))                      # QuickGELU'(m), shared across the batch
-            d_h2 = torch.matmul(d_m, blk.mlp.c_fc.weight)
+            d_h2 = self._gemm(d_m, blk.mlp.c_fc.weight)
             d_x1 = ops.layernorm_bwd_add(d_h2, x1, mean2, rstd2, blk.ln_2.weight, dx)   # dx + LN2'(d_h2), one pass
             # attention branch: x1 = x + out_proj(attn(ln_1(x)))
-            d_o = torch.matmul(d_x1, at.out_proj.weight).view(B, N, at.num_heads, at.head_dim)
+            d_o = self._gemm(d_x1, at.out_proj.weight).view(B, N, at.num_heads, at.head_dim)
             need = l > first_grad_layer                                       # nothing below needs gradients
             dqkv = torch.empty(B, N, 3, at.num_heads, at.head_dim, dtype=torch.float32, device=dy.device) if need else None
             out = (dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]) if need else None
@@ -178,7 +193,7 @@ class Transformer(nn.Module):
                                  at.head_dim ** -0.5, _lib.SCALE_Q_FIRST, need_dqkv=need, layout="bnhd", out=out, batch=B)
             if not need:
                 break
-            d_h1 = torch.matmul(dqkv.view(B, N, 3 * E), at.in_proj_weight)
+            d_h1 = self._gemm(dqkv.view(B, N, 3 * E), at.in_proj_weight)
             dx = ops.layernorm_bwd_add(d_h1, x, mean1, rstd1, blk.ln_1.weight, d_x1)
 
     def forward(self, x, capture_only=False, first_grad_layer=0):
