@@ -97,3 +97,14 @@ def test_vit_half_precision_capture_slabs(dtype):
     rel = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
     assert (got - want).abs().max() <= rel * want.abs().max() + 1e-9
     model.capture_dtype = torch.float32
+
+
+def test_vit_bf16_backward_gemms_stay_close():
+    from transformer_mm_explainability_amd import vit_model
+    model = build(224, 16, 192, 3, 3, classes=11).cuda()
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(6)).cuda()
+    want = vit_model.generate_relevance_multi(model, x, [1, 4, 8]).clone()
+    model.backward_gemm_dtype = torch.bfloat16
+    got = vit_model.generate_relevance_multi(model, x, [1, 4, 8])
+    assert (got - want).abs().max() <= 2e-2 * want.abs().max()
+    assert torch.nn.functional.cosine_similarity(got, want, dim=-1).min() > 0.9995

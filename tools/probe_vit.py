@@ -31,3 +31,7 @@ for K in (1, 8):
     run = vit_model.GraphedRelevance(model, xc, indices=list(range(K)))
     tk = timed(lambda: run(xc), n=50)
     print(f"ViT-B/16 MI355X GraphedRelevance (hipGraph replay) K={K}: {tk*1e3:.2f} ms = {K/tk:.1f} maps/s")
+model.backward_gemm_dtype = torch.bfloat16
+for K in (32,):
+    tk = timed(lambda: vit_model.generate_relevance_multi(model, xc, list(range(K))))
+    print(f"ViT-B/16 MI355X generate_relevance_multi K={K}, bf16 backward GEMMs: {tk*1e3:.2f} ms = {K/tk:.1f} maps/s")

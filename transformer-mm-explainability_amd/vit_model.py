@@ -125,6 +125,18 @@ class VisionTransformer(nn.Module):
             nn.init.ones_(m.weight)
             nn.init.zeros_(m.bias)
 
+    def _gemm(self, x, weight):
+        """``x @ weight`` of the hand-written backward in ``backward_gemm_dtype`` (default fp32; ``torch.bfloat16`` =
+        bf16 MFMA with fp32 accumulation and results, see ``clip_model.Transformer._gemm``)."""
+        dt = getattr(self, "backward_gemm_dtype", torch.float32)
+        if dt == torch.float32:
+            return torch.matmul(x, weight)
+        cache = self.__dict__.setdefault("_gemm_weights", {})
+        key = (id(weight), dt)
+        if key not in cache or cache[key][0] != weight._version:
+            cache[key] = (weight._version, weight.detach().to(dt))
+        return torch.matmul(x.to(dt), cache[key][1]).float()
+
     def _slabs(self, batch, n_tokens, device, shared=False):
         b = self.buffers_
         dtype = getattr(self, "capture_dtype", torch.float32)   # torch.float16 / bfloat16: half-size slabs (N >= ~128)
@@ -191,11 +203,11 @@ class VisionTransformer(nn.Module):
             blk = self.blocks[l]
             at = blk.attn
             x, mean1, rstd1, qkv, x1, mean2, rstd2, m = tape[l]
-            d_a = torch.matmul(dx, blk.mlp.fc2.weight)
+            d_a = self._gemm(dx, blk.mlp.fc2.weight)
             gelu_prime = 0.5 * (1 + torch.erf(m / math.sqrt(2.0))) + m * torch.exp(-0.5 * m * m) / math.sqrt(2 * math.pi)
-            d_h2 = torch.matmul(d_a * gelu_prime, blk.mlp.fc1.weight)
+            d_h2 = self._gemm(d_a * gelu_prime, blk.mlp.fc1.weight)
             d_x1 = ops.layernorm_bwd_add(d_h2, x1, mean2, rstd2, blk.norm2.weight, dx)
-            d_o = torch.matmul(d_x1, at.proj.weight).view(K, N, at.num_heads, at.head_dim)
+            d_o = self._gemm(d_x1, at.proj.weight).view(K, N, at.num_heads, at.head_dim)
             need = l > 0
             dqkv = torch.empty(K, N, 3, at.num_heads, at.head_dim, dtype=torch.float32, device=dx.device) if need else None
             out = (dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]) if need else None
@@ -203,7 +215,7 @@ class VisionTransformer(nn.Module):
                                  _lib.SCALE_SCORES, need_dqkv=need, layout="bnhd", out=out, batch=K)
             if not need:
                 break
-            d_h1 = torch.matmul(dqkv.view(K, N, 3 * E), at.qkv.weight)
+            d_h1 = self._gemm(dqkv.view(K, N, 3 * E), at.qkv.weight)
             dx = ops.layernorm_bwd_add(d_h1, x, mean1, rstd1, blk.norm1.weight, d_x1)
 
 
