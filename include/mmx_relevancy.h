@@ -231,7 +231,10 @@ int mmx_attn_capture_bwd(const void* q_dev, const void* k_dev, const void* v_dev
  * P and dL/dP are rounded to nearest even when they are stored; the forward's O is computed from the unrounded P,
  * the backward reads the stored (rounded) P.  q/k/v/O and their gradients stay fp32.  Half-precision slabs are written
  * by the long-sequence streaming kernels only: head_dim % 4 == 0 and 16-byte aligned q/k/v views, else MMX_ENOTSUP.
- * The rule kernels (mmx_avg_heads*, mmx_relevancy_self_chain*) read all three slab types and accumulate in fp32. */
+ * The rule kernels (mmx_avg_heads*, mmx_relevancy_self_chain*) read all three slab types and accumulate in fp32.
+ * `fwd_o_dev` (backward, optional, may be NULL): the forward's O with its (batch, head, token) strides; batch stride 0
+ * when one forward is shared.  With it the streaming backward gets rowsum(dP * P) = rowsum(dO * O) from one row-wise
+ * dot product instead of a first sweep over all keys (a third of its MFMA work). */
 int mmx_attn_capture_fwd_ex(const void* q_dev, const void* k_dev, const void* v_dev,
                             int64_t q_sb, int64_t q_sh, int64_t q_sn,
                             int64_t k_sb, int64_t k_sh, int64_t k_sn,
@@ -246,6 +249,7 @@ int mmx_attn_capture_bwd_ex(const void* q_dev, const void* k_dev, const void* v_
                             int64_t v_sb, int64_t v_sh, int64_t v_sn,
                             const void* probs_dev, int64_t probs_sb, int slab_dtype,
                             const void* do_dev, int64_t o_sb, int64_t o_sh, int64_t o_sn,
+                            const void* fwd_o_dev, int64_t fo_sb, int64_t fo_sh, int64_t fo_sn,
                             void* dprobs_dev,
                             void* dq_dev, void* dk_dev, void* dv_dev,
                             int64_t dq_sb, int64_t dq_sh, int64_t dq_sn,

@@ -257,6 +257,11 @@ def test_attn_capture_fwd_bwd(ops, B, H, Nq, Nk, D, mode, masked, path):
     close(dq.permute(0, 2, 1, 3), qr.grad.float().numpy(), atol=2e-5)
     close(dk.permute(0, 2, 1, 3), kr.grad.float().numpy(), atol=2e-5)
     close(dv.permute(0, 2, 1, 3), vr.grad.float().numpy(), atol=2e-5)
+    # with the forward's O the streaming backward takes delta = rowsum(dO * O) instead of sweeping the keys
+    dq2, dk2, dv2 = ops.attn_capture_bwd(qc, kc, vc, probs, d_o.cuda(), torch.empty_like(dprobs), scale, mode, o=o)
+    close(dq2.permute(0, 2, 1, 3), qr.grad.float().numpy(), atol=2e-5)
+    close(dk2.permute(0, 2, 1, 3), kr.grad.float().numpy(), atol=2e-5)
+    close(dv2.permute(0, 2, 1, 3), vr.grad.float().numpy(), atol=2e-5)
     dprobs2 = torch.empty_like(dprobs)
     assert ops.attn_capture_bwd(qc, kc, vc, probs, d_o.cuda(), dprobs2, scale, mode, need_dqkv=False) == (None, None, None)
     ops.set_option("attn_small", 1)

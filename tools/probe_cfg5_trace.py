@@ -1,0 +1,22 @@
+"""Kernel-trace target: CLIP ViT-L/14@336 interpret, batch 32, bf16 image slabs + bf16 backward GEMMs (3 steps)."""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from transformer_mm_explainability_amd import clip_explainability as ce  # noqa: E402
+from transformer_mm_explainability_amd import clip_model  # noqa: E402
+
+dev = torch.device("cuda")
+model = clip_model.random_init("ViT-L/14@336", seed=0).to(dev)
+model.visual.transformer.capture_dtype = torch.bfloat16
+model.visual.transformer.backward_gemm_dtype = torch.bfloat16
+image = torch.randn(1, 3, 336, 336, device=dev)
+texts = torch.zeros(32, 77, dtype=torch.long)
+texts[:, 0] = 49406
+texts[:, 1:6] = 1000
+texts[:, 6] = 49407
+texts = texts.to(dev)
+for _ in range(3):
+    ce.interpret(image, texts, model, dev, start_layer=0, start_layer_text=0)
+torch.cuda.synchronize()

@@ -43,7 +43,8 @@ _PROTOTYPES = {
                                   _i, _i, _i, _i, _i, _f, _i, _vp]),
     "mmx_attn_capture_fwd_ex": (_i, [_vp, _vp, _vp] + [_i64] * 9 + [_vp, _i64, _i64, _vp, _i, _vp, _i64, _i64, _i64,
                                      _i, _i, _i, _i, _i, _f, _i, _vp]),
-    "mmx_attn_capture_bwd_ex": (_i, [_vp, _vp, _vp] + [_i64] * 9 + [_vp, _i64, _i, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]
+    "mmx_attn_capture_bwd_ex": (_i, [_vp, _vp, _vp] + [_i64] * 9 + [_vp, _i64, _i, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64,
+                                     _vp, _vp, _vp, _vp]
                                 + [_i64] * 9 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     "mmx_attn_capture_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "mmx_attn_capture_bwd": (_i, [_vp, _vp, _vp] + [_i64] * 9 + [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]

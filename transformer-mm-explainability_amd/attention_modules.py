@@ -118,17 +118,18 @@ class MultiheadAttention(_SlabOwner):
         o = ops.attn_capture_fwd(q, k, v, self._probs, float(D) ** -0.5, _lib.SCALE_Q_FIRST, None, layout="bnhd")
         self.save_attn(self._probs.view(H, T, S))
         self.save_attn_gradients(self._grads.view(batch * H, T, S))
-        return self.out_proj(o.reshape(1, T, self.embed_dim)), (q, k, v)
+        return self.out_proj(o.reshape(1, T, self.embed_dim)), (q, k, v, o)
 
     @torch.no_grad()
     def backward_shared(self, tape, d_out, need_input_grads=True):
         """``d_out [K, T, E]`` -> ``(d_query [K, T, E], d_key [K, S, E], d_value [K, S, E])`` (``None`` when not needed);
         always writes dL/dP of the K samples into the gradient slab."""
-        q, k, v = tape
+        q, k, v, o_fwd = tape
         K, T = d_out.shape[0], d_out.shape[1]
         d_o = torch.matmul(d_out, self.out_proj.weight).view(K, T, self.num_heads, self.head_dim)
         dq, dk, dv = ops.attn_capture_bwd(q, k, v, self._probs, d_o, self._grads, float(self.head_dim) ** -0.5,
-                                          _lib.SCALE_Q_FIRST, need_dqkv=need_input_grads, layout="bnhd", batch=K)
+                                          _lib.SCALE_Q_FIRST, need_dqkv=need_input_grads, layout="bnhd", batch=K,
+                                          o=o_fwd)
         if not need_input_grads:
             return None, None, None
         E = self.embed_dim

@@ -63,14 +63,14 @@ class _AttnCapturePacked(torch.autograd.Function):
     def forward(ctx, qkv, mask, probs_slab, grads_slab, scale, scale_mode, need_dqkv, grad_hook):
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
         o = ops.attn_capture_fwd(q, k, v, probs_slab, scale, scale_mode, mask, layout="bnhd")
-        ctx.save_for_backward(qkv)
+        ctx.save_for_backward(qkv, o)        # O: lets the long-sequence backward skip its delta sweep (rowsum(dO * O))
         ctx.probs, ctx.grads = probs_slab, grads_slab
         ctx.cfg = (scale, scale_mode, need_dqkv, grad_hook)
         return o
 
     @staticmethod
     def backward(ctx, d_o):
-        (qkv,) = ctx.saved_tensors
+        qkv, o = ctx.saved_tensors
         scale, scale_mode, need_dqkv, grad_hook = ctx.cfg
         need = bool(need_dqkv and ctx.needs_input_grad[0])
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
@@ -80,7 +80,7 @@ class _AttnCapturePacked(torch.autograd.Function):
             dqkv = torch.empty_like(qkv)
             out = (dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2])
         ops.attn_capture_bwd(q, k, v, ctx.probs, d_o, ctx.grads, scale, scale_mode, need_dqkv=need, layout="bnhd",
-                             out=out)
+                             out=out, o=o)
         if grad_hook is not None:
             grad_hook(ctx.grads)
         return dqkv, None, None, None, None, None, None, None
@@ -92,18 +92,18 @@ class _AttnCapture(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, mask, probs_slab, grads_slab, scale, scale_mode, grad_hook, anchor):
         o = ops.attn_capture_fwd(q, k, v, probs_slab, scale, scale_mode, mask, layout="bnhd")
-        ctx.save_for_backward(q, k, v)
+        ctx.save_for_backward(q, k, v, o)
         ctx.probs, ctx.grads = probs_slab, grads_slab
         ctx.cfg = (scale, scale_mode, grad_hook)
         return o
 
     @staticmethod
     def backward(ctx, d_o):
-        q, k, v = ctx.saved_tensors
+        q, k, v, o = ctx.saved_tensors
         scale, scale_mode, grad_hook = ctx.cfg
         need = any(ctx.needs_input_grad[:3])
         dq, dk, dv = ops.attn_capture_bwd(q, k, v, ctx.probs, d_o, ctx.grads, scale, scale_mode, need_dqkv=need,
-                                          layout="bnhd")
+                                          layout="bnhd", o=o)
         if grad_hook is not None:
             grad_hook(ctx.grads)
         return dq, dk, dv, None, None, None, None, None, None, None

@@ -162,7 +162,7 @@ class Transformer(nn.Module):
             h2, mean2, rstd2 = torch.native_layer_norm(x1, (E,), blk.ln_2.weight, blk.ln_2.bias, blk.ln_2.eps)
             m = blk.mlp.c_fc(h2)
             x2 = x1 + blk.mlp.c_proj(m * torch.sigmoid(1.702 * m))
-            tape.append((x, mean1, rstd1, qkv, x1, mean2, rstd2, m))
+            tape.append((x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o))
             blk.attn_probs, blk.attn_grad = buffers.layer_probs(l), buffers.layer_grads(l)
             x = x2
         return x, tape
@@ -177,7 +177,7 @@ class Transformer(nn.Module):
         for l in range(self.layers - 1, first_grad_layer - 1, -1):
             blk = self.resblocks[l]
             at = blk.attn
-            x, mean1, rstd1, qkv, x1, mean2, rstd2, m = tape[l]
+            x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o_fwd = tape[l]
             # MLP branch: x2 = x1 + c_proj(m * sigmoid(1.702 m)),  m = c_fc(ln_2(x1))
             d_a = self._gemm(dx, blk.mlp.c_proj.weight)
             sg = torch.sigmoid(1.702 * m)
@@ -190,7 +190,8 @@ class Transformer(nn.Module):
             dqkv = torch.empty(B, N, 3, at.num_heads, at.head_dim, dtype=torch.float32, device=dy.device) if need else None
             out = (dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]) if need else None
             ops.attn_capture_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], buffers.probs[l], d_o, buffers.grads[l],
-                                 at.head_dim ** -0.5, _lib.SCALE_Q_FIRST, need_dqkv=need, layout="bnhd", out=out, batch=B)
+                                 at.head_dim ** -0.5, _lib.SCALE_Q_FIRST, need_dqkv=need, layout="bnhd", out=out, batch=B,
+                                 o=o_fwd)
             if not need:
                 break
             d_h1 = self._gemm(dqkv.view(B, N, 3 * E), at.in_proj_weight)

@@ -22,6 +22,7 @@ struct AttnBwdArgs {
     Strides qs, ks, vs;
     const float* probs; int64_t probs_sb;  // batch stride of P in elements (0: one P shared by the whole batch)
     const float* dout; Strides os;
+    const float* o; Strides oos;   // optional forward output O (same logical shape as dout): delta = rowsum(dO * O) without a sweep
     float* dprobs;
     float *dq, *dk, *dv;
     Strides dqs, dks, dvs;

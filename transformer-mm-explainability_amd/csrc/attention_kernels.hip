@@ -369,7 +369,7 @@ extern "C" int mmx_attn_capture_bwd(const void* q_dev, const void* k_dev, const 
                                     int Nk, int D, float scale, int scale_mode, int need_dqkv, void* workspace_dev,
                                     size_t workspace_bytes, void* stream) {
     return mmx_attn_capture_bwd_ex(q_dev, k_dev, v_dev, q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn, probs_dev,
-                                   probs_sb, MMX_F32, do_dev, o_sb, o_sh, o_sn, dprobs_dev, dq_dev, dk_dev, dv_dev, dq_sb,
+                                   probs_sb, MMX_F32, do_dev, o_sb, o_sh, o_sn, nullptr, 0, 0, 0, dprobs_dev, dq_dev, dk_dev, dv_dev, dq_sb,
                                    dq_sh, dq_sn, dk_sb, dk_sh, dk_sn, dv_sb, dv_sh, dv_sn, B, H, Nq, Nk, D, scale,
                                    scale_mode, need_dqkv, workspace_dev, workspace_bytes, stream);
 }
@@ -377,7 +377,8 @@ extern "C" int mmx_attn_capture_bwd(const void* q_dev, const void* k_dev, const 
 extern "C" int mmx_attn_capture_bwd_ex(const void* q_dev, const void* k_dev, const void* v_dev, int64_t q_sb,
                                        int64_t q_sh, int64_t q_sn, int64_t k_sb, int64_t k_sh, int64_t k_sn, int64_t v_sb,
                                        int64_t v_sh, int64_t v_sn, const void* probs_dev, int64_t probs_sb, int slab_dtype,
-                                       const void* do_dev, int64_t o_sb, int64_t o_sh, int64_t o_sn, void* dprobs_dev,
+                                       const void* do_dev, int64_t o_sb, int64_t o_sh, int64_t o_sn, const void* fwd_o_dev,
+                                       int64_t fo_sb, int64_t fo_sh, int64_t fo_sn, void* dprobs_dev,
                                        void* dq_dev, void* dk_dev, void* dv_dev, int64_t dq_sb, int64_t dq_sh,
                                        int64_t dq_sn, int64_t dk_sb, int64_t dk_sh, int64_t dk_sn, int64_t dv_sb,
                                        int64_t dv_sh, int64_t dv_sn, int B, int H, int Nq, int Nk, int D, float scale,
@@ -401,6 +402,8 @@ extern "C" int mmx_attn_capture_bwd_ex(const void* q_dev, const void* k_dev, con
     a.qs = {q_sb, q_sh, q_sn}; a.ks = {k_sb, k_sh, k_sn}; a.vs = {v_sb, v_sh, v_sn};
     a.probs = static_cast<const float*>(probs_dev); a.probs_sb = probs_sb;
     a.dout = static_cast<const float*>(do_dev); a.os = {o_sb, o_sh, o_sn};
+    a.o = static_cast<const float*>(fwd_o_dev); a.oos = {fo_sb, fo_sh, fo_sn};
+    if (reinterpret_cast<uintptr_t>(fwd_o_dev) % 16 || fo_sb % 4 || fo_sh % 4 || fo_sn % 4) a.o = nullptr;   // a hint only
     a.dprobs = static_cast<float*>(dprobs_dev);
     a.dq = static_cast<float*>(dq_dev); a.dk = static_cast<float*>(dk_dev); a.dv = static_cast<float*>(dv_dev);
     a.dqs = {dq_sb, dq_sh, dq_sn}; a.dks = {dk_sb, dk_sh, dk_sn}; a.dvs = {dv_sb, dv_sh, dv_sn};

@@ -309,7 +309,25 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
     };
 
     float delta[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.need_dqkv) {
+    if (a.need_dqkv && a.o) {
+        // delta = rowsum(P * dP) = rowsum(dO * O)  (sum_k P_k (dO . V_k) = dO . sum_k P_k V_k): with the forward's O at
+        // hand no sweep over the keys is needed.  Lane (row i, slot g) holds dO[row i][its d's]; the four slots of a
+        // row are added with two cross-row shuffles, then the C-layout rows 4g + r pick their value up.
+        const float* ob = a.o + b * a.oos.sb + h * a.oos.sh;
+        f32x4 oa[NB];
+        load_a_rows<DP>(oa, ob, a.oos.sn, min(rw + i, a.Nq - 1), a.D, g, 1.f);
+        float part = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+            part += doa[blk][0] * oa[blk][0] + doa[blk][1] * oa[blk][1] + doa[blk][2] * oa[blk][2] + doa[blk][3] * oa[blk][3];
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);                         // every lane with lane & 15 == i now holds delta of row rw + i
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            delta[r] = __shfl(part, 4 * g + r);
+            if (i == 0 && rows[r] < a.Nq) a.delta[head * a.Nq + rows[r]] = delta[r];
+        }
+    } else if (a.need_dqkv) {
         // ---- sweep 1: delta (dP is recomputed in sweep 2 instead of being read back)
         auto sweep1 = [&](int kt, auto edge) {
             float p[4][4];

@@ -380,11 +380,12 @@ def attn_capture_fwd(q, k, v, probs_out, scale, scale_mode=_lib.SCALE_Q_FIRST, m
 
 
 def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCALE_Q_FIRST, need_dqkv=True,
-                     layout="bnhd", out=None, batch=None):
+                     layout="bnhd", out=None, batch=None, o=None):
     """Writes dP into ``dprobs_out`` and returns ``(dq, dk, dv)`` (``None`` when ``need_dqkv`` is False).
     ``out=(dq, dk, dv)`` lets the caller hand in (strided) views, e.g. of one packed dqkv tensor.
     ``batch``: shared-forward mode -- q/k/v/probs come from ONE forward (batch 1) and are broadcast (stride 0) over the
-    ``batch`` upstream gradients in ``d_o``; dq/dk/dv/dprobs are per sample."""
+    ``batch`` upstream gradients in ``d_o``; dq/dk/dv/dprobs are per sample.
+    ``o``: the forward's output (same layout as ``q``), optional: saves the long-sequence kernels a sweep over the keys."""
     _dev(q, k, v, probs, d_o, dprobs_out)
     if probs.dtype not in _DTYPES or probs.dtype != dprobs_out.dtype:
         raise MMXError("attn_capture_bwd: probs / dprobs slabs must share one of fp32 / fp16 / bf16")
@@ -400,6 +401,8 @@ def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCA
             raise MMXError("shared-forward backward needs batch-1 q/k/v")
         B = batch
         q, k, v = (t.expand(B, *t.shape[1:]) for t in (q, k, v))      # stride-0 views, no copy
+        if o is not None:
+            o = o.expand(B, *o.shape[1:])
     probs_sb = 0 if shared else H * Nq * Nk
     if d_o.stride(-1) != 1:
         d_o = d_o.contiguous()
@@ -414,10 +417,12 @@ def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCA
         need = lib().mmx_attn_capture_bwd_workspace_bytes(B, H, Nq)
         ws = _workspace(need, q.device, "attn_bwd")
     zero3 = (0, 0, 0)
+    if o is not None and (o.dtype != torch.float32 or o.stride(-1) != 1):
+        o = None                                               # only a hint: fall back to the two-sweep form
     check(lib().mmx_attn_capture_bwd_ex(
         _p(q), _p(k), _p(v), *_bhnd_strides(q, layout), *_bhnd_strides(k, layout), *_bhnd_strides(v, layout),
-        _p(probs), probs_sb, _DTYPES[probs.dtype], _p(d_o), *_bhnd_strides(d_o, layout), _p(dprobs_out), _p(dq), _p(dk),
-        _p(dv),
+        _p(probs), probs_sb, _DTYPES[probs.dtype], _p(d_o), *_bhnd_strides(d_o, layout),
+        _p(o), *(_bhnd_strides(o, layout) if o is not None else zero3), _p(dprobs_out), _p(dq), _p(dk), _p(dv),
         *(_bhnd_strides(dq, layout) if need_dqkv else zero3), *(_bhnd_strides(dk, layout) if need_dqkv else zero3),
         *(_bhnd_strides(dv, layout) if need_dqkv else zero3),
         B, H, Nq, Nk, D, float(scale), scale_mode, int(need_dqkv), _p(ws), need, _stream()), "mmx_attn_capture_bwd")

@@ -176,7 +176,7 @@ class VisionTransformer(nn.Module):
             h2, mean2, rstd2 = torch.native_layer_norm(x1, (E,), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
             m = blk.mlp.fc1(h2)
             x2 = x1 + blk.mlp.fc2(F.gelu(m))
-            tape.append((x, mean1, rstd1, qkv, x1, mean2, rstd2, m))
+            tape.append((x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o))
             at.attention_map, at.attn_gradients = buf.probs[l], buf.grads[l]
             x = x2
         f, mean, rstd = torch.native_layer_norm(x, (E,), self.norm.weight, self.norm.bias, self.norm.eps)
@@ -202,7 +202,7 @@ class VisionTransformer(nn.Module):
         for l in range(self.depth - 1, -1, -1):
             blk = self.blocks[l]
             at = blk.attn
-            x, mean1, rstd1, qkv, x1, mean2, rstd2, m = tape[l]
+            x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o_fwd = tape[l]
             d_a = self._gemm(dx, blk.mlp.fc2.weight)
             gelu_prime = 0.5 * (1 + torch.erf(m / math.sqrt(2.0))) + m * torch.exp(-0.5 * m * m) / math.sqrt(2 * math.pi)
             d_h2 = self._gemm(d_a * gelu_prime, blk.mlp.fc1.weight)
@@ -212,7 +212,7 @@ class VisionTransformer(nn.Module):
             dqkv = torch.empty(K, N, 3, at.num_heads, at.head_dim, dtype=torch.float32, device=dx.device) if need else None
             out = (dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]) if need else None
             ops.attn_capture_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], buf.probs[l], d_o, buf.grads[l], 1.0 / at.scale,
-                                 _lib.SCALE_SCORES, need_dqkv=need, layout="bnhd", out=out, batch=K)
+                                 _lib.SCALE_SCORES, need_dqkv=need, layout="bnhd", out=out, batch=K, o=o_fwd)
             if not need:
                 break
             d_h1 = self._gemm(dqkv.view(K, N, 3 * E), at.qkv.weight)
