@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 1
+#define MMX_ABI_VERSION 1   /* within a version entry points are only ever ADDED (the *_ex forms); a binding checks == */
 #define MMX_MAX_LAYERS 48
 
 enum mmx_dtype { MMX_F32 = 0, MMX_F16 = 1, MMX_BF16 = 2 };
