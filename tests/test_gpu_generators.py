@@ -428,3 +428,17 @@ def test_detr_mask_generator_r50_shape():
         assert (masks[0, idx] != ref).float().mean() < 0.01
     rollout_masks, _ = mg.get_masks(feats, "rollout")
     assert set(rollout_masks[0, kept].unique().tolist()) <= {0.0, 255.0}
+
+
+def test_detr_bf16_backward_gemms_stay_close(golden):
+    """Opt-in bf16 input-gradient GEMMs in the shared-forward DETR backward: relevancies within bf16 precision."""
+    from transformer_mm_explainability_amd.detr_explainability import Generator
+    g = golden("detr_transformer")
+    model = _detr_from_golden(g)
+    feats = cu(g["features"])
+    targets = torch.tensor([4, 0, 6], device="cuda")
+    want = Generator(model).generate_ours_multi(feats, targets).clone()
+    model.transformer.backward_gemm_dtype = torch.bfloat16
+    got = Generator(model).generate_ours_multi(feats, targets)
+    assert (got - want).abs().max() <= 3e-2 * want.abs().max()
+    assert torch.nn.functional.cosine_similarity(got.reshape(3, -1), want.reshape(3, -1), dim=-1).min() > 0.999

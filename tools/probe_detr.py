@@ -48,3 +48,9 @@ for K in (5, 10, 20):
     t = torch.arange(K, device="cuda") * 3
     ms = timed(lambda: gen.generate_ours_multi(feats, t, share_forward=False), n=5, warm=2)
     print("  replicated forward       K=%-2d %.2f ms  (%.2f ms/query)" % (K, ms, ms / K))
+
+model.transformer.backward_gemm_dtype = torch.bfloat16
+for K in (10, 20):
+    t = torch.arange(K, device="cuda") * 3
+    ms = timed(lambda: gen.generate_ours_multi(feats, t), n=5, warm=2)
+    print("  bf16 backward GEMMs      K=%-2d %.2f ms  (%.2f ms/query, %.0f queries/s)" % (K, ms, ms / K, K / ms * 1e3))

@@ -121,21 +121,21 @@ class MultiheadAttention(_SlabOwner):
         return self.out_proj(o.reshape(1, T, self.embed_dim)), (q, k, v, o)
 
     @torch.no_grad()
-    def backward_shared(self, tape, d_out, need_input_grads=True):
+    def backward_shared(self, tape, d_out, need_input_grads=True, gemm_dtype=torch.float32):
         """``d_out [K, T, E]`` -> ``(d_query [K, T, E], d_key [K, S, E], d_value [K, S, E])`` (``None`` when not needed);
         always writes dL/dP of the K samples into the gradient slab."""
         q, k, v, o_fwd = tape
         K, T = d_out.shape[0], d_out.shape[1]
-        d_o = torch.matmul(d_out, self.out_proj.weight).view(K, T, self.num_heads, self.head_dim)
+        d_o = ops.backward_gemm(d_out, self.out_proj.weight, gemm_dtype).view(K, T, self.num_heads, self.head_dim)
         dq, dk, dv = ops.attn_capture_bwd(q, k, v, self._probs, d_o, self._grads, float(self.head_dim) ** -0.5,
                                           _lib.SCALE_Q_FIRST, need_dqkv=need_input_grads, layout="bnhd", batch=K,
                                           o=o_fwd)
         if not need_input_grads:
             return None, None, None
         E = self.embed_dim
-        return (torch.matmul(dq.reshape(K, T, E), self.q_proj.weight),
-                torch.matmul(dk.reshape(K, -1, E), self.k_proj.weight),
-                torch.matmul(dv.reshape(K, -1, E), self.v_proj.weight))
+        return (ops.backward_gemm(dq.reshape(K, T, E), self.q_proj.weight, gemm_dtype),
+                ops.backward_gemm(dk.reshape(K, -1, E), self.k_proj.weight, gemm_dtype),
+                ops.backward_gemm(dv.reshape(K, -1, E), self.v_proj.weight, gemm_dtype))
 
 
 class BertStyleAttention(_SlabOwner):

@@ -120,14 +120,7 @@ class Transformer(nn.Module):
 
     def _gemm(self, x, weight):
         """``x @ weight`` for the hand-written backward, in ``backward_gemm_dtype`` (cached converted weights)."""
-        dt = self.backward_gemm_dtype
-        if dt == torch.float32:
-            return torch.matmul(x, weight)
-        cache = self.__dict__.setdefault("_gemm_weights", {})
-        key = (id(weight), dt)
-        if key not in cache or cache[key][0] != weight._version:
-            cache[key] = (weight._version, weight.detach().to(dt))
-        return torch.matmul(x.to(dt), cache[key][1]).float()
+        return ops.backward_gemm(x, weight, getattr(self, "backward_gemm_dtype", torch.float32))
 
     def _ensure_buffers(self, batch, n_tokens, device, shared_probs=False):
         if self.buffers is None or not self.buffers.matches(self.layers, batch, self.heads, n_tokens, n_tokens, device,

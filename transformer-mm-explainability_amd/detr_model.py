@@ -61,10 +61,10 @@ class _FeedForward:
         h = self.linear1(x)
         return self.linear2(F.relu(h)), h
 
-    def _ffn_bwd_shared(self, h, d_out):
+    def _ffn_bwd_shared(self, h, d_out, gemm_dtype=torch.float32):
         """``d_out [K, T, E]`` -> gradient w.r.t. the feed-forward input; ``h [1, T, F]`` is the shared pre-activation."""
-        d_h = torch.matmul(d_out, self.linear2.weight) * (h > 0)
-        return torch.matmul(d_h, self.linear1.weight)
+        d_h = ops.backward_gemm(d_out, self.linear2.weight, gemm_dtype) * (h > 0)
+        return ops.backward_gemm(d_h, self.linear1.weight, gemm_dtype)
 
 
 class TransformerEncoderLayer(nn.Module, _FeedForward):
@@ -100,11 +100,11 @@ class TransformerEncoderLayer(nn.Module, _FeedForward):
         out, ln2 = _ln_fwd(self.norm2, src1 + ff)
         return out, (att, ln1, h, ln2)
 
-    def backward_shared(self, tape, d_out, need_input_grad=True):
+    def backward_shared(self, tape, d_out, need_input_grad=True, gemm_dtype=torch.float32):
         att, ln1, h, ln2 = tape
         d_z2 = _ln_bwd(self.norm2, ln2, d_out)                           # w.r.t. src1 + ff
-        d_z1 = _ln_bwd(self.norm1, ln1, d_z2 + self._ffn_bwd_shared(h, d_z2))   # w.r.t. src + attention output
-        dq, dk, dv = self.self_attn.backward_shared(att, d_z1, need_input_grad)
+        d_z1 = _ln_bwd(self.norm1, ln1, d_z2 + self._ffn_bwd_shared(h, d_z2, gemm_dtype))   # w.r.t. src + attention output
+        dq, dk, dv = self.self_attn.backward_shared(att, d_z1, need_input_grad, gemm_dtype)
         return d_z1 + dq + dk + dv if need_input_grad else None          # pos is a constant: q, k and v all lead to src
 
 
@@ -153,14 +153,14 @@ class TransformerDecoderLayer(nn.Module, _FeedForward):
         out, ln3 = _ln_fwd(self.norm3, tgt2 + ff)
         return out, (t_self, ln1, t_cross, ln2, h, ln3)
 
-    def backward_shared(self, tape, d_out, need_tgt_grad=True):
+    def backward_shared(self, tape, d_out, need_tgt_grad=True, gemm_dtype=torch.float32):
         """``d_out [K, Q, E]`` -> ``(d_tgt [K, Q, E] | None, d_memory [K, N, E])``."""
         t_self, ln1, t_cross, ln2, h, ln3 = tape
         d_z3 = _ln_bwd(self.norm3, ln3, d_out)                             # w.r.t. tgt2 + ff
-        d_z2 = _ln_bwd(self.norm2, ln2, d_z3 + self._ffn_bwd_shared(h, d_z3))   # w.r.t. tgt1 + cross-attention output
-        dq, dk, dv = self.multihead_attn.backward_shared(t_cross, d_z2)
+        d_z2 = _ln_bwd(self.norm2, ln2, d_z3 + self._ffn_bwd_shared(h, d_z3, gemm_dtype))   # w.r.t. tgt1 + cross-attn output
+        dq, dk, dv = self.multihead_attn.backward_shared(t_cross, d_z2, True, gemm_dtype)
         d_z1 = _ln_bwd(self.norm1, ln1, d_z2 + dq)                         # w.r.t. tgt + self-attention output
-        sq, sk, sv = self.self_attn.backward_shared(t_self, d_z1, need_tgt_grad)
+        sq, sk, sv = self.self_attn.backward_shared(t_self, d_z1, need_tgt_grad, gemm_dtype)
         return (d_z1 + sq + sk + sv if need_tgt_grad else None), dk + dv
 
 
@@ -253,13 +253,14 @@ class Transformer(nn.Module):
     def backward_shared(self, tape, d_hs):
         """``d_hs [K, Q, C]``: per-sample upstream gradients of ``hs_last``; fills every block's gradient slab."""
         enc_tapes, dec_tapes, ln = tape
+        gd = getattr(self, "backward_gemm_dtype", torch.float32)      # torch.bfloat16: opt-in bf16 MFMA for the dX GEMMs
         d_out = _ln_bwd(self.decoder.norm, ln, d_hs)
         d_memory = None
         for i in range(len(self.decoder.layers) - 1, -1, -1):
-            d_out, d_mem = self.decoder.layers[i].backward_shared(dec_tapes[i], d_out, need_tgt_grad=i > 0)
+            d_out, d_mem = self.decoder.layers[i].backward_shared(dec_tapes[i], d_out, need_tgt_grad=i > 0, gemm_dtype=gd)
             d_memory = d_mem if d_memory is None else d_memory + d_mem
         for i in range(len(self.encoder.layers) - 1, -1, -1):         # the first layer's input is a constant of the pass
-            d_memory = self.encoder.layers[i].backward_shared(enc_tapes[i], d_memory, need_input_grad=i > 0)
+            d_memory = self.encoder.layers[i].backward_shared(enc_tapes[i], d_memory, need_input_grad=i > 0, gemm_dtype=gd)
 
 
 class PositionEmbeddingSine(nn.Module):

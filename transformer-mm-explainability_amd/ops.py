@@ -173,6 +173,22 @@ def layernorm_bwd_add(dy, x, mean, rstd, gamma, d_res=None):
     return dx
 
 
+_GEMM_WEIGHTS = {}
+
+
+def backward_gemm(x, weight, dtype=torch.float32):
+    """``x @ weight`` for the hand-written (shared-forward) backward passes.  ``dtype=torch.bfloat16`` (opt-in per tower /
+    body, ``backward_gemm_dtype``) runs it on the bf16 MFMA with fp32 accumulation and an fp32 result; the converted
+    weight is cached until the parameter is modified in place.  A plain library GEMM either way (hipBLASLt / rocBLAS)."""
+    if dtype == torch.float32:
+        return torch.matmul(x, weight)
+    key = (id(weight), dtype)
+    hit = _GEMM_WEIGHTS.get(key)
+    if hit is None or hit[0] != weight._version or hit[1].device != weight.device:
+        hit = _GEMM_WEIGHTS[key] = (weight._version, weight.detach().to(dtype))
+    return torch.matmul(x.to(dtype), hit[1]).float()
+
+
 class ChainPlan:
     """A prepared ``relevancy_self_chain`` launch over persistent slabs: pointer tables, scratch and the output tensor are
     built once; ``launch()`` is a single C call (no per-call Python tensor plumbing).  The captured slabs of a tower

@@ -128,14 +128,7 @@ class VisionTransformer(nn.Module):
     def _gemm(self, x, weight):
         """``x @ weight`` of the hand-written backward in ``backward_gemm_dtype`` (default fp32; ``torch.bfloat16`` =
         bf16 MFMA with fp32 accumulation and results, see ``clip_model.Transformer._gemm``)."""
-        dt = getattr(self, "backward_gemm_dtype", torch.float32)
-        if dt == torch.float32:
-            return torch.matmul(x, weight)
-        cache = self.__dict__.setdefault("_gemm_weights", {})
-        key = (id(weight), dt)
-        if key not in cache or cache[key][0] != weight._version:
-            cache[key] = (weight._version, weight.detach().to(dt))
-        return torch.matmul(x.to(dt), cache[key][1]).float()
+        return ops.backward_gemm(x, weight, getattr(self, "backward_gemm_dtype", torch.float32))
 
     def _slabs(self, batch, n_tokens, device, shared=False):
         b = self.buffers_
