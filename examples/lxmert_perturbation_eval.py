@@ -55,42 +55,40 @@ def main():
     torch.manual_seed(0)
     model = lm.LxmertForQuestionAnswering(cfg).to(dev).eval()
     indices = sharding.perturbation_sample_indices(args.dataset_len, args.num_samples)      # same list on every rank
-    mine = sharding.shard_indices(indices)
-    store = sharding.PartialScores(args.resume_dir, rank) if args.resume_dir else None
-    todo = [k for k in mine if store is None or k not in store.done()]
-    items = [synthetic_item(k, 36, cfg.visual_feat_dim, cfg.vocab_size, cfg.num_qa_labels) for k in todo]
     gen = le.GeneratorOurs(type("Usage", (), {"model": model})())
     pert = lp.LxmertPerturbation(model)
-    fresh = torch.zeros(len(todo), len(lp.PERT_STEPS), device=dev)
+    store = sharding.PartialScores(args.resume_dir, rank) if args.resume_dir else None
+    cache = {}
 
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for T, positions in sharding.length_buckets([it["input_ids"].numel() for it in items], args.max_batch):
-        B = len(positions)
-        batch = dict(input_ids=torch.stack([items[p]["input_ids"] for p in positions]).to(dev),
+    def item(k):
+        if k not in cache:
+            cache[k] = synthetic_item(k, 36, cfg.visual_feat_dim, cfg.vocab_size, cfg.num_qa_labels)
+        return cache[k]
+
+    def process_batch(ids):                    # explain + perturb one bucket of equal-length items -> [B, 9] accuracies
+        items = [cache.pop(k, None) or synthetic_item(k, 36, cfg.visual_feat_dim, cfg.vocab_size, cfg.num_qa_labels) for k in ids]
+        B, T = len(items), items[0]["input_ids"].numel()
+        batch = dict(input_ids=torch.stack([it["input_ids"] for it in items]).to(dev),
                      attention_mask=torch.ones(B, T, device=dev), token_type_ids=torch.zeros(B, T, dtype=torch.long, device=dev),
-                     visual_feats=torch.stack([items[p]["visual_feats"] for p in positions]).to(dev),
-                     visual_pos=torch.stack([items[p]["visual_pos"] for p in positions]).to(dev))
+                     visual_feats=torch.stack([it["visual_feats"] for it in items]).to(dev),
+                     visual_pos=torch.stack([it["visual_pos"] for it in items]).to(dev))
         R_t_t, R_t_i = gen.generate_ours_batch(batch)
         cam_image, cam_text = lp.normalize_cams_batch(R_t_t, R_t_i)
         scores = pert.perturbation_text(batch, cam_text, args.positive) if args.text else \
             pert.perturbation_image(batch, cam_image, args.positive)
-        labels = torch.stack([items[p]["label"] for p in positions]).to(dev)
-        acc_rows = lp.LxmertPerturbation.accuracy(scores, labels)
-        fresh[torch.tensor(positions, device=dev)] = acc_rows
-        if store is not None:
-            store.add([todo[p] for p in positions], acc_rows)
+        labels = torch.stack([it["label"] for it in items]).to(dev)
+        return lp.LxmertPerturbation.accuracy(scores, labels)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    per_sample = sharding.evaluate_sharded(indices, lambda k: item(k)["input_ids"].numel(), process_batch,
+                                           len(lp.PERT_STEPS), max_batch=args.max_batch, store=store, device=dev)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if store is not None:
-        local = store.table(mine, device=dev)            # resumed rows + the ones computed now, in shard order
-    else:
-        local = fresh
-    per_sample = sharding.gather_per_sample(local, len(indices))                             # the one exchange step
     acc = sharding.mean_step_accuracy(per_sample)
     if rank == 0:
         print(json.dumps({"samples": len(indices), "n_gpus": world, "seconds": round(elapsed, 3),

@@ -47,3 +47,40 @@ def test_reference_sample_selection_is_reproduced():
     random.shuffle(ref)
     assert sharding.perturbation_sample_indices(50, 20) == ref[:20]
     assert sharding.shard_indices(list(range(10)), 1, 4) == [1, 5, 9]
+
+
+def _eval_worker(rank, world_size, port, total, tmpdir, resume):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from transformer_mm_explainability_amd import sharding
+    ids = sharding.perturbation_sample_indices(200, total)
+    calls = []
+
+    def process(batch_ids):                       # fake scorer: row = [id, id^2 mod 97, bucket length]
+        calls.append(list(batch_ids))
+        assert len({k % 5 for k in batch_ids}) == 1, "a batch must hold samples of one length"
+        return torch.tensor([[float(k), float(k * k % 97), float(6 + k % 5)] for k in batch_ids])
+
+    store = sharding.PartialScores(os.path.join(tmpdir, "partial"), rank) if resume else None
+    full = sharding.evaluate_sharded(ids, lambda k: 6 + k % 5, process, 3, max_batch=4, store=store)
+    want = torch.tensor([[float(k), float(k * k % 97), float(6 + k % 5)] for k in ids])
+    torch.save({"ok": bool(torch.equal(full, want)), "n_calls": len(calls), "max_batch": max((len(c) for c in calls), default=0)},
+               os.path.join(tmpdir, "e%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_evaluate_sharded_world2_and_resume(tmp_path):
+    """Whole evaluator data flow on 2 ranks: shards -> length buckets -> batches <= max_batch -> one gather; a second
+    run over the same partial-score directory recomputes nothing and returns the same table."""
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_eval_worker, args=(2, port, 23, str(tmp_path), True), nprocs=2, join=True)
+    first = [torch.load(tmp_path / ("e%d.pt" % r)) for r in (0, 1)]
+    assert all(f["ok"] for f in first) and all(0 < f["max_batch"] <= 4 for f in first)
+    mp.spawn(_eval_worker, args=(2, port + 1, 23, str(tmp_path), True), nprocs=2, join=True)
+    second = [torch.load(tmp_path / ("e%d.pt" % r)) for r in (0, 1)]
+    assert all(s["ok"] for s in second) and all(s["n_calls"] == 0 for s in second)
+    (tmp_path / "fresh").mkdir()
+    mp.spawn(_eval_worker, args=(2, port + 2, 5, str(tmp_path / "fresh"), False), nprocs=2, join=True)
+    assert all(torch.load(tmp_path / "fresh" / ("e%d.pt" % r))["ok"] for r in (0, 1))

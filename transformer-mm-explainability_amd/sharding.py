@@ -77,6 +77,37 @@ def gather_per_sample(local, total, fill=float("nan")):
     return out.transpose(0, 1).reshape((per * world_size,) + tuple(local.shape[1:]))[:total]
 
 
+def evaluate_sharded(sample_ids, length_of, process_batch, n_cols, max_batch=128, store=None, device="cpu"):
+    """The sharded evaluator loop in one place (``examples/lxmert_perturbation_eval.py`` is this plus a model).
+
+    ``sample_ids``: the FULL, identically ordered sample list (every rank passes the same one).  This rank takes its
+    rank-strided shard, skips what ``store`` (a ``PartialScores``) already holds, buckets the rest by ``length_of(id)``
+    (equal-length batches of at most ``max_batch``), calls ``process_batch(ids) -> [len(ids), n_cols]`` per bucket,
+    records the rows in ``store`` if given, and finally all-gathers every rank's rows back into ``sample_ids`` order.
+    Returns ``[len(sample_ids), n_cols]`` on every rank.  The only collective is that final gather.
+    """
+    mine = shard_indices(sample_ids)
+    todo = [k for k in mine if store is None or k not in store.done()]
+    fresh = {}
+    for _, positions in length_buckets([length_of(k) for k in todo], max_batch):
+        ids = [todo[p] for p in positions]
+        rows = process_batch(ids)
+        if tuple(rows.shape) != (len(ids), n_cols):
+            raise ValueError("process_batch returned %s for %d ids x %d columns" % (tuple(rows.shape), len(ids), n_cols))
+        if store is not None:
+            store.add(ids, rows)
+        else:
+            for k, row in zip(ids, rows):
+                fresh[k] = row
+    if store is not None:
+        local = store.table(mine, device=device)
+    elif mine:
+        local = torch.stack([fresh[k] for k in mine]).to(device=device, dtype=torch.float32)
+    else:
+        local = torch.zeros(0, n_cols, dtype=torch.float32, device=device)
+    return gather_per_sample(local, len(sample_ids))
+
+
 def mean_step_accuracy(per_sample_scores):
     """``[total, n_steps]`` per-sample scores -> the evaluators' printed metric: mean over samples x 100
     (perturbation.py:250-251).  NaN padding rows are never present after ``gather_per_sample``."""
