@@ -104,3 +104,25 @@ def test_partial_scores_resume(tmp_path):
     again.close()
     assert sharding.PartialScores(str(tmp_path), rank=3).done() == {11, 4, 7, 99}
     assert sharding.PartialScores(str(tmp_path), rank=0).done() == set()
+
+
+def test_forward_for_backward_freezes_when_possible_and_falls_back_otherwise():
+    """rules.forward_for_backward: parameters frozen if the score stays differentiable (input leaf / capture-op bodies),
+    else the reference route (parameters requiring grad); requires_grad flags are always restored."""
+    import torch.nn as nn
+    from transformer_mm_explainability_amd import rules
+    lin = nn.Linear(4, 3)
+    x_leaf = torch.randn(2, 4, requires_grad=True)
+    out = rules.forward_for_backward(lin, lambda: lin(x_leaf))
+    out.sum().backward()
+    assert lin.weight.grad is None and x_leaf.grad is not None          # frozen route: activation gradients only
+    assert all(p.requires_grad for p in lin.parameters())
+    x_const = torch.randn(2, 4)
+    out = rules.forward_for_backward(lin, lambda: lin(x_const))          # detached under frozen parameters -> fallback
+    out.sum().backward()
+    assert lin.weight.grad is not None
+    with rules.frozen_parameters(lin):
+        assert not any(p.requires_grad for p in lin.parameters())
+    assert all(p.requires_grad for p in lin.parameters())
+    not_a_module = type("M", (), {})()
+    assert rules.forward_for_backward(not_a_module, lambda: x_leaf * 2).requires_grad
