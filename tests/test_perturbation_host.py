@@ -126,3 +126,25 @@ def test_forward_for_backward_freezes_when_possible_and_falls_back_otherwise():
     assert all(p.requires_grad for p in lin.parameters())
     not_a_module = type("M", (), {})()
     assert rules.forward_for_backward(not_a_module, lambda: x_leaf * 2).requires_grad
+
+
+def test_backward_gemm_cache_follows_the_parameter():
+    """ops.backward_gemm: fp32 = plain matmul; bf16 = converted weight cached per parameter, refreshed after an in-place
+    update, dropped with the parameter."""
+    import gc
+    from transformer_mm_explainability_amd import ops
+    w = torch.nn.Parameter(torch.randn(8, 16))
+    x = torch.randn(3, 8)
+    assert torch.equal(ops.backward_gemm(x, w), x @ w)
+    y = ops.backward_gemm(x, w, torch.bfloat16)
+    assert y.dtype == torch.float32 and torch.allclose(y, x @ w, rtol=3e-2, atol=3e-2)
+    cached = ops._GEMM_WEIGHTS[id(w)][torch.bfloat16][1]
+    assert ops.backward_gemm(x, w, torch.bfloat16) is not None and ops._GEMM_WEIGHTS[id(w)][torch.bfloat16][1] is cached
+    with torch.no_grad():
+        w.mul_(2.0)
+    y2 = ops.backward_gemm(x, w, torch.bfloat16)
+    assert ops._GEMM_WEIGHTS[id(w)][torch.bfloat16][1] is not cached and torch.allclose(y2, 2 * y, rtol=1e-2, atol=1e-2)
+    n = len(ops._GEMM_WEIGHTS)
+    del w, cached
+    gc.collect()
+    assert len(ops._GEMM_WEIGHTS) == n - 1

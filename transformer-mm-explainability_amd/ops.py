@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -173,7 +175,7 @@ def layernorm_bwd_add(dy, x, mean, rstd, gamma, d_res=None):
     return dx
 
 
-_GEMM_WEIGHTS = {}
+_GEMM_WEIGHTS = {}   # id(parameter) -> {dtype: (version, converted copy)}; the entry is dropped when the parameter dies
 
 
 def backward_gemm(x, weight, dtype=torch.float32):
@@ -182,10 +184,13 @@ def backward_gemm(x, weight, dtype=torch.float32):
     weight is cached until the parameter is modified in place.  A plain library GEMM either way (hipBLASLt / rocBLAS)."""
     if dtype == torch.float32:
         return torch.matmul(x, weight)
-    key = (id(weight), dtype)
-    hit = _GEMM_WEIGHTS.get(key)
+    per_weight = _GEMM_WEIGHTS.get(id(weight))
+    if per_weight is None:
+        per_weight = _GEMM_WEIGHTS[id(weight)] = {}
+        weakref.finalize(weight, _GEMM_WEIGHTS.pop, id(weight), None)
+    hit = per_weight.get(dtype)
     if hit is None or hit[0] != weight._version or hit[1].device != weight.device:
-        hit = _GEMM_WEIGHTS[key] = (weight._version, weight.detach().to(dtype))
+        hit = per_weight[dtype] = (weight._version, weight.detach().to(dtype))
     return torch.matmul(x.to(dtype), hit[1]).float()
 
 
