@@ -152,13 +152,20 @@ def main():
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # Test hooks for a 1-GPU box (the N > 1 path cannot otherwise be exercised there): MMX_BENCH_SHARE_DEVICE=1 puts every
+    # rank on cuda:0, MMX_BENCH_BACKEND=gloo swaps RCCL (which refuses two ranks per GPU) for gloo.  Never set by the driver.
+    backend = os.environ.get("MMX_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("MMX_BENCH_SHARE_DEVICE") else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from transformer_mm_explainability_amd import clip_explainability as ce
     from transformer_mm_explainability_amd import clip_model, ops
@@ -177,7 +184,10 @@ def main():
     def step():
         R_text, R_image = run(image, texts)
         if world > 1:   # the evaluators' exchange step: per-sample maps gathered on every rank (KB-scale)
-            dist.all_gather_into_tensor(gathered, R_image.contiguous())
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered, R_image.contiguous())
+            else:           # gloo test hook: list form
+                dist.all_gather(list(gathered.view(world, BATCH, 49).unbind(0)), R_image.contiguous())
         return R_text, R_image
 
     def sync():
