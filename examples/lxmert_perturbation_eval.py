@@ -57,7 +57,9 @@ def main():
     indices = sharding.perturbation_sample_indices(args.dataset_len, args.num_samples)      # same list on every rank
     gen = le.GeneratorOurs(type("Usage", (), {"model": model})())
     pert = lp.LxmertPerturbation(model)
-    store = sharding.PartialScores(args.resume_dir, rank) if args.resume_dir else None
+    run_cfg = {"evaluator": "lxmert_perturbation", "method": "ours_no_lrp", "test": "text" if args.text else "image",
+               "positive": bool(args.positive), "steps": list(lp.PERT_STEPS), "dataset_len": args.dataset_len}
+    store = sharding.PartialScores(args.resume_dir, rank, config=run_cfg) if args.resume_dir else None
     cache = {}
 
     def item(k):

@@ -277,6 +277,134 @@ def gen_visualbert_chain():
          input_mask=input_mask, out=out, rollout_out=roll)
 
 
+# ----------------------------------------------------------------------------- LRP route on fake slots (round 2)
+class SlotCam(Slot):
+    """A hooked attention module after an LRP pass: ``get_attn_cam()`` returns a fixed per-head relevance."""
+
+    def __init__(self, attn, grad, cam):
+        super().__init__(attn, grad)
+        self._c = cam
+
+    def get_attn_cam(self):
+        return self._c
+
+
+def _lrp_cam(g, *shape):
+    """Stand-in for an alpha-beta LRP relevance of the attention probabilities: signed, sparse-ish, O(1e-1)."""
+    return torch.randn(*shape, generator=g) * 0.2 * (torch.rand(*shape, generator=g) > 0.3)
+
+
+def gen_detr_chain_lrp():
+    """``use_lrp=True`` (the DEFAULT of ``Generator.generate_ours``), ``generate_transformer_att`` and
+    ``generate_partial_lrp`` of the reference on slots that carry an ``attn_cam``; ``model.relprop`` records its call."""
+    g = torch.Generator().manual_seed(210)
+    H, Ni, Nq, Le, Ld = 4, 23, 9, 2, 3
+
+    def trio(nq, nk):
+        return softmax_attn(g, H, nq, nk), torch.randn(H, nq, nk, generator=g) * 0.1, _lrp_cam(g, H, nq, nk)
+
+    enc = [trio(Ni, Ni) for _ in range(Le)]
+    dself = [trio(Nq, Nq) for _ in range(Ld)]
+    dcross = [trio(Nq, Ni) for _ in range(Ld)]
+    logits = torch.randn(1, Nq, 7, generator=g).requires_grad_(True)
+    calls = []
+    model = FakeBody()
+    model.forward = lambda img: {"pred_logits": logits}
+    model.relprop = lambda one_hot, **kw: calls.append((one_hot.detach().clone(), dict(kw)))
+    model.transformer = types.SimpleNamespace(
+        encoder=types.SimpleNamespace(layers=[types.SimpleNamespace(self_attn=SlotCam(*t)) for t in enc]),
+        decoder=types.SimpleNamespace(layers=[
+            types.SimpleNamespace(self_attn=SlotCam(*dself[i]), multihead_attn=SlotCam(*dcross[i])) for i in range(Ld)]))
+    tgt = torch.tensor([5])
+    gen = detr_eg.Generator(model)
+    out = gen.generate_ours(None, tgt)                                   # default arguments: use_lrp=True
+    assert len(calls) == 1 and calls[0][1]["alpha"] == 1
+    arrays = dict(target_index=tgt, logits=logits, out_default=out, R_i_i=gen.R_i_i, R_q_q=gen.R_q_q,
+                  relprop_one_hot=calls[0][0], relprop_target_class=calls[0][1]["target_class"],
+                  transformer_att_out=detr_eg.Generator(model).generate_transformer_att(None, tgt),
+                  partial_lrp_out=detr_eg.Generator(model).generate_partial_lrp(None, tgt),
+                  abl_lrp_out=detr_eg.GeneratorAlbationNoAgg(model).generate_ours_abl(None, tgt, use_lrp=True),
+                  abl_noself_out=detr_eg.GeneratorAlbationNoAgg(model).generate_ours_abl(
+                      None, tgt, apply_self_in_rule_10=False))
+    for name, layers in (("enc", enc), ("dself", dself), ("dcross", dcross)):
+        arrays[name + "_attn"] = torch.stack([t[0] for t in layers])
+        arrays[name + "_grad"] = torch.stack([t[1] for t in layers])
+        arrays[name + "_cam"] = torch.stack([t[2] for t in layers])
+    save("detr_chain_lrp", **arrays)
+
+
+def gen_lxmert_chain_lrp():
+    g = torch.Generator().manual_seed(260)
+    H, T, I, Ll, Lr, Lx = 4, 8, 11, 3, 2, 3
+
+    def trio(nq, nk):
+        return (softmax_attn(g, 1, H, nq, nk), torch.randn(1, H, nq, nk, generator=g) * 0.1,
+                _lrp_cam(g, 1, H, nq, nk).abs())          # non-negative cams keep handle_residual's diag >= 0 contract
+
+    lang = [trio(T, T) for _ in range(Ll)]
+    vis = [trio(I, I) for _ in range(Lr)]
+    xl = [dict(lang_cross=trio(T, I), img_cross=trio(I, T), lang_self=trio(T, T), img_self=trio(I, I))
+          for _ in range(Lx)]
+    score = torch.randn(1, 11, generator=g).requires_grad_(True)
+    calls = []
+
+    def sa(t):
+        return types.SimpleNamespace(self=SlotCam(*t))
+
+    model = FakeBody()
+    model.device = torch.device("cpu")
+    model.relprop = lambda one_hot, **kw: calls.append((one_hot.detach().clone(), dict(kw)))
+    model.lxmert = types.SimpleNamespace(encoder=types.SimpleNamespace(
+        layer=[types.SimpleNamespace(attention=sa(t)) for t in lang],
+        r_layers=[types.SimpleNamespace(attention=sa(t)) for t in vis],
+        x_layers=[types.SimpleNamespace(
+            visual_attention=types.SimpleNamespace(att=SlotCam(*b["lang_cross"])),
+            visual_attention_copy=types.SimpleNamespace(att=SlotCam(*b["img_cross"])),
+            lang_self_att=sa(b["lang_self"]), visn_self_att=sa(b["img_self"])) for b in xl]))
+    usage = types.SimpleNamespace(model=model, text_len=T, image_boxes_len=I,
+                                  forward=lambda item: types.SimpleNamespace(question_answering_score=score))
+    gen = lx_eg.GeneratorOurs(usage)
+    R_t_t, R_t_i = gen.generate_ours(None)                               # default arguments: use_lrp=True
+    assert len(calls) == 1
+    arrays = dict(score=score, R_t_t=R_t_t, R_t_i=R_t_i, R_i_i=gen.R_i_i, R_i_t=gen.R_i_t, relprop_one_hot=calls[0][0])
+    base = lx_eg.GeneratorBaselines(usage)
+    arrays["tattr_R_t_t"], arrays["tattr_R_t_i"] = base.generate_transformer_attr(None)
+    arrays["plrp_R_t_t"], arrays["plrp_R_t_i"] = lx_eg.GeneratorBaselines(usage).generate_partial_lrp(None)
+    for name, layers in (("lang", lang), ("vis", vis)):
+        for j, part in enumerate(("attn", "grad", "cam")):
+            arrays["%s_%s" % (name, part)] = torch.stack([t[j] for t in layers])
+    for key in ("lang_cross", "img_cross", "lang_self", "img_self"):
+        for j, part in enumerate(("attn", "grad", "cam")):
+            arrays["x_%s_%s" % (key, part)] = torch.stack([b[key][j] for b in xl])
+    save("lxmert_chain_lrp", **arrays)
+
+
+def gen_visualbert_chain_lrp():
+    g = torch.Generator().manual_seed(410)
+    H, N, L = 4, 19, 4
+    layers = [(softmax_attn(g, 1, H, N, N), torch.randn(1, H, N, N, generator=g) * 0.1, _lrp_cam(g, 1, H, N, N))
+              for _ in range(L)]
+    scores = torch.randn(1, 9, generator=g).requires_grad_(True)
+    calls = []
+    model = FakeBody()
+    model.forward = lambda inp: {"scores": scores}
+    model.relprop = lambda one_hot, **kw: calls.append((one_hot.detach().clone(), dict(kw)))
+    model.model = types.SimpleNamespace(bert=types.SimpleNamespace(encoder=types.SimpleNamespace(
+        layer=[types.SimpleNamespace(attention=types.SimpleNamespace(self=SlotCam(*t))) for t in layers])))
+    input_mask = torch.zeros(1, N, dtype=torch.long)
+    input_mask[0, :7] = 1
+    arrays = dict(scores=scores, input_mask=input_mask,
+                  attn=torch.stack([t[0] for t in layers]), grad=torch.stack([t[1] for t in layers]),
+                  cam=torch.stack([t[2] for t in layers]),
+                  transformer_att_out=vb_eg.SelfAttentionGenerator(model).generate_transformer_att({"input_mask": input_mask}),
+                  transformer_att_s1=vb_eg.SelfAttentionGenerator(model).generate_transformer_att(
+                      {"input_mask": input_mask}, start_layer=1),
+                  partial_lrp_out=vb_eg.SelfAttentionGenerator(model).generate_partial_lrp({"input_mask": input_mask}))
+    assert len(calls) == 3
+    arrays["relprop_one_hot"] = calls[0][0]
+    save("visualbert_chain_lrp", **arrays)
+
+
 # ----------------------------------------------------------------------------- real hooked modules
 def gen_clip_tiny():
     aux = load_by_path("clip_ref_pkg.auxilary", os.path.join(REF, "CLIP/clip/auxilary.py"))
@@ -398,7 +526,7 @@ def gen_detr_transformer():
     save("detr_transformer", **arrays)
 
 
-def gen_lxmert_model():
+def _build_lxmert_ref():
     """The REAL reference LXMERT body (lxmert/lxmert/src/lxmert_lrp.py: embeddings, encoder with hooked attention,
     pooler, answer head) driven by the reference GeneratorOurs / GeneratorBaselines.  ``LxmertModel`` itself derives
     from a transformers base class whose API moved, so its forward (mask extension, lxmert_lrp.py:1188-1225) is
@@ -454,6 +582,11 @@ def gen_lxmert_model():
                   attention_mask=torch.ones(1, T), token_type_ids=torch.zeros(1, T, dtype=torch.long))
     # no padded text tokens: a padded query row has zero gradient, so its row of R_tt - I sums to 0 and the reference's
     # handle_residual (no nan_to_num in the LXMERT flavour) trips its own ``assert diag.min() >= 0`` on the NaN
+    return model, weights, inputs, cfg, T, I
+
+
+def gen_lxmert_model():
+    model, weights, inputs, cfg, T, I = _build_lxmert_ref()
     usage = types.SimpleNamespace(model=model, text_len=T, image_boxes_len=I, forward=lambda item: model(**inputs))
     gen = lx_eg.GeneratorOurs(usage)
     R_t_t, R_t_i = gen.generate_ours(None, use_lrp=False)
@@ -473,7 +606,7 @@ def gen_lxmert_model():
     save("lxmert_model", **arrays)
 
 
-def gen_visualbert_model():
+def _build_visualbert_ref():
     """The REAL reference BERT stack of VisualBERT (backends/BERT_ours.py: BertEncoder with hooked BertSelfAttention,
     BertPredictionHeadTransform) driven by the reference SelfAttentionGenerator.  mmf's own modules (the
     visio-linguistic embedding sum, the VisualBERT wrapper's sample_list massaging) need an installed ``mmf`` to
@@ -560,6 +693,11 @@ def gen_visualbert_model():
                 "segment_ids": torch.zeros(1, Tpad, dtype=torch.long), "image_feature_0": feats}
 
     feats = torch.randn(1, V, vdim, generator=g)
+    return model, sample, cfg, ids, mask, feats, vdim, labels
+
+
+def gen_visualbert_model():
+    model, sample, cfg, ids, mask, feats, vdim, labels = _build_visualbert_ref()
     arrays = dict(dims=np.array([cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size,
                                  cfg.num_hidden_layers, cfg.vocab_size, cfg.max_position_embeddings, vdim, labels]),
                   input_ids=ids, input_mask=mask, image_feature_0=feats, scores=model(sample())["scores"],
@@ -573,21 +711,157 @@ def gen_visualbert_model():
     save("visualbert_model", **arrays)
 
 
+# ----------------------------------------------------------------------------- perturbation evaluators (round 2)
+_tensor_to = torch.Tensor.to
+
+
+def _to_without_cuda(self, *args, **kwargs):
+    """``x.to("cuda")`` -> ``x`` on this CPU-only box (the evaluators hard-code it, like ``.cuda()`` above)."""
+    if args and (args[0] == "cuda" or (isinstance(args[0], torch.device) and args[0].type == "cuda")):
+        return self
+    return _tensor_to(self, *args, **kwargs)
+
+
+def reference_function(rel_path, class_name, func_name, namespace):
+    """Source of ``class_name.func_name`` cut out of a reference file that cannot be imported as a module (its top-level
+    imports need hub downloads / mmf) and exec'd unchanged -- the same technique as the notebook cells."""
+    import ast
+    import textwrap
+    src = open(os.path.join(REF, rel_path)).read()
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.ClassDef) and node.name == class_name:
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and item.name == func_name:
+                    exec(textwrap.dedent(ast.get_source_segment(src, item)), namespace)
+                    return namespace[func_name]
+    raise KeyError((class_name, func_name))
+
+
+def gen_lxmert_perturbation():
+    """``ModelPert.perturbation_image`` / ``perturbation_text`` (lxmert/lxmert/perturbation.py:85-194) -- the reference's
+    own method bodies, exec'd from the file -- driving the REAL reference LXMERT body of ``gen_lxmert_model`` (same
+    weights: lxmert_model.npz).  The Faster R-CNN / tokenizer / dataset objects those methods touch are stand-ins that
+    return the fixture's tensors; every answer-score vector of the 9 steps is recorded."""
+    torch.Tensor.to = _to_without_cuda
+    model, weights, inputs, cfg, T, I = _build_lxmert_ref()
+    usage = types.SimpleNamespace(model=model, text_len=T, image_boxes_len=I, forward=lambda item: model(**inputs))
+    R_t_t, R_t_i = lx_eg.GeneratorOurs(usage).generate_ours(None, use_lrp=False)
+    cam_image, cam_text = R_t_i[0], R_t_t[0]                       # perturbation.py:242-245
+    cam_image = (cam_image - cam_image.min()) / (cam_image.max() - cam_image.min())
+    cam_text = (cam_text - cam_text.min()) / (cam_text.max() - cam_text.min())
+    g = torch.Generator().manual_seed(23)
+    label_scores = torch.rand(cfg.num_qa_labels, generator=g).round(decimals=1)          # soft VQA accuracies per answer id
+    recorded = []
+
+    def lxmert_vqa(**kw):
+        kw.pop("return_dict"), kw.pop("output_attentions")
+        out = model(**kw)
+        recorded.append(out.question_answering_score.detach().clone())
+        return out
+
+    arrays = {"cam_image": cam_image, "cam_text": cam_text, "label_scores": label_scores}
+    for name in ("perturbation_image", "perturbation_text"):
+        fn = reference_function("lxmert/lxmert/perturbation.py", "ModelPert", name, {"torch": torch, "np": np})
+        for positive in (False, True):
+            recorded.clear()
+            me = types.SimpleNamespace(
+                COCO_VAL_PATH="", image_preprocess=lambda path: (None, None, None),
+                frcnn=lambda *a, **k: {"normalized_boxes": inputs["visual_pos"], "roi_features": inputs["visual_feats"]},
+                frcnn_cfg=types.SimpleNamespace(max_detections=I),
+                lxmert_tokenizer=lambda *a, **k: types.SimpleNamespace(
+                    input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
+                    token_type_ids=inputs["token_type_ids"]),
+                pert_steps=[0, 0.25, 0.5, 0.75, 0.8, 0.85, 0.9, 0.95, 1], pert_acc=[0] * 9, image_boxes_len=I,
+                lxmert_vqa=lxmert_vqa, vqa_answers=[str(i) for i in range(cfg.num_qa_labels)])
+            item = {"img_id": "x", "sent": "x",
+                    "label": {str(i): float(v) for i, v in enumerate(label_scores) if v > 0}}
+            acc = fn(me, item, cam_image.clone(), cam_text.clone(), positive)
+            tag = "%s_%s" % (name.split("_")[1], "pos" if positive else "neg")
+            arrays["scores_" + tag] = torch.cat(recorded)                       # [9, num_answers]
+            arrays["acc_" + tag] = np.asarray(acc, dtype=np.float32)            # per-step accuracies of this ONE item
+    save("lxmert_perturbation", **arrays)
+
+
+def gen_visualbert_perturbation():
+    """``TrainerEvaluationLoopMixinPert.evaluation_loop`` (VisualBERT/mmf/trainers/core/evaluation_loop.py:72-169) -- the
+    reference's own loop, exec'd from the file -- around the reference ``SelfAttentionGenerator`` and the REAL BERT_ours
+    stack of ``gen_visualbert_model`` (same weights: visualbert_model.npz), two items, all four (modality, sign)
+    combinations.  Records every forward's scores and what the loop prints (incl. its ``i > num_samples`` /
+    divide-by-``num_samples`` arithmetic)."""
+    torch.Tensor.to = _to_without_cuda
+    model, sample, cfg, ids, mask, feats, vdim, labels = _build_visualbert_ref()
+    g = torch.Generator().manual_seed(33)
+    targets = torch.rand(1, labels, generator=g).round(decimals=1)
+    feats2 = torch.randn(2, *feats.shape[1:], generator=g)            # region features of items 1 and 2 (item 0: the fixture's)
+    V = feats.shape[1]
+
+    def batch(which):
+        b = sample()
+        if which:
+            b["image_feature_0"] = feats2[which - 1:which].clone()
+        b["image_info_0"] = {"bbox": [np.arange(V * 4, dtype=np.float32).reshape(V, 4)],
+                             "max_features": torch.tensor(V).view(1), "num_boxes": [V]}
+        b["tokens"] = [["t%d" % i for i in range(ids.shape[1])]]
+        b["targets"] = targets
+        return b
+
+    arrays = {"targets": targets, "image_features_1_2": feats2}
+    for modality in ("image", "text"):
+        for positive in (False, True):
+            recorded, printed = [], []
+
+            def _forward(b):
+                out = model(b)
+                recorded.append(out["scores"].detach().clone())
+                return {"targets": b["targets"], "scores": out["scores"]}
+
+            pert_args = types.SimpleNamespace(args=types.SimpleNamespace(
+                method="ours_no_lrp", is_positive_pert=positive, is_text_pert=(modality == "text"), num_samples=2))
+            ns = {"torch": torch, "np": np, "ExplanationGenerator": vb_eg, "perturbation_arguments": pert_args,
+                  "tqdm": types.SimpleNamespace(tqdm=lambda it, **k: it), "is_master": lambda: True,
+                  "print": lambda *a: printed.append(a)}
+            loop = reference_function("VisualBERT/mmf/trainers/core/evaluation_loop.py", "TrainerEvaluationLoopMixinPert",
+                                      "evaluation_loop", ns)
+            me = types.SimpleNamespace(model=model, _forward=_forward)
+            # THREE items with num_samples = 2: the loop's ``i > num_samples`` test lets a third item through and the
+            # printed accuracies are still divided by num_samples (SURVEY.md section 3.5)
+            loop(me, [batch(0), batch(1), batch(2)], None)
+            tag = "%s_%s" % (modality, "pos" if positive else "neg")
+            arrays["scores_" + tag] = torch.cat(recorded).reshape(3, 9, labels)
+            arrays["printed_step_acc_" + tag] = np.asarray(printed[-1][0], dtype=np.float64)
+    save("visualbert_perturbation", **arrays)
+
+
+ROUND1 = ("rules", "detr_chain", "lxmert_chain", "vit_chain", "visualbert_chain", "clip_tiny", "detr_mha",
+          "detr_transformer", "lxmert_model", "visualbert_model")
+
+
+def main(which):
+    """``python make_golden.py`` regenerates everything; ``python make_golden.py NAME...`` only the named groups."""
+    todo = {
+        "rules": gen_rules,
+        "detr_chain": lambda: (
+            gen_detr_chain("detr_chain", 200, H=4, Ni=35, Nq=10, Le=3, Ld=3, targets=[2, 7]),
+            gen_detr_chain("detr_chain_nonorm", 201, H=2, Ni=20, Nq=6, Le=2, Ld=2, targets=[0],
+                           normalize_self_attention=False),
+            gen_detr_chain("detr_chain_noself", 202, H=2, Ni=20, Nq=6, Le=2, Ld=2, targets=[1],
+                           apply_self_in_rule_10=False)),
+        "lxmert_chain": lambda: (
+            gen_lxmert_chain("lxmert_chain", 250, H=4, T=7, I=12, Ll=3, Lr=2, Lx=3),
+            gen_lxmert_chain("lxmert_chain_full", 251, H=12, T=14, I=36, Ll=9, Lr=5, Lx=5),
+            gen_lxmert_chain("lxmert_chain_nonorm", 252, H=2, T=5, I=6, Ll=2, Lr=1, Lx=2,
+                             normalize_self_attention=False)),
+        "vit_chain": gen_vit_chain, "visualbert_chain": gen_visualbert_chain, "clip_tiny": gen_clip_tiny,
+        "detr_mha": gen_detr_mha, "detr_transformer": gen_detr_transformer, "lxmert_model": gen_lxmert_model,
+        "visualbert_model": gen_visualbert_model,
+        # round 2
+        "detr_chain_lrp": gen_detr_chain_lrp, "lxmert_chain_lrp": gen_lxmert_chain_lrp,
+        "visualbert_chain_lrp": gen_visualbert_chain_lrp,
+        "lxmert_perturbation": gen_lxmert_perturbation, "visualbert_perturbation": gen_visualbert_perturbation,
+    }
+    for name in (which or list(todo)):
+        todo[name]()
+
+
 if __name__ == "__main__":
-    gen_rules()
-    gen_detr_chain("detr_chain", 200, H=4, Ni=35, Nq=10, Le=3, Ld=3, targets=[2, 7])
-    gen_detr_chain("detr_chain_nonorm", 201, H=2, Ni=20, Nq=6, Le=2, Ld=2, targets=[0],
-                   normalize_self_attention=False)
-    gen_detr_chain("detr_chain_noself", 202, H=2, Ni=20, Nq=6, Le=2, Ld=2, targets=[1],
-                   apply_self_in_rule_10=False)
-    gen_lxmert_chain("lxmert_chain", 250, H=4, T=7, I=12, Ll=3, Lr=2, Lx=3)
-    gen_lxmert_chain("lxmert_chain_full", 251, H=12, T=14, I=36, Ll=9, Lr=5, Lx=5)
-    gen_lxmert_chain("lxmert_chain_nonorm", 252, H=2, T=5, I=6, Ll=2, Lr=1, Lx=2,
-                     normalize_self_attention=False)
-    gen_vit_chain()
-    gen_visualbert_chain()
-    gen_clip_tiny()
-    gen_detr_mha()
-    gen_detr_transformer()
-    gen_lxmert_model()
-    gen_visualbert_model()
+    main(sys.argv[1:])

@@ -197,3 +197,25 @@ def test_bf16_backward_gemms_stay_close(golden):
     assert torch.nn.functional.cosine_similarity(R_image, want, dim=-1).min() > 0.9995
     model.visual.transformer.backward_gemm_dtype = torch.float32
     close(ce.interpret(image, texts, model, "cuda", start_layer=0, start_layer_text=0)[1], g["R_image_all"])
+
+
+def test_graphed_interpret_survives_buffer_replacement(golden):
+    """a captured graph holds raw slab addresses.  An eager call with another batch / sharing mode
+    makes the towers allocate NEW slabs; the graph must keep its own alive and still replay correctly afterwards, and
+    ``blk.attn_probs`` must again point at what the replay wrote."""
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    g, model = load_tiny(golden)
+    image, texts = torch.from_numpy(g["image"]).cuda(), torch.from_numpy(g["texts"]).cuda()
+    run = ce.GraphedInterpret(model, image, texts, 0, 0)
+    pinned = model.visual.transformer.buffers
+    ce.interpret(image, texts[:2], model, "cuda", 0, 0)                           # other batch -> new slabs
+    ce.interpret(image, texts, model, "cuda", 0, 0, share_image_forward=False)    # other sharing mode -> new slabs
+    assert model.visual.transformer.buffers is not pinned
+    junk = [torch.randn(1 << 20, device="cuda") for _ in range(8)]                # would land on freed slabs
+    R_text, R_image = run()
+    close(R_text, g["R_text_all"])
+    close(R_image, g["R_image_all"])
+    assert model.visual.transformer.buffers is pinned
+    blk = model.visual.transformer.resblocks[0]
+    close(blk.attn_grad, g["img_grad"][0], atol=1e-6)
+    del junk

@@ -195,6 +195,21 @@ def test_rules_golden(ops, golden):
     sq, ss = ops.mm_attention_rules(eye_s, eye_q, dev(g["cam_sq"]), R_qs=dev(g["R_qs"]))
     close(sq, g["mm_lx_nan_sq_add"])
     close(ss, g["mm_lx_nan_ss_add"])
+    # apply_self_in_rule_10=False returns cam_sq -- the DETR flavour scrubs ITS NaNs as well (reference
+    # DETR/...:40-42), and handle_residual (with its diag >= 0 assert) still runs when normalisation is on (:36-38)
+    cam_nan = dev(g["cam_sq"]).clone()
+    cam_nan[1, 2] = float("nan")
+    out = ops.mm_attention_rules(dev(g["R_ss"]), dev(g["R_qq"]), cam_nan, apply_self_in_rule_10=False, nan_to_zero=True)
+    want = g["cam_sq"].copy()
+    want[1, 2] = 0
+    close(out, want)
+    kept = ops.mm_attention_rules(dev(g["R_ss"]), dev(g["R_qq"]), cam_nan, apply_self_in_rule_10=False)
+    assert torch.isnan(kept[1, 2]) and torch.isnan(kept).sum() == 1          # LXMERT flavour: NaN propagates
+    bad = dev(g["R_ss"] - 2 * np.eye(g["R_ss"].shape[0], dtype=np.float32))
+    with pytest.raises(AssertionError):
+        ops.mm_attention_rules(bad, dev(g["R_qq"]), dev(g["cam_sq"]), apply_self_in_rule_10=False, nan_to_zero=True)
+    ops.mm_attention_rules(bad, dev(g["R_qq"]), dev(g["cam_sq"]), apply_normalization=False,
+                           apply_self_in_rule_10=False, nan_to_zero=True)   # no normalisation -> no assert (reference)
 
 
 def test_rollout_golden(ops, golden):

@@ -1,0 +1,131 @@
+"""-m gpu: parity against the ORACLE at the sizes BASELINE.json measures (VERDICT r01 "next" item 1).
+
+  * cfg 2 exactly as ``bench.py`` runs it: CLIP ViT-B/32, batch 64, all 12+12 layers, bench.py's seeds -- eager with
+    the shared image forward, eager with B image copies, and the hipGraph replay, each vs ``oracle/clip_torch.interpret``
+    (the notebook algorithm: one ``autograd.grad`` per layer) at 1e-5;
+  * cfg 5's token count (ViT-L/14@336: 577 image tokens, 16 heads; the streaming attention kernels and the N > 128
+    chain), reduced depth/batch so the CPU oracle finishes in seconds;
+  * cfg 3's DETR encoder size (Ni = 25x38 = 950, d = 32, 8 heads; 100 queries): the capture op vs
+    ``oracle/attention_torch`` and the rule schedule vs ``oracle/relevancy_np.detr_generate_ours_chain`` on the slabs.
+Tolerances are the north star's: relevancy maps 1e-5 abs; probabilities 2e-6, gradients 2e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, atol=1e-5, rtol=1e-4):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def bench_inputs(batch, seed=0, context=77, vocab_hi=49405, sot=49406, eot=49407, res=224):
+    """``bench.synthetic_inputs`` restated (bench.py sets process-wide TunableOp env at import, so it is not imported)."""
+    g = torch.Generator().manual_seed(1 + seed)
+    image = torch.randn(1, 3, res, res, generator=g)
+    texts = torch.zeros(batch, context, dtype=torch.long)
+    g2 = torch.Generator().manual_seed(2 + seed)
+    for b in range(batch):
+        n = int(torch.randint(3, 11, (1,), generator=g2))
+        texts[b, 0] = sot
+        texts[b, 1:1 + n] = torch.randint(1, vocab_hi, (n,), generator=g2)
+        texts[b, 1 + n] = eot
+    return image, texts
+
+
+def test_cfg2_batch64_vs_oracle():
+    """The measured configuration at its own size: every map of the 64-pair batch within 1e-5 of the oracle, for all
+    three ways bench.py can run the step (layer-group split G = 4 and the shared-forward backward at B = 64 included)."""
+    from oracle import clip_torch
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    from transformer_mm_explainability_amd import clip_model
+    model = clip_model.random_init("ViT-B/32", seed=0)
+    image, texts = bench_inputs(64)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    sd = clip_torch.prepare_state_dict(model.state_dict(), 8)
+    want_text, want_img = clip_torch.interpret(sd, image, texts, 0, 0)
+    model = model.cuda()
+    image, texts = image.cuda(), texts.cuda()
+    for share in (True, False):
+        R_text, R_image = ce.interpret(image, texts, model, "cuda", 0, 0, share_image_forward=share)
+        close(R_text, want_text)
+        close(R_image, want_img)
+    run = ce.GraphedInterpret(model, image, texts, start_layer=0, start_layer_text=0)
+    R_text, R_image = run()
+    close(R_text, want_text)
+    close(R_image, want_img)
+    run_ns = ce.GraphedInterpret(model, image, texts, start_layer=0, start_layer_text=0, share_image_forward=False)
+    R_text, R_image = run_ns()
+    close(R_text, want_text)
+    close(R_image, want_img)
+
+
+def test_cfg5_token_count_vs_oracle():
+    """ViT-L/14@336 geometry (577 image tokens, width 1024 / 16 heads; text width 768 / 12 heads), 2 + 2 layers, B = 2."""
+    from oracle import clip_torch
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    from transformer_mm_explainability_amd import clip_model
+    torch.manual_seed(0)
+    model = clip_model.CLIP(768, 336, 2, 1024, 14, 77, 49408, 768, 12, 2).float().eval()
+    image, texts = bench_inputs(2, res=336)
+    sd = clip_torch.prepare_state_dict(model.state_dict(), 12)
+    want_text, want_img = clip_torch.interpret(sd, image, texts, 0, 0)
+    assert want_img.shape == (2, 576)
+    model = model.cuda()
+    for share in (True, False):
+        R_text, R_image = ce.interpret(image.cuda(), texts.cuda(), model, "cuda", 0, 0, share_image_forward=share)
+        close(R_text, want_text)
+        close(R_image, want_img)
+
+
+@pytest.mark.parametrize("Nq,Nk", [(950, 950), (100, 950), (577, 577)])
+def test_capture_op_at_size_vs_oracle(Nq, Nk):
+    """The capture op at the DETR-encoder / DETR-cross / ViT-L token counts vs the oracle's hooked attention core."""
+    from oracle import attention_torch as oat
+    from transformer_mm_explainability_amd import ops
+    H, D = (8, 32) if Nk == 950 else (4, 64)
+    g = torch.Generator().manual_seed(Nq + Nk)
+    q, k, v, d_o = (torch.randn(1, n, H, D, generator=g) for n in (Nq, Nk, Nk, Nq))
+    bh = lambda t: t.permute(0, 2, 1, 3)
+    P, O, dP, dq, dk, dv = oat.capture(bh(q), bh(k), bh(v), bh(d_o), D ** -0.5)
+    probs = torch.empty(1, H, Nq, Nk, device="cuda")
+    dprobs = torch.empty_like(probs)
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    o = ops.attn_capture_fwd(qc, kc, vc, probs, D ** -0.5)
+    close(probs, P, atol=2e-6)
+    close(bh(o), O)
+    gq, gk, gv = ops.attn_capture_bwd(qc, kc, vc, probs, d_o.cuda(), dprobs, D ** -0.5, o=o)
+    close(dprobs, dP, atol=2e-5)
+    close(bh(gq), dq, atol=2e-5)
+    close(bh(gk), dk, atol=2e-5)
+    close(bh(gv), dv, atol=2e-5)
+
+
+def test_detr_ni950_rules_vs_oracle():
+    """cfg 3 at its real size: the rule schedule of ``generate_ours`` (encoder chain at N = 950, decoder rules 6/7/10)
+    on the slabs captured by the same run vs ``oracle/relevancy_np.detr_generate_ours_chain``; the batched-target route
+    (``generate_ours_multi``) must agree as well."""
+    from oracle import relevancy_np as onp
+    from transformer_mm_explainability_amd import detr_model
+    from transformer_mm_explainability_amd.detr_explainability import Generator
+    torch.manual_seed(0)
+    model = detr_model.detr_resnet50_head().cuda().eval()
+    feats = torch.randn(1, 2048, 25, 38, device="cuda") * 0.5
+    gen = Generator(model)
+    tgt = torch.tensor([57], device="cuda")               # one kept query per call, as DETR/mask_generator.py:91 does
+    out = gen.generate_ours(feats, tgt, use_lrp=False).clone()
+    enc, dec = model.transformer.encoder.layers, model.transformer.decoder.layers
+    slab = lambda m: (m.get_attn().cpu().numpy(), m.get_attn_gradients().cpu().numpy())
+    ea, eg = zip(*[slab(b.self_attn) for b in enc])
+    sa, sg = zip(*[slab(b.self_attn) for b in dec])
+    ca, cg = zip(*[slab(b.multihead_attn) for b in dec])
+    want = onp.detr_generate_ours_chain(ea, eg, sa, sg, ca, cg, tgt.cpu().numpy())
+    assert want.shape == out.shape == (1, 1, 1, 950)
+    close(out, want, atol=1e-5)
+    both = torch.tensor([3, 57], device="cuda")
+    multi = Generator(model).generate_ours_multi(feats, both)
+    close(multi[:, :, 1:2], want, atol=1e-5)

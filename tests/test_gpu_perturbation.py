@@ -159,7 +159,7 @@ def test_visualbert_perturbation_equals_sequential(positive):
     c = -cam if positive else cam
     cls_index = n_text - 2
     with torch.no_grad():
-        for s, step in enumerate(vp.PERT_STEPS):
+        for s, (step, step_txt) in enumerate(zip(pert.image_steps, pert.text_steps)):
             sl = sample()
             idx = c[0, n_text:].topk(k=int((1 - step) * V), dim=-1).indices
             sl["image_feature_0"] = sl["image_feature_0"][:, idx]
@@ -167,7 +167,7 @@ def test_visualbert_perturbation_equals_sequential(positive):
                 torch.testing.assert_close(got_img[s], model(sl)["scores"][0], rtol=1e-4, atol=1e-5)
             sl = sample()
             scores = c[0, 1:cls_index]
-            top = scores.topk(k=int((1 - step) * scores.shape[0]), dim=-1).indices.tolist()
+            top = scores.topk(k=int((1 - step_txt) * scores.shape[0]), dim=-1).indices.tolist()
             kept = sorted([0, cls_index, cls_index + 1] + [i + 1 for i in top])
             T = sl["input_ids"].shape[1]
             sl["input_ids"] = torch.cat((sl["input_ids"][:, kept], sl["input_ids"][:, n_text:]), dim=1)
@@ -194,3 +194,107 @@ def test_visualbert_generate_ours_batch_equals_per_item():
         one = {k: v[b:b + 1].clone() for k, v in batch.items()}
         want = vb.SelfAttentionGenerator(model).generate_ours(one)
         torch.testing.assert_close(got[b:b + 1], want, rtol=1e-4, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Against the REFERENCE's own evaluator code: tests/golden/{lxmert,visualbert}_perturbation.npz hold
+# the answer scores of every one of the 9 re-runs that ``ModelPert.perturbation_image/_text`` (lxmert/lxmert/perturbation.py:
+# 85-194) and ``TrainerEvaluationLoopMixinPert.evaluation_loop`` (VisualBERT/.../evaluation_loop.py:73-169) -- exec'd from
+# the reference files -- produced on the reference bodies (weights: lxmert_model.npz / visualbert_model.npz).
+# ----------------------------------------------------------------------------------------------------------------------
+def _cu(x):
+    import numpy as np
+    return torch.from_numpy(np.asarray(x)).cuda()
+
+
+@pytest.mark.parametrize("modality", ["image", "text"])
+@pytest.mark.parametrize("positive", [False, True])
+def test_lxmert_perturbation_vs_reference_evaluator(golden, modality, positive):
+    from transformer_mm_explainability_amd import lxmert_explainability as le
+    from transformer_mm_explainability_amd import lxmert_perturbation as lp
+    from transformer_mm_explainability_amd import lxmert_model as lm
+    import types
+    gm, g = golden("lxmert_model"), golden("lxmert_perturbation")
+    hidden, heads, inter, ll, xl, rl, feat, vocab, labels, max_pos, T, I = (int(x) for x in gm["dims"])
+    model = lm.LxmertForQuestionAnswering(lm.LxmertConfig(
+        hidden_size=hidden, num_attention_heads=heads, intermediate_size=inter, l_layers=ll, x_layers=xl, r_layers=rl,
+        visual_feat_dim=feat, vocab_size=vocab, num_qa_labels=labels, max_position_embeddings=max_pos))
+    model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in gm.items() if k.startswith("w__")}, strict=True)
+    model = model.cuda().eval()
+    inputs = {k[4:]: _cu(v) for k, v in gm.items() if k.startswith("in__")}
+    usage = types.SimpleNamespace(model=model, text_len=T, image_boxes_len=I, forward=lambda item: model(**inputs))
+    # the cams the reference evaluator used are the normalised first rows of ITS generator's maps; ours must agree
+    R_t_t, R_t_i = le.GeneratorOurs(usage).generate_ours(None, use_lrp=False)
+    cam_image, cam_text = lp.normalize_cams(R_t_t, R_t_i)
+    torch.testing.assert_close(cam_image.cpu(), torch.from_numpy(g["cam_image"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(cam_text.cpu(), torch.from_numpy(g["cam_text"]), rtol=1e-4, atol=1e-5)
+    pert = lp.LxmertPerturbation(model)
+    tag = "%s_%s" % (modality, "pos" if positive else "neg")
+    if modality == "image":
+        scores = pert.perturbation_image(inputs, _cu(g["cam_image"]), positive)
+    else:
+        scores = pert.perturbation_text(inputs, _cu(g["cam_text"]), positive)
+    torch.testing.assert_close(scores.cpu(), torch.from_numpy(g["scores_" + tag]), rtol=1e-4, atol=1e-5)
+    acc = pert.accuracy(scores, _cu(g["label_scores"]))
+    torch.testing.assert_close(acc.cpu(), torch.from_numpy(g["acc_" + tag]), rtol=0, atol=1e-6)
+
+
+def _visualbert_from_golden(g):
+    from transformer_mm_explainability_amd import visualbert_model as vm
+    hidden, heads, inter, layers, vocab, max_pos, vdim, labels = (int(x) for x in g["dims"])
+    model = vm.VisualBERT(vm.VisualBertConfig(hidden_size=hidden, num_attention_heads=heads, intermediate_size=inter,
+                                              num_hidden_layers=layers, vocab_size=vocab, max_position_embeddings=max_pos,
+                                              visual_embedding_dim=vdim, num_labels=labels))
+    model.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w__")}, strict=False)
+    return model.cuda().eval()
+
+
+@pytest.mark.parametrize("modality", ["image", "text"])
+@pytest.mark.parametrize("positive", [False, True])
+def test_visualbert_perturbation_vs_reference_evaluator(golden, modality, positive):
+    """Scores of all 3 x 9 re-runs and the numbers the reference loop PRINTS (its ``i > num_samples`` accounting: three
+    items evaluated, divided by ``num_samples = 2``) -- ``reference_exact=True``; the default counts ``num_samples`` items."""
+    from transformer_mm_explainability_amd import visualbert_explainability as vb
+    from transformer_mm_explainability_amd import visualbert_perturbation as vp
+    gm, g = golden("visualbert_model"), golden("visualbert_perturbation")
+    model = _visualbert_from_golden(gm)
+    feats = [_cu(gm["image_feature_0"])] + [_cu(f[None]) for f in g["image_features_1_2"]]
+
+    def item(i):
+        return {"input_ids": _cu(gm["input_ids"]), "input_mask": _cu(gm["input_mask"]),
+                "segment_ids": torch.zeros_like(_cu(gm["input_ids"])), "image_feature_0": feats[i],
+                "targets": _cu(g["targets"])}
+
+    tag = "%s_%s" % (modality, "pos" if positive else "neg")
+    gen = vb.SelfAttentionGenerator(model)
+    pert = vp.VisualBertPerturbation(model)
+    for i in range(3):
+        cam = gen.generate_ours(item(i)).detach()
+        run = pert.perturbation_image if modality == "image" else pert.perturbation_text
+        scores = run(item(i), cam, positive)
+        torch.testing.assert_close(scores.cpu(), torch.from_numpy(g["scores_" + tag][i]), rtol=1e-4, atol=1e-5)
+    printed = vp.evaluation_loop(gen.generate_ours, pert, [item(0), item(1), item(2)], num_samples=2, modality=modality,
+                                 is_positive_pert=positive, reference_exact=True)
+    torch.testing.assert_close(printed, torch.from_numpy(g["printed_step_acc_" + tag]), rtol=0, atol=1e-4)
+    plain = vp.evaluation_loop(gen.generate_ours, pert, [item(0), item(1), item(2)], num_samples=2, modality=modality,
+                               is_positive_pert=positive)
+    assert (plain <= printed + 1e-9).all()                    # two items instead of three, same divisor
+
+
+def test_ranking_tie_policy_is_stable_and_prefix_consistent():
+    """with tied scores ``topk(k)`` for different k need not be nested; the evaluator ranks ONCE with a stable
+    sort (ties -> lower index first), so every step keeps a prefix of the same order, and for distinct scores the kept
+    sets equal the reference's per-step ``topk``."""
+    from transformer_mm_explainability_amd import lxmert_perturbation as lp
+    cam = torch.tensor([0.5, 0.0, 0.5, 1.0, 0.0, 0.5, 0.0, 0.25], device="cuda")
+    keep = lp.image_keep_masks(cam)
+    assert lp.ranking(cam).tolist() == [3, 0, 2, 5, 7, 1, 4, 6]
+    for s in range(1, keep.shape[0]):
+        assert (keep[s] <= keep[s - 1]).all()                  # nested kept sets
+    g = torch.Generator().manual_seed(0)
+    cam = torch.rand(36, generator=g).cuda()
+    keep = lp.image_keep_masks(cam)
+    for s, step in enumerate(lp.PERT_STEPS):
+        want = torch.zeros(36, device="cuda")
+        want[cam.topk(int((1 - step) * 36)).indices] = 1
+        assert torch.equal(keep[s], want)

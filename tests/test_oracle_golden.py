@@ -182,3 +182,38 @@ def test_detr_sine_position_embedding(golden):
     np.testing.assert_allclose(PositionEmbeddingSine(d // 2, normalize=True)(mask).numpy(), g["sine_pos"], atol=1e-6)
     np.testing.assert_allclose(PositionEmbeddingSine(d // 2, normalize=False)(mask).numpy(), g["sine_pos_raw"],
                                atol=1e-6)
+
+
+def test_attention_oracle_vs_reference_mha(golden):
+    """``oracle/attention_torch.py`` (the hooked attention core + DETR's MHA wrapper) == the reference's own module
+    (DETR/modules/layers.py ``MultiheadAttention``, outputs in detr_mha.npz): output, captured P, captured dP, input
+    gradients.  The same ``core`` then serves the full-size (N = 577 / 950) GPU parity tests."""
+    import torch
+    from oracle import attention_torch as oat
+    g = golden("detr_mha")
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w__")}
+    got = oat.detr_mha(sd, *(torch.from_numpy(g[n]) for n in ("query", "key", "value")), int(g["num_heads"]),
+                       torch.from_numpy(g["upstream"]))
+    for name in ("out", "attn", "attn_grad", "dquery", "dkey", "dvalue"):
+        close(got[name].numpy(), g[name])
+
+
+def test_lrp_route_is_the_same_schedule_on_cams(golden):
+    """``use_lrp=True`` (the reference default) differs from ``use_lrp=False`` only in WHICH tensor is the cam
+    (``get_attn_cam`` vs ``get_attn``): the oracle schedules fed with the fixtures' cams reproduce the reference
+    generators' default-argument outputs (DETR/...:113-116, lxmert/...:64-67)."""
+    g = golden("detr_chain_lrp")
+    out = onp.detr_generate_ours_chain(list(g["enc_cam"]), list(g["enc_grad"]), list(g["dself_cam"]),
+                                       list(g["dself_grad"]), list(g["dcross_cam"]), list(g["dcross_grad"]),
+                                       g["target_index"])
+    close(out, g["out_default"], atol=1e-5)
+    close(onp.avg_heads(g["dcross_cam"][-1], g["dcross_grad"][-1])[g["target_index"]][None, None],
+          g["transformer_att_out"])
+    g = golden("lxmert_chain_lrp")
+    n_x = g["x_lang_cross_cam"].shape[0]
+    x_layers = [{k: (g["x_%s_cam" % k][i], g["x_%s_grad" % k][i])
+                 for k in ("lang_cross", "img_cross", "lang_self", "img_self")} for i in range(n_x)]
+    R_t_t, R_t_i = onp.lxmert_generate_ours_chain(list(g["lang_cam"]), list(g["lang_grad"]),
+                                                  list(g["vis_cam"]), list(g["vis_grad"]), x_layers)
+    close(R_t_t, g["R_t_t"], atol=1e-5)
+    close(R_t_i, g["R_t_i"], atol=1e-5)

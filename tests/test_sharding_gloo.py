@@ -84,3 +84,30 @@ def test_evaluate_sharded_world2_and_resume(tmp_path):
     (tmp_path / "fresh").mkdir()
     mp.spawn(_eval_worker, args=(2, port + 2, 5, str(tmp_path / "fresh"), False), nprocs=2, join=True)
     assert all(torch.load(tmp_path / "fresh" / ("e%d.pt" % r))["ok"] for r in (0, 1))
+
+
+def test_empty_shard_with_store_world2(tmp_path):
+    """more ranks than samples -- the rank with an EMPTY shard and a resumable store must still hand a
+    ``[0, n_cols]`` table to the fixed-shape gather (it used to pass shape ``[0]`` and mismatch the other rank)."""
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_eval_worker, args=(2, port, 1, str(tmp_path), True), nprocs=2, join=True)
+    assert all(torch.load(tmp_path / ("e%d.pt" % r))["ok"] for r in (0, 1))
+
+
+def test_partial_scores_header_guards_against_stale_rows(tmp_path):
+    """a store written for one (method, test) must not be resumed for another."""
+    sys.path.insert(0, ROOT)
+    from transformer_mm_explainability_amd import sharding
+    cfg = {"method": "ours_no_lrp", "test": "image", "positive": False, "steps": (0, 0.5, 1)}
+    st = sharding.PartialScores(str(tmp_path), 0, config=cfg)
+    st.add([3, 4], torch.tensor([[1.0, 2.0], [3.0, 4.0]]))
+    st.close()
+    again = sharding.PartialScores(str(tmp_path), 0, config=cfg)            # same run description: rows are reused
+    assert again.done() == {3, 4} and torch.equal(again.table([4, 3]), torch.tensor([[3.0, 4.0], [1.0, 2.0]]))
+    again.close()
+    with pytest.raises(ValueError, match="another run"):
+        sharding.PartialScores(str(tmp_path), 0, config=dict(cfg, method="rollout"))
+    with pytest.raises(ValueError, match="another run"):
+        sharding.PartialScores(str(tmp_path), 0)                             # header present, caller states none
+    with pytest.raises(ValueError, match="empty id list"):
+        sharding.PartialScores(str(tmp_path / "x"), 0).table([])

@@ -12,7 +12,9 @@ forward hook and a tensor backward hook.  These classes keep that surface but th
     VisualBERT/.../BERT_ours.py:234-343 (``BertSelfAttention``): ``query/key/value`` Linear, ``scores/sqrt(d) + mask``,
     inputs ``[B, N, E]``, ``get_attn()`` -> ``[B, H, Nq, Nk]`` (captured before dropout; eval mode => identical).
 
-LRP (``relprop`` / ``get_attn_cam``) is out of scope: ``get_attn_cam`` raises.
+``save_attn_cam`` / ``get_attn_cam`` are the plain slot of the reference (DETR/modules/layers.py:699-703): an LRP pass
+supplied by the caller (``model.relprop``) stores its per-head relevance there and the rule kernels read it like any other
+cam.  Producing the cam (the ``relprop`` of layers.py:770-801) is not done here; reading an empty slot raises.
 """
 from __future__ import annotations
 
@@ -32,6 +34,7 @@ class _SlabOwner(nn.Module):
         self._grads = None
         self.attn = None
         self.attn_gradients = None
+        self.attn_cam = None
 
     def _slabs(self, B, H, Nq, Nk, device):
         shape = (B, H, Nq, Nk)
@@ -55,10 +58,13 @@ class _SlabOwner(nn.Module):
         return self.attn_gradients
 
     def save_attn_cam(self, cam):
-        raise NotImplementedError("LRP attention cams (relprop) are out of scope; use the *_no_lrp methods")
+        self.attn_cam = cam
 
     def get_attn_cam(self):
-        raise NotImplementedError("LRP attention cams (relprop) are out of scope; use the *_no_lrp methods")
+        if self.attn_cam is None:
+            raise NotImplementedError("no LRP attention cam has been saved on this module: an LRP pass (model.relprop) "
+                                      "must call save_attn_cam first; use the *_no_lrp methods otherwise")
+        return self.attn_cam
 
 
 class MultiheadAttention(_SlabOwner):

@@ -125,8 +125,23 @@ class GraphedInterpret:
         # thread captures; only calls made by the capturing thread must be capture-safe
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.outputs = self._call()
+        # The graph bakes in the raw addresses of the towers' capture slabs and of the cached chain plans' scratch.  Pin
+        # them: a later interpret() / GraphedInterpret on the same model with another batch, sharing mode or text length
+        # makes ``Transformer._ensure_buffers`` install NEW slabs, and without this reference the old ones would be
+        # freed under the graph.  ``__call__`` re-installs the pinned slabs so that ``blk.attn_probs`` / ``attn_grad``
+        # and a following eager call see what the replay wrote.
+        vis, txt = model.visual.transformer, model.transformer
+        self._pinned = (vis.buffers, txt.buffers)
+
+    def _reinstall(self):
+        for tr, buf in zip((self.model.visual.transformer, self.model.transformer), self._pinned):
+            if tr.buffers is not buf:
+                tr.buffers = buf
+                for l, blk in enumerate(tr.resblocks):
+                    blk.attn_probs, blk.attn_grad = buf.layer_probs(l), buf.layer_grads(l)
 
     def __call__(self, image=None, texts=None):
+        self._reinstall()
         if image is not None:
             self.image.copy_(image)
         if texts is not None:

@@ -713,6 +713,14 @@ extern "C" int mmx_handle_residual(const void* R_dev, void* out_dev, int batch, 
 }
 
 // ----------------------------------------------------------------------------------------- rules 10/11
+__global__ void copy_scrub_kernel(const float* __restrict__ in, float* __restrict__ out, long n, int nan_to_zero) {
+    const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float v = in[i];
+        out[i] = (nan_to_zero && v != v) ? 0.0f : v;
+    }
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
 
 extern "C" size_t mmx_mm_rules_workspace_bytes(int Ns, int Nq) {
@@ -739,28 +747,34 @@ extern "C" int mmx_mm_attention_rules(const void* R_ss_dev, const void* R_qq_dev
     float* tmp = reinterpret_cast<float*>(ws + align256(sizeof(float) * Ns * Ns) + align256(sizeof(float) * Nq * Nq));
     const int nan0 = (flags & MMX_MM_NAN_TO_ZERO) ? 1 : 0;
     int rc;
-    if (flags & MMX_MM_SELF_IN_RULE10) {
-        const float* ss = static_cast<const float*>(R_ss_dev);
-        const float* qq = static_cast<const float*>(R_qq_dev);
-        if (flags & MMX_MM_NORMALIZE) {
-            // both residual normalisations share diag_min (min over both diagonals)
-            float* dm = static_cast<float*>(diag_min_dev);
-            if (dm) fill_scalar_kernel<<<1, 1, 0, s>>>(dm, __builtin_inff());
+    const float* ss = static_cast<const float*>(R_ss_dev);
+    const float* qq = static_cast<const float*>(R_qq_dev);
+    if (flags & MMX_MM_NORMALIZE) {
+        // The reference normalises (and asserts diag >= 0) BEFORE it looks at apply_self_in_rule_10
+        // (DETR/modules/ExplanationGenerator.py:36-38, lxmert/.../ExplanationGenerator.py:35-37), so the check word is
+        // produced in both branches.  Both residual normalisations share diag_min (min over both diagonals).
+        float* dm = static_cast<float*>(diag_min_dev);
+        if (dm) fill_scalar_kernel<<<1, 1, 0, s>>>(dm, __builtin_inff());
+        if ((flags & MMX_MM_SELF_IN_RULE10) || dm) {
             row_normalise_kernel<<<(Ns + 3) / 4, 256, 0, s>>>(ss, Rn_ss, Ns, Ns, 0, dm);
             row_normalise_kernel<<<(Nq + 3) / 4, 256, 0, s>>>(qq, Rn_qq, Nq, Nq, 0, dm);
             MMX_LAUNCH_CHECK("row_normalise_kernel");
-            ss = Rn_ss;
-            qq = Rn_qq;
         }
+        ss = Rn_ss;
+        qq = Rn_qq;
+    }
+    if (flags & MMX_MM_SELF_IN_RULE10) {
         // tmp = cam_sq . Rn_qq ; R_sq_add = Rn_ss^T . tmp
         rc = mmx_bmm_f32(cam_sq_dev, qq, nullptr, tmp, 1, Ns, Nq, Nq, 0, 0, 0, 0, 0, stream);
         if (rc) return rc;
         rc = mmx_bmm_f32(ss, tmp, nullptr, R_sq_add_dev, 1, Ns, Nq, Ns, 1, 0, 0, 0, nan0, stream);
         if (rc) return rc;
     } else {
-        // reference returns cam_sq itself (DETR additionally scrubs NaN in place)
-        hipError_t e = hipMemcpyAsync(R_sq_add_dev, cam_sq_dev, sizeof(float) * Ns * Nq, hipMemcpyDeviceToDevice, s);
-        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(cam_sq)");
+        // the reference returns cam_sq itself; the DETR flavour scrubs its NaNs too (:40-42)
+        const long n = static_cast<long>(Ns) * Nq;
+        copy_scrub_kernel<<<static_cast<unsigned>((n + 255) / 256), 256, 0, s>>>(
+            static_cast<const float*>(cam_sq_dev), static_cast<float*>(R_sq_add_dev), n, nan0);
+        MMX_LAUNCH_CHECK("copy_scrub_kernel");
     }
     if (R_qs_dev) {
         rc = mmx_bmm_f32(cam_sq_dev, R_qs_dev, nullptr, R_ss_add_dev, 1, Ns, Ns, Nq, 0, 0, 0, 0, 0, stream);

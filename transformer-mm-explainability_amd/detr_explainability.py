@@ -9,8 +9,12 @@ them straight from the capture slabs).
 
 What changes underneath: the 6-layer encoder chain is ONE ``relevancy_self_chain`` call, each decoder self-attention
 block is one call carrying both right-hand sides (rules 6+7), rule 10 runs on the MFMA matmul + row-normalise kernels.
-LRP variants (``use_lrp=True``, ``generate_transformer_att``, ``generate_partial_lrp``) need the reference's LRP layer
-library and are out of scope: they raise NotImplementedError.
+LRP variants (``use_lrp=True``, ``generate_transformer_att``, ``generate_partial_lrp``): the rule kernels take any cam, so
+these run exactly the reference's schedule on ``get_attn_cam()`` instead of ``get_attn()`` -- PROVIDED the body brings its
+own LRP pass (``model.relprop(one_hot, alpha=1, target_index=..., target_class=...)`` filling ``save_attn_cam`` on every
+attention module, as the reference's LRP layer library does, DETR/modules/layers.py:770-801).  The bodies in this package
+(``detr_model``) have no ``relprop`` (producing the LRP cams is SURVEY section 8f row 4): with them these entry points
+raise ``NotImplementedError`` naming the missing method.
 """
 from __future__ import annotations
 
@@ -29,16 +33,38 @@ def _logits_for_backward(model, img):
     return rules.forward_for_backward(model, lambda: model(img)["pred_logits"])
 
 
-def _one_hot_backward(model, outputs, target_index, index):
-    """DETR/modules/ExplanationGenerator.py:153-163: one-hot on (query, class), zero_grad, backward."""
+def _one_hot_backward(model, outputs, target_index, index, backward=True):
+    """DETR/modules/ExplanationGenerator.py:153-163: one-hot on (query, class), zero_grad, backward.
+    Returns ``(index, one_hot_vector)``."""
     if index is None:
         index = outputs[0, target_index, :-1].max(1)[1]
     one_hot = torch.zeros_like(outputs)
     one_hot[0, target_index, index] = 1
-    loss = torch.sum(one_hot * outputs)
-    model.zero_grad()
-    loss.backward(retain_graph=True)
-    return index
+    if backward:
+        loss = torch.sum(one_hot * outputs)
+        model.zero_grad()
+        loss.backward(retain_graph=True)
+    return index, one_hot
+
+
+def _require_relprop(model):
+    if not hasattr(model, "relprop"):
+        raise NotImplementedError(
+            "use_lrp=True / transformer_att / partial_lrp read LRP attention cams (get_attn_cam) that the body's "
+            "relprop() must produce; %s has no relprop().  Use use_lrp=False (the evaluators' 'ours_no_lrp'), or plug "
+            "a body built on an LRP layer library (reference: DETR/modules/layers.py)." % type(model).__name__)
+
+
+def _relprop(model, one_hot_vector, target_index, index):
+    """The reference's LRP pass (DETR/modules/ExplanationGenerator.py:165-166, 84, 213): the BODY's ``relprop`` leaves an
+    ``attn_cam`` on every attention module (``save_attn_cam``, DETR/modules/layers.py:776)."""
+    _require_relprop(model)
+    model.relprop(one_hot_vector.clone().detach(), alpha=1, target_index=target_index, target_class=index)
+
+
+def _cam(module, use_lrp):
+    """``get_attn_cam()`` on the LRP route, ``get_attn()`` otherwise (reference :113-116, 122-125, 132-135)."""
+    return (module.get_attn_cam() if use_lrp else module.get_attn()).detach()
 
 
 class Generator:
@@ -52,20 +78,20 @@ class Generator:
     # ------------------------------------------------------------------ ours (rules 5, 6, 7, 10)
     def handle_self_attention_image(self, blocks):
         """Encoder chain (reference :110-118) in one launch."""
-        attn = [blk.self_attn.get_attn().detach() for blk in blocks]
+        attn = [_cam(blk.self_attn, self.use_lrp) for blk in blocks]
         grad = [blk.self_attn.get_attn_gradients().detach() for blk in blocks]
         self.R_i_i = ops.relevancy_self_chain(attn, grad, 1, R_init=self.R_i_i)[0]
 
     def handle_co_attn_self_query(self, block):
         """Rules 6+7 (reference :120-129): ``R_q_q += cam@R_q_q; R_q_i += cam@R_q_i``."""
-        attn = block.self_attn.get_attn().detach()
+        attn = _cam(block.self_attn, self.use_lrp)
         grad = block.self_attn.get_attn_gradients().detach()
         R_qq, R_qi = ops.relevancy_self_chain([attn], [grad], 1, R_init=self.R_q_q, R_sq_init=self.R_q_i)
         self.R_q_q, self.R_q_i = R_qq[0], R_qi[0]
 
     def handle_co_attn_query(self, block):
         """Rule 10 (reference :131-140)."""
-        cam_q_i = avg_heads(block.multihead_attn.get_attn().detach(), block.multihead_attn.get_attn_gradients().detach())
+        cam_q_i = avg_heads(_cam(block.multihead_attn, self.use_lrp), block.multihead_attn.get_attn_gradients().detach())
         self.R_q_i = self.R_q_i + apply_mm_attention_rules(self.R_q_q, self.R_i_i, cam_q_i,
                                                            apply_normalization=self.normalize_self_attention,
                                                            apply_self_in_rule_10=self.apply_self_in_rule_10)
@@ -73,13 +99,14 @@ class Generator:
     def generate_ours(self, img, target_index, index=None, use_lrp=True, normalize_self_attention=True,
                       apply_self_in_rule_10=True):
         if use_lrp:
-            raise NotImplementedError("use_lrp=True needs the reference's LRP layer library (model.relprop); "
-                                      "call with use_lrp=False (the evaluator default 'ours_no_lrp')")
+            _require_relprop(self.model)                 # fail before the forward / backward, not after
         self.use_lrp = use_lrp
         self.normalize_self_attention = normalize_self_attention
         self.apply_self_in_rule_10 = apply_self_in_rule_10
         outputs = _logits_for_backward(self.model, img)
-        _one_hot_backward(self.model, outputs, target_index, index)
+        index, one_hot_vector = _one_hot_backward(self.model, outputs, target_index, index)
+        if use_lrp:
+            _relprop(self.model, one_hot_vector, target_index, index)
 
         decoder_blocks = self.model.transformer.decoder.layers
         encoder_blocks = self.model.transformer.encoder.layers
@@ -208,10 +235,25 @@ class Generator:
         return self.R_q_i.unsqueeze_(0)[:, target_index, :].unsqueeze_(0)
 
     def generate_transformer_att(self, img, target_index, index=None):
-        raise NotImplementedError("transformer_att needs model.relprop (LRP layer library): out of scope")
+        """Reference :64-108: rule 5 on the LRP cam of the LAST decoder cross-attention (needs the body's ``relprop``)."""
+        _require_relprop(self.model)
+        outputs = _logits_for_backward(self.model, img)
+        index, one_hot_vector = _one_hot_backward(self.model, outputs, target_index, index)
+        _relprop(self.model, one_hot_vector, target_index, index)
+        last = self.model.transformer.decoder.layers[-1].multihead_attn
+        self.R_q_i = avg_heads(last.get_attn_cam().detach(), last.get_attn_gradients().detach())
+        return self.R_q_i.unsqueeze_(0)[:, target_index, :].unsqueeze_(0)
 
     def generate_partial_lrp(self, img, target_index, index=None):
-        raise NotImplementedError("partial_lrp needs model.relprop (LRP layer library): out of scope")
+        """Reference :197-223: head-mean of the last cross-attention's LRP cam, min-max normalised (no backward)."""
+        _require_relprop(self.model)
+        outputs = self.model(img)["pred_logits"]
+        index, one_hot_vector = _one_hot_backward(self.model, outputs, target_index, index, backward=False)
+        _relprop(self.model, one_hot_vector, target_index, index)
+        cam_q_i = self.model.transformer.decoder.layers[-1].multihead_attn.get_attn_cam().detach()
+        cam_q_i = cam_q_i.reshape(-1, cam_q_i.shape[-2], cam_q_i.shape[-1]).mean(dim=0)
+        self.R_q_i = (cam_q_i - cam_q_i.min()) / (cam_q_i.max() - cam_q_i.min())
+        return self.R_q_i.unsqueeze_(0)[:, target_index, :].unsqueeze_(0)
 
 
 class GeneratorAlbationNoAgg:
@@ -226,26 +268,28 @@ class GeneratorAlbationNoAgg:
 
     def handle_self_attention_image(self, blocks):
         for blk in blocks:
-            cam = avg_heads(blk.self_attn.get_attn().detach(), blk.self_attn.get_attn_gradients().detach())
+            cam = avg_heads(_cam(blk.self_attn, self.use_lrp), blk.self_attn.get_attn_gradients().detach())
             self.R_i_i = ops.matmul(cam, self.R_i_i)
 
     def handle_co_attn_self_query(self, block):
-        cam = avg_heads(block.self_attn.get_attn().detach(), block.self_attn.get_attn_gradients().detach())
+        cam = avg_heads(_cam(block.self_attn, self.use_lrp), block.self_attn.get_attn_gradients().detach())
         self.R_q_q, self.R_q_i = apply_self_attention_rules(self.R_q_q, self.R_q_i, cam)
 
     def handle_co_attn_query(self, block):
-        cam_q_i = avg_heads(block.multihead_attn.get_attn().detach(), block.multihead_attn.get_attn_gradients().detach())
+        cam_q_i = avg_heads(_cam(block.multihead_attn, self.use_lrp), block.multihead_attn.get_attn_gradients().detach())
         self.R_q_i = apply_mm_attention_rules(self.R_q_q, self.R_i_i, cam_q_i,
-                                              apply_normalization=self.normalize_self_attention)
+                                              apply_normalization=self.normalize_self_attention,
+                                              apply_self_in_rule_10=self.apply_self_in_rule_10)
 
     def generate_ours_abl(self, img, target_index, index=None, use_lrp=False, normalize_self_attention=False,
                           apply_self_in_rule_10=True):
-        if use_lrp:
-            raise NotImplementedError("use_lrp=True needs the reference's LRP layer library: out of scope")
         self.use_lrp = use_lrp
         self.normalize_self_attention = normalize_self_attention
+        self.apply_self_in_rule_10 = apply_self_in_rule_10          # reference :342, forwarded to rule 10 (:347-349)
         outputs = _logits_for_backward(self.model, img)
-        _one_hot_backward(self.model, outputs, target_index, index)
+        index, one_hot_vector = _one_hot_backward(self.model, outputs, target_index, index)
+        if use_lrp:
+            _relprop(self.model, one_hot_vector, target_index, index)
         decoder_blocks = self.model.transformer.decoder.layers
         encoder_blocks = self.model.transformer.encoder.layers
         ref = encoder_blocks[0].self_attn.get_attn()

@@ -10,7 +10,10 @@ lxmert/lxmert/perturbation.py:45-83).  Attention modules are reached through the
 Underneath: the 9 language and 5 vision self-attention layers are one chain launch each (rules 6+7 carry the
 cross matrices as second right-hand side), the cross layers use the rule-10/11 kernels; both cross directions are
 computed from the pre-update state and added afterwards, exactly like the reference (:176-196).
-LRP methods need the LRP layer library: out of scope.
+LRP methods (``use_lrp=True``, ``generate_transformer_attr``, ``generate_partial_lrp``) run the reference's schedule on
+``get_attn_cam()`` when the body brings its own LRP pass (``model.relprop(one_hot, alpha=1)`` filling ``save_attn_cam``,
+lxmert/lxmert/src/lxmert_lrp.py:422-461); ``lxmert_model`` has none and these then raise
+``NotImplementedError`` naming the missing method.
 """
 from __future__ import annotations
 
@@ -24,21 +27,35 @@ apply_self_attention_rules = rules.apply_self_attention_rules
 apply_mm_attention_rules = rules.apply_mm_attention_rules_lxmert
 
 
-def _pair(module):
-    return module.get_attn().detach(), module.get_attn_gradients().detach()
+def _pair(module, use_lrp=False):
+    """``(cam, grad)``: the LRP cam on the LRP route, the attention probabilities otherwise (reference :64-67 etc.)."""
+    return (module.get_attn_cam() if use_lrp else module.get_attn()).detach(), module.get_attn_gradients().detach()
 
 
-def _backward_on_answer(model_usage, input, index):
-    """lxmert/.../ExplanationGenerator.py:136,153-163."""
+def _require_relprop(model):
+    if not hasattr(model, "relprop"):
+        raise NotImplementedError(
+            "use_lrp=True / transformer_attr / partial_lrp read LRP attention cams (get_attn_cam) that the body's "
+            "relprop() must produce; %s has no relprop().  Use use_lrp=False (the evaluator's 'ours_no_lrp'), or plug a "
+            "body built on an LRP layer library (reference: lxmert/lxmert/src/lxmert_lrp.py)." % type(model).__name__)
+
+
+def _backward_on_answer(model_usage, input, index, use_lrp=False, backward=True):
+    """lxmert/.../ExplanationGenerator.py:136,153-165: forward, one-hot on the answer, backward [, the body's relprop]."""
     model = model_usage.model
+    if use_lrp:
+        _require_relprop(model)
     output = rules.forward_for_backward(model, lambda: model_usage.forward(input).question_answering_score)
     if index is None:
         index = np.argmax(output.cpu().data.numpy(), axis=-1)
     one_hot = torch.zeros_like(output)
     one_hot[0, index] = 1
-    loss = torch.sum(one_hot * output)
-    model.zero_grad()
-    loss.backward(retain_graph=True)
+    if backward:
+        loss = torch.sum(one_hot * output)
+        model.zero_grad()
+        loss.backward(retain_graph=True)
+    if use_lrp:
+        model.relprop(one_hot.detach().clone(), alpha=1)
     return model
 
 
@@ -52,10 +69,11 @@ class GeneratorOurs:
         """All 38 rule applications in ONE kernel launch (``mmx_lxmert_schedule``); same results as the per-rule path."""
         enc = model.lxmert.encoder
         xs = list(enc.x_layers)
+        u = self.use_lrp
         R_tt, R_ti, R_ii, R_it = ops.lxmert_schedule(
-            [_pair(b.attention.self) for b in enc.layer], [_pair(b.attention.self) for b in enc.r_layers],
-            [_pair(b.visual_attention.att) for b in xs], [_pair(b.visual_attention_copy.att) for b in xs[:-1]],
-            [_pair(b.lang_self_att.self) for b in xs], [_pair(b.visn_self_att.self) for b in xs[:-1]],
+            [_pair(b.attention.self, u) for b in enc.layer], [_pair(b.attention.self, u) for b in enc.r_layers],
+            [_pair(b.visual_attention.att, u) for b in xs], [_pair(b.visual_attention_copy.att, u) for b in xs[:-1]],
+            [_pair(b.lang_self_att.self, u) for b in xs], [_pair(b.visn_self_att.self, u) for b in xs[:-1]],
             apply_normalization=self.normalize_self_attention, apply_self_in_rule_10=self.apply_self_in_rule_10)
         self.R_t_t, self.R_t_i, self.R_i_i, self.R_i_t = R_tt[0], R_ti[0], R_ii[0], R_it[0]
         return self.R_t_t, self.R_t_i
@@ -104,38 +122,35 @@ class GeneratorOurs:
         return R_ss[0], R_sq[0]
 
     def handle_self_attention_lang(self, blocks):
-        self.R_t_t, self.R_t_i = self._self_chain([_pair(b.attention.self) for b in blocks], self.R_t_t, self.R_t_i)
+        self.R_t_t, self.R_t_i = self._self_chain([_pair(b.attention.self, self.use_lrp) for b in blocks], self.R_t_t, self.R_t_i)
 
     def handle_self_attention_image(self, blocks):
-        self.R_i_i, self.R_i_t = self._self_chain([_pair(b.attention.self) for b in blocks], self.R_i_i, self.R_i_t)
+        self.R_i_i, self.R_i_t = self._self_chain([_pair(b.attention.self, self.use_lrp) for b in blocks], self.R_i_i, self.R_i_t)
 
     def handle_co_attn_self_lang(self, block):
-        self.R_t_t, self.R_t_i = self._self_chain([_pair(block.lang_self_att.self)], self.R_t_t, self.R_t_i)
+        self.R_t_t, self.R_t_i = self._self_chain([_pair(block.lang_self_att.self, self.use_lrp)], self.R_t_t, self.R_t_i)
 
     def handle_co_attn_self_image(self, block):
-        self.R_i_i, self.R_i_t = self._self_chain([_pair(block.visn_self_att.self)], self.R_i_i, self.R_i_t)
+        self.R_i_i, self.R_i_t = self._self_chain([_pair(block.visn_self_att.self, self.use_lrp)], self.R_i_i, self.R_i_t)
 
     def handle_co_attn_lang(self, block):
-        cam_t_i = avg_heads(*_pair(block.visual_attention.att))
+        cam_t_i = avg_heads(*_pair(block.visual_attention.att, self.use_lrp))
         return apply_mm_attention_rules(self.R_t_t, self.R_i_i, self.R_i_t, cam_t_i,
                                         apply_normalization=self.normalize_self_attention,
                                         apply_self_in_rule_10=self.apply_self_in_rule_10)
 
     def handle_co_attn_image(self, block):
-        cam_i_t = avg_heads(*_pair(block.visual_attention_copy.att))
+        cam_i_t = avg_heads(*_pair(block.visual_attention_copy.att, self.use_lrp))
         return apply_mm_attention_rules(self.R_i_i, self.R_t_t, self.R_t_i, cam_i_t,
                                         apply_normalization=self.normalize_self_attention,
                                         apply_self_in_rule_10=self.apply_self_in_rule_10)
 
     def generate_ours(self, input, index=None, use_lrp=True, normalize_self_attention=True, apply_self_in_rule_10=True,
                       method_name="ours"):
-        if use_lrp:
-            raise NotImplementedError("use_lrp=True needs model.relprop (LRP layer library); call with use_lrp=False "
-                                      "(the evaluator's 'ours_no_lrp')")
         self.use_lrp = use_lrp
         self.normalize_self_attention = normalize_self_attention
         self.apply_self_in_rule_10 = apply_self_in_rule_10
-        model = _backward_on_answer(self.model_usage, input, index)
+        model = _backward_on_answer(self.model_usage, input, index, use_lrp)
         text_tokens = self.model_usage.text_len
         image_bboxes = self.model_usage.image_boxes_len
         dev = model.device
@@ -177,16 +192,14 @@ class GeneratorOursAblationNoAggregation:
         self.save_visualization = save_visualization
 
     def _self(self, module, R_ss, R_sq):
-        cam = avg_heads(*_pair(module))
+        cam = avg_heads(*_pair(module, self.use_lrp))
         return apply_self_attention_rules(R_ss, R_sq, cam)
 
     def generate_ours_no_agg(self, input, index=None, use_lrp=False, normalize_self_attention=True,
                              method_name="ours_no_agg"):
-        if use_lrp:
-            raise NotImplementedError("use_lrp=True needs model.relprop: out of scope")
         self.use_lrp = use_lrp
         self.normalize_self_attention = normalize_self_attention
-        model = _backward_on_answer(self.model_usage, input, index)
+        model = _backward_on_answer(self.model_usage, input, index, use_lrp)
         T, I = self.model_usage.text_len, self.model_usage.image_boxes_len
         dev = model.device
         self.R_t_t, self.R_i_i = torch.eye(T, T, device=dev), torch.eye(I, I, device=dev)
@@ -197,12 +210,12 @@ class GeneratorOursAblationNoAggregation:
             self.R_i_i, self.R_i_t = self._self(blk.attention.self, self.R_i_i, self.R_i_t)
 
         def co_lang(blk):
-            cam = avg_heads(*_pair(blk.visual_attention.att))
+            cam = avg_heads(*_pair(blk.visual_attention.att, self.use_lrp))
             return apply_mm_attention_rules(self.R_t_t, self.R_i_i, self.R_i_t, cam,
                                             apply_normalization=self.normalize_self_attention)
 
         def co_img(blk):
-            cam = avg_heads(*_pair(blk.visual_attention_copy.att))
+            cam = avg_heads(*_pair(blk.visual_attention_copy.att, self.use_lrp))
             return apply_mm_attention_rules(self.R_i_i, self.R_t_t, self.R_t_i, cam,
                                             apply_normalization=self.normalize_self_attention)
 
@@ -224,7 +237,7 @@ class GeneratorOursAblationNoAggregation:
 
 class GeneratorBaselines:
     """Attention-only baselines of the reference (:368-665): raw attention, attention GradCAM, rollout.
-    ``generate_transformer_attr`` / ``generate_partial_lrp`` need LRP and raise."""
+    ``generate_transformer_attr`` / ``generate_partial_lrp`` read LRP cams: they need a body with ``relprop`` (module docstring)."""
 
     def __init__(self, model_usage, save_visualization=False):
         self.model_usage = model_usage
@@ -283,7 +296,31 @@ class GeneratorBaselines:
         return self.R_t_t, self.R_t_i
 
     def generate_transformer_attr(self, input, index=None, method_name="transformer_attr"):
-        raise NotImplementedError("transformer_attr needs model.relprop (LRP layer library): out of scope")
+        """Reference :373-460: rule 6 only (``R_ss += cam.R_ss``) per stream on the LRP cams -- one chain launch per
+        stream -- and ``R_t_i`` = rule 5 of the last cross-attention's cam."""
+        model = _backward_on_answer(self.model_usage, input, index, use_lrp=True)
+        enc = model.lxmert.encoder
+        xs = list(enc.x_layers)
+        lang = [_pair(b.attention.self, True) for b in enc.layer] + [_pair(b.lang_self_att.self, True) for b in xs]
+        img = [_pair(b.attention.self, True) for b in enc.r_layers] + [_pair(b.visn_self_att.self, True) for b in xs[:-1]]
+        self.R_t_t = ops.relevancy_self_chain([a for a, _ in lang], [g for _, g in lang], 1)[0]
+        self.R_i_i = ops.relevancy_self_chain([a for a, _ in img], [g for _, g in img], 1)[0]
+        self.R_t_i = avg_heads(*_pair(xs[-1].visual_attention.att, True))
+        self.R_i_t = torch.zeros(self.R_i_i.shape[0], self.R_t_t.shape[0], device=self.R_t_t.device)
+        self.R_t_t[0, 0] = 0
+        return self.R_t_t, self.R_t_i
 
     def generate_partial_lrp(self, input, index=None, method_name="partial_lrp"):
-        raise NotImplementedError("partial_lrp needs model.relprop (LRP layer library): out of scope")
+        """Reference :462-506: head-means of the last x-layer's LRP cams, each min-max normalised (no backward)."""
+        model = _backward_on_answer(self.model_usage, input, index, use_lrp=True, backward=False)
+        blk = model.lxmert.encoder.x_layers[-1]
+
+        def mean_cam(module):
+            cam = module.get_attn_cam().detach()
+            cam = cam.reshape(-1, cam.shape[-2], cam.shape[-1]).mean(dim=0)
+            return (cam - cam.min()) / (cam.max() - cam.min())
+
+        self.R_t_i = mean_cam(blk.visual_attention.att)
+        self.R_t_t = mean_cam(blk.lang_self_att.self)
+        self.R_t_t[0, 0] = 0
+        return self.R_t_t, self.R_t_i

@@ -14,7 +14,14 @@ Here the 9 perturbed inputs of one sample are ONE batch:
     sorted for positional embedding to work"), so the kept ids are gathered, left-aligned and padded; padding is masked.
 
 Everything (``topk``, mask / gather construction, arg-max, accuracy lookup) stays on the device; one host read per
-sample at most.  Results equal the sequential loop up to fp32 summation order (tests/test_gpu_perturbation.py).
+sample at most.  Results equal the sequential loop up to fp32 summation order; pinned against the 9 score vectors the
+reference's own ``perturbation_image`` / ``perturbation_text`` produce on the reference LXMERT body
+(``tests/golden/lxmert_perturbation.npz``, ``tests/test_gpu_perturbation.py``).
+
+Tie policy: the reference calls ``topk(k)`` once per step; which of several EQUAL scores it keeps is whatever the
+backend's ``topk`` does for that ``k`` (not specified, and different between CPU and GPU builds of torch).  Here the
+ranking is ONE stable descending sort -- among equal scores the lower index ranks first -- so every step keeps a prefix
+of the same order.  With distinct scores (any real relevancy map) this equals the reference's per-step ``topk`` exactly.
 """
 from __future__ import annotations
 
@@ -39,12 +46,17 @@ def normalize_cams_batch(R_t_t, R_t_i):
     return minmax(R_t_i[:, 0]), minmax(R_t_t[:, 0])
 
 
+def ranking(scores):
+    """Indices by descending score, ties by ascending index (module docstring: tie policy)."""
+    return torch.sort(scores, dim=-1, descending=True, stable=True).indices
+
+
 def image_keep_masks(cam_image, steps=PERT_STEPS, is_positive_pert=False):
     """``[S, I]`` float 0/1: row s keeps the ``int((1 - step_s) * I)`` top-scoring regions (``perturbation.py:114-117``)."""
     cam = -cam_image if is_positive_pert else cam_image
     n = cam.shape[-1]
     keep = torch.zeros(len(steps), n, dtype=torch.float32, device=cam.device)
-    order = cam.topk(k=n, dim=-1).indices                     # topk(k) for every k is a prefix of topk(n)
+    order = ranking(cam)                                      # every step keeps a prefix of ONE ranking
     for s, step in enumerate(steps):
         keep[s, order[: int((1 - step) * n)]] = 1.0
     return keep
@@ -57,7 +69,7 @@ def text_keep_batch(input_ids, token_type_ids, cam_text, steps=PERT_STEPS, is_po
     cam = -cam_text if is_positive_pert else cam_text
     T = cam.shape[-1]
     inner = cam[1:-1]
-    order = inner.topk(k=T - 2, dim=-1).indices + 1
+    order = ranking(inner) + 1
     S = len(steps)
     keep = torch.zeros(S, T, dtype=torch.bool, device=cam.device)
     keep[:, 0] = keep[:, T - 1] = True

@@ -287,8 +287,8 @@ def mm_attention_rules(R_ss, R_qq, cam_sq, R_qs=None, apply_normalization=True, 
     if R_qs is not None:
         R_qs = _f32c(R_qs)
         ss_add = torch.empty(ns, ns, dtype=torch.float32, device=cam_sq.device)
-    want_diag = check_diag and apply_normalization and apply_self_in_rule_10
-    dmin = torch.empty(1, dtype=torch.float32, device=cam_sq.device) if want_diag else None
+    want_diag = check_diag and apply_normalization      # the reference asserts in handle_residual even when the
+    dmin = torch.empty(1, dtype=torch.float32, device=cam_sq.device) if want_diag else None   # self terms are unused
     need = lib().mmx_mm_rules_workspace_bytes(ns, nq)
     ws = _workspace(need, cam_sq.device)
     check(lib().mmx_mm_attention_rules(_p(R_ss), _p(R_qq), _p(R_qs), _p(cam_sq), _p(sq_add), _p(ss_add), ns, nq,

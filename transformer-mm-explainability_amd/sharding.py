@@ -87,7 +87,8 @@ def evaluate_sharded(sample_ids, length_of, process_batch, n_cols, max_batch=128
     Returns ``[len(sample_ids), n_cols]`` on every rank.  The only collective is that final gather.
     """
     mine = shard_indices(sample_ids)
-    todo = [k for k in mine if store is None or k not in store.done()]
+    done = store.done() if store is not None else ()           # computed once (a 10k-sample resume: not once per id)
+    todo = [k for k in mine if k not in done]
     fresh = {}
     for _, positions in length_buckets([length_of(k) for k in todo], max_batch):
         ids = [todo[p] for p in positions]
@@ -99,7 +100,7 @@ def evaluate_sharded(sample_ids, length_of, process_batch, n_cols, max_batch=128
         else:
             for k, row in zip(ids, rows):
                 fresh[k] = row
-    if store is not None:
+    if store is not None and mine:
         local = store.table(mine, device=device)
     elif mine:
         local = torch.stack([fresh[k] for k in mine]).to(device=device, dtype=torch.float32)
@@ -124,10 +125,13 @@ class PartialScores:
     order the gather expects.  A torn last line (killed mid-write) is ignored.
     """
 
-    def __init__(self, directory, rank):
+    def __init__(self, directory, rank, config=None):
+        """``config``: any JSON-serialisable description of WHAT is being scored (method, test type, steps ...).  It is
+        written as the file's header record and must match on resume: rows of another method / test are never reused."""
         os.makedirs(directory, exist_ok=True)
         self.path = os.path.join(directory, "scores_rank%d.jsonl" % rank)
         self.rows = {}
+        header = None
         if os.path.exists(self.path):
             with open(self.path) as f:
                 for line in f:
@@ -135,13 +139,24 @@ class PartialScores:
                         rec = json.loads(line)
                     except ValueError:
                         continue                      # torn tail of an interrupted write
+                    if "config" in rec:
+                        header = rec["config"]
+                        continue
                     for k, row in zip(rec["ids"], rec["rows"]):
                         self.rows[int(k)] = row
+        config = json.loads(json.dumps(config)) if config is not None else None       # normalised (tuples -> lists)
+        if (self.rows or header is not None) and header != config:
+            raise ValueError("%s holds rows of another run (%r), not of %r: use a fresh directory" %
+                             (self.path, header, config))
+        fresh = not os.path.exists(self.path) or os.path.getsize(self.path) == 0
         torn = os.path.exists(self.path) and os.path.getsize(self.path) > 0 and \
             open(self.path, "rb").read()[-1:] != b"\n"
         self._f = open(self.path, "a")
         if torn:
             self._f.write("\n")                  # finish the torn line so the next record starts on its own line
+        if fresh and config is not None:
+            self._f.write(json.dumps({"config": config}) + "\n")
+            self._f.flush()
 
     def done(self):
         return set(self.rows)
@@ -158,7 +173,10 @@ class PartialScores:
 
     def table(self, sample_ids, device="cpu"):
         """Rows of ``sample_ids`` in that order (every id must be done) -> ``[len(ids), n_cols]`` fp32 tensor."""
-        return torch.tensor([self.rows[int(k)] for k in sample_ids], dtype=torch.float32, device=device)
+        rows = [self.rows[int(k)] for k in sample_ids]
+        if not rows:
+            raise ValueError("PartialScores.table: empty id list (the column count is unknown here)")
+        return torch.tensor(rows, dtype=torch.float32, device=device)
 
     def close(self):
         self._f.close()

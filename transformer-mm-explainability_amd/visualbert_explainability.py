@@ -4,7 +4,9 @@ surface (``SelfAttentionGenerator``) on the HIP kernels.
 ``model`` is duck-typed as in the reference: ``model(input)['scores']``, ``model.model.bert.encoder.layer[i].attention.self``
 with ``get_attn()`` / ``get_attn_gradients()`` -> ``[1, H, N, N]``; ``input['input_mask']`` gives the ``[CLS]``-row index
 ``input_mask.sum(1) - 2`` (reference :94-95).  Visualisation flags are accepted and ignored (cv2 drawing is not part of
-the path).  LRP methods (``generate_transformer_att``, ``generate_partial_lrp``) need ``model.relprop``: out of scope.
+the path).  LRP methods (``generate_transformer_att``, ``generate_partial_lrp``) run on ``get_attn_cam()`` when the body
+brings its own LRP pass (``model.relprop(one_hot, alpha=1)`` filling ``save_attn_cam``, BERT_ours.py:345-395);
+``visualbert_model`` has none and they then raise ``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -16,15 +18,22 @@ from . import ops, rules
 compute_rollout_attention = rules.compute_rollout_attention_batched
 
 
-def _backward_on_answer(model, input, index):
+def _backward_on_answer(model, input, index, use_lrp=False, backward=True):
+    if use_lrp and not hasattr(model, "relprop"):
+        raise NotImplementedError(
+            "transformer_att / partial_lrp read LRP attention cams (get_attn_cam) that the body's relprop() must produce; "
+            "%s has no relprop().  Plug a body built on an LRP layer library (reference: BERT_ours.py)." % type(model).__name__)
     output = rules.forward_for_backward(model, lambda: model(input)["scores"])
     if index is None:
         index = np.argmax(output.cpu().data.numpy(), axis=-1)
     one_hot = torch.zeros_like(output)
     one_hot[0, index] = 1
-    loss = torch.sum(one_hot * output)
-    model.zero_grad()
-    loss.backward(retain_graph=True)
+    if backward:
+        loss = torch.sum(one_hot * output)
+        model.zero_grad()
+        loss.backward(retain_graph=True)
+    if use_lrp:
+        model.relprop(one_hot.detach().clone(), alpha=1)
 
 
 class SelfAttentionGenerator:
@@ -115,7 +124,24 @@ class SelfAttentionGenerator:
 
     def generate_transformer_att(self, input, index=None, start_layer=0, save_visualization=False,
                                  save_visualization_per_token=False):
-        raise NotImplementedError("transformer_att needs model.relprop (LRP layer library): out of scope")
+        """Reference :24-66: rule 5 on the LRP cams, then the un-normalised batched rollout from ``start_layer``."""
+        _backward_on_answer(self.model, input, index, use_lrp=True)
+        cams = []
+        for blk in self._blocks():
+            sa = blk.attention.self
+            cams.append(ops.avg_heads(sa.get_attn_cam()[0], sa.get_attn_gradients()[0], batch_size=1))     # [1, N, N]
+        rollout = compute_rollout_attention(cams, start_layer=start_layer)
+        cls_index = input["input_mask"].sum(1) - 2
+        cls_per_token_score = rollout[0, cls_index]
+        cls_per_token_score[:, cls_index] = 0
+        return cls_per_token_score
 
     def generate_partial_lrp(self, input, index=None, save_visualization=False):
-        raise NotImplementedError("partial_lrp needs model.relprop (LRP layer library): out of scope")
+        """Reference :109-130: head-mean of the last layer's LRP cam, min-max normalised (no backward)."""
+        _backward_on_answer(self.model, input, index, use_lrp=True, backward=False)
+        cam = self._blocks()[-1].attention.self.get_attn_cam()[0].mean(dim=0).unsqueeze(0)
+        cam = (cam - cam.min()) / (cam.max() - cam.min())
+        cls_index = input["input_mask"].sum(1) - 2
+        cls_per_token_score = cam[0, cls_index]
+        cls_per_token_score[:, cls_index] = 0
+        return cls_per_token_score

@@ -16,7 +16,11 @@ from __future__ import annotations
 
 import torch
 
-from .lxmert_perturbation import PERT_STEPS, image_keep_masks
+from .lxmert_perturbation import PERT_STEPS, image_keep_masks, ranking
+
+# evaluation_loop.py:93-96: the image test removes regions on a finer scale near "all removed" than the text test
+IMAGE_STEPS = (0, 0.5, 0.75, 0.95, 0.96, 0.97, 0.98, 0.99, 1)
+TEXT_STEPS = PERT_STEPS
 
 
 def text_keep_batch(input_ids, segment_ids, text_scores, n_text, steps=PERT_STEPS):
@@ -25,7 +29,7 @@ def text_keep_batch(input_ids, segment_ids, text_scores, n_text, steps=PERT_STEP
     T = input_ids.shape[1]
     cls_index = n_text - 2
     n_inner = text_scores.shape[-1]
-    order = text_scores.topk(k=n_inner, dim=-1).indices + 1
+    order = ranking(text_scores) + 1
     S = len(steps)
     keep = torch.zeros(S, T, dtype=torch.bool, device=input_ids.device)
     keep[:, 0] = keep[:, cls_index] = keep[:, cls_index + 1] = True
@@ -42,11 +46,13 @@ def text_keep_batch(input_ids, segment_ids, text_scores, n_text, steps=PERT_STEP
 class VisualBertPerturbation:
     """``model``: a ``visualbert_model.VisualBERT``.  ``sample``: ``input_ids``, ``input_mask``, ``segment_ids``
     (``[1, T]``, padding allowed), ``image_feature_0`` (``[1, V, dim]``).  ``method_cam``: the generator's ``[1, N]`` row
-    (``N = n_text + V``).  Both methods return the 9 steps' ``scores [S, num_labels]``."""
+    (``N = n_text + V``).  Both methods return the 9 steps' ``scores [S, num_labels]``.  ``steps=None`` (default): the
+    reference's step lists, which differ per modality (``IMAGE_STEPS`` / ``TEXT_STEPS``, evaluation_loop.py:93-96)."""
 
-    def __init__(self, model, steps=PERT_STEPS):
+    def __init__(self, model, steps=None):
         self.model = model
-        self.steps = tuple(steps)
+        self.image_steps = tuple(IMAGE_STEPS if steps is None else steps)
+        self.text_steps = tuple(TEXT_STEPS if steps is None else steps)
 
     def _run(self, ids, seg, input_mask, feats, visual_mask):
         S = ids.shape[0]
@@ -57,8 +63,8 @@ class VisualBertPerturbation:
     @torch.no_grad()
     def perturbation_image(self, sample, method_cam, is_positive_pert=False):
         n_text = int(sample["input_mask"].sum())                      # one host read per sample, as in the reference
-        S = len(self.steps)
-        keep = image_keep_masks(method_cam[0, n_text:], self.steps, is_positive_pert).long()          # [S, V]
+        S = len(self.image_steps)
+        keep = image_keep_masks(method_cam[0, n_text:], self.image_steps, is_positive_pert).long()    # [S, V]
         ids = sample["input_ids"][:, :n_text].expand(S, -1)
         seg = sample["segment_ids"][:, :n_text].expand(S, -1)
         return self._run(ids, seg, torch.ones_like(ids), sample["image_feature_0"], keep)
@@ -68,12 +74,33 @@ class VisualBertPerturbation:
         n_text = int(sample["input_mask"].sum())
         cam = -method_cam if is_positive_pert else method_cam
         ids, seg, mask = text_keep_batch(sample["input_ids"][:, :n_text], sample["segment_ids"][:, :n_text],
-                                         cam[0, 1:n_text - 2], n_text, self.steps)
+                                         cam[0, 1:n_text - 2], n_text, self.text_steps)
         feats = sample["image_feature_0"]
-        visual_mask = torch.ones(len(self.steps), feats.shape[1], dtype=torch.long, device=feats.device)
+        visual_mask = torch.ones(len(self.text_steps), feats.shape[1], dtype=torch.long, device=feats.device)
         return self._run(ids, seg, mask, feats, visual_mask)
 
     @staticmethod
     def accuracy(scores, targets):
         """``targets [num_labels]``: the item's soft scores per answer (``report['targets'][0]``) -> ``[S]``."""
         return targets[scores.argmax(dim=-1)]
+
+
+def evaluation_loop(generate, pert, loader, num_samples, modality="image", is_positive_pert=False, reference_exact=False):
+    """``TrainerEvaluationLoopMixinPert.evaluation_loop`` (evaluation_loop.py:73-169) on the batched evaluator: for every
+    item ``method_cam = generate(item)``, the 9 perturbed re-runs in ONE forward, ``step_acc[s] += targets[argmax]``.
+    Returns the per-step accuracies in percent (what the reference prints) as a ``[9]`` fp64 tensor.
+
+    ``reference_exact=True`` reproduces the reference's sample accounting: its ``i > num_samples`` test stops only AFTER
+    item ``num_samples + 1`` and it still divides by ``num_samples``.  The default evaluates exactly ``num_samples`` items.
+    ``loader`` yields ``sample_list`` dicts carrying ``targets [1, num_labels]``."""
+    steps = pert.image_steps if modality == "image" else pert.text_steps
+    step_acc = torch.zeros(len(steps), dtype=torch.float64)
+    limit = num_samples + 1 if reference_exact else num_samples
+    for i, item in enumerate(loader):
+        if i >= limit:
+            break
+        cam = generate(item).detach()
+        run = pert.perturbation_image if modality == "image" else pert.perturbation_text
+        scores = run(item, cam, is_positive_pert)
+        step_acc += pert.accuracy(scores, item["targets"][0]).double().cpu()
+    return step_acc / num_samples * 100
