@@ -57,6 +57,7 @@ const char* mmx_last_error(void);
  *   "self_chain_algo"    0 auto | 1 one workgroup per (sample, layer group), no scratch beyond the partial products |
  *                        2 one workgroup per (sample, layer) + last-arriver chain (bit-identical to 1 at groups = 1)
  *   "self_chain_groups"  0 auto | 1..8 layer groups per sample of the fused chain kernel (1 = strict sequential order)
+ *   "attn_head"          1 (default) register-resident whole-head attention kernels (Nk <= 128, Nq <= 256) | 0 never
  *   "attn_small"         1 (default) whole-head-in-LDS attention kernels where the head fits | 0 never
  *   "attn_stream"        1 (default) long-sequence streaming attention kernels | 0 first-generation tiled kernels
  *   "debug_flags"        profiling only (phase skipping); 0 in production
@@ -271,6 +272,14 @@ int mmx_quick_gelu_bwd(const void* x_dev, const void* dy_dev, void* dx_dev, int6
  * dx: [rows, E]; x: [x_rows, E]; mean, rstd: [x_rows]; gamma: [E]; fp32 contiguous, E % 4 == 0. */
 int mmx_layernorm_bwd_add(const void* dy_dev, const void* x_dev, const void* mean_dev, const void* rstd_dev,
                           const void* gamma_dev, const void* d_res_dev, void* dx_dev, int64_t rows, int x_rows, int E,
+                          void* stream);
+
+/* Residual add fused with the LayerNorm that follows it in a pre-LN block (CLIP/clip/model.py:195-197: x = x + attn(...);
+ * ... ln_2(x)): sum = x + y (written to sum_dev: the next residual), h = LayerNorm(sum) * gamma + beta, and the row
+ * statistics mean / rstd that mmx_layernorm_bwd_add consumes.  y_dev == NULL: plain LayerNorm of x (sum_dev unused).
+ * x, y, sum, h: [rows, E]; mean, rstd: [rows]; gamma, beta: [E]; fp32 contiguous, E % 4 == 0, E <= 4096. */
+int mmx_add_layernorm_fwd(const void* x_dev, const void* y_dev, const void* gamma_dev, const void* beta_dev,
+                          void* sum_dev, void* h_dev, void* mean_dev, void* rstd_dev, int64_t rows, int E, float eps,
                           void* stream);
 
 /* ---------------------------------------------------------------------------------------------

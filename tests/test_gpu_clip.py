@@ -52,13 +52,14 @@ def test_capture_slabs_match_reference_hooks(golden, share):
     ce.interpret(image, texts, model, "cuda", 0, 0, share_image_forward=share)
     vis = list(model.visual.transformer.resblocks.children())
     txt = list(model.transformer.resblocks.children())
+    # tolerances of DESIGN.md section 6: probabilities 2e-6, gradients 2e-5 (here 5e-6: the values are O(0.1))
     for l, blk in enumerate(vis):
         want = g["img_attn"][l]
-        close(blk.attn_probs, want[:blk.attn_probs.shape[0]] if share else want, atol=1e-6)
-        close(blk.attn_grad, g["img_grad"][l], atol=1e-6)
+        close(blk.attn_probs, want[:blk.attn_probs.shape[0]] if share else want, atol=2e-6)
+        close(blk.attn_grad, g["img_grad"][l], atol=5e-6)
     for l, blk in enumerate(txt):
-        close(blk.attn_probs, g["txt_attn"][l], atol=1e-6)
-        close(blk.attn_grad, g["txt_grad"][l], atol=1e-6)
+        close(blk.attn_probs, g["txt_attn"][l], atol=2e-6)
+        close(blk.attn_grad, g["txt_grad"][l], atol=5e-6)
     with torch.no_grad():
         pass
     logits, _ = model(image.repeat(texts.shape[0], 1, 1, 1), texts)

@@ -237,12 +237,15 @@ def torch_attention(q, k, v, scale, mode, mask):
     (2, 12, 14, 36, 64, 1, False), (1, 2, 1, 3, 16, 1, False), (1, 4, 197, 197, 64, 0, False),
     (1, 2, 33, 130, 48, 1, True), (1, 4, 15, 15, 8, 0, False), (1, 4, 7, 15, 8, 0, False), (2, 3, 9, 20, 4, 1, False),
     (1, 2, 20, 20, 24, 0, False), (1, 8, 200, 330, 32, 0, False), (2, 4, 130, 70, 64, 1, True),
-    (1, 3, 65, 129, 48, 0, True),
+    (1, 3, 65, 129, 48, 0, True), (2, 12, 128, 128, 64, 1, True), (1, 4, 14, 36, 64, 1, False), (1, 2, 36, 14, 64, 1, False),
+    (1, 2, 250, 100, 32, 0, False), (3, 2, 77, 77, 20, 0, True),
 ])
-@pytest.mark.parametrize("path", ["small", "stream", "tiled"])
+@pytest.mark.parametrize("path", ["head", "small", "stream", "tiled"])
 def test_attn_capture_fwd_bwd(ops, B, H, Nq, Nk, D, mode, masked, path):
-    """small: whole-head-in-LDS kernels where eligible (else the next path); stream: the long-sequence kernels
-    (K/V streamed in 64-row tiles) for every shape; tiled: the first-generation fallback for every shape."""
+    """head: register-resident whole-head kernels where eligible (else the next path); small: whole-head-in-LDS kernels
+    where eligible; stream: the long-sequence kernels (K/V streamed in 64-row tiles) for every shape; tiled: the
+    first-generation fallback for every shape."""
+    ops.set_option("attn_head", int(path == "head"))
     ops.set_option("attn_small", int(path == "small"))
     ops.set_option("attn_stream", int(path != "tiled"))
     g = torch.Generator().manual_seed(Nq * 7 + Nk)
@@ -279,6 +282,7 @@ def test_attn_capture_fwd_bwd(ops, B, H, Nq, Nk, D, mode, masked, path):
     close(dv2.permute(0, 2, 1, 3), vr.grad.float().numpy(), atol=2e-5)
     dprobs2 = torch.empty_like(dprobs)
     assert ops.attn_capture_bwd(qc, kc, vc, probs, d_o.cuda(), dprobs2, scale, mode, need_dqkv=False) == (None, None, None)
+    ops.set_option("attn_head", 1)
     ops.set_option("attn_small", 1)
     ops.set_option("attn_stream", 1)
     assert torch.equal(dprobs, dprobs2)

@@ -52,6 +52,7 @@ _PROTOTYPES = {
     "mmx_quick_gelu_fwd": (_i, [_vp, _vp, _i64, _vp]),
     "mmx_quick_gelu_bwd": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "mmx_layernorm_bwd_add": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "mmx_add_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     "mmx_event_create": (_i, [_vpp]),
     "mmx_event_destroy": (_i, [_vp]),
     "mmx_event_record": (_i, [_vp, _vp]),

@@ -8,8 +8,9 @@ Reference entry points mirrored here:
   * ``text_scores(text_encoding, R_text)`` -- notebook cell 8:5-7 post-processing (on device)
 
 What is different under the hood (results agree to fp32 rounding, see tests/test_gpu_clip.py):
-  * the reference issues one ``torch.autograd.grad`` per layer (24 partial backward passes); here ONE backward
-    fills every layer's gradient slab (``capture_only`` also drops weight/input gradients);
+  * the reference issues one ``torch.autograd.grad`` per layer (24 partial backward passes); here ONE hand-written
+    backward per tower (``clip_model.Transformer.forward_tape`` / ``backward_tape``: no autograd graph through the bodies,
+    no weight gradients, fused LayerNorm / QuickGELU / attention-capture kernels) fills every layer's gradient slab;
   * the per-layer reshape/mul/clamp/mean/bmm/add launches are one ``relevancy_self_chain`` launch per tower.
 """
 from __future__ import annotations
@@ -62,27 +63,25 @@ def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, 
     batch_size = texts.shape[0]
     sl = model.visual.transformer.layers - 1 if start_layer == -1 else start_layer
     slt = model.transformer.layers - 1 if start_layer_text == -1 else start_layer_text
-    prev = (model.capture_only, model.first_grad_layers)
-    model.capture_only, model.first_grad_layers = True, (sl, slt)    # no gradient work below the start layers
-    try:
-        with _Frozen(model), torch.enable_grad():
-            eye = torch.eye(batch_size, dtype=torch.float32, device=texts.device)
-            n_text = _n_text
-            if trim_text_padding and n_text is None:
-                n_text = int(texts.argmax(dim=-1).max()) + 1                              # one D2H read of the ids
-            if share_image_forward and image.shape[0] == 1 and batch_size > 1:
-                feat1, state = model.visual.forward_shared(image.type(model.dtype), batch_size)
-                image_features = feat1.expand(batch_size, -1).contiguous().requires_grad_(True)   # per-sample leaf
-                logits_per_image, _ = model.logits(image_features, model.encode_text(texts, n_text))
-                torch.autograd.backward(logits_per_image, grad_tensors=eye)
-                model.visual.backward_shared(state, image_features.grad, sl)
-            else:
-                images = image.repeat(batch_size, 1, 1, 1)
-                logits_per_image, _ = model.logits(model.encode_image(images), model.encode_text(texts, n_text))
-                # one_hot = sum_i logits_per_image[i, i]  (cell 6:6-10)  ->  d one_hot / d logits = I
-                torch.autograd.backward(logits_per_image, grad_tensors=eye)
-    finally:
-        model.capture_only, model.first_grad_layers = prev
+    n_text = _n_text
+    if trim_text_padding and n_text is None:
+        n_text = int(texts.argmax(dim=-1).max()) + 1                                      # one D2H read of the ids
+    shared = share_image_forward and image.shape[0] == 1 and batch_size > 1
+    # Both towers on the tape path (clip_model.Transformer.forward_tape / backward_tape): no autograd graph through the
+    # bodies, no weight gradients; only the cosine-similarity head (B x embed_dim features) goes through autograd.
+    images = image.type(model.dtype) if shared or image.shape[0] == batch_size else \
+        image.type(model.dtype).repeat(batch_size, 1, 1, 1)                                # cell 6:3
+    img_feat, img_state = model.visual.forward_tape(images, batch_size, sl)
+    txt_feat, txt_state = model.encode_text_tape(texts, n_text, slt)
+    with torch.enable_grad():
+        image_features = img_feat.expand(batch_size, -1).contiguous().requires_grad_(True)   # per-sample leaves
+        text_features = txt_feat.detach().requires_grad_(True)
+        logits_per_image, _ = model.logits(image_features, text_features)
+        # one_hot = sum_i logits_per_image[i, i]  (cell 6:6-10)  ->  d one_hot / d logits = I
+        eye = torch.eye(batch_size, dtype=torch.float32, device=texts.device)
+        torch.autograd.backward(logits_per_image, grad_tensors=eye, inputs=[image_features, text_features])
+    model.visual.backward_tape(img_state, image_features.grad, sl)
+    model.backward_text_tape(txt_state, text_features.grad, slt)
     R_text, R = _chains(model, batch_size, start_layer, start_layer_text)
     if R_text.shape[-1] != texts.shape[1]:       # trimmed run: the rest of the [B, 77, 77] matrix is the identity
         n = R_text.shape[-1]

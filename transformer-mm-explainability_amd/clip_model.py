@@ -130,65 +130,139 @@ class Transformer(nn.Module):
         return self.buffers
 
     # ------------------------------------------------------------------------------------------------------------
-    # Shared-forward / batched-backward (CLIP ``interpret`` repeats ONE image B times, notebook cell 6:3): the B copies
-    # have identical activations, only the upstream gradients differ.  The forward runs ONCE at batch 1 and keeps a
-    # small tape; the backward is the same chain of vector-Jacobian products autograd would run -- input-gradient
-    # GEMMs at batch B, LayerNorm backward with the shared statistics, our attention backward kernel with batch-stride-0
-    # q/k/v/P -- written out by hand because autograd cannot replay one graph for B different upstream gradients
-    # through a custom op.  Weight gradients are never formed.
+    # Tape forward / hand-written backward -- the path ``interpret`` runs for BOTH towers.
+    #
+    # The explainability pass needs d(logit)/d(attention probabilities) only.  Autograd would rebuild a graph per call
+    # (and the reference even runs one partial backward per layer); here the forward keeps a small tape and the backward
+    # is the same chain of vector-Jacobian products written out: input-gradient GEMMs, the fused LayerNorm-backward +
+    # residual kernel, the fused QuickGELU backward, our attention backward.  Weight gradients are never formed.
+    #
+    # Shared-forward mode (``x`` has batch 1, ``batch`` > 1): CLIP ``interpret`` repeats ONE image B times (notebook
+    # cell 6:3); the B copies have identical activations and differ only in their upstream gradients.  The forward runs
+    # ONCE, the backward runs at batch B with batch-stride-0 q / k / v / P and LayerNorm statistics shared by the batch.
     # ------------------------------------------------------------------------------------------------------------
-    @torch.no_grad()
-    def forward_shared(self, x, batch):
-        """``x``: ``[1, N, E]`` (already through ``ln_pre``).  Returns ``(y [1, N, E], tape)``."""
-        if x.shape[0] != 1:
-            raise ValueError("forward_shared takes the single shared sample")
-        N, E = x.shape[1], x.shape[2]
-        buffers = self._ensure_buffers(batch, N, x.device, shared_probs=True)
-        tape = []
-        for l, blk in enumerate(self.resblocks):
-            at = blk.attn
-            h1, mean1, rstd1 = torch.native_layer_norm(x, (E,), blk.ln_1.weight, blk.ln_1.bias, blk.ln_1.eps)
-            qkv = F.linear(h1, at.in_proj_weight, at.in_proj_bias).view(1, N, 3, at.num_heads, at.head_dim)
-            o = ops.attn_capture_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], buffers.probs[l], at.head_dim ** -0.5,
-                                     _lib.SCALE_Q_FIRST, blk.attn_mask, layout="bnhd")
-            x1 = x + at.out_proj(o.view(1, N, E))
-            h2, mean2, rstd2 = torch.native_layer_norm(x1, (E,), blk.ln_2.weight, blk.ln_2.bias, blk.ln_2.eps)
-            m = blk.mlp.c_fc(h2)
-            x2 = x1 + blk.mlp.c_proj(m * torch.sigmoid(1.702 * m))
-            tape.append((x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o))
-            blk.attn_probs, blk.attn_grad = buffers.layer_probs(l), buffers.layer_grads(l)
-            x = x2
-        return x, tape
+    def _mask_for(self, blk, n_tokens, device):
+        mask = blk.attn_mask
+        if mask is None:
+            return None
+        if mask.device != device:
+            blk.attn_mask = mask = mask.to(device=device, dtype=torch.float32)
+        if mask.shape[-1] != n_tokens:
+            mask = mask[:n_tokens, :n_tokens].contiguous()               # trimmed (padding-free) text batch
+        return mask
 
     @torch.no_grad()
-    def backward_shared(self, tape, dy, first_grad_layer=0):
+    def forward_tape(self, x, batch=None, first_grad_layer=0):
+        """``x``: ``[Bx, N, E]`` block input (embedded, through ``ln_pre`` for the image tower).  ``batch``: how many
+        upstream gradients ``backward_tape`` will carry (default ``Bx``; ``Bx == 1 < batch`` = shared-forward mode).
+        Returns ``(y [Bx, N, E], tape)``; the probabilities of every block are in the capture slabs afterwards."""
+        if not x.is_cuda:
+            raise _lib.MMXError("the CLIP body runs its attention on the HIP capture op: move the model and "
+                                "inputs to the MI355X (there is no CPU attention path)")
+        Bx, N, E = x.shape
+        batch = Bx if batch is None else batch
+        shared = Bx == 1 and batch > 1
+        if not shared and Bx != batch:
+            raise ValueError("forward_tape: %d inputs for %d upstream gradients (only a single input can be shared)" % (Bx, batch))
+        buffers = self._ensure_buffers(batch, N, x.device, shared_probs=shared)
+        blocks = list(self.resblocks)
+        mask = self._mask_for(blocks[0], N, x.device) if blocks else None
+        tape = []
+        # every LayerNorm but the first is fused with the residual add that produces its input
+        first = blocks[0].ln_1
+        _, h1, mean1, rstd1 = ops.add_layernorm(x, None, first.weight, first.bias, first.eps)
+        for l, blk in enumerate(blocks):
+            at = blk.attn
+            qkv = F.linear(h1, at.in_proj_weight, at.in_proj_bias).view(Bx, N, 3, at.num_heads, at.head_dim)
+            o = ops.attn_capture_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], buffers.probs[l], at.head_dim ** -0.5,
+                                     _lib.SCALE_Q_FIRST, mask, layout="bnhd")
+            x1, h2, mean2, rstd2 = ops.add_layernorm(x, at.out_proj(o.view(Bx, N, E)), blk.ln_2.weight, blk.ln_2.bias,
+                                                     blk.ln_2.eps)
+            m = blk.mlp.c_fc(h2)
+            mlp_out = blk.mlp.c_proj(ops.quick_gelu_fwd(m))
+            tape.append((x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o) if l >= first_grad_layer else None)
+            blk.attn_probs, blk.attn_grad = buffers.layer_probs(l), buffers.layer_grads(l)
+            if l + 1 < len(blocks):
+                nxt = blocks[l + 1].ln_1
+                x, h1, mean1, rstd1 = ops.add_layernorm(x1, mlp_out, nxt.weight, nxt.bias, nxt.eps)
+            else:
+                x = x1 + mlp_out
+        return x, tape
+
+    def forward_shared(self, x, batch):
+        """Shared-forward mode of ``forward_tape`` (kept under its round-1 name)."""
+        if x.shape[0] != 1:
+            raise ValueError("forward_shared takes the single shared sample")
+        return self.forward_tape(x, batch)
+
+    @torch.no_grad()
+    def backward_tape(self, tape, dy, first_grad_layer=0, dy_rows=None):
         """``dy``: ``[B, N, E]`` upstream gradients w.r.t. the tower output; fills ``buffers.grads`` of every block
-        ``>= first_grad_layer``."""
+        ``>= first_grad_layer``.
+
+        ``dy_rows`` (``[B]`` long, optional): promise that ``dy`` is zero outside row ``dy_rows[b]`` of sample ``b`` -- both
+        CLIP towers read their feature from ONE token (class token / EOT token).  The top block's MLP and ``out_proj``
+        vector-Jacobian products are row-wise, so they then run on those B rows instead of B*N (3 of the 4 GEMMs of
+        that block); below the top block's attention the gradient is dense and everything runs in full."""
         B, N, E = dy.shape
         buffers = self.buffers
+        top = self.layers - 1
         dx = dy
-        for l in range(self.layers - 1, first_grad_layer - 1, -1):
+        for l in range(top, first_grad_layer - 1, -1):
             blk = self.resblocks[l]
             at = blk.attn
             x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o_fwd = tape[l]
-            # MLP branch: x2 = x1 + c_proj(m * sigmoid(1.702 m)),  m = c_fc(ln_2(x1))
-            d_a = self._gemm(dx, blk.mlp.c_proj.weight)
-            sg = torch.sigmoid(1.702 * m)
-            d_m = d_a * (sg + 1.702 * m * sg * (1 - sg))                      # QuickGELU'(m), shared across the batch
-            d_h2 = self._gemm(d_m, blk.mlp.c_fc.weight)
-            d_x1 = ops.layernorm_bwd_add(d_h2, x1, mean2, rstd2, blk.ln_2.weight, dx)   # dx + LN2'(d_h2), one pass
-            # attention branch: x1 = x + out_proj(attn(ln_1(x)))
-            d_o = self._gemm(d_x1, at.out_proj.weight).view(B, N, at.num_heads, at.head_dim)
+            shared = x.shape[0] != B
+            if l == top and dy_rows is not None:
+                d_x1, d_o = self._top_block_rows(blk, tape[l], dy, dy_rows, shared)
+            else:
+                # MLP branch: x2 = x1 + c_proj(m * sigmoid(1.702 m)),  m = c_fc(ln_2(x1))
+                d_a = self._gemm(dx, blk.mlp.c_proj.weight)
+                if shared:
+                    sg = torch.sigmoid(1.702 * m)
+                    d_m = d_a * (sg + 1.702 * m * sg * (1 - sg))              # QuickGELU'(m), shared across the batch
+                else:
+                    d_m = ops.quick_gelu_bwd(m, d_a)
+                d_h2 = self._gemm(d_m, blk.mlp.c_fc.weight)
+                d_x1 = ops.layernorm_bwd_add(d_h2, x1, mean2, rstd2, blk.ln_2.weight, dx)   # dx + LN2'(d_h2), one pass
+                # attention branch: x1 = x + out_proj(attn(ln_1(x)))
+                d_o = self._gemm(d_x1, at.out_proj.weight)
+            d_o = d_o.view(B, N, at.num_heads, at.head_dim)
             need = l > first_grad_layer                                       # nothing below needs gradients
             dqkv = torch.empty(B, N, 3, at.num_heads, at.head_dim, dtype=torch.float32, device=dy.device) if need else None
             out = (dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]) if need else None
             ops.attn_capture_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], buffers.probs[l], d_o, buffers.grads[l],
-                                 at.head_dim ** -0.5, _lib.SCALE_Q_FIRST, need_dqkv=need, layout="bnhd", out=out, batch=B,
-                                 o=o_fwd)
+                                 at.head_dim ** -0.5, _lib.SCALE_Q_FIRST, need_dqkv=need, layout="bnhd", out=out,
+                                 batch=B if shared else None, o=o_fwd)
             if not need:
                 break
             d_h1 = self._gemm(dqkv.view(B, N, 3 * E), at.in_proj_weight)
             dx = ops.layernorm_bwd_add(d_h1, x, mean1, rstd1, blk.ln_1.weight, d_x1)
+
+    def _top_block_rows(self, blk, entry, dy, rows, shared):
+        """MLP / ``out_proj`` backward of the top block on the one row per sample that carries a gradient.
+        Returns dense ``(d_x1 [B, N, E], d_o [B, N, E])`` that are zero elsewhere."""
+        x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o_fwd = entry
+        B, N, E = dy.shape
+        ar = torch.arange(B, device=dy.device)
+        src = torch.zeros_like(rows) if shared else ar                     # sample index into the (shared) tape
+        g = dy[ar, rows]                                                     # [B, E]
+        m_r = m[src, rows]                                                   # [B, 4E]
+        d_a = self._gemm(g, blk.mlp.c_proj.weight)
+        sg = torch.sigmoid(1.702 * m_r)
+        d_h2 = self._gemm(d_a * (sg + 1.702 * m_r * sg * (1 - sg)), blk.mlp.c_fc.weight)
+        flat = src * N + rows                                                # row of the [Bx*N] statistics
+        d_x1_r = ops.layernorm_bwd_add(d_h2, x1[src, rows], mean2.reshape(-1)[flat], rstd2.reshape(-1)[flat],
+                                       blk.ln_2.weight, g)
+        d_x1 = torch.zeros_like(dy)
+        d_x1[ar, rows] = d_x1_r
+        d_o = torch.zeros_like(dy)
+        d_o[ar, rows] = self._gemm(d_x1_r, blk.attn.out_proj.weight)
+        return d_x1, d_o
+
+    def backward_shared(self, tape, dy, first_grad_layer=0):
+        """Round-1 name of ``backward_tape``."""
+        return self.backward_tape(tape, dy, first_grad_layer)
 
     def forward(self, x, capture_only=False, first_grad_layer=0):
         """``x``: ``[B, N, E]``.  ``capture_only``: only d(loss)/d(probs) of blocks ``>= first_grad_layer`` is wanted
@@ -246,17 +320,21 @@ class VisualTransformer(nn.Module):
         return x @ self.proj if self.proj is not None else x
 
     @torch.no_grad()
-    def forward_shared(self, image, batch):
-        """Shared-forward mode: ``image [1, 3, R, R]`` -> ``(features [1, output_dim], tape)``; see ``Transformer``."""
-        y, tape = self.transformer.forward_shared(self._embed(image), batch)
+    def forward_tape(self, image, batch=None, first_grad_layer=0):
+        """``image [Bx, 3, R, R]`` -> ``(features [Bx, output_dim], state)``; ``Bx == 1 < batch``: shared-forward mode
+        (see ``Transformer.forward_tape``)."""
+        y, tape = self.transformer.forward_tape(self._embed(image), batch, first_grad_layer)
         cls = y[:, 0, :]
         f, mean, rstd = torch.native_layer_norm(cls, (cls.shape[-1],), self.ln_post.weight, self.ln_post.bias,
                                                 self.ln_post.eps)
         return f @ self.proj, (tape, y.shape, cls, mean, rstd)
 
+    def forward_shared(self, image, batch):
+        return self.forward_tape(image, batch)
+
     @torch.no_grad()
-    def backward_shared(self, state, d_features, first_grad_layer=0):
-        """``d_features [B, output_dim]``: per-sample upstream gradients of the (shared) image features."""
+    def backward_tape(self, state, d_features, first_grad_layer=0):
+        """``d_features [B, output_dim]``: per-sample upstream gradients of the image features."""
         tape, y_shape, cls, mean, rstd = state
         B = d_features.shape[0]
         d_f = torch.matmul(d_features, self.proj.t())
@@ -265,7 +343,11 @@ class VisualTransformer(nn.Module):
             rstd.expand(B, -1).contiguous(), self.ln_post.weight, self.ln_post.bias, [True, False, False])[0]
         dy = torch.zeros(B, y_shape[1], y_shape[2], dtype=torch.float32, device=d_features.device)
         dy[:, 0, :] = d_cls                                                  # only the class token feeds the features
-        self.transformer.backward_shared(tape, dy, first_grad_layer)
+        self.transformer.backward_tape(tape, dy, first_grad_layer,
+                                       dy_rows=torch.zeros(B, dtype=torch.long, device=dy.device))
+
+    def backward_shared(self, state, d_features, first_grad_layer=0):
+        return self.backward_tape(state, d_features, first_grad_layer)
 
 
 class CLIP(nn.Module):
@@ -327,6 +409,33 @@ class CLIP(nn.Module):
         x = self.ln_final(x)
         # features at the EOT token = highest token id in each sequence (model.py:360)
         return x[torch.arange(x.shape[0], device=x.device), text.argmax(dim=-1)] @ self.text_projection
+
+    @torch.no_grad()
+    def encode_text_tape(self, text, n_tokens=None, first_grad_layer=0):
+        """``encode_text`` on the tape path -> ``(features [B, embed_dim], state)`` for ``backward_text_tape``."""
+        if n_tokens is not None and n_tokens < text.shape[1]:
+            text = text[:, :n_tokens]
+        n = text.shape[1]
+        x = self.token_embedding(text).type(self.dtype) + self.positional_embedding[:n].type(self.dtype)
+        y, tape = self.transformer.forward_tape(x, first_grad_layer=first_grad_layer)
+        eot = text.argmax(dim=-1)                                            # model.py:360
+        rows = y[torch.arange(y.shape[0], device=y.device), eot]
+        f, mean, rstd = torch.native_layer_norm(rows, (rows.shape[-1],), self.ln_final.weight, self.ln_final.bias,
+                                                self.ln_final.eps)
+        return f @ self.text_projection, (tape, y.shape, rows, mean, rstd, eot)
+
+    @torch.no_grad()
+    def backward_text_tape(self, state, d_features, first_grad_layer=0):
+        """``d_features [B, embed_dim]`` -> fills the text tower's gradient slabs (``ln_final`` is row-wise, so only the
+        EOT rows carry a gradient into the stack)."""
+        tape, y_shape, rows, mean, rstd, eot = state
+        d_f = torch.matmul(d_features, self.text_projection.t())
+        d_rows = torch.ops.aten.native_layer_norm_backward(
+            d_f.contiguous(), rows.contiguous(), (rows.shape[-1],), mean, rstd, self.ln_final.weight, self.ln_final.bias,
+            [True, False, False])[0]
+        dy = torch.zeros(y_shape, dtype=torch.float32, device=d_features.device)
+        dy[torch.arange(y_shape[0], device=dy.device), eot] = d_rows
+        self.transformer.backward_tape(tape, dy, first_grad_layer, dy_rows=eot)
 
     def forward(self, image, text):
         return self.logits(self.encode_image(image), self.encode_text(text))

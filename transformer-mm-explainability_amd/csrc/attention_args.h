@@ -30,8 +30,11 @@ struct AttnBwdArgs {
     int B, H, Nq, Nk, D;
     float scale; int scale_mode; int need_dqkv;
     int slab_dt;  // element type behind `probs` and `dprobs` (see AttnFwdArgs)
+    int debug;    // tuning knob of attention_head.hip (stagger)
 };
 
+int attn_fwd_head_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out);    // attention_head.hip (register-resident)
+int attn_bwd_head_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);
 int attn_fwd_small_try(AttnFwdArgs& a, hipStream_t s, int* rc_out);
 int attn_bwd_small_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);
 int attn_fwd_stream_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out);   // attention_stream.hip

@@ -350,7 +350,8 @@ extern "C" int mmx_attn_capture_fwd_ex(const void* q_dev, const void* k_dev, con
         set_error("mmx_attn_capture_fwd: fp16 / bf16 capture slabs need head_dim %% 4 == 0 and 16-byte aligned q/k/v views");
         return MMX_ENOTSUP;
     }
-    if (attn_fwd_small_try(a, s, &rc)) return rc;   // whole head resident in LDS (short sequences)
+    if (attn_fwd_head_try(a, s, &rc)) return rc;    // short sequences: a wave owns 16 query rows, scores in registers
+    if (attn_fwd_small_try(a, s, &rc)) return rc;   // whole head resident in LDS (first generation of the above)
     if (attn_fwd_stream_try(a, s, &rc)) return rc;  // long sequences: K/V streamed, nothing of size Nk on chip
     if (D <= 32) return launch_dyn(attn_capture_fwd_kernel<32>, a, grid, attn_lds_bytes(32, Nk), s, "attn_capture_fwd_kernel<32>");
     return launch_dyn(attn_capture_fwd_kernel<64>, a, grid, attn_lds_bytes(64, Nk), s, "attn_capture_fwd_kernel<64>");
@@ -416,7 +417,8 @@ extern "C" int mmx_attn_capture_bwd_ex(const void* q_dev, const void* k_dev, con
         set_error("mmx_attn_capture_bwd: fp16 / bf16 capture slabs need head_dim %% 4 == 0 and 16-byte aligned views");
         return MMX_ENOTSUP;
     }
-    if (attn_bwd_small_try(a, s, &rc)) return rc;   // whole head resident in LDS (short sequences)
+    if (attn_bwd_head_try(a, s, &rc)) return rc;    // short sequences: a wave owns 16 query rows, scores in registers
+    if (attn_bwd_small_try(a, s, &rc)) return rc;   // whole head resident in LDS (first generation of the above)
     if (attn_bwd_stream_try(a, s, &rc)) return rc;  // long sequences
     dim3 gq((Nq + kTQ - 1) / kTQ, H, B), gk((Nk + 15) / 16, H, B);
     if (D <= 32) {

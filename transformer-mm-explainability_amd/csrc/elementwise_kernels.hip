@@ -137,3 +137,90 @@ extern "C" int mmx_layernorm_bwd_add(const void* dy_dev, const void* x_dev, cons
     MMX_LAUNCH_CHECK("layernorm_bwd_add_kernel");
     return MMX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Residual add fused with the LayerNorm that follows it (pre-LN blocks: x1 = x + attn_out; h = LN(x1), CLIP/clip/model.py:
+// 195-197):  sum = x + y (written out: it is the next residual), h = (sum - mean) * rstd * gamma + beta, plus the row
+// statistics the hand-written backward needs.  y == NULL: plain LayerNorm of x with statistics.  ATen runs the add and the
+// LayerNorm as two kernels (3 reads + 2 writes of the [rows, E] activation); this is 2 reads + 2 writes in one pass.  One
+// wave per row, the row lives in registers (E <= 64 * 4 * NV); two-pass mean / variance like ATen's row-wise moments.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace mmx {
+
+template <int NV>
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ sum_out, float* __restrict__ h_out,
+                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                int64_t rows, int E, float eps) {
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63, n4 = E >> 2;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + r * E);
+    const f32x4* yr = y ? reinterpret_cast<const f32x4*>(y + r * E) : nullptr;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = lane + 64 * j;
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < n4) {
+            v[j] = xr[i];
+            if (yr) v[j] = v[j] + yr[i];
+            s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mu = s / static_cast<float>(E);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+        if (lane + 64 * j < n4) {
+            const f32x4 d = v[j] - mu;
+            q += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    const float rs = rsqrtf(q / static_cast<float>(E) + eps);
+    if (lane == 0) {
+        mean_out[r] = mu;
+        rstd_out[r] = rs;
+    }
+    const f32x4* gm = reinterpret_cast<const f32x4*>(gamma);
+    const f32x4* bt = reinterpret_cast<const f32x4*>(beta);
+    f32x4* so = (sum_out && yr) ? reinterpret_cast<f32x4*>(sum_out + r * E) : nullptr;
+    f32x4* ho = reinterpret_cast<f32x4*>(h_out + r * E);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = lane + 64 * j;
+        if (i < n4) {
+            if (so) so[i] = v[j];
+            ho[i] = (v[j] - mu) * rs * gm[i] + bt[i];
+        }
+    }
+}
+
+}  // namespace mmx
+
+extern "C" int mmx_add_layernorm_fwd(const void* x_dev, const void* y_dev, const void* gamma_dev, const void* beta_dev,
+                                     void* sum_dev, void* h_dev, void* mean_dev, void* rstd_dev, int64_t rows, int E,
+                                     float eps, void* stream) {
+    MMX_CHECK_ARG(x_dev && gamma_dev && beta_dev && h_dev && mean_dev && rstd_dev, "mmx_add_layernorm_fwd: null pointer");
+    MMX_CHECK_ARG(!y_dev || sum_dev, "mmx_add_layernorm_fwd: the sum x + y needs an output buffer");
+    MMX_CHECK_ARG(rows > 0 && E > 0 && E % 4 == 0 && E <= 4096, "mmx_add_layernorm_fwd: rows=%ld E=%d (E %% 4 == 0, E <= 4096)",
+                  static_cast<long>(rows), E);
+    const unsigned grid = static_cast<unsigned>((rows + 3) / 4);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float *x = static_cast<const float*>(x_dev), *y = static_cast<const float*>(y_dev);
+    const float *g = static_cast<const float*>(gamma_dev), *b = static_cast<const float*>(beta_dev);
+    float *so = static_cast<float*>(sum_dev), *ho = static_cast<float*>(h_dev);
+    float *mo = static_cast<float*>(mean_dev), *ro = static_cast<float*>(rstd_dev);
+    if (E <= 256) mmx::add_layernorm_fwd_kernel<1><<<grid, 256, 0, s>>>(x, y, g, b, so, ho, mo, ro, rows, E, eps);
+    else if (E <= 512) mmx::add_layernorm_fwd_kernel<2><<<grid, 256, 0, s>>>(x, y, g, b, so, ho, mo, ro, rows, E, eps);
+    else if (E <= 1024) mmx::add_layernorm_fwd_kernel<4><<<grid, 256, 0, s>>>(x, y, g, b, so, ho, mo, ro, rows, E, eps);
+    else if (E <= 2048) mmx::add_layernorm_fwd_kernel<8><<<grid, 256, 0, s>>>(x, y, g, b, so, ho, mo, ro, rows, E, eps);
+    else mmx::add_layernorm_fwd_kernel<16><<<grid, 256, 0, s>>>(x, y, g, b, so, ho, mo, ro, rows, E, eps);
+    MMX_LAUNCH_CHECK("add_layernorm_fwd_kernel");
+    return MMX_OK;
+}

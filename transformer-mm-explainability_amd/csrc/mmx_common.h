@@ -132,6 +132,7 @@ inline size_t dtype_size(int dt) { return dt == MMX_F32 ? 4 : 2; }
 
 void set_error(const char* fmt, ...);
 void attn_small_enable(int on);
+void attn_head_enable(int on);
 void attn_stream_enable(int on);
 int hip_fail(hipError_t e, const char* what);
 

@@ -837,6 +837,10 @@ extern "C" int mmx_set_option(const char* key, int value) {
         attn_small_enable(value);
         return MMX_OK;
     }
+    if (key && strcmp(key, "attn_head") == 0) {
+        attn_head_enable(value);
+        return MMX_OK;
+    }
     if (key && strcmp(key, "attn_stream") == 0) {
         attn_stream_enable(value);
         return MMX_OK;

@@ -161,6 +161,46 @@ def quick_gelu(x):
     return _QuickGELU.apply(x)
 
 
+def quick_gelu_fwd(x):
+    """``x * sigmoid(1.702 x)``, no autograd (the hand-written backward passes keep ``x`` themselves)."""
+    _dev(x)
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    check(lib().mmx_quick_gelu_fwd(_p(x), _p(y), x.numel(), _stream()), "mmx_quick_gelu_fwd")
+    return y
+
+
+def quick_gelu_bwd(x, dy):
+    """``dy * QuickGELU'(x)`` in one pass (same shapes)."""
+    _dev(x, dy)
+    x, dy = _f32c(x), _f32c(dy)
+    if x.shape != dy.shape:
+        raise MMXError("quick_gelu_bwd: x %s vs dy %s" % (tuple(x.shape), tuple(dy.shape)))
+    dx = torch.empty_like(x)
+    check(lib().mmx_quick_gelu_bwd(_p(x), _p(dy), _p(dx), x.numel(), _stream()), "mmx_quick_gelu_bwd")
+    return dx
+
+
+def add_layernorm(x, y, gamma, beta, eps=1e-5):
+    """``s = x + y; h = LayerNorm(s)`` in one pass -> ``(s, h, mean, rstd)`` (``y=None``: ``s`` is ``x`` itself).
+    ``mean`` / ``rstd``: ``[rows]`` fp32, what ``layernorm_bwd_add`` takes."""
+    _dev(x, y, gamma, beta)
+    x = _f32c(x)
+    E = x.shape[-1]
+    rows = x.numel() // E
+    if y is not None:
+        y = _f32c(y)
+        if y.shape != x.shape:
+            raise MMXError("add_layernorm: x %s vs y %s" % (tuple(x.shape), tuple(y.shape)))
+    s = torch.empty_like(x) if y is not None else x
+    h = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib().mmx_add_layernorm_fwd(_p(x), _p(y), _p(_f32c(gamma)), _p(_f32c(beta)), _p(s) if y is not None else _p(None),
+                                      _p(h), _p(mean), _p(rstd), rows, E, float(eps), _stream()), "mmx_add_layernorm_fwd")
+    return s, h, mean, rstd
+
+
 def layernorm_bwd_add(dy, x, mean, rstd, gamma, d_res=None):
     """``d_res + LayerNorm'(dy)`` with forward statistics shared across the batch: ``dy``/``d_res`` ``[B, N, E]``,
     ``x`` ``[1, N, E]`` (or ``[B, N, E]``), ``mean``/``rstd`` matching ``x``'s rows."""
