@@ -8,15 +8,19 @@ that fills every layer's gradient slab, the fused relevancy chain for both tower
 ``start_layer=0``).  Rank 0 prints ONE JSON line.  Inputs are resident in HBM before the timed region.
 
 Extra objects in the line:
-  roofline     -- the chain kernel (text-tower instantiation, the longer one): algorithmic bytes / HIP-event time
-                  measured on the stream the kernel runs on, against the 8 TB/s HBM peak
-  cpu_baseline -- the reference algorithm (oracle/clip_torch.py: per-layer autograd.grad like the notebook) on this
+  roofline      -- the chain kernel (text-tower instantiation, the longer one): algorithmic bytes / HIP-event time
+                   measured on the stream the kernel runs on, against the 8 TB/s HBM peak
+  roofline_step -- the WHOLE step against what really bounds it: the exact-fp32 matrix FLOPs the step executes (body
+                   GEMMs + attention products + chain) / ms_per_step vs the 157.3 TFLOP/s fp32 MFMA peak, with the
+                   kernel-time split of the committed rocprofv3 summary next to it
+  cpu_baseline  -- the reference algorithm (oracle/clip_torch.py: per-layer autograd.grad like the notebook) on this
                   box's host cores, rank 0 / N=1 only, on a bounded sample
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import shutil
@@ -48,8 +52,29 @@ enable_tuned_gemms()
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, exact fp32 (no TF32 / xf32 on gfx950)
 BATCH = 64
 MODEL = "ViT-B/32"
+
+
+def step_flops(batch):
+    """Matrix FLOPs ONE headline step executes (CLIP ViT-B/32, all layers, shared image forward), by operation.  Row-wise
+    products of the two top blocks run on one row per sample (``backward_tape(dy_rows=...)``); the lowest block has no
+    in-projection backward.  Everything is exact fp32 on the MFMA (library GEMMs or our kernels)."""
+    def tower(L, E, N, H, m_fwd, m_bwd):
+        gemm_fwd = L * 2 * m_fwd * 12 * E * E                      # in_proj 3E^2 + out_proj E^2 + c_fc 4E^2 + c_proj 4E^2
+        full, top, low = 2 * m_bwd * 12 * E * E, 2 * m_bwd * 3 * E * E + 2 * batch * 9 * E * E, 2 * m_bwd * 9 * E * E
+        gemm_bwd = (L - 2) * full + top + low
+        d = E // H
+        attn_fwd = L * 4 * (m_fwd // N) * H * N * N * d
+        attn_bwd = (L - 1) * 8 * (m_bwd // N) * H * N * N * d + 2 * (m_bwd // N) * H * N * N * d   # lowest block: dP only
+        chain = L * ((m_bwd // N) * (2 * H * N * N + 2 * N * N * N))
+        return {"gemm_fwd": gemm_fwd, "gemm_bwd": gemm_bwd, "attention": attn_fwd + attn_bwd, "chain": chain}
+    img = tower(12, 768, 50, 12, 50, batch * 50)                   # forward once (shared), backward at batch B
+    txt = tower(12, 512, 77, 8, batch * 77, batch * 77)
+    out = {k: img[k] + txt[k] for k in img}
+    out["total"] = sum(out.values())
+    return out
 
 
 def synthetic_inputs(batch, device, seed):
@@ -136,9 +161,12 @@ _T0 = time.perf_counter()
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)     # ~1.4 s timed region
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the variant rates (eager, distinct images, last layer, trimmed): what the rocprofv3 "
+                         "kernel-split run uses, so that the trace holds headline steps only")
     ap.add_argument("--cpu-baseline-worker", nargs=2, type=int, metavar=("BATCH", "REPS"), help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -174,7 +202,10 @@ def main():
     model = clip_model.random_init(MODEL, seed=0)
     model = model.to(device)
     image, texts = synthetic_inputs(BATCH, device, seed=rank)
-    gathered = torch.empty(world * BATCH, 49, device=device) if world > 1 else None
+    # the exchange step moves the FULL per-sample result: image relevancy [49] and text relevancy [77 x 77] per pair
+    row = 49 + 77 * 77
+    gathered = torch.empty(world * BATCH, row, device=device) if world > 1 else None
+    packed = torch.empty(BATCH, row, device=device) if world > 1 else None
 
     # The step is ~600 short launches; eager it is bound by the Python + launch path on the host, so the whole step
     # (forward, autograd backward, hand-written image backward, both chain launches) is captured ONCE into a hipGraph
@@ -183,11 +214,13 @@ def main():
 
     def step():
         R_text, R_image = run(image, texts)
-        if world > 1:   # the evaluators' exchange step: per-sample maps gathered on every rank (KB-scale)
+        if world > 1:   # the evaluators' exchange step: per-sample maps gathered on every rank (1.5 MB per rank)
+            packed[:, :49] = R_image
+            packed[:, 49:] = R_text.reshape(BATCH, -1)
             if backend == "nccl":
-                dist.all_gather_into_tensor(gathered, R_image.contiguous())
+                dist.all_gather_into_tensor(gathered, packed)
             else:           # gloo test hook: list form
-                dist.all_gather(list(gathered.view(world, BATCH, 49).unbind(0)), R_image.contiguous())
+                dist.all_gather(list(gathered.view(world, BATCH, row).unbind(0)), packed)
         return R_text, R_image
 
     def sync():
@@ -224,47 +257,83 @@ def main():
         torch.cuda.synchronize()
         return BATCH / ((time.perf_counter() - t0) / reps)
 
-    eager = rate(lambda: ce.interpret(image, texts, model, device, 0, 0), args.steps)
-    # ---- variants, reported beside the headline (all eager unless noted)
-    no_share = rate(lambda: ce.interpret(image, texts, model, device, 0, 0, share_image_forward=False), args.steps)
-    last_only = rate(lambda: ce.interpret(image, texts, model, device), args.steps)          # notebook default
-    run_last = ce.GraphedInterpret(model, image, texts)
-    last_only_graph = rate(run_last, args.steps)
-    run_trim = ce.GraphedInterpret(model, image, texts, 0, 0, trim_text_padding=True)          # opt-in, exact
-    trimmed_graph = rate(run_trim, args.steps)
-    del run_last, run_trim
+    variants = None
+    if not args.headline_only:
+        reps = min(args.steps, 30)
+        eager = rate(lambda: ce.interpret(image, texts, model, device, 0, 0), reps)
+        # ---- variants, reported beside the headline (all eager unless noted)
+        no_share = rate(lambda: ce.interpret(image, texts, model, device, 0, 0, share_image_forward=False), reps)
+        # 64 DISTINCT images x 64 texts (nothing to share between the pairs), replayed from a hipGraph: the rate for a
+        # workload that is not the reference's "one image, B captions" call
+        g = torch.Generator().manual_seed(100 + rank)
+        images64 = torch.randn(BATCH, 3, 224, 224, generator=g).to(device)
+        run_distinct = ce.GraphedInterpret(model, images64, texts, 0, 0, share_image_forward=False)
+        distinct_graph = rate(run_distinct, reps)
+        del run_distinct, images64
+        last_only = rate(lambda: ce.interpret(image, texts, model, device), reps)          # notebook default
+        run_last = ce.GraphedInterpret(model, image, texts)
+        last_only_graph = rate(run_last, reps)
+        run_trim = ce.GraphedInterpret(model, image, texts, 0, 0, trim_text_padding=True)          # opt-in, exact
+        trimmed_graph = rate(run_trim, reps)
+        del run_last, run_trim
+        variants = {"eager_maps_per_s": round(eager, 2),
+                    "eager_B_image_copies_maps_per_s": round(no_share, 2),
+                    "distinct_images_hipgraph_maps_per_s": round(distinct_graph, 2),
+                    "last_layer_only_maps_per_s": {"eager": round(last_only, 2), "hipgraph": round(last_only_graph, 2)},
+                    "trim_text_padding_hipgraph_maps_per_s": round(trimmed_graph, 2)}
 
-    # ---- roofline of the chain kernel, HIP events on the launch stream, buffers as the last step left them
-    vis, txt = model.visual.transformer, model.transformer
-    stream = torch.cuda.current_stream()
+    roofline = None
+    if not args.headline_only:
+        # ---- roofline of the chain kernel, HIP events on the launch stream, buffers as the last step left them
+        vis, txt = model.visual.transformer, model.transformer
+        stream = torch.cuda.current_stream()
 
-    ce.interpret(image, texts, model, device, 0, 0, share_image_forward=False)   # per-sample slabs for both towers
+        ce.interpret(image, texts, model, device, 0, 0, share_image_forward=False)   # per-sample slabs for both towers
 
-    def chain(tr):
-        b = tr.buffers   # prepared launch: the timed loop is one C call per launch, not Python tensor plumbing
-        return ops.ChainPlan([b.probs[l] for l in range(tr.layers)], [b.grads[l] for l in range(tr.layers)], BATCH).launch
+        def chain(tr):
+            b = tr.buffers   # prepared launch: the timed loop is one C call per launch, not Python tensor plumbing
+            return ops.ChainPlan([b.probs[l] for l in range(tr.layers)], [b.grads[l] for l in range(tr.layers)], BATCH).launch
 
-    def chain_bytes(tr, n):
-        return 2 * tr.layers * BATCH * tr.heads * n * n * 4 + BATCH * n * n * 4
+        def chain_bytes(tr, n):
+            return 2 * tr.layers * BATCH * tr.heads * n * n * 4 + BATCH * n * n * 4
 
-    log("kernel-only timing")
-    us_txt = kernel_time_us(chain(txt), 20, stream)
-    us_img = kernel_time_us(chain(vis), 20, stream)
-    by_txt, by_img = chain_bytes(txt, 77), chain_bytes(vis, 50)
-    ach = by_txt / us_txt / 1e3  # GB/s
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_chain.json")   # PMC passes cannot run inside this process
-    if os.path.exists(pmc_file):
-        pmc = json.load(open(pmc_file)).get("self_chain_fused_kernel<5, 0>")
-        if pmc:
-            traffic = pmc["fetch_bytes"] + pmc["write_bytes"]
-    roofline = {"bound": "hbm", "kernel": "self_chain_fused_kernel<NT=5,f32> (text tower)",
-                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "traffic_source": "profiles/r01_pmc_chain.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, "
-                "FETCH_SIZE x2 per the gfx950 correction), bytes per launch", "bytes_per_launch": by_txt, "us_per_launch": round(us_txt, 2),
-                "image_tower": {"kernel": "self_chain_fused_kernel<NT=4,f32>", "bytes_per_launch": by_img,
-                                "us_per_launch": round(us_img, 2), "achieved": round(by_img / us_img / 1e3, 1)},
-                "kernel_only_maps_per_s": round(BATCH / ((us_txt + us_img) * 1e-6), 1)}
+        log("kernel-only timing")
+        us_txt = kernel_time_us(chain(txt), 20, stream)
+        us_img = kernel_time_us(chain(vis), 20, stream)
+        by_txt, by_img = chain_bytes(txt, 77), chain_bytes(vis, 50)
+        ach = by_txt / us_txt / 1e3  # GB/s
+        # HBM traffic of the same launch from the PMC passes (they cannot run inside this process): the newest committed
+        # profiles/rNN_pmc_chain.json, which tools/pmc_chain_json.py regenerates from the two rocprofv3 --pmc summaries
+        # (tests/test_profiles.py checks that it matches them)
+        traffic, pmc_name = None, None
+        for pmc_file in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_chain.json")), reverse=True):
+            pmc = json.load(open(pmc_file)).get("self_chain_fused_kernel<5, 0>")
+            if pmc:
+                traffic, pmc_name = pmc["fetch_bytes"] + pmc["write_bytes"], os.path.relpath(pmc_file, ROOT)
+                break
+        roofline = {"bound": "hbm", "kernel": "self_chain_fused_kernel<NT=5,f32> (text tower)",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "traffic_source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per "
+                    "the gfx950 correction; regenerated by tools/pmc_chain_json.py), bytes per launch" % pmc_name,
+                    "bytes_per_launch": by_txt, "us_per_launch": round(us_txt, 2),
+                    "image_tower": {"kernel": "self_chain_fused_kernel<NT=4,f32>", "bytes_per_launch": by_img,
+                                    "us_per_launch": round(us_img, 2), "achieved": round(by_img / us_img / 1e3, 1)},
+                    "kernel_only_maps_per_s": round(BATCH / ((us_txt + us_img) * 1e-6), 1)}
+
+    fl = step_flops(BATCH)
+    tf = world * fl["total"] / (elapsed / args.steps) / 1e12
+    split_file = None
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_split.json")), reverse=True):
+        split_file = cand
+        break
+    roofline_step = {"bound": "mfma", "achieved": round(tf / world, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tf / world / FP32_MFMA_PEAK_TFLOPS, 4), "per": "GPU",
+                     "flop_per_step": fl, "what": "exact-fp32 matrix FLOPs the step executes (body GEMMs forward + "
+                     "input-gradient GEMMs, attention products, chain) / ms_per_step; the reference's fp32 contract rules "
+                     "out the bf16 MFMA for the body",
+                     "floor_ms_at_peak": round(fl["total"] / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3, 3),
+                     "kernel_time_split": json.load(open(split_file)) if split_file else None,
+                     "kernel_time_split_source": os.path.relpath(split_file, ROOT) if split_file else None}
 
     if rank == 0:
         line = {
@@ -275,13 +344,12 @@ def main():
             "config": {"workload": "CLIP ViT-B/32 image<->text relevancy, batch=64 fp32 per GPU, all 12+12 layers "
                                    "(start_layer=0); random-init weights, synthetic image + token ids",
                        "global_batch": world * BATCH, "parallelism": "dp%d (independent batches, all-gather of maps)" % world,
-                       "launch": "whole step captured once into a hipGraph and replayed; eager (Python-launch-bound): "
-                                 "%.2f maps/s" % eager,
+                       "launch": "whole step captured once into a hipGraph and replayed",
                        "image_tower": "forward shared by the batch (the reference API repeats ONE image B times), "
-                                      "backward per sample; eager maps/s with B full copies like the reference: %.2f" % no_share,
-                       "last_layer_only_maps_per_s": {"eager": round(last_only, 2), "hipgraph": round(last_only_graph, 2)},
-                       "trim_text_padding_hipgraph_maps_per_s": round(trimmed_graph, 2)},
+                                      "backward per sample",
+                       "variants": variants},
             "roofline": roofline,
+            "roofline_step": roofline_step,
         }
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (child process, <= 240 s)")

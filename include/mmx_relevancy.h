@@ -266,6 +266,9 @@ int mmx_attn_capture_bwd_ex(const void* q_dev, const void* k_dev, const void* v_
  */
 int mmx_quick_gelu_fwd(const void* x_dev, void* y_dev, int64_t n, void* stream);
 int mmx_quick_gelu_bwd(const void* x_dev, const void* dy_dev, void* dx_dev, int64_t n, void* stream);
+/* Same with x ([x_n] elements) broadcast over the leading dimension of dy / dx ([n] elements, n % x_n == 0, x_n % 4 == 0):
+ * the shared-forward backward has ONE activation tensor for B upstream gradients. */
+int mmx_quick_gelu_bwd_bcast(const void* x_dev, const void* dy_dev, void* dx_dev, int64_t n, int64_t x_n, void* stream);
 
 /* LayerNorm input gradient + residual add with forward statistics shared by the batch (shared-forward backward of the
  * CLIP image tower / ViT): dx[r] = d_res[r] + LN'(dy[r]; x[r % x_rows], mean, rstd, gamma).  dy, d_res (may be NULL),

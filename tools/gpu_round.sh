@@ -1,16 +1,21 @@
 #!/bin/bash
 # One GPU-box round: gpu tests, smoke, bench (JSON line), rocprofv3 kernel trace + PMC passes. Outputs under gpurun_out/$TAG.
-TAG=${1:-r01}
+#   $2 = "notest" skips the pytest / smoke legs (profiles only)
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-timeout 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee $OUT/pytest_gpu.txt
+if [ "$2" != "notest" ]; then
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee $OUT/pytest_gpu.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.txt
-timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.log; tail -2 $OUT/bench.log; cut -c1-300 $OUT/bench.json
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_traced.json 2> $OUT/trace.log
-python tools/prof_summary.py $OUT/trace/bench_results.db "" --by-grid > $OUT/kernel_stats.txt 2>&1; grep mmx $OUT/kernel_stats.txt
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.log
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.log
+fi
+timeout 600 python bench.py --steps 100 --warmup 5 > $OUT/bench.json 2> $OUT/bench.log; tail -2 $OUT/bench.log; cut -c1-400 $OUT/bench.json
+# kernel trace of headline steps only (2 capture warm-ups + 3 warm-up replays + 20 timed replays = 25 steps in the trace)
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --headline-only > $OUT/bench_traced.json 2> $OUT/trace.log
+python tools/prof_summary.py $OUT/trace/bench_results.db "" --by-grid > $OUT/kernel_stats.txt 2>&1; grep mmx $OUT/kernel_stats.txt | cut -c1-200
+python tools/kernel_split.py $OUT/trace/bench_results.db 26 > $OUT/kernel_split.json; cat $OUT/kernel_split.json
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --headline-only > /dev/null 2> $OUT/pmc_fetch.log
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --headline-only > /dev/null 2> $OUT/pmc_write.log
 python tools/pmc_summary.py $OUT/pmc_fetch/bench_counter_collection.csv mmx:: > $OUT/pmc_fetch.txt; python tools/pmc_summary.py $OUT/pmc_write/bench_counter_collection.csv mmx:: > $OUT/pmc_write.txt
 cat $OUT/pmc_fetch.txt $OUT/pmc_write.txt
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/trace

@@ -51,6 +51,7 @@ _PROTOTYPES = {
                              + [_i64] * 9 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     "mmx_quick_gelu_fwd": (_i, [_vp, _vp, _i64, _vp]),
     "mmx_quick_gelu_bwd": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "mmx_quick_gelu_bwd_bcast": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "mmx_layernorm_bwd_add": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     "mmx_add_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     "mmx_event_create": (_i, [_vpp]),

@@ -21,20 +21,6 @@ import torch
 from . import ops
 from .rules import frozen_parameters as _Frozen
 
-def _chains(model, batch_size, start_layer, start_layer_text):
-    vis, txt = model.visual.transformer, model.transformer
-    if start_layer == -1:
-        start_layer = vis.layers - 1
-    if start_layer_text == -1:
-        start_layer_text = txt.layers - 1
-    vb, tb = vis.buffers, txt.buffers
-    # Same stream, back to back: each launch already fills the chip (layer-group split), and measured on MI355X two
-    # concurrent chain kernels on two streams are slower than the two in sequence (profiles/r01_chain_probe.txt).
-    R_text = _plan(tb, start_layer_text, txt.layers, batch_size, False).launch()
-    R = _plan(vb, start_layer, vis.layers, batch_size, vb.shared_probs and batch_size > 1).launch()
-    return R_text, R
-
-
 def _plan(buffers, first, last, batch_size, shared):
     """Prepared chain launch, cached on the slab object (the slabs keep their addresses from call to call)."""
     cache = buffers.__dict__.setdefault("_chain_plans", {})
@@ -45,8 +31,19 @@ def _plan(buffers, first, last, batch_size, shared):
     return cache[key]
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One side stream per device for the image tower (created once: a hipGraph capture must not create streams)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
+
+
 def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, share_image_forward=True,
-              trim_text_padding=False, _n_text=None):
+              trim_text_padding=False, _n_text=None, overlap_towers=True):
     """CLIP_explainability.ipynb cell 6.  ``image``: ``[1,3,R,R]``, ``texts``: ``[B, context]`` token ids.
 
     ``share_image_forward`` (extra keyword, default on): the reference repeats the ONE image B times (cell 6:3) and
@@ -59,6 +56,9 @@ def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, 
     last EOT of the batch influence nothing: their gradient rows are exactly zero and the returned ``R_text`` is the
     identity there.  With the flag the text tower runs only on the first ``max(EOT)+1`` positions and the ``[B,77,77]``
     result is assembled around that block -- identical output, 5-6x less text-tower work for caption-length inputs.
+
+    ``overlap_towers`` (extra keyword, default on): image tower on a side stream, text tower on the current one (they
+    only meet in the similarity head); ``False`` runs them back to back on the current stream.  Same results bit for bit.
     """
     batch_size = texts.shape[0]
     sl = model.visual.transformer.layers - 1 if start_layer == -1 else start_layer
@@ -71,8 +71,17 @@ def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, 
     # bodies, no weight gradients; only the cosine-similarity head (B x embed_dim features) goes through autograd.
     images = image.type(model.dtype) if shared or image.shape[0] == batch_size else \
         image.type(model.dtype).repeat(batch_size, 1, 1, 1)                                # cell 6:3
-    img_feat, img_state = model.visual.forward_tape(images, batch_size, sl)
+    # The two towers are independent up to the similarity head.  The image tower runs on a side stream: its shared
+    # forward is ~120 batch-1 launches of a few microseconds (latency-bound) that hide completely behind the text
+    # tower's GEMMs, and in the backward the kernel-boundary gaps of one tower are filled by the other's kernels.
+    # Fork / join with stream waits only, so the whole thing still captures into one hipGraph (parallel branches).
+    main = torch.cuda.current_stream()
+    side = _side_stream(texts.device) if overlap_towers else main
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        img_feat, img_state = model.visual.forward_tape(images, batch_size, sl)
     txt_feat, txt_state = model.encode_text_tape(texts, n_text, slt)
+    main.wait_stream(side)
     with torch.enable_grad():
         image_features = img_feat.expand(batch_size, -1).contiguous().requires_grad_(True)   # per-sample leaves
         text_features = txt_feat.detach().requires_grad_(True)
@@ -80,9 +89,15 @@ def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, 
         # one_hot = sum_i logits_per_image[i, i]  (cell 6:6-10)  ->  d one_hot / d logits = I
         eye = torch.eye(batch_size, dtype=torch.float32, device=texts.device)
         torch.autograd.backward(logits_per_image, grad_tensors=eye, inputs=[image_features, text_features])
-    model.visual.backward_tape(img_state, image_features.grad, sl)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        model.visual.backward_tape(img_state, image_features.grad, sl)
+        vis = model.visual.transformer
+        R = _plan(vis.buffers, sl, vis.layers, batch_size, vis.buffers.shared_probs and batch_size > 1).launch()
     model.backward_text_tape(txt_state, text_features.grad, slt)
-    R_text, R = _chains(model, batch_size, start_layer, start_layer_text)
+    txt = model.transformer
+    R_text = _plan(txt.buffers, slt, txt.layers, batch_size, False).launch()
+    main.wait_stream(side)
     if R_text.shape[-1] != texts.shape[1]:       # trimmed run: the rest of the [B, 77, 77] matrix is the identity
         n = R_text.shape[-1]
         full = torch.eye(texts.shape[1], dtype=R_text.dtype, device=R_text.device).repeat(batch_size, 1, 1)

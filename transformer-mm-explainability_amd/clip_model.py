@@ -218,11 +218,7 @@ class Transformer(nn.Module):
             else:
                 # MLP branch: x2 = x1 + c_proj(m * sigmoid(1.702 m)),  m = c_fc(ln_2(x1))
                 d_a = self._gemm(dx, blk.mlp.c_proj.weight)
-                if shared:
-                    sg = torch.sigmoid(1.702 * m)
-                    d_m = d_a * (sg + 1.702 * m * sg * (1 - sg))              # QuickGELU'(m), shared across the batch
-                else:
-                    d_m = ops.quick_gelu_bwd(m, d_a)
+                d_m = ops.quick_gelu_bwd(m, d_a)          # shared mode: m [1, N, 4E] is broadcast inside the kernel
                 d_h2 = self._gemm(d_m, blk.mlp.c_fc.weight)
                 d_x1 = ops.layernorm_bwd_add(d_h2, x1, mean2, rstd2, blk.ln_2.weight, dx)   # dx + LN2'(d_h2), one pass
                 # attention branch: x1 = x + out_proj(attn(ln_1(x)))

@@ -20,11 +20,13 @@ __global__ __launch_bounds__(256) void quick_gelu_fwd_kernel(const f32x4* __rest
     if (blockIdx.x == 0 && threadIdx.x < tail) yt[threadIdx.x] = xt[threadIdx.x] * sigmoid_f(1.702f * xt[threadIdx.x]);
 }
 
+// x_n4: number of 16-byte groups of x; x_n4 < n4 broadcasts x over the leading (batch) dimension of dy -- the shared-forward
+// backward has ONE activation tensor for B upstream gradients.
 __global__ __launch_bounds__(256) void quick_gelu_bwd_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ dy,
-                                                             f32x4* __restrict__ dx, int64_t n4, const float* xt,
+                                                             f32x4* __restrict__ dx, int64_t n4, int64_t x_n4, const float* xt,
                                                              const float* dyt, float* dxt, int tail) {
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += static_cast<int64_t>(gridDim.x) * 256) {
-        const f32x4 v = x[i];
+        const f32x4 v = x[x_n4 == n4 ? i : i % x_n4];
         const f32x4 g = dy[i];
         f32x4 o;
 #pragma unroll
@@ -62,6 +64,21 @@ extern "C" int mmx_quick_gelu_fwd(const void* x_dev, void* y_dev, int64_t n, voi
     return MMX_OK;
 }
 
+extern "C" int mmx_quick_gelu_bwd_bcast(const void* x_dev, const void* dy_dev, void* dx_dev, int64_t n, int64_t x_n,
+                                        void* stream) {
+    MMX_CHECK_ARG(x_dev && dy_dev && dx_dev && n > 0 && x_n > 0, "mmx_quick_gelu_bwd_bcast: bad argument");
+    MMX_CHECK_ARG(n % x_n == 0 && x_n % 4 == 0, "mmx_quick_gelu_bwd_bcast: n=%ld must be a multiple of x_n=%ld, x_n %% 4 == 0",
+                  static_cast<long>(n), static_cast<long>(x_n));
+    MMX_CHECK_ARG(((reinterpret_cast<uintptr_t>(x_dev) | reinterpret_cast<uintptr_t>(dy_dev) |
+                    reinterpret_cast<uintptr_t>(dx_dev)) & 15u) == 0, "mmx_quick_gelu_bwd_bcast: pointers must be 16-byte aligned");
+    const int64_t n4 = n / 4;
+    quick_gelu_bwd_kernel<<<gelu_grid(n4), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const f32x4*>(x_dev), static_cast<const f32x4*>(dy_dev), static_cast<f32x4*>(dx_dev), n4, x_n / 4, nullptr,
+        nullptr, nullptr, 0);
+    MMX_LAUNCH_CHECK("quick_gelu_bwd_kernel");
+    return MMX_OK;
+}
+
 extern "C" int mmx_quick_gelu_bwd(const void* x_dev, const void* dy_dev, void* dx_dev, int64_t n, void* stream) {
     MMX_CHECK_ARG(x_dev && dy_dev && dx_dev && n > 0, "mmx_quick_gelu_bwd: bad argument");
     MMX_CHECK_ARG(((reinterpret_cast<uintptr_t>(x_dev) | reinterpret_cast<uintptr_t>(dy_dev) |
@@ -71,7 +88,7 @@ extern "C" int mmx_quick_gelu_bwd(const void* x_dev, const void* dy_dev, void* d
     const float* dy = static_cast<const float*>(dy_dev);
     float* dx = static_cast<float*>(dx_dev);
     quick_gelu_bwd_kernel<<<gelu_grid(n4), 256, 0, static_cast<hipStream_t>(stream)>>>(
-        reinterpret_cast<const f32x4*>(x), reinterpret_cast<const f32x4*>(dy), reinterpret_cast<f32x4*>(dx), n4, x + n4 * 4,
+        reinterpret_cast<const f32x4*>(x), reinterpret_cast<const f32x4*>(dy), reinterpret_cast<f32x4*>(dx), n4, n4, x + n4 * 4,
         dy + n4 * 4, dx + n4 * 4, static_cast<int>(n - n4 * 4));
     MMX_LAUNCH_CHECK("quick_gelu_bwd_kernel");
     return MMX_OK;

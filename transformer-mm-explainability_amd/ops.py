@@ -171,13 +171,18 @@ def quick_gelu_fwd(x):
 
 
 def quick_gelu_bwd(x, dy):
-    """``dy * QuickGELU'(x)`` in one pass (same shapes)."""
+    """``dy * QuickGELU'(x)`` in one pass.  ``x`` has ``dy``'s shape, or batch 1 where ``dy`` has batch B (shared-forward
+    mode: the ONE activation tensor is broadcast over the B upstream gradients inside the kernel)."""
     _dev(x, dy)
     x, dy = _f32c(x), _f32c(dy)
-    if x.shape != dy.shape:
+    dx = torch.empty_like(dy)
+    if x.shape == dy.shape:
+        check(lib().mmx_quick_gelu_bwd(_p(x), _p(dy), _p(dx), x.numel(), _stream()), "mmx_quick_gelu_bwd")
+    elif x.shape[0] == 1 and x.shape[1:] == dy.shape[1:] and x.numel() % 4 == 0:
+        check(lib().mmx_quick_gelu_bwd_bcast(_p(x), _p(dy), _p(dx), dy.numel(), x.numel(), _stream()),
+              "mmx_quick_gelu_bwd_bcast")
+    else:
         raise MMXError("quick_gelu_bwd: x %s vs dy %s" % (tuple(x.shape), tuple(dy.shape)))
-    dx = torch.empty_like(x)
-    check(lib().mmx_quick_gelu_bwd(_p(x), _p(dy), _p(dx), x.numel(), _stream()), "mmx_quick_gelu_bwd")
     return dx
 
 
