@@ -370,3 +370,55 @@ def test_attn_capture_half_precision_slabs(ops, dtype, rel, B, H, Nq, Nk, D, mas
     abar = ops.avg_heads(p16.view(B * H, Nq, Nk), dp16.view(B * H, Nq, Nk), batch_size=B)
     want = (p16.float() * dp16.float()).clamp(min=0).view(B, H, Nq, Nk).mean(1)
     torch.testing.assert_close(abar, want, rtol=1e-5, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K1-big: the one-launch persistent team kernel for N > 128 (relevancy_chain_big.hip) vs the oracle and vs the split path
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,B,H,N,with_init", [
+    (3, 2, 4, 197, False),      # ViT-B/16 token count (cfg 1), team of 4
+    (2, 3, 2, 577, True),       # ViT-L/14@336 token count (cfg 5), team of 10, explicit R_init
+    (2, 1, 2, 950, False),      # DETR encoder size (cfg 3), team of 15
+    (4, 70, 2, 130, False),     # more samples than resident teams can take at once? (persistent loop over samples)
+    (1, 2, 3, 129, False), (3, 2, 2, 1100, False),
+])
+def test_self_chain_big_vs_oracle(ops, L, B, H, N, with_init):
+    attn, grad = make_layers(N + L, L, B, H, N)
+    R0 = None
+    if with_init:
+        g = torch.Generator().manual_seed(9)
+        R0 = torch.eye(N).expand(B, N, N) + 0.05 * torch.rand(B, N, N, generator=g)
+    want = onp.self_chain([a.numpy() for a in attn], [x.numpy() for x in grad], B)
+    if with_init:          # chain applied to an existing state: R = prod(I + A_bar_l) . R0
+        want = np.matmul(want, R0.numpy())
+    ops.set_option("self_chain_big", 2)
+    try:
+        got = ops.relevancy_self_chain([a.cuda() for a in attn], [x.cuda() for x in grad], B,
+                                       R_init=R0.cuda() if with_init else None)
+    finally:
+        ops.set_option("self_chain_big", 1)
+    close(got, want, atol=2e-5 if with_init else ATOL)
+    ops.set_option("self_chain_big", 0)
+    try:
+        split = ops.relevancy_self_chain([a.cuda() for a in attn], [x.cuda() for x in grad], B,
+                                         R_init=R0.cuda() if with_init else None)
+    finally:
+        ops.set_option("self_chain_big", 1)
+    close(got, split.cpu().numpy(), atol=2e-6)
+
+
+def test_self_chain_big_shared_attn_and_bf16(ops):
+    """Shared-forward mode (ONE probability slab for the batch, batch stride 0) and bf16 capture slabs at N = 197."""
+    L, B, H, N = 3, 5, 4, 197
+    attn, grad = make_layers(77, L, B, H, N)
+    a1 = [a[:H].contiguous() for a in attn]                       # the single shared sample's heads
+    want = onp.self_chain([a1[l].repeat(B, 1, 1).numpy() for l in range(L)], [x.numpy() for x in grad], B)
+    ops.set_option("self_chain_big", 2)
+    try:
+        got = ops.relevancy_self_chain([a.cuda() for a in a1], [x.cuda() for x in grad], B, shared_attn=True)
+        close(got, want)
+        a16, g16 = [a.bfloat16() for a in attn], [x.bfloat16() for x in grad]
+        want16 = onp.self_chain([a.float().numpy() for a in a16], [x.float().numpy() for x in g16], B)
+        close(ops.relevancy_self_chain([a.cuda() for a in a16], [x.cuda() for x in g16], B), want16)
+    finally:
+        ops.set_option("self_chain_big", 1)

@@ -51,6 +51,52 @@ __device__ __forceinline__ f32x4 load4_as_f32<MMX_F16>(const void* base, int64_t
     o[2] = f16_bits_to_f32(r.v[2]); o[3] = f16_bits_to_f32(r.v[3]);
     return o;
 }
+// Same for a latency-sensitive streaming loop (few waves per CU): 16-bit slabs whose element index is ODD are only 2-byte
+// aligned, which the generic helper above has to fetch as four 2-byte loads (a slab of odd N^2 starts every second head
+// on such an offset).  Here the three ALIGNED dwords that cover the chunk are loaded instead (one dwordx3).
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+struct __attribute__((packed, aligned(4))) u32x3_u { u32x3 v; };
+// Split into the LOAD (raw registers, no dependent instruction and NO branch: a caller can issue a whole batch before
+// the first use) and the CONVERSION.  16-bit slabs: always the three aligned dwords from element (idx & ~1) -- for an
+// even idx the third one is an over-read of two elements, so the caller must guarantee idx + 5 is still inside the
+// tensor -- and the chunk is cut out with a funnel shift by 0 or 2 bytes.
+template <int DT> struct stream_raw { u32x3 v; };
+template <> struct stream_raw<MMX_F32> { f32x4 v; };
+template <int DT>
+__device__ __forceinline__ stream_raw<DT> load4_stream_raw(const void* base, int64_t idx) {
+    stream_raw<DT> r;
+    if constexpr (DT == MMX_F32) {
+        r.v = ldg4_u(static_cast<const float*>(base) + idx);
+    } else {
+        const unsigned short* p = static_cast<const unsigned short*>(base) + (idx & ~static_cast<int64_t>(1));
+        r.v = reinterpret_cast<const u32x3_u*>(p)->v;
+    }
+    return r;
+}
+template <int DT>
+__device__ __forceinline__ f32x4 stream_cvt(const stream_raw<DT>& r, int64_t idx) {
+    if constexpr (DT == MMX_F32) {
+        return r.v;
+    } else {
+        const unsigned sh = (idx & 1) ? 2u : 0u;
+        const unsigned lo = __builtin_amdgcn_alignbyte(r.v[1], r.v[0], sh);
+        const unsigned hi = __builtin_amdgcn_alignbyte(r.v[2], r.v[1], sh);
+        f32x4 o;
+        if constexpr (DT == MMX_BF16) {
+            o[0] = __uint_as_float(lo << 16); o[1] = __uint_as_float(lo & 0xffff0000u);
+            o[2] = __uint_as_float(hi << 16); o[3] = __uint_as_float(hi & 0xffff0000u);
+        } else {
+            o[0] = f16_bits_to_f32(static_cast<unsigned short>(lo)); o[1] = f16_bits_to_f32(static_cast<unsigned short>(lo >> 16));
+            o[2] = f16_bits_to_f32(static_cast<unsigned short>(hi)); o[3] = f16_bits_to_f32(static_cast<unsigned short>(hi >> 16));
+        }
+        return o;
+    }
+}
+template <int DT>
+__device__ __forceinline__ f32x4 load4_stream(const void* base, int64_t idx) {
+    return stream_cvt<DT>(load4_stream_raw<DT>(base, idx), idx);
+}
+
 template <int DT>
 __device__ __forceinline__ float load1_as_f32(const void* base, int64_t idx);
 template <>
@@ -133,6 +179,11 @@ inline size_t dtype_size(int dt) { return dt == MMX_F32 ? 4 : 2; }
 void set_error(const char* fmt, ...);
 void attn_small_enable(int on);
 void attn_head_enable(int on);
+void chain_big_enable(int on);
+size_t self_chain_big_workspace(int B, int N);
+int self_chain_big_try(const void* const* attn_layers, const void* const* grad_layers, int n_layers, int B, int H, int N,
+                       int dtype, int64_t attn_bstride, const void* R_init, void* R_out, void* workspace,
+                       size_t workspace_bytes, hipStream_t s, int* rc_out);
 void attn_stream_enable(int on);
 int hip_fail(hipError_t e, const char* what);
 

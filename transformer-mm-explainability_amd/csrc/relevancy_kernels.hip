@@ -23,12 +23,15 @@ __global__ __launch_bounds__(256) void avg_heads_kernel(const void* __restrict__
     const int64_t base = static_cast<int64_t>(b) * H * NN + p;
     const int64_t base_a = static_cast<int64_t>(b) * attn_bstride + p;   // attn_bstride = 0: one forward shared by the batch
     const float fH = static_cast<float>(H);
-    if (p + 3 < NN) {
+    // fast path: one aligned load per (head, array).  16-bit slabs of odd N^2 start every second head on a 2-byte
+    // boundary; load4_stream fetches the three aligned dwords around the chunk instead of four 2-byte loads (it
+    // over-reads two elements, hence p + 5 < NN; the last chunk of a slab takes the element-wise path)
+    if (p + 5 < NN) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
         for (int h = 0; h < H; ++h) {
-            const f32x4 a = load4_as_f32<DT>(attn, base_a + h * NN);
-            const f32x4 g = load4_as_f32<DT>(grad, base + h * NN);
+            const f32x4 a = load4_stream<DT>(attn, base_a + h * NN);
+            const f32x4 g = load4_stream<DT>(grad, base + h * NN);
             const f32x4 x = g * a;
             s[0] += relu_nan(x[0]); s[1] += relu_nan(x[1]);
             s[2] += relu_nan(x[2]); s[3] += relu_nan(x[3]);
@@ -837,6 +840,10 @@ extern "C" int mmx_set_option(const char* key, int value) {
         attn_small_enable(value);
         return MMX_OK;
     }
+    if (key && strcmp(key, "self_chain_big") == 0) {
+        chain_big_enable(value);
+        return MMX_OK;
+    }
     if (key && strcmp(key, "attn_head") == 0) {
         attn_head_enable(value);
         return MMX_OK;
@@ -886,7 +893,9 @@ extern "C" size_t mmx_self_chain_workspace_bytes(int n_layers, int B, int H, int
     }
     const size_t mat = align256(sizeof(float) * static_cast<size_t>(B) * N * N);
     const size_t sq = M > 0 ? align256(sizeof(float) * static_cast<size_t>(B) * N * M) : 0;
-    return 2 * mat + sq;  // A_bar + R ping-pong [+ R_sq ping-pong]
+    const size_t split = 2 * mat + sq;  // A_bar + R ping-pong [+ R_sq ping-pong]
+    const size_t big = M == 0 ? self_chain_big_workspace(B, N) : 0;   // one-launch long-sequence kernel (relevancy_chain_big.hip)
+    return split > big ? split : big;
 }
 
 template <int NT>
@@ -1022,6 +1031,13 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
             case 7: return launch_fused<7>(args, dtype, s);
             default: return launch_fused<8>(args, dtype, s);
         }
+    }
+
+    if (M == 0) {   // N > 128: the persistent team kernel (one launch for all layers) when the grid fills the chip
+        int rc = MMX_OK;
+        if (self_chain_big_try(attn_layers, grad_layers, n_layers, B, H, N, dtype, attn_batch_stride, R_init_dev, R_out_dev,
+                               workspace_dev, workspace_bytes, s, &rc))
+            return rc;
     }
 
     // ---- split path: per layer  A_bar = avg_heads(A_l, G_l);  R' = R + A_bar . R  [; R_sq' = R_sq + A_bar . R_sq]
