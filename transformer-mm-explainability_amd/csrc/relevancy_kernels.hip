@@ -599,10 +599,18 @@ __global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ 
             }
 }
 
+static int g_bmm_tile = 64;   // 128: try the 128 x 128 tiling where the grid is large enough (A/B profiling)
+
 static void launch_bmm(const float* A, const float* B, const float* Cin, float* C, int batch, int M, int N, int K,
                        int trans_a, int64_t sa, int64_t sb, int64_t sc, int nan_to_zero, hipStream_t s) {
     const int64_t wgs64 = static_cast<int64_t>((N + 63) / 64) * ((M + 63) / 64) * batch;
-    if (wgs64 >= 1024) {
+    const int64_t wgs128 = static_cast<int64_t>((N + 127) / 128) * ((M + 127) / 128) * batch;
+    if (wgs128 >= 512 && g_bmm_tile == 128) {
+        // 128 x 128 per workgroup (each wave 64 x 64 = 16 accumulator tiles).  Measured SLOWER than 64 x 64 at the
+        // long-sequence chain shapes (profiles/r02_bmm_probe.txt: 384 vs 281 us at [32 x 577 x 577]^2), so opt-in only.
+        bmm_f32_kernel<128><<<dim3((N + 127) / 128, (M + 127) / 128, batch), 256, 0, s>>>(A, B, Cin, C, M, N, K, trans_a,
+                                                                                       sa, sb, sc, nan_to_zero);
+    } else if (wgs64 >= 1024) {
         bmm_f32_kernel<64><<<dim3((N + 63) / 64, (M + 63) / 64, batch), 256, 0, s>>>(A, B, Cin, C, M, N, K, trans_a, sa,
                                                                                     sb, sc, nan_to_zero);
     } else {
@@ -838,6 +846,10 @@ extern "C" int mmx_set_option(const char* key, int value) {
     }
     if (key && strcmp(key, "attn_small") == 0) {
         attn_small_enable(value);
+        return MMX_OK;
+    }
+    if (key && strcmp(key, "bmm_tile") == 0) {
+        g_bmm_tile = value;
         return MMX_OK;
     }
     if (key && strcmp(key, "self_chain_big") == 0) {
