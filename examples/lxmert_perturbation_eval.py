@@ -1,6 +1,7 @@
 """Sharded LXMERT perturbation evaluation on synthetic data -- the shape of ``lxmert/lxmert/perturbation.py``'s main
-loop (BASELINE.json config 4) on this package: one process per GPU, samples sharded rank-strided, items of equal
-question length explained and perturbed as one batch, ONE all-gather of the per-sample step accuracies at the end.
+loop (BASELINE.json config 4) on this package: one process per GPU, samples sharded rank-strided, batches of items of
+ANY question length (padded; the schedule kernel takes per-sample lengths) explained from ONE captured hipGraph and
+perturbed as one batch, ONE all-gather of the per-sample step accuracies at the end.
 
     python examples/lxmert_perturbation_eval.py --num-samples 512                      # one GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \\
@@ -42,6 +43,8 @@ def main():
     ap.add_argument("--text", action="store_true", help="text perturbation test instead of the image one")
     ap.add_argument("--positive", action="store_true")
     ap.add_argument("--resume-dir", default=None, help="per-rank partial score files; finished samples are skipped on restart")
+    ap.add_argument("--bucket-by-length", action="store_true",
+                    help="round-1 behaviour: group items by question length, eager explain pass per group")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
@@ -67,23 +70,43 @@ def main():
             cache[k] = synthetic_item(k, 36, cfg.visual_feat_dim, cfg.vocab_size, cfg.num_qa_labels)
         return cache[k]
 
-    def process_batch(ids):                    # explain + perturb one bucket of equal-length items -> [B, 9] accuracies
+    T_PAD = 20                                 # the synthetic questions have 6..20 tokens
+    graphed = {}
+
+    def process_batch(ids):                    # explain + perturb one batch -> [len(ids), 9] accuracies
         items = [cache.pop(k, None) or synthetic_item(k, 36, cfg.visual_feat_dim, cfg.vocab_size, cfg.num_qa_labels) for k in ids]
-        B, T = len(items), items[0]["input_ids"].numel()
-        batch = dict(input_ids=torch.stack([it["input_ids"] for it in items]).to(dev),
-                     attention_mask=torch.ones(B, T, device=dev), token_type_ids=torch.zeros(B, T, dtype=torch.long, device=dev),
+        n = len(items)
+        if args.bucket_by_length:
+            B, T = n, items[0]["input_ids"].numel()
+        else:                                  # fixed shape: pad the tail batch with copies of its last item
+            B, T = args.max_batch, T_PAD
+            items = items + [items[-1]] * (B - n)
+        input_ids = torch.zeros(B, T, dtype=torch.long)
+        mask = torch.zeros(B, T)
+        for b, it in enumerate(items):
+            t = it["input_ids"].numel()
+            input_ids[b, :t] = it["input_ids"]
+            mask[b, :t] = 1
+        batch = dict(input_ids=input_ids.to(dev), attention_mask=mask.to(dev),
+                     token_type_ids=torch.zeros(B, T, dtype=torch.long, device=dev),
                      visual_feats=torch.stack([it["visual_feats"] for it in items]).to(dev),
                      visual_pos=torch.stack([it["visual_pos"] for it in items]).to(dev))
-        R_t_t, R_t_i = gen.generate_ours_batch(batch)
-        cam_image, cam_text = lp.normalize_cams_batch(R_t_t, R_t_i)
+        if args.bucket_by_length:
+            R_t_t, R_t_i = gen.generate_ours_batch(batch)
+        else:
+            if "run" not in graphed:           # captured once; serves every later batch whatever its question lengths
+                graphed["run"] = le.GraphedGenerateOursBatch(model, batch)
+            R_t_t, R_t_i = graphed["run"](batch)
+        cam_image, cam_text = lp.normalize_cams_batch(R_t_t, R_t_i, batch["attention_mask"])
         scores = pert.perturbation_text(batch, cam_text, args.positive) if args.text else \
             pert.perturbation_image(batch, cam_image, args.positive)
         labels = torch.stack([it["label"] for it in items]).to(dev)
-        return lp.LxmertPerturbation.accuracy(scores, labels)
+        return lp.LxmertPerturbation.accuracy(scores, labels)[:n]
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    per_sample = sharding.evaluate_sharded(indices, lambda k: item(k)["input_ids"].numel(), process_batch,
+    length_of = (lambda k: item(k)["input_ids"].numel()) if args.bucket_by_length else (lambda k: 0)   # 0: one bucket
+    per_sample = sharding.evaluate_sharded(indices, length_of, process_batch,
                                            len(lp.PERT_STEPS), max_batch=args.max_batch, store=store, device=dev)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0

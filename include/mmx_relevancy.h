@@ -164,6 +164,20 @@ int mmx_lxmert_schedule(const void* const* lang_attn, const void* const* lang_gr
                         int B, int H, int T, int I, unsigned flags,
                         void* R_tt_dev, void* R_ti_dev, void* R_ii_dev, void* R_it_dev,
                         void* diag_min_dev, void* stream);
+/* Same, for a batch that is PADDED to T question tokens: text_len_dev = device array of B ints, the real number of question
+ * tokens of every sample (1..T; NULL = all T).  The slabs keep their padded [.., T, ..] shape (padded keys carry zero
+ * probability under the attention mask); sample b's rules run on its leading text_len[b] tokens only, and rows / columns
+ * of R_tt / R_ti / R_it beyond them are written as zero.  One padded batch replaces the grouping of samples by question
+ * length (lxmert/lxmert/perturbation.py:45-83 tokenises one question per call, so the reference never pads). */
+int mmx_lxmert_schedule_ex(const void* const* lang_attn, const void* const* lang_grad, int n_lang,
+                        const void* const* vis_attn, const void* const* vis_grad, int n_vis,
+                        const void* const* x_lang_cross_attn, const void* const* x_lang_cross_grad,
+                        const void* const* x_img_cross_attn, const void* const* x_img_cross_grad,
+                        const void* const* x_lang_self_attn, const void* const* x_lang_self_grad,
+                        const void* const* x_img_self_attn, const void* const* x_img_self_grad, int n_x,
+                        int B, int H, int T, int I, unsigned flags, const void* text_len_dev,
+                        void* R_tt_dev, void* R_ti_dev, void* R_ii_dev, void* R_it_dev,
+                        void* diag_min_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Attention rollout: prod_{i >= start}( (A_i + I) [/ rowsum] ), left-multiplied.

@@ -253,9 +253,11 @@ def _detr_from_golden(g):
     missing, unexpected = model.load_state_dict(weights, strict=False)
     assert not unexpected and all(m.startswith("bbox_embed.") for m in missing), (missing, unexpected)
     model = model.cuda().eval()
+    pos_dev = cu(g["pos"])                      # on the device once (a forward may run inside a hipGraph capture)
+
     class FixedPos(nn.Module):                  # the fixture used a random position tensor, not the sine one
         def forward(self, mask):
-            return cu(g["pos"])
+            return pos_dev
 
     model.position = FixedPos()
     return model
@@ -442,3 +444,31 @@ def test_detr_bf16_backward_gemms_stay_close(golden):
     got = Generator(model).generate_ours_multi(feats, targets)
     assert (got - want).abs().max() <= 3e-2 * want.abs().max()
     assert torch.nn.functional.cosine_similarity(got.reshape(3, -1), want.reshape(3, -1), dim=-1).min() > 0.999
+
+
+def test_detr_graphed_generate_ours_multi(golden):
+    """hipGraph replay of the K-slot batched DETR pass == the eager pass: fewer targets than slots (padded with repeats),
+    more targets than slots (chunks), new features copied in; the deferred diag word replaces the 7 per-call asserts."""
+    from transformer_mm_explainability_amd.detr_explainability import Generator, GraphedGenerateOursMulti, MaskGenerator
+    g = golden("detr_transformer")
+    model = _detr_from_golden(g)
+    feats = cu(g["features"])
+    run = GraphedGenerateOursMulti(model, feats, K=4)
+    for targets in ([4, 0, 6], [1, 2, 3, 4, 5, 6, 0], [2]):
+        t = torch.tensor(targets, device="cuda")
+        want = Generator(model).generate_ours_multi(feats, t)
+        got = run(feats, t)
+        assert got.shape == want.shape
+        close(got, want.cpu().numpy(), atol=1e-6)
+    feats2 = feats.flip(-1).contiguous()
+    t = torch.tensor([4, 0, 6], device="cuda")
+    close(run(feats2, t), Generator(model).generate_ours_multi(feats2, t).cpu().numpy(), atol=1e-6)
+    assert float(run.diag_min) >= 0
+    # MaskGenerator through the graph == eager MaskGenerator
+    mg_e, mg_g = MaskGenerator(model, threshold=0.0), MaskGenerator(model, threshold=0.0, graph_slots=4)
+    with torch.no_grad():
+        th = float(model(feats)["pred_logits"].softmax(-1)[0, :, :-1].max(-1).values.sort().values[-3])
+    mg_e.threshold = mg_g.threshold = th - 1e-6
+    masks_e, keep_e = mg_e.get_masks(feats, "ours_no_lrp")
+    masks_g, keep_g = mg_g.get_masks(feats, "ours_no_lrp")
+    assert torch.equal(keep_e, keep_g) and (masks_e != masks_g).float().mean() < 0.01

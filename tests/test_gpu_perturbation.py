@@ -298,3 +298,71 @@ def test_ranking_tie_policy_is_stable_and_prefix_consistent():
         want = torch.zeros(36, device="cuda")
         want[cam.topk(int((1 - step) * 36)).indices] = 1
         assert torch.equal(keep[s], want)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Ragged question lengths inside ONE padded batch + the hipGraph replay of the batched explain pass
+# ----------------------------------------------------------------------------------------------------------------------
+def _ragged_batch(g, lens, I=20, T=12):
+    B = len(lens)
+    ids = torch.zeros(B, T, dtype=torch.long)
+    mask = torch.zeros(B, T)
+    for b, n in enumerate(lens):
+        ids[b, :n] = torch.randint(1, 200, (n,), generator=g)
+        mask[b, :n] = 1
+    return dict(input_ids=ids.cuda(), attention_mask=mask.cuda(), token_type_ids=torch.zeros(B, T, dtype=torch.long).cuda(),
+                visual_feats=torch.randn(B, I, 40, generator=g).cuda(), visual_pos=torch.rand(B, I, 4, generator=g).cuda())
+
+
+def test_generate_ours_batch_with_per_sample_question_lengths():
+    """A batch padded to T = 12 with questions of 5 / 12 / 8 / 9 tokens == each item explained alone, unpadded (the way
+    the reference's evaluator calls the generator); rows / columns beyond a sample's length come back as zero."""
+    import types
+    from transformer_mm_explainability_amd import lxmert_explainability as le
+    model, _, g = _model_and_inputs()
+    lens = [5, 12, 8, 9]
+    batch = _ragged_batch(g, lens)
+    gen = le.GeneratorOurs(types.SimpleNamespace(model=model))
+    R_t_t, R_t_i = gen.generate_ours_batch(batch)
+    assert R_t_t.shape == (4, 12, 12) and R_t_i.shape == (4, 12, 20)
+    for b, n in enumerate(lens):
+        one = {k: v[b:b + 1, :n] if k in ("input_ids", "attention_mask", "token_type_ids") else v[b:b + 1]
+               for k, v in batch.items()}
+        usage = types.SimpleNamespace(model=model, text_len=n, image_boxes_len=20, forward=lambda item: model(**one))
+        want_tt, want_ti = le.GeneratorOurs(usage).generate_ours(None, use_lrp=False)
+        torch.testing.assert_close(R_t_t[b, :n, :n], want_tt, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(R_t_i[b, :n], want_ti, rtol=1e-4, atol=1e-5)
+        assert (R_t_t[b, n:] == 0).all() and (R_t_t[b, :, n:] == 0).all() and (R_t_i[b, n:] == 0).all()
+
+
+def test_graphed_generate_ours_batch_replays_any_lengths():
+    """ONE captured graph (padded length 12) serves batches of different question lengths; the deferred diag word is
+    checked once per batch and nothing else synchronises."""
+    import types
+    from transformer_mm_explainability_amd import lxmert_explainability as le
+    from transformer_mm_explainability_amd import lxmert_perturbation as lp
+    model, _, g = _model_and_inputs()
+    first = _ragged_batch(g, [12, 12, 12, 12])
+    run = le.GraphedGenerateOursBatch(model, first)
+    gen = le.GeneratorOurs(types.SimpleNamespace(model=model))
+    for lens in ([12, 12, 12, 12], [6, 11, 9, 7]):
+        batch = _ragged_batch(g, lens)
+        want_tt, want_ti = (t.clone() for t in gen.generate_ours_batch(batch))
+        got_tt, got_ti = run(batch)
+        torch.testing.assert_close(got_tt, want_tt, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(got_ti, want_ti, rtol=1e-5, atol=1e-6)
+        assert float(run.diag_min) >= 0
+        # the evaluator's next step on the padded batch: cams over real tokens only, both perturbation tests
+        cam_image, cam_text = lp.normalize_cams_batch(got_tt, got_ti, batch["attention_mask"])
+        assert torch.isfinite(cam_image).all() and torch.isfinite(cam_text).all()
+        pert = lp.LxmertPerturbation(model)
+        img = pert.perturbation_image(batch, cam_image)
+        txt = pert.perturbation_text(batch, cam_text)
+        assert img.shape == txt.shape == (4, 9, 31)
+        b, n = 1, lens[1]                       # the padded text test == the unpadded one of the same item
+        one = {k: v[b:b + 1, :n] if k in ("input_ids", "attention_mask", "token_type_ids") else v[b:b + 1]
+               for k, v in batch.items()}
+        torch.testing.assert_close(txt[b], pert.perturbation_text(one, cam_text[b, :n]), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(img[b], pert.perturbation_image(one, cam_image[b]), rtol=1e-4, atol=1e-5)
+    with pytest.raises(ValueError, match="captured"):
+        run(_ragged_batch(g, [5, 5, 5]))

@@ -60,6 +60,11 @@ for B in (8, 32):
                  token_type_ids=torch.zeros(B, T, dtype=torch.long).cuda(),
                  visual_feats=torch.randn(B, I, 2048, generator=gb).cuda(), visual_pos=torch.rand(B, I, 4, generator=gb).cuda())
     ms = timed(lambda: gen.generate_ours_batch(batch), n=5)
+    run = le.GraphedGenerateOursBatch(model, batch)
+    mg = timed(lambda: run(batch), n=10)
+    print("B=%-2d generate_ours_batch eager %.2f ms | hipGraph replay (+ one deferred diag check) %.2f ms = %.3f ms/sample"
+          % (B, ms, mg, mg / B))
+    del run
     cams = torch.rand(B, I, generator=gb).cuda()
     mp = timed(lambda: pert.perturbation_image(batch, cams), n=5)
     print("B=%-2d generate_ours_batch %.2f ms (%.2f ms/sample) | image test %.2f ms (%.2f ms/sample) -> %.0f samples/s for both"

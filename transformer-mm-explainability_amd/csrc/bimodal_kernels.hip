@@ -29,6 +29,7 @@ struct BimodalArgs {
     unsigned flags;                 // MMX_MM_NORMALIZE | MMX_MM_SELF_IN_RULE10
     float *R_tt, *R_ti, *R_ii, *R_it;  // outputs [B,T,T] [B,T,I] [B,I,I] [B,I,T]
     float* diag_min;                // min over every handle_residual call of diag(R - I), or null
+    const int* text_len;            // [B] real question length of every sample (<= T, the padded slab size), or null (= T)
 };
 
 struct Mat {      // an LDS matrix [rows][kBmLd]
@@ -36,26 +37,30 @@ struct Mat {      // an LDS matrix [rows][kBmLd]
     __device__ __forceinline__ float& at(int i, int j) const { return p[i * kBmLd + j]; }
 };
 
-// rule 5: cam[i][j] = (1/H) sum_h max(G*A, 0); heads in order, 4 (A, G) pairs in flight
+// rule 5: cam[i][j] = (1/H) sum_h max(G*A, 0); heads in order, 4 (A, G) pairs in flight.  The slab of a head is
+// [pq][pk] (padded sizes); only its leading nq x nk block is read (per-sample question lengths inside one padded batch).
 __device__ __forceinline__ void avg_heads_lds(Mat cam, const float* A, const float* G, int64_t sample, int H, int nq,
-                                              int nk, int tid) {
+                                              int nk, int pq, int pk, int tid) {
     const int nn = nq * nk;
+    const int64_t hs = static_cast<int64_t>(pq) * pk;
     const float fH = static_cast<float>(H);
     for (int e = tid; e < nn; e += kBmThreads) {
+        const int i = e / nk, j = e - i * nk;
+        const int64_t off = sample + static_cast<int64_t>(i) * pk + j;
         float s = 0.f;
         int h = 0;
         for (; h + 4 <= H; h += 4) {
             float a[4], g[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                a[u] = A[sample + static_cast<int64_t>(h + u) * nn + e];
-                g[u] = G[sample + static_cast<int64_t>(h + u) * nn + e];
+                a[u] = A[off + (h + u) * hs];
+                g[u] = G[off + (h + u) * hs];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) s += relu_nan(g[u] * a[u]);
         }
-        for (; h < H; ++h) s += relu_nan(G[sample + static_cast<int64_t>(h) * nn + e] * A[sample + static_cast<int64_t>(h) * nn + e]);
-        cam.at(e / nk, e % nk) = s / fH;
+        for (; h < H; ++h) s += relu_nan(G[off + h * hs] * A[off + h * hs]);
+        cam.at(i, j) = s / fH;
     }
 }
 
@@ -112,10 +117,11 @@ __global__ __launch_bounds__(kBmThreads) void lxmert_schedule_kernel(const Bimod
     Mat add0{smem + 8 * MS}, add1{smem + 9 * MS}, add2{smem + 10 * MS}, add3{smem + 11 * MS};
 
     const int tid = threadIdx.x, b = blockIdx.x;
-    const int T = a.T, I = a.I, H = a.H;
+    const int PT = a.T, I = a.I, H = a.H;                       // PT: padded question length = slab size
+    const int T = a.text_len ? min(max(a.text_len[b], 1), PT) : PT;   // this sample's real question length
     const bool normalize = a.flags & MMX_MM_NORMALIZE, self10 = a.flags & MMX_MM_SELF_IN_RULE10;
-    const int64_t s_tt = static_cast<int64_t>(b) * H * T * T, s_ii = static_cast<int64_t>(b) * H * I * I;
-    const int64_t s_ti = static_cast<int64_t>(b) * H * T * I;
+    const int64_t s_tt = static_cast<int64_t>(b) * H * PT * PT, s_ii = static_cast<int64_t>(b) * H * I * I;
+    const int64_t s_ti = static_cast<int64_t>(b) * H * PT * I;
 
     for (int e = tid; e < kBmMax * kBmMax; e += kBmThreads) {
         const int i = e / kBmMax, j = e - i * kBmMax;
@@ -127,8 +133,8 @@ __global__ __launch_bounds__(kBmThreads) void lxmert_schedule_kernel(const Bimod
     __syncthreads();
 
     // rules 6 + 7 for one self-attention block: R_ss += cam.R_ss ; R_sq += cam.R_sq  (both from the old state)
-    auto self_block = [&](const float* A, const float* G, int64_t sample, Mat R_ss, Mat R_sq, int ns, int nq) {
-        avg_heads_lds(cam, A, G, sample, H, ns, ns, tid);
+    auto self_block = [&](const float* A, const float* G, int64_t sample, Mat R_ss, Mat R_sq, int ns, int nq, int ps) {
+        avg_heads_lds(cam, A, G, sample, H, ns, ns, ps, ps, tid);
         __syncthreads();
         matmul_lds<false>(add0, cam, R_ss, ns, ns, ns, tid);
         matmul_lds<false>(add1, cam, R_sq, ns, ns, nq, tid);
@@ -140,8 +146,8 @@ __global__ __launch_bounds__(kBmThreads) void lxmert_schedule_kernel(const Bimod
     // rules 10 + 11 for one cross-attention (queries s, keys q):
     //   sq_add = Rn_ss^T.(cam_sq.Rn_qq) (or cam_sq) ; ss_add = cam_sq.R_qs      -- written to (o_sq, o_ss), NOT applied
     auto cross_block = [&](const float* A, const float* G, int64_t sample, Mat R_ss, Mat R_qq, Mat R_qs, int ns, int nq,
-                           Mat o_sq, Mat o_ss) {
-        avg_heads_lds(cam, A, G, sample, H, ns, nq, tid);
+                           int ps, int pq, Mat o_sq, Mat o_ss) {
+        avg_heads_lds(cam, A, G, sample, H, ns, nq, ps, pq, tid);
         if (self10 && normalize) {
             handle_residual_lds(N_a, R_ss, ns, a.diag_min, tid);
             if (tid >= 64 && tid < 64 + nq) handle_residual_lds(N_b, R_qq, nq, a.diag_min, tid - 64);
@@ -160,33 +166,43 @@ __global__ __launch_bounds__(kBmThreads) void lxmert_schedule_kernel(const Bimod
         __syncthreads();
     };
 
-    for (int l = 0; l < a.n_lang; ++l) self_block(a.lang_a[l], a.lang_g[l], s_tt, R_tt, R_ti, T, I);
-    for (int l = 0; l < a.n_vis; ++l) self_block(a.vis_a[l], a.vis_g[l], s_ii, R_ii, R_it, I, T);
+    for (int l = 0; l < a.n_lang; ++l) self_block(a.lang_a[l], a.lang_g[l], s_tt, R_tt, R_ti, T, I, PT);
+    for (int l = 0; l < a.n_vis; ++l) self_block(a.vis_a[l], a.vis_g[l], s_ii, R_ii, R_it, I, T, I);
     for (int x = 0; x < a.n_x; ++x) {
         const bool last = (x == a.n_x - 1);
         // both directions are computed from the pre-update state, then added (reference :181-189)
-        cross_block(a.xlc_a[x], a.xlc_g[x], s_ti, R_tt, R_ii, R_it, T, I, add2, add3);      // (R_ti_add, R_tt_add)
+        cross_block(a.xlc_a[x], a.xlc_g[x], s_ti, R_tt, R_ii, R_it, T, I, PT, I, add2, add3);      // (R_ti_add, R_tt_add)
         if (!last) {
             // the second direction needs its own outputs: reuse add0/add1 (free outside self_block)
-            cross_block(a.xic_a[x], a.xic_g[x], s_ti, R_ii, R_tt, R_ti, I, T, add0, add1);  // (R_it_add, R_ii_add)
+            cross_block(a.xic_a[x], a.xic_g[x], s_ti, R_ii, R_tt, R_ti, I, T, I, PT, add0, add1);  // (R_it_add, R_ii_add)
             add_into(R_it, add0, I, T, tid);
             add_into(R_ii, add1, I, I, tid);
         }
         add_into(R_ti, add2, T, I, tid);
         add_into(R_tt, add3, T, T, tid);
         __syncthreads();
-        self_block(a.xls_a[x], a.xls_g[x], s_tt, R_tt, R_ti, T, I);
-        if (!last) self_block(a.xis_a[x], a.xis_g[x], s_ii, R_ii, R_it, I, T);
+        self_block(a.xls_a[x], a.xls_g[x], s_tt, R_tt, R_ti, T, I, PT);
+        if (!last) self_block(a.xis_a[x], a.xis_g[x], s_ii, R_ii, R_it, I, T, I);
     }
     if (tid == 0) R_tt.at(0, 0) = 0.f;   // disregard the [CLS] token itself (:210)
     __syncthreads();
 
-    for (int e = tid; e < T * T; e += kBmThreads) a.R_tt[static_cast<int64_t>(b) * T * T + e] = R_tt.at(e / T, e % T);
-    for (int e = tid; e < T * I; e += kBmThreads) a.R_ti[static_cast<int64_t>(b) * T * I + e] = R_ti.at(e / I, e % I);
+    // outputs are [PT]-padded; rows / columns beyond this sample's question length are zero
+    for (int e = tid; e < PT * PT; e += kBmThreads) {
+        const int i = e / PT, j = e - i * PT;
+        a.R_tt[static_cast<int64_t>(b) * PT * PT + e] = (i < T && j < T) ? R_tt.at(i, j) : 0.f;
+    }
+    for (int e = tid; e < PT * I; e += kBmThreads) {
+        const int i = e / I, j = e - i * I;
+        a.R_ti[static_cast<int64_t>(b) * PT * I + e] = (i < T) ? R_ti.at(i, j) : 0.f;
+    }
     if (a.R_ii)
         for (int e = tid; e < I * I; e += kBmThreads) a.R_ii[static_cast<int64_t>(b) * I * I + e] = R_ii.at(e / I, e % I);
     if (a.R_it)
-        for (int e = tid; e < I * T; e += kBmThreads) a.R_it[static_cast<int64_t>(b) * I * T + e] = R_it.at(e / T, e % T);
+        for (int e = tid; e < I * PT; e += kBmThreads) {
+            const int i = e / PT, j = e - i * PT;
+            a.R_it[static_cast<int64_t>(b) * I * PT + e] = (j < T) ? R_it.at(i, j) : 0.f;
+        }
 }
 
 __global__ void bm_fill_scalar_kernel(float* p, float v) { *p = v; }
@@ -194,6 +210,15 @@ __global__ void bm_fill_scalar_kernel(float* p, float v) { *p = v; }
 }  // namespace mmx
 
 using namespace mmx;
+
+extern "C" int mmx_lxmert_schedule_ex(const void* const* lang_attn, const void* const* lang_grad, int n_lang,
+                                      const void* const* vis_attn, const void* const* vis_grad, int n_vis,
+                                      const void* const* x_lang_cross_attn, const void* const* x_lang_cross_grad,
+                                      const void* const* x_img_cross_attn, const void* const* x_img_cross_grad,
+                                      const void* const* x_lang_self_attn, const void* const* x_lang_self_grad,
+                                      const void* const* x_img_self_attn, const void* const* x_img_self_grad, int n_x,
+                                      int B, int H, int T, int I, unsigned flags, const void* text_len_dev, void* R_tt_dev,
+                                      void* R_ti_dev, void* R_ii_dev, void* R_it_dev, void* diag_min_dev, void* stream);
 
 extern "C" int mmx_lxmert_schedule(const void* const* lang_attn, const void* const* lang_grad, int n_lang,
                                    const void* const* vis_attn, const void* const* vis_grad, int n_vis,
@@ -203,6 +228,20 @@ extern "C" int mmx_lxmert_schedule(const void* const* lang_attn, const void* con
                                    const void* const* x_img_self_attn, const void* const* x_img_self_grad, int n_x,
                                    int B, int H, int T, int I, unsigned flags, void* R_tt_dev, void* R_ti_dev,
                                    void* R_ii_dev, void* R_it_dev, void* diag_min_dev, void* stream) {
+    return mmx_lxmert_schedule_ex(lang_attn, lang_grad, n_lang, vis_attn, vis_grad, n_vis, x_lang_cross_attn,
+                                  x_lang_cross_grad, x_img_cross_attn, x_img_cross_grad, x_lang_self_attn, x_lang_self_grad,
+                                  x_img_self_attn, x_img_self_grad, n_x, B, H, T, I, flags, nullptr, R_tt_dev, R_ti_dev,
+                                  R_ii_dev, R_it_dev, diag_min_dev, stream);
+}
+
+extern "C" int mmx_lxmert_schedule_ex(const void* const* lang_attn, const void* const* lang_grad, int n_lang,
+                                   const void* const* vis_attn, const void* const* vis_grad, int n_vis,
+                                   const void* const* x_lang_cross_attn, const void* const* x_lang_cross_grad,
+                                   const void* const* x_img_cross_attn, const void* const* x_img_cross_grad,
+                                   const void* const* x_lang_self_attn, const void* const* x_lang_self_grad,
+                                   const void* const* x_img_self_attn, const void* const* x_img_self_grad, int n_x,
+                                   int B, int H, int T, int I, unsigned flags, const void* text_len_dev, void* R_tt_dev,
+                                   void* R_ti_dev, void* R_ii_dev, void* R_it_dev, void* diag_min_dev, void* stream) {
     MMX_CHECK_ARG(R_tt_dev && R_ti_dev, "mmx_lxmert_schedule: null output");
     MMX_CHECK_ARG(B > 0 && H > 0 && T > 0 && I > 0 && n_x >= 1, "mmx_lxmert_schedule: non-positive size");
     MMX_CHECK_ARG(n_lang >= 0 && n_vis >= 0 && n_lang <= kBmMaxLayers && n_vis <= kBmMaxLayers && n_x <= kBmMaxLayers,
@@ -231,6 +270,7 @@ extern "C" int mmx_lxmert_schedule(const void* const* lang_attn, const void* con
     a.R_tt = static_cast<float*>(R_tt_dev); a.R_ti = static_cast<float*>(R_ti_dev);
     a.R_ii = static_cast<float*>(R_ii_dev); a.R_it = static_cast<float*>(R_it_dev);
     a.diag_min = static_cast<float*>(diag_min_dev);
+    a.text_len = static_cast<const int*>(text_len_dev);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.diag_min) bm_fill_scalar_kernel<<<1, 1, 0, s>>>(a.diag_min, __builtin_inff());
     const size_t lds = sizeof(float) * 12 * kBmMax * kBmLd;

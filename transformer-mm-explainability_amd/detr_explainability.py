@@ -125,7 +125,7 @@ class Generator:
         return aggregated[:, target_index, :].unsqueeze_(0).detach()
 
     def generate_ours_multi(self, img, target_indices, index=None, normalize_self_attention=True,
-                            apply_self_in_rule_10=True, share_forward=True):
+                            apply_self_in_rule_10=True, share_forward=True, check_diag=True):
         """All kept queries of one image in ONE pass.
 
         Equal to ``torch.cat([generate_ours(img, t, index, use_lrp=False, ...) for t in target_indices], dim=2)`` --
@@ -141,6 +141,10 @@ class Generator:
         their upstream gradients, so the forward runs ONCE at batch 1 and the backward -- the same chain of
         vector-Jacobian products, written out by hand -- runs at batch K; every block then holds ONE probability slab
         and K gradient slabs, which the rule kernels read with batch stride 0.  Same results to fp32 rounding.
+
+        ``check_diag``: the reference asserts ``diag(R - I) >= 0`` inside every ``handle_residual`` (a device->host
+        read each, 7 per call here).  ``True``: the 7 device words are reduced and asserted ONCE at the end; ``"defer"``:
+        the reduced word is left in ``self.diag_min`` and nothing synchronises (``GraphedGenerateOursMulti``).
         """
         self.use_lrp = False
         self.normalize_self_attention = normalize_self_attention
@@ -155,9 +159,12 @@ class Generator:
             with torch.no_grad():
                 logits, state = self.model.forward_shared(img, K)                                     # [1, Q, C+1]
                 if index is None:
-                    index = logits[0, targets, :-1].argmax(dim=-1)
-                one_hot = torch.zeros(K, *logits.shape[1:], dtype=logits.dtype, device=img.device)
-                one_hot[rows, targets, index] = 1
+                    index = logits[0].index_select(0, targets)[:, :-1].argmax(dim=-1)
+                # one-hot seeds by scatter (an index_put with tensor indices cannot be captured into a hipGraph)
+                n_cls = logits.shape[-1]
+                one_hot = torch.zeros(K, logits.shape[1] * n_cls, dtype=logits.dtype, device=img.device)
+                one_hot.scatter_(1, (targets * n_cls + index).reshape(K, 1), 1.0)
+                one_hot = one_hot.view(K, logits.shape[1], n_cls)
                 self.model.backward_shared(state, one_hot)
         else:
             batch = img.expand(K, *img.shape[1:])
@@ -183,8 +190,10 @@ class Generator:
         self.R_q_i = torch.zeros(K, n_q, n_img, device=img.device)
         use_self = apply_self_in_rule_10
         R_ii_hat = self.R_i_i
+        diag_words = []
         if use_self and normalize_self_attention:
-            R_ii_hat = ops.handle_residual(self.R_i_i)
+            R_ii_hat, word = ops.handle_residual(self.R_i_i, check_diag="defer")
+            diag_words.append(word)
         for blk in decoder_blocks:
             a, g = pair(blk.self_attn)
             self.R_q_q, self.R_q_i = ops.relevancy_self_chain([a], [g], K, R_init=self.R_q_q, R_sq_init=self.R_q_i,
@@ -193,11 +202,18 @@ class Generator:
             if not use_self:                                   # ablation: the addition is the cross-attention map
                 self.R_q_i = self.R_q_i + cam
                 continue
-            R_qq_hat = ops.handle_residual(self.R_q_q) if normalize_self_attention else self.R_q_q
+            R_qq_hat = self.R_q_q
+            if normalize_self_attention:
+                R_qq_hat, word = ops.handle_residual(self.R_q_q, check_diag="defer")
+                diag_words.append(word)
             # R_q_i += nan_to_zero( R_qq_hat^T . (cam . R_ii_hat) )      (rule 10, DETR/...:33-43)
             addition = ops.matmul(R_qq_hat, ops.matmul(cam, R_ii_hat), trans_a=True, nan_to_zero=True)
             self.R_q_i = self.R_q_i + addition
-        return self.R_q_i[rows, targets].reshape(1, 1, K, n_img).detach()
+        self.diag_min = torch.cat(diag_words).min() if diag_words else None
+        if check_diag is True and self.diag_min is not None:
+            assert self.diag_min.item() >= 0          # the reference's handle_residual asserts, one read for all of them
+        picked = torch.gather(self.R_q_i, 1, targets.reshape(K, 1, 1).expand(K, 1, n_img))          # row targets[k] of sample k
+        return picked.reshape(1, 1, K, n_img).detach()
 
     # ------------------------------------------------------------------ baselines on the same slabs
     def generate_raw_attn(self, img, target_index):
@@ -319,11 +335,16 @@ class MaskGenerator:
     _BATCHED = {"ours_no_lrp": {}, "ablation_no_self_in_10": {"apply_self_in_rule_10": False},
                 "ours_no_lrp_no_norm": {"normalize_self_attention": False}}
 
-    def __init__(self, model, threshold=0.5):
+    def __init__(self, model, threshold=0.5, graph_slots=None):
+        """``graph_slots`` (e.g. 16): run the batched methods through ``GraphedGenerateOursMulti`` with that many target
+        slots (captured on the first image of a given feature-map size; the evaluator's images are resized to a common
+        size per batch, ``DETR/datasets/coco.py:138-140``)."""
         self.gen = Generator(model)
         self.abl = GeneratorAlbationNoAgg(model)
         self.model = model
         self.threshold = threshold
+        self.graph_slots = graph_slots
+        self._graphs = {}
 
     def _per_query(self, img, idx, method):
         if method == "ablation_no_aggregation":
@@ -346,9 +367,63 @@ class MaskGenerator:
         masks = torch.full((1, probas.shape[0], h, w), -1.0, device=img.device)
         if kept.numel() == 0:
             return masks, keep
-        if method in self._BATCHED:
+        if method in self._BATCHED and self.graph_slots and hasattr(self.model, "forward_shared"):
+            key = (method, tuple(img.shape))
+            if key not in self._graphs:
+                self._graphs[key] = GraphedGenerateOursMulti(self.model, img, self.graph_slots, **self._BATCHED[method])
+            cams = self._graphs[key](img, kept)[0, 0]
+        elif method in self._BATCHED:
             cams = self.gen.generate_ours_multi(img, kept, **self._BATCHED[method])[0, 0]          # [K, Ni]
         else:
             cams = torch.cat([self._per_query(img, idx.reshape(1), method).reshape(1, -1) for idx in kept])
         masks[0, kept] = postprocess.otsu_masks(cams).reshape(-1, h, w)
         return masks, keep
+
+
+class GraphedGenerateOursMulti:
+    """``Generator.generate_ours_multi`` (shared forward, all K kept queries of an image in one pass) captured into a
+    hipGraph for a FIXED number of target slots ``K`` and replayed: the pass is ~600 launches for ~3 ms of GPU work, i.e.
+    host-bound when run eagerly.  An image with fewer kept queries fills the spare slots with repeats of its last target
+    (their rows are dropped); one with more is processed in chunks of ``K``.  The ``handle_residual`` asserts become ONE
+    device word read per call.
+
+        run = GraphedGenerateOursMulti(model, example_features, K=16)
+        maps = run(features, kept_query_indices)        # [1, 1, len(kept), Ni], == Generator(model).generate_ours_multi(...)
+    """
+
+    def __init__(self, model, example_img, K=16, normalize_self_attention=True, apply_self_in_rule_10=True, warmup=2):
+        if not hasattr(model, "forward_shared"):
+            raise ValueError("GraphedGenerateOursMulti needs a body with forward_shared / backward_shared (detr_model)")
+        self.K = K
+        self.img = example_img.clone()
+        self.targets = torch.zeros(K, dtype=torch.long, device=example_img.device)
+        self.gen = Generator(model)
+        kw = dict(normalize_self_attention=normalize_self_attention, apply_self_in_rule_10=apply_self_in_rule_10,
+                  check_diag="defer")
+        self._call = lambda: self.gen.generate_ours_multi(self.img, self.targets, **kw)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._call()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.out = self._call()
+            self.diag_min = self.gen.diag_min
+
+    def __call__(self, img, target_indices, check=True):
+        targets = torch.as_tensor(target_indices, device=self.img.device).reshape(-1)
+        n = targets.numel()
+        self.img.copy_(img)
+        chunks = []
+        for i in range(0, n, self.K):
+            part = targets[i:i + self.K]
+            self.targets[:part.numel()] = part
+            if part.numel() < self.K:
+                self.targets[part.numel():] = part[-1]
+            self.graph.replay()
+            if check and self.diag_min is not None:
+                assert self.diag_min.item() >= 0
+            chunks.append(self.out[:, :, :part.numel()].clone())
+        return torch.cat(chunks, dim=2) if len(chunks) != 1 else chunks[0]

@@ -323,13 +323,26 @@ class DETRFromFeatures(nn.Module):
         self.input_proj = nn.Conv2d(backbone_channels, d, kernel_size=1)
         self.position = PositionEmbeddingSine(d // 2, normalize=pos_normalize)
 
+    def _unpadded(self, features):
+        """``(mask, position embedding)`` of an unpadded feature map, computed once per (batch, h, w, device): the same
+        tensors for every image of that size (and nothing to compute inside a hipGraph capture)."""
+        key = (features.shape[0], features.shape[-2], features.shape[-1], features.device)
+        cache = self.__dict__.setdefault("_pos_cache", {})
+        if key not in cache:
+            mask = torch.zeros(features.shape[0], *features.shape[-2:], dtype=torch.bool, device=features.device)
+            with torch.no_grad():
+                cache[key] = (mask, self.position(mask))
+        return cache[key]
+
     def forward(self, features, mask=None):
         if mask is None:
-            mask = torch.zeros(features.shape[0], *features.shape[-2:], dtype=torch.bool, device=features.device)
+            mask, pos = self._unpadded(features)
+        else:
+            pos = self.position(mask)
         self.spatial_dim = features.shape[-2:]
         # 1x1 convolution == per-pixel Linear: run it as a GEMM (MIOpen's generic conv path is far slower on gfx950)
         proj = F.linear(features.permute(0, 2, 3, 1), self.input_proj.weight.flatten(1), self.input_proj.bias)
-        hs, memory = self.transformer(proj.permute(0, 3, 1, 2), mask, self.query_embed.weight, self.position(mask))
+        hs, memory = self.transformer(proj.permute(0, 3, 1, 2), mask, self.query_embed.weight, pos)
         self.memory_shape = memory.shape
         return {"pred_logits": self.class_embed(hs[-1]), "pred_boxes": self.bbox_embed(hs[-1]).sigmoid()}
 
@@ -339,12 +352,10 @@ class DETRFromFeatures(nn.Module):
         ``(pred_logits [1, Q, classes+1], state)``; see ``Transformer.forward_shared``."""
         if features.shape[0] != 1:
             raise ValueError("forward_shared takes the single shared image")
-        if mask is None:
-            mask = torch.zeros(1, *features.shape[-2:], dtype=torch.bool, device=features.device)
+        pos = self._unpadded(features)[1] if mask is None else self.position(mask)
         self.spatial_dim = features.shape[-2:]
         proj = F.linear(features.permute(0, 2, 3, 1), self.input_proj.weight.flatten(1), self.input_proj.bias)
-        hs, tape = self.transformer.forward_shared(proj.permute(0, 3, 1, 2), self.query_embed.weight,
-                                                   self.position(mask), batch)
+        hs, tape = self.transformer.forward_shared(proj.permute(0, 3, 1, 2), self.query_embed.weight, pos, batch)
         return self.class_embed(hs), tape
 
     @torch.no_grad()

@@ -78,18 +78,25 @@ class GeneratorOurs:
         self.R_t_t, self.R_t_i, self.R_i_i, self.R_i_t = R_tt[0], R_ti[0], R_ii[0], R_it[0]
         return self.R_t_t, self.R_t_i
 
-    def generate_ours_batch(self, model_inputs, index=None, normalize_self_attention=True, apply_self_in_rule_10=True):
-        """B samples with the same number of question tokens in ONE forward + ONE backward + ONE schedule launch.
+    def generate_ours_batch(self, model_inputs, index=None, normalize_self_attention=True, apply_self_in_rule_10=True,
+                            check_diag=True):
+        """B samples in ONE forward + ONE backward (B one-hot seeds) + ONE schedule launch.
 
         The evaluator (``perturbation.py:216-250``) explains one item per call; every per-item pass is ~1000 launches on
         a batch-1 body, i.e. bound by the host, not by the GPU.  Samples are independent (sample b's score depends on
         sample b's inputs only), so a batch of B one-hot seeds in one backward leaves exactly the per-sample
-        gradients in the slabs, and the schedule kernel already runs one workgroup per sample.  Group the items by
-        question length (no padding: a padded query row would have zero gradient and 0/0 in ``handle_residual``, the
-        failure the reference's own assert guards against).
+        gradients in the slabs, and the schedule kernel runs one workgroup per sample.
+
+        Question lengths may DIFFER inside the batch: pad ``input_ids`` / ``token_type_ids`` to a common ``T`` and mark
+        the real tokens in ``attention_mask`` (1 = real, left-aligned).  Padded keys carry zero probability and padded
+        query rows zero gradient; the schedule kernel runs sample b's rules on its leading ``attention_mask[b].sum()``
+        tokens only (a padded row inside ``handle_residual`` would be the 0/0 the reference's own assert guards
+        against) and returns zeros beyond them.
 
         ``model_inputs``: the keyword tensors of the model, batch-first (``input_ids [B, T]``, ``visual_feats [B, I, F]``,
         ...).  ``index``: ``None`` (arg-max answer per sample, chosen on the device) or ``[B]`` answer ids.
+        ``check_diag``: ``True`` asserts ``handle_residual``'s ``diag >= 0`` now (one device->host read); ``"defer"``
+        leaves the device word in ``self.diag_min`` and synchronises nothing (``GraphedGenerateOursBatch`` uses it).
         Returns ``(R_t_t [B, T, T], R_t_i [B, T, I])``; ``self.R_i_i`` / ``self.R_i_t`` hold the image-side matrices.
         """
         self.use_lrp = False
@@ -105,13 +112,18 @@ class GeneratorOurs:
         if max(T, I) > ops.LXMERT_FUSED_MAX_TOKENS:
             raise NotImplementedError("generate_ours_batch runs the one-launch schedule (T, I <= %d)"
                                       % ops.LXMERT_FUSED_MAX_TOKENS)
+        mask = model_inputs.get("attention_mask")
+        text_len = mask.sum(dim=1).to(torch.int32) if mask is not None else None       # stays on the device
         enc = model.lxmert.encoder
         xs = list(enc.x_layers)
-        self.R_t_t, self.R_t_i, self.R_i_i, self.R_i_t = ops.lxmert_schedule(
+        out = ops.lxmert_schedule(
             [_pair(b.attention.self) for b in enc.layer], [_pair(b.attention.self) for b in enc.r_layers],
             [_pair(b.visual_attention.att) for b in xs], [_pair(b.visual_attention_copy.att) for b in xs[:-1]],
             [_pair(b.lang_self_att.self) for b in xs], [_pair(b.visn_self_att.self) for b in xs[:-1]],
-            apply_normalization=normalize_self_attention, apply_self_in_rule_10=apply_self_in_rule_10)
+            apply_normalization=normalize_self_attention, apply_self_in_rule_10=apply_self_in_rule_10,
+            check_diag=check_diag, text_len=text_len)
+        self.R_t_t, self.R_t_i, self.R_i_i, self.R_i_t = out[:4]
+        self.diag_min = out[4] if check_diag == "defer" else None
         return self.R_t_t, self.R_t_i
 
     # ---- single-stream pieces: rules 6+7 for a list of blocks in one chain launch
@@ -324,3 +336,54 @@ class GeneratorBaselines:
         self.R_t_t = mean_cam(blk.lang_self_att.self)
         self.R_t_t[0, 0] = 0
         return self.R_t_t, self.R_t_i
+
+
+class GraphedGenerateOursBatch:
+    """``GeneratorOurs.generate_ours_batch`` captured once into a hipGraph and replayed.
+
+    A batched explain pass is ~1000 launches (19 captured attention layers, each a handful of body ops forward and
+    backward) and costs the same ~19 ms at B = 8 and at B = 32: it is bound by the host.  Because the schedule kernel takes
+    per-sample question lengths, ONE graph captured at a padded length ``T`` serves every batch whose questions are at
+    most ``T`` tokens long -- no grouping by length, no re-capture.  Nothing in the captured pass synchronises: the
+    reference's ``handle_residual`` assert becomes the device word ``diag_min``, checked by ``__call__`` when it hands out
+    the results (``check=True``, one device->host read per batch instead of one per rule).
+
+        run = GraphedGenerateOursBatch(model, example_inputs)          # example: padded [B, T] ids, [B, I, F] features ...
+        R_t_t, R_t_i = run(inputs)                                      # same shapes; returns the graph's output buffers
+    """
+
+    def __init__(self, model, example_inputs, index=None, normalize_self_attention=True, apply_self_in_rule_10=True,
+                 warmup=2):
+        self.static = {k: v.clone() for k, v in example_inputs.items()}
+        self.static_index = None if index is None else torch.as_tensor(index, device=self.static["input_ids"].device).clone()
+        self.gen = GeneratorOurs(type("Usage", (), {"model": model})())
+        kw = dict(normalize_self_attention=normalize_self_attention, apply_self_in_rule_10=apply_self_in_rule_10,
+                  check_diag="defer")
+        self._call = lambda: self.gen.generate_ours_batch(self.static, self.static_index, **kw)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._call()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.outputs = self._call()
+            self.diag_min = self.gen.diag_min
+            self.R_i_i, self.R_i_t = self.gen.R_i_i, self.gen.R_i_t
+
+    def __call__(self, inputs=None, index=None, check=True):
+        if inputs is not None:
+            for k, v in inputs.items():
+                if v.shape != self.static[k].shape:
+                    raise ValueError("%s: %s, but the graph was captured for %s (pad the batch to the captured shape)"
+                                     % (k, tuple(v.shape), tuple(self.static[k].shape)))
+                self.static[k].copy_(v)
+        if index is not None:
+            if self.static_index is None:
+                raise ValueError("the graph was captured with index=None (arg-max answers)")
+            self.static_index.copy_(torch.as_tensor(index))
+        self.graph.replay()
+        if check and self.diag_min is not None:
+            assert self.diag_min.item() >= 0        # the reference's handle_residual assert, once per batch
+        return self.outputs

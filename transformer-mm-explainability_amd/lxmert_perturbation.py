@@ -38,12 +38,20 @@ def normalize_cams(R_t_t, R_t_i):
     return cam_image, cam_text
 
 
-def normalize_cams_batch(R_t_t, R_t_i):
-    """``normalize_cams`` for ``[B, T, T]`` / ``[B, T, I]`` relevancies -> ``(cam_image [B, I], cam_text [B, T])``."""
-    def minmax(x):
-        lo, hi = x.min(dim=-1, keepdim=True).values, x.max(dim=-1, keepdim=True).values
-        return (x - lo) / (hi - lo)
-    return minmax(R_t_i[:, 0]), minmax(R_t_t[:, 0])
+def normalize_cams_batch(R_t_t, R_t_i, attention_mask=None):
+    """``normalize_cams`` for ``[B, T, T]`` / ``[B, T, I]`` relevancies -> ``(cam_image [B, I], cam_text [B, T])``.
+    ``attention_mask [B, T]`` (padded batch): the text min / max run over each sample's real tokens only and the padded
+    positions of ``cam_text`` come back as 0."""
+    def minmax(x, valid=None):
+        if valid is None:
+            lo, hi = x.min(dim=-1, keepdim=True).values, x.max(dim=-1, keepdim=True).values
+            return (x - lo) / (hi - lo)
+        inf = torch.full_like(x, float("inf"))
+        lo = torch.where(valid, x, inf).min(dim=-1, keepdim=True).values
+        hi = torch.where(valid, x, -inf).max(dim=-1, keepdim=True).values
+        return torch.where(valid, (x - lo) / (hi - lo), torch.zeros_like(x))
+    valid = attention_mask.bool() if attention_mask is not None else None
+    return minmax(R_t_i[:, 0]), minmax(R_t_t[:, 0], valid)
 
 
 def ranking(scores):
@@ -62,25 +70,27 @@ def image_keep_masks(cam_image, steps=PERT_STEPS, is_positive_pert=False):
     return keep
 
 
-def text_keep_batch(input_ids, token_type_ids, cam_text, steps=PERT_STEPS, is_positive_pert=False):
+def text_keep_batch(input_ids, token_type_ids, cam_text, steps=PERT_STEPS, is_positive_pert=False, n_tokens=None):
     """Perturbed question batch (``perturbation.py:158-176``): [CLS] and [SEP] always stay, the
     ``int((1 - step) * (T - 2))`` top-scoring inner tokens stay in their original order, the rest is dropped.
-    Returns ``(ids [S, T], token_types [S, T], attention_mask [S, T])`` with the kept tokens left-aligned."""
+    Returns ``(ids [S, T], token_types [S, T], attention_mask [S, T])`` with the kept tokens left-aligned.
+    ``n_tokens``: the question's real length when ``input_ids`` is padded to a longer ``T`` ([SEP] sits at ``n_tokens - 1``)."""
     cam = -cam_text if is_positive_pert else cam_text
-    T = cam.shape[-1]
-    inner = cam[1:-1]
+    P = cam.shape[-1]                       # padded length
+    T = P if n_tokens is None else int(n_tokens)
+    inner = cam[1:T - 1]
     order = ranking(inner) + 1
     S = len(steps)
-    keep = torch.zeros(S, T, dtype=torch.bool, device=cam.device)
+    keep = torch.zeros(S, P, dtype=torch.bool, device=cam.device)
     keep[:, 0] = keep[:, T - 1] = True
     for s, step in enumerate(steps):
         keep[s, order[: int((1 - step) * (T - 2))]] = True
     # stable left-alignment: kept positions sorted by index first, dropped ones after
-    pos = torch.arange(T, device=cam.device).expand(S, T)
-    perm = torch.argsort(torch.where(keep, pos, pos + T), dim=1)
+    pos = torch.arange(P, device=cam.device).expand(S, P)
+    perm = torch.argsort(torch.where(keep, pos, pos + P), dim=1)
     mask = torch.gather(keep, 1, perm)
-    ids = torch.gather(input_ids.expand(S, T), 1, perm) * mask
-    types = torch.gather(token_type_ids.expand(S, T), 1, perm) * mask
+    ids = torch.gather(input_ids.expand(S, P), 1, perm) * mask
+    types = torch.gather(token_type_ids.expand(S, P), 1, perm) * mask
     return ids, types, mask.to(torch.float32)
 
 
@@ -139,8 +149,11 @@ class LxmertPerturbation:
         single = cam_text.dim() == 1
         cams = cam_text.reshape(-1, cam_text.shape[-1])
         B, S = cams.shape[0], len(self.steps)
+        # per-sample question lengths (a padded batch): one device->host read for the whole batch
+        mask = inputs.get("attention_mask")
+        lens = mask.sum(dim=1).tolist() if mask is not None and mask.shape[1] == cams.shape[1] else [None] * B
         parts = [text_keep_batch(inputs["input_ids"][b:b + 1], inputs["token_type_ids"][b:b + 1], cams[b], self.steps,
-                                 is_positive_pert) for b in range(B)]
+                                 is_positive_pert, n_tokens=lens[b]) for b in range(B)]
         ids, types, mask = (torch.cat([p[k] for p in parts]) for k in range(3))                     # [B*S, T]
         out = self.model(input_ids=ids, attention_mask=mask, token_type_ids=types,
                          visual_feats=self._rep(inputs["visual_feats"], S),

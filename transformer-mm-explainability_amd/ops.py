@@ -304,6 +304,9 @@ def matmul(a, b, add_to=None, trans_a=False, nan_to_zero=False):
 
 # ------------------------------------------------------------------------------------------- eq. 8-9
 def handle_residual(R, check_diag=True):
+    """Eq. 8-9 on ``[.., N, N]``.  ``check_diag``: ``True`` asserts ``min diag(R - I) >= 0`` now, like the reference's
+    assert (one device->host read); ``False`` skips the check; ``"defer"`` returns ``(out, diag_min)`` with the device
+    word, so that a caller can check many calls with ONE read (or none, inside a hipGraph)."""
     _dev(R)
     R = _f32c(R)
     n = R.shape[-1]
@@ -311,6 +314,8 @@ def handle_residual(R, check_diag=True):
     out = torch.empty_like(R)
     dmin = torch.empty(1, dtype=torch.float32, device=R.device) if check_diag else None
     check(lib().mmx_handle_residual(_p(R), _p(out), batch, n, _p(dmin), _stream()), "mmx_handle_residual")
+    if check_diag == "defer":
+        return out, dmin
     if check_diag:
         assert dmin.item() >= 0  # same contract as the reference's assert (it also syncs)
     return out
@@ -347,10 +352,16 @@ LXMERT_FUSED_MAX_TOKENS = 48
 
 
 def lxmert_schedule(lang, vis, x_lang_cross, x_img_cross, x_lang_self, x_img_self, apply_normalization=True,
-                    apply_self_in_rule_10=True, check_diag=True):
+                    apply_self_in_rule_10=True, check_diag=True, text_len=None):
     """The whole LXMERT rule schedule in one launch.  Every argument is a list of ``(attn, grad)`` pairs of fp32
     ``[B, H, Nq, Nk]`` tensors (``x_img_*`` may omit the last cross layer).  Returns ``(R_tt, R_ti, R_ii, R_it)``
-    with a leading batch dim."""
+    with a leading batch dim.
+
+    ``text_len`` (``[B]`` int tensor, optional): the batch is padded to ``T`` question tokens and sample ``b`` has
+    ``text_len[b]`` real ones; its rules run on that leading block, the rest of its outputs is zero.
+    ``check_diag``: ``True`` asserts the reference's ``handle_residual`` contract right away (one device->host read, like
+    the reference's own assert); ``"defer"`` returns the device word as a fifth value instead -- nothing synchronises,
+    the call can be captured into a hipGraph, and the caller asserts ``diag_min >= 0`` when it reads the results."""
     groups = [lang, vis, x_lang_cross, x_img_cross, x_lang_self, x_img_self]
     flat = [t for grp in groups for pair in grp for t in pair]
     _dev(*flat)
@@ -367,8 +378,13 @@ def lxmert_schedule(lang, vis, x_lang_cross, x_img_cross, x_lang_self, x_img_sel
     R_ti = torch.empty(B, T, I, dtype=torch.float32, device=dev)
     R_ii = torch.empty(B, I, I, dtype=torch.float32, device=dev)
     R_it = torch.empty(B, I, T, dtype=torch.float32, device=dev)
-    want_diag = check_diag and apply_normalization and apply_self_in_rule_10
+    want_diag = bool(check_diag) and apply_normalization and apply_self_in_rule_10
     dmin = torch.empty(1, dtype=torch.float32, device=dev) if want_diag else None
+    if text_len is not None:
+        _dev(text_len)
+        text_len = text_len.to(dtype=torch.int32).contiguous()
+        if text_len.numel() != B:
+            raise MMXError("lxmert_schedule: text_len needs one entry per sample")
     tables, alive = [], []
     for grp in keep:
         for which in (0, 1):
@@ -377,9 +393,11 @@ def lxmert_schedule(lang, vis, x_lang_cross, x_img_cross, x_lang_self, x_img_sel
             alive.append(arr)
     flags = (_lib.MM_NORMALIZE if apply_normalization else 0) | (_lib.MM_SELF_IN_RULE10 if apply_self_in_rule_10 else 0)
     la, lg, va, vg, xlca, xlcg, xica, xicg, xlsa, xlsg, xisa, xisg = tables
-    check(lib().mmx_lxmert_schedule(la, lg, len(keep[0]), va, vg, len(keep[1]), xlca, xlcg, xica, xicg, xlsa, xlsg,
-                                    xisa, xisg, n_x, B, H, T, I, flags, _p(R_tt), _p(R_ti), _p(R_ii), _p(R_it), _p(dmin),
-                                    _stream()), "mmx_lxmert_schedule")
+    check(lib().mmx_lxmert_schedule_ex(la, lg, len(keep[0]), va, vg, len(keep[1]), xlca, xlcg, xica, xicg, xlsa, xlsg,
+                                       xisa, xisg, n_x, B, H, T, I, flags, _p(text_len), _p(R_tt), _p(R_ti), _p(R_ii),
+                                       _p(R_it), _p(dmin), _stream()), "mmx_lxmert_schedule_ex")
+    if check_diag == "defer":
+        return R_tt, R_ti, R_ii, R_it, dmin
     if want_diag:
         assert dmin.item() >= 0   # the reference's handle_residual assert
     return R_tt, R_ti, R_ii, R_it
