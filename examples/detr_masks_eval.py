@@ -1,0 +1,109 @@
+"""Sharded DETR ``--masks`` evaluation on synthetic features -- the shape of ``DETR/engine.py:153-215`` (``evaluate``: one
+``MaskGenerator.get_panoptic`` per validation image, results gathered over the ranks) and ``DETR/main.py:151-153``
+(``DistributedSampler(dataset_val, shuffle=False)``) on this package: one process per GPU, images sharded rank-strided,
+every kept query of an image explained in ONE batched pass (replayed from a hipGraph), all Otsu masks of an image in one
+launch, ONE all-gather of fixed-shape per-image mask statistics at the end.
+
+    python examples/detr_masks_eval.py --num-images 64                               # one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29512 \\
+        examples/detr_masks_eval.py --num-images 5000                                # one rank per GPU, RCCL
+
+What is NOT here (control plane around the path): the ResNet backbone (the body starts at its
+feature map), COCO loading, the Hungarian criterion, pycocotools' segmentation AP.  The per-image row that is gathered
+instead -- kept queries, mean mask area, a checksum of the masks -- is what a COCO evaluator would consume per image; the
+numbers that mean something with random weights are images/s and queries/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from transformer_mm_explainability_amd import sharding  # noqa: E402
+
+STAT_COLS = 4      # kept queries, mean mask area fraction over the kept queries, mask checksum, image id
+
+
+def synthetic_features(k, channels=2048, h=25, w=38):
+    """Backbone feature map of image ``k`` (seeded by its index: any rank can materialise any image)."""
+    g = torch.Generator().manual_seed(5000 + k)
+    return torch.randn(1, channels, h, w, generator=g) * 0.5
+
+
+def image_stats(masks, keep, image_id):
+    """``masks [1, Q, h, w]`` (0 / 255 on kept queries, -1 elsewhere), ``keep [Q]`` -> one fixed-shape row."""
+    kept = masks[0, keep]
+    n = float(keep.sum())
+    area = float((kept == 255).float().mean()) if n else 0.0
+    checksum = float((kept == 255).float().sum() % 65521) if n else 0.0
+    return torch.tensor([n, area, checksum, float(image_id)], dtype=torch.float32)
+
+
+def evaluate(image_ids, masks_of, store=None, device="cpu"):
+    """The sharded loop: every rank explains its rank-strided share of ``image_ids`` with ``masks_of(id) -> (masks, keep)``
+    and all ranks end with the ``[len(image_ids), STAT_COLS]`` table in the ORIGINAL order.  One collective."""
+    def process_batch(ids):                     # one image per "batch": images differ in their number of kept queries
+        return torch.stack([image_stats(*masks_of(k), k) for k in ids])
+    return sharding.evaluate_sharded(image_ids, lambda k: 0, process_batch, STAT_COLS, max_batch=1, store=store, device=device)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num-images", type=int, default=64)
+    ap.add_argument("--method", default="ours_no_lrp")
+    ap.add_argument("--graph-slots", type=int, default=16, help="target slots of the captured explain pass (0: eager)")
+    ap.add_argument("--keep-top", type=int, default=8, help="random-init logits are flat: keep this many queries per image")
+    ap.add_argument("--resume-dir", default=None)
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from transformer_mm_explainability_amd import detr_model
+    from transformer_mm_explainability_amd.detr_explainability import MaskGenerator
+
+    torch.manual_seed(0)
+    model = detr_model.detr_resnet50_head().to(dev).eval()
+    mg = MaskGenerator(model, threshold=0.5, graph_slots=args.graph_slots or None)
+    queries = [0]
+
+    def masks_of(k):
+        feats = synthetic_features(k).to(dev)
+        with torch.no_grad():       # the 0.5 confidence cut of mask_generator.py:50 keeps nothing on random weights
+            conf = model(feats)["pred_logits"].softmax(-1)[0, :, :-1].max(-1).values
+        mg.threshold = float(conf.sort().values[-args.keep_top - 1])
+        masks, keep = mg.get_masks(feats, args.method)
+        queries[0] += int(keep.sum())
+        return masks.cpu(), keep.cpu()
+
+    cfg = {"evaluator": "detr_masks", "method": args.method, "keep_top": args.keep_top}
+    store = sharding.PartialScores(args.resume_dir, rank, config=cfg) if args.resume_dir else None
+    ids = list(range(args.num_images))          # DistributedSampler(shuffle=False): the dataset order
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    table = evaluate(ids, masks_of, store=store, device=dev)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"images": len(ids), "n_gpus": world, "seconds": round(elapsed, 3),
+                          "images_per_s": round(len(ids) / elapsed, 1),
+                          "queries_per_s_this_rank": round(queries[0] / elapsed, 1), "method": args.method,
+                          "mean_kept": round(float(table[:, 0].mean()), 2),
+                          "mean_mask_area": round(float(table[:, 1].mean()), 4)}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

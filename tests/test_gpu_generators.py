@@ -472,3 +472,27 @@ def test_detr_graphed_generate_ours_multi(golden):
     masks_e, keep_e = mg_e.get_masks(feats, "ours_no_lrp")
     masks_g, keep_g = mg_g.get_masks(feats, "ours_no_lrp")
     assert torch.equal(keep_e, keep_g) and (masks_e != masks_g).float().mean() < 0.01
+
+
+@pytest.mark.gpu
+def test_detr_graph_replay_after_unrelated_eager_work():
+    """Full-size (950 image tokens, 100 queries) replay with eager work between capture and replay.  Regression: the
+    split chain path used to zero its state with hipMemsetAsync, and that memset NODE replayed with a corrupted 64-bit
+    pattern (every even column of R_i_i garbage) once an eager forward had run after the capture; the library now fills
+    with kernels (csrc/mmx_runtime.hip zero_async / identity_async)."""
+    from transformer_mm_explainability_amd import detr_model
+    from transformer_mm_explainability_amd.detr_explainability import Generator, GraphedGenerateOursMulti
+    torch.manual_seed(0)
+    model = detr_model.detr_resnet50_head().cuda().eval()
+    run = GraphedGenerateOursMulti(model, torch.randn(1, 2048, 25, 38, device="cuda") * 0.5, K=8)
+    gen = torch.Generator().manual_seed(5000)
+    feats = (torch.randn(1, 2048, 25, 38, generator=gen) * 0.5).cuda()
+    t = torch.tensor([25, 33, 46, 49, 53, 60, 89, 95], device="cuda")
+    with torch.no_grad():
+        model(feats)                                   # the eager forward MaskGenerator runs before every replay
+    got = run(feats, t).clone()
+    want = Generator(model).generate_ours_multi(feats, t)
+    one = Generator(model).generate_ours(feats, t[3:4], use_lrp=False)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-6 * max(scale, 1e-6) + 1e-9
+    assert float((got[:, :, 3:4] - one).abs().max()) <= 1e-4 * scale

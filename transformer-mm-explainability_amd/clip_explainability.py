@@ -146,6 +146,7 @@ class GraphedInterpret:
         # and a following eager call see what the replay wrote.
         vis, txt = model.visual.transformer, model.transformer
         self._pinned = (vis.buffers, txt.buffers)
+        self._pinned_scratch = ops.pinned_state()          # grow-only scratch buffers the graph has raw addresses of
 
     def _reinstall(self):
         for tr, buf in zip((self.model.visual.transformer, self.model.transformer), self._pinned):

@@ -186,6 +186,11 @@ int self_chain_big_try(const void* const* attn_layers, const void* const* grad_l
                        size_t workspace_bytes, hipStream_t s, int* rc_out);
 void attn_stream_enable(int on);
 int hip_fail(hipError_t e, const char* what);
+// Fill kernels instead of hipMemsetAsync: a memset NODE of a captured hipGraph was observed (ROCm 7.2, gfx950) to replay
+// with a corrupted 64-bit pattern once other work had run between capture and replay (every second fp32 word garbage);
+// kernel nodes carry their arguments by value and do not have that problem.  ``bytes`` must be a multiple of 4.
+int zero_async(void* dst, size_t bytes, hipStream_t s);
+int identity_async(float* R, int batch, int N, hipStream_t s);   // R[b] = I  (N x N, contiguous)
 
 }  // namespace mmx
 

@@ -376,8 +376,8 @@ static int launch_big(ChainBigArgs& args, int dtype, void* workspace, hipStream_
     args.status = reinterpret_cast<unsigned*>(ws);
     args.counters = reinterpret_cast<unsigned*>(ws + 256);
     args.abar = reinterpret_cast<float*>(ws + 256 + align256b(sizeof(unsigned) * nteams));
-    e = hipMemsetAsync(ws, 0, 256 + align256b(sizeof(unsigned) * nteams), s);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(counters)");
+    int zrc = zero_async(ws, 256 + align256b(sizeof(unsigned) * nteams), s);
+    if (zrc) return zrc;
     kern<<<nteams * args.T, kBigThreads, lds, s>>>(args);
     MMX_LAUNCH_CHECK("self_chain_big_kernel");
     return MMX_OK;

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(THREADS) void self_chain_fused_kernel(const ChainAr
 //            registers (MFMA C/D layout, as in the fused kernel) and A_bar_l prefetched global->regs->LDS one
 //            layer ahead of the MFMAs.  Same summation order as the per-sample fused kernel: results are
 //            bit-identical between the two algorithms.
-// Counters are zeroed by the host (hipMemsetAsync node) before every launch.
+// Counters are zeroed by the host (a zero_async kernel node) before every launch.
 // =====================================================================================================
 struct ChainV2Args {
     const void* attn[MMX_MAX_LAYERS];
@@ -924,8 +924,9 @@ static int launch_v2(ChainV2Args& args, int dtype, void* workspace, hipStream_t 
     }
     args.counters = static_cast<unsigned*>(workspace);
     args.abar = reinterpret_cast<float*>(static_cast<char*>(workspace) + v2_counter_bytes(args.B));
-    hipError_t e = hipMemsetAsync(args.counters, 0, sizeof(unsigned) * args.B, s);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(counters)");
+    int zrc = zero_async(args.counters, sizeof(unsigned) * args.B, s);
+    if (zrc) return zrc;
+    hipError_t e;
     if (lds > 48 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(lds));
@@ -953,8 +954,8 @@ static int launch_fused(const ChainArgs& args, int dtype, hipStream_t s) {
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
     if (args.G > 1) {
-        hipError_t e = hipMemsetAsync(args.counters, 0, sizeof(unsigned) * args.B, s);
-        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(counters)");
+        int zrc = zero_async(args.counters, sizeof(unsigned) * args.B, s);
+        if (zrc) return zrc;
     }
     kern<<<args.B * args.G, kChainThreads, lds, s>>>(args);
     MMX_LAUNCH_CHECK("self_chain_fused_kernel");
@@ -1075,16 +1076,17 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
         e = hipMemcpyAsync(Rcur, R_init_dev, sizeof(float) * B * nn, hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(R_init)");
     } else {
-        // identity: (0 + I) via the rollout-prep row kernel on a zeroed buffer
-        e = hipMemsetAsync(Rcur, 0, sizeof(float) * B * nn, s);
-        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(R)");
-        int rc = launch_rows(Rcur, Rcur, B, N, 2, nullptr, s);
+        int rc = identity_async(Rcur, B, N, s);
         if (rc) return rc;
     }
     if (M > 0) {
-        if (Rsq_init_dev) e = hipMemcpyAsync(SQcur, Rsq_init_dev, sizeof(float) * B * nm, hipMemcpyDeviceToDevice, s);
-        else e = hipMemsetAsync(SQcur, 0, sizeof(float) * B * nm, s);
-        if (e != hipSuccess) return hip_fail(e, "init R_sq");
+        if (Rsq_init_dev) {
+            e = hipMemcpyAsync(SQcur, Rsq_init_dev, sizeof(float) * B * nm, hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(R_sq_init)");
+        } else {
+            int rc = zero_async(SQcur, sizeof(float) * B * nm, s);
+            if (rc) return rc;
+        }
     }
     for (int l = 0; l < n_layers; ++l) {
         int rc = avg_heads_launch(attn_layers[l], grad_layers[l], abar, B, H, N, N, dtype, attn_batch_stride, stream);

@@ -158,8 +158,12 @@ class Generator:
         if shared:
             with torch.no_grad():
                 logits, state = self.model.forward_shared(img, K)                                     # [1, Q, C+1]
+                own = logits[0].index_select(0, targets)[:, :-1].argmax(dim=-1)
                 if index is None:
-                    index = logits[0].index_select(0, targets)[:, :-1].argmax(dim=-1)
+                    index = own
+                else:                                  # entries < 0 of a given index tensor mean "arg-max" (graph slots)
+                    index = torch.as_tensor(index, device=img.device).reshape(-1)
+                    index = torch.where(index < 0, own, index)
                 # one-hot seeds by scatter (an index_put with tensor indices cannot be captured into a hipGraph)
                 n_cls = logits.shape[-1]
                 one_hot = torch.zeros(K, logits.shape[1] * n_cls, dtype=logits.dtype, device=img.device)
@@ -212,7 +216,8 @@ class Generator:
         self.diag_min = torch.cat(diag_words).min() if diag_words else None
         if check_diag is True and self.diag_min is not None:
             assert self.diag_min.item() >= 0          # the reference's handle_residual asserts, one read for all of them
-        picked = torch.gather(self.R_q_i, 1, targets.reshape(K, 1, 1).expand(K, 1, n_img))          # row targets[k] of sample k
+        # row targets[k] of sample k (capture-safe: one index_select on the flattened [K * Q, Ni] matrix)
+        picked = self.R_q_i.reshape(K * n_q, n_img).index_select(0, rows * n_q + targets)
         return picked.reshape(1, 1, K, n_img).detach()
 
     # ------------------------------------------------------------------ baselines on the same slabs
@@ -367,13 +372,16 @@ class MaskGenerator:
         masks = torch.full((1, probas.shape[0], h, w), -1.0, device=img.device)
         if kept.numel() == 0:
             return masks, keep
+        # the class each kept query is explained for = arg-max of THIS forward (mask_generator.py passes index=None and
+        # the generator re-derives it from a second, identical forward)
+        classes = outputs["pred_logits"][0, kept, :-1].argmax(dim=-1)
         if method in self._BATCHED and self.graph_slots and hasattr(self.model, "forward_shared"):
             key = (method, tuple(img.shape))
             if key not in self._graphs:
                 self._graphs[key] = GraphedGenerateOursMulti(self.model, img, self.graph_slots, **self._BATCHED[method])
-            cams = self._graphs[key](img, kept)[0, 0]
+            cams = self._graphs[key](img, kept, index=classes)[0, 0]
         elif method in self._BATCHED:
-            cams = self.gen.generate_ours_multi(img, kept, **self._BATCHED[method])[0, 0]          # [K, Ni]
+            cams = self.gen.generate_ours_multi(img, kept, index=classes, **self._BATCHED[method])[0, 0]   # [K, Ni]
         else:
             cams = torch.cat([self._per_query(img, idx.reshape(1), method).reshape(1, -1) for idx in kept])
         masks[0, kept] = postprocess.otsu_masks(cams).reshape(-1, h, w)
@@ -397,10 +405,14 @@ class GraphedGenerateOursMulti:
         self.K = K
         self.img = example_img.clone()
         self.targets = torch.zeros(K, dtype=torch.long, device=example_img.device)
+        # class per slot: -1 = "arg-max of this pass's own logits" (the reference's index=None), else the given class.
+        # A caller that already ran the forward (MaskGenerator) hands in ITS arg-max: two forwards of the same image can
+        # round differently (library GEMM selection inside / outside a capture) and flip a near-tie between classes.
+        self.index = torch.full((K,), -1, dtype=torch.long, device=example_img.device)
         self.gen = Generator(model)
         kw = dict(normalize_self_attention=normalize_self_attention, apply_self_in_rule_10=apply_self_in_rule_10,
                   check_diag="defer")
-        self._call = lambda: self.gen.generate_ours_multi(self.img, self.targets, **kw)
+        self._call = lambda: self.gen.generate_ours_multi(self.img, self.targets, index=self.index, **kw)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -411,17 +423,25 @@ class GraphedGenerateOursMulti:
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = self._call()
             self.diag_min = self.gen.diag_min
+        # the graph holds raw addresses of the attention modules' slabs and of scratch buffers that were allocated by the
+        # warm-up calls: keep them alive (an eager forward with another batch size replaces the modules' slabs)
+        self._pinned = ops.pinned_state(model)
 
-    def __call__(self, img, target_indices, check=True):
+    def __call__(self, img, target_indices, index=None, check=True):
         targets = torch.as_tensor(target_indices, device=self.img.device).reshape(-1)
         n = targets.numel()
+        classes = None if index is None else torch.as_tensor(index, device=self.img.device).reshape(-1)
         self.img.copy_(img)
         chunks = []
         for i in range(0, n, self.K):
             part = targets[i:i + self.K]
             self.targets[:part.numel()] = part
+            self.index.fill_(-1)
+            if classes is not None:
+                self.index[:part.numel()] = classes[i:i + self.K]
             if part.numel() < self.K:
                 self.targets[part.numel():] = part[-1]
+                self.index[part.numel():] = self.index[part.numel() - 1]
             self.graph.replay()
             if check and self.diag_min is not None:
                 assert self.diag_min.item() >= 0

@@ -371,6 +371,7 @@ class GraphedGenerateOursBatch:
             self.outputs = self._call()
             self.diag_min = self.gen.diag_min
             self.R_i_i, self.R_i_t = self.gen.R_i_i, self.gen.R_i_t
+        self._pinned = ops.pinned_state(model)     # slabs / scratch the graph has raw addresses of (see ops.pinned_state)
 
     def __call__(self, inputs=None, index=None, check=True):
         if inputs is not None:

@@ -64,6 +64,24 @@ def _workspace(nbytes, device, tag="default"):
     return buf
 
 
+def pinned_state(model=None):
+    """Everything a captured hipGraph may have baked raw addresses of, besides its own pool: the grow-only scratch
+    buffers of this module and (``model`` given) the capture slabs of every hooked attention module.  A ``Graphed*``
+    wrapper keeps the returned list alive: a later EAGER call that needs a bigger scratch buffer or other slab shapes
+    replaces those tensors, and without this reference the old ones would be freed under the graph."""
+    keep = list(_ws_cache.values())
+    if model is not None:
+        for mod in model.modules():
+            for name in ("_probs", "_grads"):
+                t = getattr(mod, name, None)
+                if torch.is_tensor(t):
+                    keep.append(t)
+            buf = getattr(mod, "buffers", None)
+            if buf is not None and hasattr(buf, "probs") and hasattr(buf, "grads"):
+                keep.extend([buf.probs, buf.grads, buf])
+    return keep
+
+
 # ------------------------------------------------------------------------------------------- rule 5
 def avg_heads(cam, grad, batch_size=1, shared_attn=False):
     """``mean_h(clamp(grad*cam, 0))`` -> ``[batch_size, Nq, Nk]`` fp32 (leading dims flattened into B*H).
