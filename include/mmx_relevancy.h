@@ -33,6 +33,10 @@ extern "C" {
 #define MMX_MAX_LAYERS 48
 
 enum mmx_dtype { MMX_F32 = 0, MMX_F16 = 1, MMX_BF16 = 2 };
+/* OR-ed into the `slab_dtype` argument of mmx_attn_capture_fwd_ex / _bwd_ex: run the attention products on the bf16 matrix
+ * cores (v_mfma_f32_16x16x32_bf16: operands rounded to bf16 as they are read, fp32 accumulation, softmax / dS arithmetic in
+ * fp32) instead of the exact-fp32 MFMA.  BASELINE config 5 (a bf16 CLIP body, CLIP/clip/model.py:381-402). */
+#define MMX_ATTN_MMA_BF16 0x100
 
 enum mmx_status {
     MMX_OK = 0,
@@ -274,6 +278,31 @@ int mmx_attn_capture_bwd_ex(const void* q_dev, const void* k_dev, const void* v_
                             int64_t dv_sb, int64_t dv_sh, int64_t dv_sn,
                             int B, int H, int Nq, int Nk, int D, float scale, int scale_mode,
                             int need_dqkv, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Row-relevancy mode of the backward (BASELINE config 5; CLIP `interpret`, CLIP/clip/... notebook cell 7:27-37, returns
+ * only `R[:, 0, 1:]` of the image tower): row 0 of  R_final = (I + A_L) ... (I + A_start)  is  e_0^T (I + A_L) ... , i.e.
+ * a ROW vector carried from the top layer down -- the order the backward visits the layers anyway:
+ *     rel_out[b] = rel_in[b] + rel_in[b] . A_bar_l[b],   A_bar_l = mean_h clamp(dP * P, 0).
+ * The query-side kernel reduces that product from the dP / P values it already holds (deterministic: per-workgroup
+ * partial rows summed in a fixed order), so for this layer dP is neither written nor re-read and no N x N A_bar or R
+ * exists.  Same arguments as mmx_attn_capture_bwd_ex plus the two rows (`rel_in_dev`, `rel_out_dev`: fp32 [B, Nq],
+ * may not alias); `dprobs_dev` may be NULL; `slab_dtype` must carry MMX_ATTN_MMA_BF16; Nq == Nk. */
+size_t mmx_attn_capture_bwd_rowrel_workspace_bytes(int B, int H, int Nq, int Nk);
+int mmx_attn_capture_bwd_rowrel(const void* q_dev, const void* k_dev, const void* v_dev,
+                                int64_t q_sb, int64_t q_sh, int64_t q_sn,
+                                int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                                int64_t v_sb, int64_t v_sh, int64_t v_sn,
+                                const void* probs_dev, int64_t probs_sb, int slab_dtype,
+                                const void* do_dev, int64_t o_sb, int64_t o_sh, int64_t o_sn,
+                                const void* fwd_o_dev, int64_t fo_sb, int64_t fo_sh, int64_t fo_sn,
+                                void* dprobs_dev,
+                                void* dq_dev, void* dk_dev, void* dv_dev,
+                                int64_t dq_sb, int64_t dq_sh, int64_t dq_sn,
+                                int64_t dk_sb, int64_t dk_sh, int64_t dk_sn,
+                                int64_t dv_sb, int64_t dv_sh, int64_t dv_sn,
+                                int B, int H, int Nq, int Nk, int D, float scale, int scale_mode,
+                                int need_dqkv, const void* rel_in_dev, void* rel_out_dev,
+                                void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused QuickGELU of the CLIP body's MLP, y = x * sigmoid(1.702 x) (CLIP/clip/model.py:162-164): one HBM pass forward,

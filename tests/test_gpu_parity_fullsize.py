@@ -82,6 +82,48 @@ def test_cfg5_token_count_vs_oracle():
         close(R_image, want_img)
 
 
+def test_cfg5_bf16_body_vs_oracle():
+    """BASELINE config 5's bf16 body (``CLIP.set_body_dtype(torch.bfloat16)``: GEMMs and the image tower's attention
+    products on the bf16 matrix cores, fp32 accumulation, fp32 LayerNorm / softmax / relevancy) at the ViT-L/14@336
+    geometry, 3 + 2 layers, B = 3, vs the fp32 oracle.  Stated tolerance (bf16 has 8 significant bits and the maps are
+    products of ~1e-3-sized gradients through the layers): per sample max |diff| <= 3e-2 * max |map| and cosine
+    similarity >= 0.999.  The row-relevancy mode (no gradient slab; the class-token row of R carried through the
+    backward) must agree with the slab + chain route of the same bf16 body to 2e-3 of max |map| (they differ by the
+    slab's bf16 rounding of dP only), and a hipGraph replay must reproduce the eager call bit for bit."""
+    from oracle import clip_torch
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    from transformer_mm_explainability_amd import clip_model
+    torch.manual_seed(0)
+    model = clip_model.CLIP(768, 336, 3, 1024, 14, 77, 49408, 768, 12, 2).float().eval()
+    image, texts = bench_inputs(3, res=336)
+    sd = clip_torch.prepare_state_dict(model.state_dict(), 12)
+    want_text, want_img = clip_torch.interpret(sd, image, texts, 0, 0)
+    model = model.cuda()
+    model.set_body_dtype(torch.bfloat16)
+    assert model.visual.row_relevancy_ok()
+    R_text, R_image = ce.interpret(image.cuda(), texts.cuda(), model, "cuda", 0, 0)
+    assert model.visual.transformer.buffers.grads is None            # row mode: no gradient slab was allocated
+
+    def near(got, want, tol, cos_min):
+        got, want = got.float().cpu().reshape(got.shape[0], -1), want.float().reshape(want.shape[0], -1)
+        for b in range(got.shape[0]):
+            assert float((got[b] - want[b]).abs().max()) <= tol * float(want[b].abs().max())
+            assert float(torch.nn.functional.cosine_similarity(got[b], want[b], dim=0)) >= cos_min
+
+    near(R_image, want_img, 3e-2, 0.999)
+    off = torch.eye(77, dtype=torch.bool).logical_not()
+    near(R_text[:, off], want_text[:, off], 3e-2, 0.999)
+    row = R_image.clone()
+    model.visual.row_relevancy_ok = lambda: False                    # slab + chain route of the same bf16 body
+    _, R_slab = ce.interpret(image.cuda(), texts.cuda(), model, "cuda", 0, 0)
+    assert model.visual.transformer.buffers.grads is not None
+    near(row, R_slab.cpu(), 2e-3, 0.99999)
+    del model.visual.row_relevancy_ok
+    run = ce.GraphedInterpret(model, image.cuda(), texts.cuda(), start_layer=0, start_layer_text=0)
+    _, R_graph = run()
+    assert torch.equal(R_graph, row)
+
+
 @pytest.mark.parametrize("Nq,Nk", [(950, 950), (100, 950), (577, 577)])
 def test_capture_op_at_size_vs_oracle(Nq, Nk):
     """The capture op at the DETR-encoder / DETR-cross / ViT-L token counts vs the oracle's hooked attention core."""
@@ -103,6 +145,50 @@ def test_capture_op_at_size_vs_oracle(Nq, Nk):
     close(bh(gq), dq, atol=2e-5)
     close(bh(gk), dk, atol=2e-5)
     close(bh(gv), dv, atol=2e-5)
+
+
+@pytest.mark.parametrize("Nq,Nk,slab", [(577, 577, torch.bfloat16), (577, 577, torch.float32), (100, 950, torch.bfloat16),
+                                        (200, 130, torch.float32)])
+def test_capture_op_bf16_matrix_cores_vs_oracle(Nq, Nk, slab):
+    """``MMX_ATTN_MMA_BF16`` (BASELINE config 5's bf16 body): attention products on v_mfma_f32_16x16x32_bf16, operands
+    rounded to bf16 as they are read, fp32 accumulation / softmax / dS.  Oracle: the fp32 hooked-attention core on the
+    bf16-ROUNDED q, k, v, dO.  Stated tolerances, relative to each tensor's max |x|: what is a product of exactly
+    representable operands (S -> P, dP = dO.V^T) 1e-4 (+ the slab's own rounding, 2^-8, when the slab is bf16); what has a
+    second, re-rounded operand (O = P.V, dQ = dS.K, dK = dS^T.Q, dV = P^T.dO) 2^-7 = 8e-3.  Shared-forward mode too."""
+    from oracle import attention_torch as oat
+    from transformer_mm_explainability_amd import ops
+    H, D = (8, 32) if Nk == 950 else (4, 64)
+    B = 2
+    g = torch.Generator().manual_seed(Nq * 3 + Nk)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    q, k, v = (rb(torch.randn(1, n, H, D, generator=g)) for n in (Nq, Nk, Nk))
+    d_o = rb(torch.randn(B, Nq, H, D, generator=g))
+    bh = lambda t: t.permute(0, 2, 1, 3)
+
+    def rel(got, want, tol):
+        got, want = got.float().cpu(), want.float()
+        assert got.shape == want.shape
+        assert float((got - want).abs().max()) <= tol * float(want.abs().max()), \
+            (float((got - want).abs().max()), float(want.abs().max()))
+
+    slab_tol = 2.0 ** -8 if slab == torch.bfloat16 else 0.0
+    p_tol = 1e-4 + slab_tol if D == 64 else 2.0 ** -7    # d = 32: q * 32^-0.5 is rounded AFTER scaling (not a power of two)
+    probs = torch.empty(1, H, Nq, Nk, device="cuda", dtype=slab)
+    dprobs = torch.empty(B, H, Nq, Nk, device="cuda", dtype=slab)
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    o = ops.attn_capture_fwd(qc, kc, vc, probs, D ** -0.5, mma_bf16=True)
+    for use_o in (True, False):
+        gq, gk, gv = ops.attn_capture_bwd(qc, kc, vc, probs, d_o.cuda(), dprobs, D ** -0.5, batch=B,
+                                          o=o if use_o else None, mma_bf16=True)
+        for b in range(B):
+            P, O, dP, dq, dk, dv = oat.capture(bh(q), bh(k), bh(v), bh(d_o[b:b + 1]), D ** -0.5)
+            if b == 0 and use_o:
+                rel(probs, P, p_tol)
+                rel(bh(o), O, 2.0 ** -7)
+            rel(dprobs[b:b + 1], dP, 1e-4 + slab_tol)        # dO, V are used as rounded by the caller: exact products
+            rel(bh(gq[b:b + 1]), dq, 2.0 ** -7)
+            rel(bh(gk[b:b + 1]), dk, 2.0 ** -7)
+            rel(bh(gv[b:b + 1]), dv, 2.0 ** -7)
 
 
 def test_detr_ni950_rules_vs_oracle():

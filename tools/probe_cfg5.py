@@ -42,6 +42,15 @@ if len(_sys.argv) > 2 and _sys.argv[2] == "gemm":
     cos = torch.nn.functional.cosine_similarity(got, ref, dim=-1)
     print("backward GEMMs in bf16: min cosine similarity of the image maps vs fp32 GEMMs = %.6f, max rel err = %.3e"
           % (cos.min().item(), ((got - ref).abs().max() / ref.abs().max()).item()))
+if len(_sys.argv) > 3 and _sys.argv[3] == "body":
+    ref = ce.interpret(image, prompts(4), model, dev, start_layer=0, start_layer_text=0)
+    ref = [r.clone() for r in ref]
+    model.set_body_dtype(torch.bfloat16)
+    got = ce.interpret(image, prompts(4), model, dev, start_layer=0, start_layer_text=0)
+    for name, a_, b_ in (("text", got[0], ref[0]), ("image", got[1], ref[1])):
+        cos = torch.nn.functional.cosine_similarity(a_, b_, dim=-1)
+        print("bf16 body (all GEMMs + image attention on the bf16 matrix cores) vs the previous setting, %s maps: min cosine "
+              "= %.6f, max rel err = %.3e" % (name, cos.min().item(), ((a_ - b_).abs().max() / b_.abs().max()).item()))
 for B in ((128,) if len(_sys.argv) > 1 else (16, 64, 128)):
     texts = prompts(B)
     torch.cuda.reset_peak_memory_stats()

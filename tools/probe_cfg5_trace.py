@@ -1,4 +1,4 @@
-"""Kernel-trace target: CLIP ViT-L/14@336 interpret, batch 32, bf16 image slabs + bf16 backward GEMMs (3 steps)."""
+"""Kernel-trace target: CLIP ViT-L/14@336 interpret, batch 32, the bf16 body of clip_model.CLIP.set_body_dtype (3 steps)."""
 import sys
 
 import torch
@@ -9,8 +9,7 @@ from transformer_mm_explainability_amd import clip_model  # noqa: E402
 
 dev = torch.device("cuda")
 model = clip_model.random_init("ViT-L/14@336", seed=0).to(dev)
-model.visual.transformer.capture_dtype = torch.bfloat16
-model.visual.transformer.backward_gemm_dtype = torch.bfloat16
+model.set_body_dtype(torch.bfloat16)
 image = torch.randn(1, 3, 336, 336, device=dev)
 texts = torch.zeros(32, 77, dtype=torch.long)
 texts[:, 0] = 49406

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmmx_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mmx_relevancy.h")
 
 MMX_F32, MMX_F16, MMX_BF16 = 0, 1, 2
+MMX_ATTN_MMA_BF16 = 0x100       # OR-ed into slab_dtype of the attention *_ex entry points (bf16 matrix cores)
 MM_NORMALIZE, MM_SELF_IN_RULE10, MM_NAN_TO_ZERO = 1, 2, 4
 SCALE_Q_FIRST, SCALE_SCORES = 0, 1
 MAX_LAYERS = 48
@@ -48,6 +49,10 @@ _PROTOTYPES = {
     "mmx_attn_capture_bwd_ex": (_i, [_vp, _vp, _vp] + [_i64] * 9 + [_vp, _i64, _i, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64,
                                      _vp, _vp, _vp, _vp]
                                 + [_i64] * 9 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
+    "mmx_attn_capture_bwd_rowrel": (_i, [_vp, _vp, _vp] + [_i64] * 9 + [_vp, _i64, _i, _vp, _i64, _i64, _i64, _vp, _i64, _i64,
+                                         _i64, _vp, _vp, _vp, _vp]
+                                    + [_i64] * 9 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "mmx_attn_capture_bwd_rowrel_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mmx_attn_capture_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "mmx_attn_capture_bwd": (_i, [_vp, _vp, _vp] + [_i64] * 9 + [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]
                              + [_i64] * 9 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),

@@ -21,7 +21,8 @@ class CaptureBuffers:
     """Two ``[L, B, H, Nq, Nk]`` slabs (probabilities and their gradients) for one tower; fp32, or fp16 / bf16 for the
     long-sequence towers (half the resident bytes and half the rule kernels' traffic; the rules accumulate in fp32)."""
 
-    def __init__(self, n_layers, batch, heads, n_q, n_k=None, device="cuda", shared_probs=False, dtype=torch.float32):
+    def __init__(self, n_layers, batch, heads, n_q, n_k=None, device="cuda", shared_probs=False, dtype=torch.float32,
+                 grads=True):
         """``shared_probs``: the probabilities come from ONE forward pass shared by the whole batch (``probs`` has batch
         1, ``grads`` has batch ``batch``) -- CLIP ``interpret`` repeats one image ``batch`` times."""
         n_k = n_q if n_k is None else n_k
@@ -29,7 +30,8 @@ class CaptureBuffers:
         self.shared_probs = shared_probs
         self.dtype = dtype
         self.probs = torch.empty((n_layers, 1 if shared_probs else batch, heads, n_q, n_k), dtype=dtype, device=device)
-        self.grads = torch.empty(self.shape, dtype=dtype, device=device)
+        # grads=False: probabilities only (row-relevancy mode of the backward never stores dP)
+        self.grads = torch.empty(self.shape, dtype=dtype, device=device) if grads else None
 
     @property
     def n_layers(self):
@@ -39,9 +41,9 @@ class CaptureBuffers:
     def batch(self):
         return self.shape[1]
 
-    def matches(self, n_layers, batch, heads, n_q, n_k, device, shared_probs=False, dtype=torch.float32):
+    def matches(self, n_layers, batch, heads, n_q, n_k, device, shared_probs=False, dtype=torch.float32, grads=True):
         return self.shape == (n_layers, batch, heads, n_q, n_k) and self.probs.device == torch.device(device) \
-            and self.shared_probs == shared_probs and self.dtype == dtype
+            and self.shared_probs == shared_probs and self.dtype == dtype and (self.grads is not None) == bool(grads)
 
     def layer_probs(self, l):
         """``[B*H, Nq, Nk]`` view, the shape the reference's ``attn_probs`` / ``get_attn()`` has."""
@@ -53,7 +55,7 @@ class CaptureBuffers:
         return self.grads[l].view(b * h, nq, nk)
 
     def nbytes(self):
-        return (self.probs.numel() + self.grads.numel()) * self.probs.element_size()
+        return (self.probs.numel() + (self.grads.numel() if self.grads is not None else 0)) * self.probs.element_size()
 
 
 class _AttnCapturePacked(torch.autograd.Function):

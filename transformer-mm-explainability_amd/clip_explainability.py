@@ -78,8 +78,11 @@ def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, 
     main = torch.cuda.current_stream()
     side = _side_stream(texts.device) if overlap_towers else main
     side.wait_stream(main)
+    # bf16-body image tower (cfg 5): only R[:, 0, 1:] is returned, so the relevancy ROW is carried through the backward
+    # (clip_model.Transformer.backward_tape, rel_row) -- no gradient slabs, no A-bar / R matrices for the image side
+    row_mode = shared and model.visual.row_relevancy_ok()
     with torch.cuda.stream(side):
-        img_feat, img_state = model.visual.forward_tape(images, batch_size, sl)
+        img_feat, img_state = model.visual.forward_tape(images, batch_size, sl, grads=not row_mode)
     txt_feat, txt_state = model.encode_text_tape(texts, n_text, slt)
     main.wait_stream(side)
     with torch.enable_grad():
@@ -91,9 +94,13 @@ def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, 
         torch.autograd.backward(logits_per_image, grad_tensors=eye, inputs=[image_features, text_features])
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        model.visual.backward_tape(img_state, image_features.grad, sl)
         vis = model.visual.transformer
-        R = _plan(vis.buffers, sl, vis.layers, batch_size, vis.buffers.shared_probs and batch_size > 1).launch()
+        if row_mode:
+            image_relevance = model.visual.backward_tape(img_state, image_features.grad, sl, cls_row=True)[:, 1:]
+        else:
+            model.visual.backward_tape(img_state, image_features.grad, sl)
+            R = _plan(vis.buffers, sl, vis.layers, batch_size, vis.buffers.shared_probs and batch_size > 1).launch()
+            image_relevance = R[:, 0, 1:]
     model.backward_text_tape(txt_state, text_features.grad, slt)
     txt = model.transformer
     R_text = _plan(txt.buffers, slt, txt.layers, batch_size, False).launch()
@@ -103,7 +110,6 @@ def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, 
         full = torch.eye(texts.shape[1], dtype=R_text.dtype, device=R_text.device).repeat(batch_size, 1, 1)
         full[:, :n, :n] = R_text
         R_text = full
-    image_relevance = R[:, 0, 1:]
     return R_text, image_relevance
 
 

@@ -117,16 +117,40 @@ class Transformer(nn.Module):
         # batch 128 is ~45 TFLOP of them).  torch.bfloat16 runs them on the bf16 MFMA with fp32 accumulation and fp32
         # results; everything else (forward, LayerNorm, attention, the relevancy rules) stays fp32.
         self.backward_gemm_dtype = torch.float32
+        # A bf16 BODY (BASELINE config 5; the reference converts the weights, CLIP/clip/model.py:381-402, and runs the
+        # whole tower in half precision): ``forward_gemm_dtype`` rounds the operands of the tape forward's GEMMs to bf16
+        # (fp32 accumulate, fp32 activations between the GEMMs), ``attention_mma_bf16`` runs the attention products of
+        # the long-sequence streaming kernels on the bf16 matrix cores (fp32 softmax).  R / A-bar stay fp32 always.
+        self.forward_gemm_dtype = torch.float32
+        self.attention_mma_bf16 = False
+        # capture slabs follow ``set_body_dtype`` (image towers: the slabs are the resident bytes of a long sequence);
+        # the 77-token text tower keeps fp32 slabs and its register-resident exact-fp32 attention kernels
+        self._long_sequence_slabs_follow_body = attn_mask is None
+
+    def set_body_dtype(self, dtype):
+        """``torch.bfloat16``: everything the reference's half-precision body would run in half precision (all GEMMs, the
+        attention products where the streaming kernels apply, the capture slabs); ``torch.float32``: the exact path."""
+        half = dtype == torch.bfloat16
+        if not half and dtype != torch.float32:
+            raise ValueError("body dtype must be torch.float32 or torch.bfloat16")
+        self.backward_gemm_dtype = self.forward_gemm_dtype = dtype
+        self.attention_mma_bf16 = half
+        if self._long_sequence_slabs_follow_body:
+            self.capture_dtype = dtype
+            self.buffers = None
+
+    def _linear(self, x, lin_weight, lin_bias):
+        return ops.linear(x, lin_weight, lin_bias, getattr(self, "forward_gemm_dtype", torch.float32))
 
     def _gemm(self, x, weight):
         """``x @ weight`` for the hand-written backward, in ``backward_gemm_dtype`` (cached converted weights)."""
         return ops.backward_gemm(x, weight, getattr(self, "backward_gemm_dtype", torch.float32))
 
-    def _ensure_buffers(self, batch, n_tokens, device, shared_probs=False):
+    def _ensure_buffers(self, batch, n_tokens, device, shared_probs=False, grads=True):
         if self.buffers is None or not self.buffers.matches(self.layers, batch, self.heads, n_tokens, n_tokens, device,
-                                                            shared_probs, self.capture_dtype):
+                                                            shared_probs, self.capture_dtype, grads):
             self.buffers = CaptureBuffers(self.layers, batch, self.heads, n_tokens, n_tokens, device=device,
-                                          shared_probs=shared_probs, dtype=self.capture_dtype)
+                                          shared_probs=shared_probs, dtype=self.capture_dtype, grads=grads)
         return self.buffers
 
     # ------------------------------------------------------------------------------------------------------------
@@ -152,10 +176,11 @@ class Transformer(nn.Module):
         return mask
 
     @torch.no_grad()
-    def forward_tape(self, x, batch=None, first_grad_layer=0):
+    def forward_tape(self, x, batch=None, first_grad_layer=0, grads=True):
         """``x``: ``[Bx, N, E]`` block input (embedded, through ``ln_pre`` for the image tower).  ``batch``: how many
         upstream gradients ``backward_tape`` will carry (default ``Bx``; ``Bx == 1 < batch`` = shared-forward mode).
-        Returns ``(y [Bx, N, E], tape)``; the probabilities of every block are in the capture slabs afterwards."""
+        Returns ``(y [Bx, N, E], tape)``; the probabilities of every block are in the capture slabs afterwards.
+        ``grads=False``: no gradient slab is allocated (``backward_tape(..., rel_row=...)`` does not store dP)."""
         if not x.is_cuda:
             raise _lib.MMXError("the CLIP body runs its attention on the HIP capture op: move the model and "
                                 "inputs to the MI355X (there is no CPU attention path)")
@@ -164,24 +189,27 @@ class Transformer(nn.Module):
         shared = Bx == 1 and batch > 1
         if not shared and Bx != batch:
             raise ValueError("forward_tape: %d inputs for %d upstream gradients (only a single input can be shared)" % (Bx, batch))
-        buffers = self._ensure_buffers(batch, N, x.device, shared_probs=shared)
+        buffers = self._ensure_buffers(batch, N, x.device, shared_probs=shared, grads=grads)
         blocks = list(self.resblocks)
         mask = self._mask_for(blocks[0], N, x.device) if blocks else None
         tape = []
+        # bf16 matrix cores for the attention products: the long-sequence streaming kernels only (the register-resident
+        # head kernels of a short tower such as CLIP's 77-token text side stay exact fp32)
+        mma = bool(getattr(self, "attention_mma_bf16", False)) and N > 128
         # every LayerNorm but the first is fused with the residual add that produces its input
         first = blocks[0].ln_1
         _, h1, mean1, rstd1 = ops.add_layernorm(x, None, first.weight, first.bias, first.eps)
         for l, blk in enumerate(blocks):
             at = blk.attn
-            qkv = F.linear(h1, at.in_proj_weight, at.in_proj_bias).view(Bx, N, 3, at.num_heads, at.head_dim)
+            qkv = self._linear(h1, at.in_proj_weight, at.in_proj_bias).view(Bx, N, 3, at.num_heads, at.head_dim)
             o = ops.attn_capture_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], buffers.probs[l], at.head_dim ** -0.5,
-                                     _lib.SCALE_Q_FIRST, mask, layout="bnhd")
-            x1, h2, mean2, rstd2 = ops.add_layernorm(x, at.out_proj(o.view(Bx, N, E)), blk.ln_2.weight, blk.ln_2.bias,
-                                                     blk.ln_2.eps)
-            m = blk.mlp.c_fc(h2)
-            mlp_out = blk.mlp.c_proj(ops.quick_gelu_fwd(m))
+                                     _lib.SCALE_Q_FIRST, mask, layout="bnhd", mma_bf16=mma)
+            x1, h2, mean2, rstd2 = ops.add_layernorm(x, self._linear(o.view(Bx, N, E), at.out_proj.weight, at.out_proj.bias),
+                                                     blk.ln_2.weight, blk.ln_2.bias, blk.ln_2.eps)
+            m = self._linear(h2, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
+            mlp_out = self._linear(ops.quick_gelu_fwd(m), blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
             tape.append((x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o) if l >= first_grad_layer else None)
-            blk.attn_probs, blk.attn_grad = buffers.layer_probs(l), buffers.layer_grads(l)
+            blk.attn_probs, blk.attn_grad = buffers.layer_probs(l), (buffers.layer_grads(l) if grads else None)
             if l + 1 < len(blocks):
                 nxt = blocks[l + 1].ln_1
                 x, h1, mean1, rstd1 = ops.add_layernorm(x1, mlp_out, nxt.weight, nxt.bias, nxt.eps)
@@ -196,9 +224,15 @@ class Transformer(nn.Module):
         return self.forward_tape(x, batch)
 
     @torch.no_grad()
-    def backward_tape(self, tape, dy, first_grad_layer=0, dy_rows=None):
+    def backward_tape(self, tape, dy, first_grad_layer=0, dy_rows=None, rel_row=None):
         """``dy``: ``[B, N, E]`` upstream gradients w.r.t. the tower output; fills ``buffers.grads`` of every block
         ``>= first_grad_layer``.
+
+        ``rel_row`` (``[B, N]`` fp32, bf16-body towers on the streaming kernels only): row-relevancy mode.  The caller
+        wants ONE row of ``R = (I + A_top) ... (I + A_first)`` (CLIP ``interpret`` returns ``R[:, 0, 1:]``): that row is
+        ``rel_row`` carried through the layers top-down -- the order this backward runs in -- as
+        ``row <- row + row . mean_h clamp(dP * P, 0)``, reduced inside the attention backward kernel.  No gradient slab is
+        written, no A-bar / R matrix is formed; the final row is returned.
 
         ``dy_rows`` (``[B]`` long, optional): promise that ``dy`` is zero outside row ``dy_rows[b]`` of sample ``b`` -- both
         CLIP towers read their feature from ONE token (class token / EOT token).  The top block's MLP and ``out_proj``
@@ -227,13 +261,19 @@ class Transformer(nn.Module):
             need = l > first_grad_layer                                       # nothing below needs gradients
             dqkv = torch.empty(B, N, 3, at.num_heads, at.head_dim, dtype=torch.float32, device=dy.device) if need else None
             out = (dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]) if need else None
-            ops.attn_capture_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], buffers.probs[l], d_o, buffers.grads[l],
-                                 at.head_dim ** -0.5, _lib.SCALE_Q_FIRST, need_dqkv=need, layout="bnhd", out=out,
-                                 batch=B if shared else None, o=o_fwd)
+            res = ops.attn_capture_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], buffers.probs[l], d_o,
+                                       buffers.grads[l] if buffers.grads is not None else None,
+                                       at.head_dim ** -0.5, _lib.SCALE_Q_FIRST, need_dqkv=need, layout="bnhd", out=out,
+                                       batch=B if shared else None, o=o_fwd,
+                                       mma_bf16=bool(getattr(self, "attention_mma_bf16", False)) and N > 128,
+                                       rel_row=rel_row)
+            if rel_row is not None:
+                rel_row = res[3]
             if not need:
                 break
             d_h1 = self._gemm(dqkv.view(B, N, 3 * E), at.in_proj_weight)
             dx = ops.layernorm_bwd_add(d_h1, x, mean1, rstd1, blk.ln_1.weight, d_x1)
+        return rel_row
 
     def _top_block_rows(self, blk, entry, dy, rows, shared):
         """MLP / ``out_proj`` backward of the top block on the one row per sample that carries a gradient.
@@ -316,10 +356,16 @@ class VisualTransformer(nn.Module):
         return x @ self.proj if self.proj is not None else x
 
     @torch.no_grad()
-    def forward_tape(self, image, batch=None, first_grad_layer=0):
+    def row_relevancy_ok(self):
+        """Can ``backward_tape(..., cls_row=True)`` run?  (bf16-body tower on the long-sequence streaming kernels.)"""
+        t = self.transformer
+        n_tokens = self.positional_embedding.shape[0]
+        return bool(getattr(t, "attention_mma_bf16", False)) and n_tokens > 128
+
+    def forward_tape(self, image, batch=None, first_grad_layer=0, grads=True):
         """``image [Bx, 3, R, R]`` -> ``(features [Bx, output_dim], state)``; ``Bx == 1 < batch``: shared-forward mode
         (see ``Transformer.forward_tape``)."""
-        y, tape = self.transformer.forward_tape(self._embed(image), batch, first_grad_layer)
+        y, tape = self.transformer.forward_tape(self._embed(image), batch, first_grad_layer, grads=grads)
         cls = y[:, 0, :]
         f, mean, rstd = torch.native_layer_norm(cls, (cls.shape[-1],), self.ln_post.weight, self.ln_post.bias,
                                                 self.ln_post.eps)
@@ -329,8 +375,10 @@ class VisualTransformer(nn.Module):
         return self.forward_tape(image, batch)
 
     @torch.no_grad()
-    def backward_tape(self, state, d_features, first_grad_layer=0):
-        """``d_features [B, output_dim]``: per-sample upstream gradients of the image features."""
+    def backward_tape(self, state, d_features, first_grad_layer=0, cls_row=False):
+        """``d_features [B, output_dim]``: per-sample upstream gradients of the image features.
+        ``cls_row=True``: row-relevancy mode (``Transformer.backward_tape``): returns row 0 (the class token's) of the
+        tower's relevancy matrix, ``[B, N]``, instead of filling gradient slabs."""
         tape, y_shape, cls, mean, rstd = state
         B = d_features.shape[0]
         d_f = torch.matmul(d_features, self.proj.t())
@@ -339,8 +387,12 @@ class VisualTransformer(nn.Module):
             rstd.expand(B, -1).contiguous(), self.ln_post.weight, self.ln_post.bias, [True, False, False])[0]
         dy = torch.zeros(B, y_shape[1], y_shape[2], dtype=torch.float32, device=d_features.device)
         dy[:, 0, :] = d_cls                                                  # only the class token feeds the features
-        self.transformer.backward_tape(tape, dy, first_grad_layer,
-                                       dy_rows=torch.zeros(B, dtype=torch.long, device=dy.device))
+        rel_row = None
+        if cls_row:
+            rel_row = torch.zeros(B, y_shape[1], dtype=torch.float32, device=dy.device)
+            rel_row[:, 0] = 1.0                                              # e_0: row 0 of the identity R starts from
+        return self.transformer.backward_tape(tape, dy, first_grad_layer,
+                                              dy_rows=torch.zeros(B, dtype=torch.long, device=dy.device), rel_row=rel_row)
 
     def backward_shared(self, state, d_features, first_grad_layer=0):
         return self.backward_tape(state, d_features, first_grad_layer)
@@ -381,6 +433,13 @@ class CLIP(nn.Module):
             nn.init.normal_(blk.mlp.c_fc.weight, std=fc_std)
             nn.init.normal_(blk.mlp.c_proj.weight, std=proj_std)
         nn.init.normal_(self.text_projection, std=w ** -0.5)
+
+    def set_body_dtype(self, dtype):
+        """``torch.bfloat16``: BASELINE config 5's bf16 body -- both towers' GEMMs on the bf16 matrix cores (fp32
+        accumulate), the image tower's attention products too, its capture slabs in bf16; relevancy (A-bar, R) stays fp32.
+        ``torch.float32``: back to the exact path.  (The reference: ``convert_weights``, CLIP/clip/model.py:381-402.)"""
+        self.visual.transformer.set_body_dtype(dtype)
+        self.transformer.set_body_dtype(dtype)
 
     def build_attention_mask(self):
         """Additive causal mask, -inf above the diagonal (model.py:334-340)."""

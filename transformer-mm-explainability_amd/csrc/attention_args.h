@@ -15,6 +15,7 @@ struct AttnFwdArgs {
     float scale; int scale_mode;
     int debug;  // profiling only (attention_small.hip)
     int slab_dt;  // MMX_F32 | MMX_F16 | MMX_BF16: element type behind `probs` (non-fp32: streaming kernels only)
+    int mma_bf16; // 1: products on v_mfma_f32_16x16x32_bf16 (operands rounded to bf16, fp32 accumulate, fp32 softmax)
 };
 
 struct AttnBwdArgs {
@@ -31,6 +32,12 @@ struct AttnBwdArgs {
     float scale; int scale_mode; int need_dqkv;
     int slab_dt;  // element type behind `probs` and `dprobs` (see AttnFwdArgs)
     int debug;    // tuning knob of attention_head.hip (stagger)
+    int mma_bf16; // see AttnFwdArgs (streaming kernels only)
+    // Row-relevancy mode (mmx_attn_capture_bwd_rowrel, streaming bf16-MFMA kernels only): instead of (or besides) storing
+    // dP, every query-side workgroup reduces  part[k] = sum_{q in its 64 rows} rel_v[b][q] * clamp(dP * P, 0)[q][k]  of
+    // its head into rel_part[b][h * nrt + row_tile][k]; rel_v == nullptr: off.
+    const float* rel_v;
+    float* rel_part;
 };
 
 int attn_fwd_head_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out);    // attention_head.hip (register-resident)

@@ -332,6 +332,8 @@ extern "C" int mmx_attn_capture_fwd_ex(const void* q_dev, const void* k_dev, con
                                        int64_t o_sn, int B, int H, int Nq, int Nk, int D, float scale, int scale_mode,
                                        void* stream) {
     MMX_CHECK_ARG(q_dev && k_dev && v_dev && probs_dev && o_dev, "mmx_attn_capture_fwd: null pointer");
+    const int mma_bf16 = (slab_dtype & MMX_ATTN_MMA_BF16) ? 1 : 0;
+    slab_dtype &= ~MMX_ATTN_MMA_BF16;
     MMX_CHECK_ARG(slab_dtype == MMX_F32 || slab_dtype == MMX_F16 || slab_dtype == MMX_BF16,
                   "mmx_attn_capture_fwd: slab dtype %d", slab_dtype);
     int rc = check_attn_dims("mmx_attn_capture_fwd", B, H, Nq, Nk, D, scale_mode);
@@ -343,11 +345,13 @@ extern "C" int mmx_attn_capture_fwd_ex(const void* q_dev, const void* k_dev, con
     a.probs = static_cast<float*>(probs_dev); a.o = static_cast<float*>(o_dev); a.os = {o_sb, o_sh, o_sn};
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale; a.scale_mode = scale_mode; a.debug = 0;
     a.slab_dt = slab_dtype;
+    a.mma_bf16 = mma_bf16;
     dim3 grid((Nq + kTQ - 1) / kTQ, H, B);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (slab_dtype != MMX_F32) {   // half-precision slabs: the streaming kernels are the only writers
+    if (slab_dtype != MMX_F32 || mma_bf16) {   // half-precision slabs / bf16 MFMA: the streaming kernels only
         if (attn_fwd_stream_try(a, s, &rc)) return rc;
-        set_error("mmx_attn_capture_fwd: fp16 / bf16 capture slabs need head_dim %% 4 == 0 and 16-byte aligned q/k/v views");
+        set_error("mmx_attn_capture_fwd: fp16 / bf16 capture slabs and MMX_ATTN_MMA_BF16 need head_dim %% 4 == 0 "
+                  "(<= 64) and 16-byte aligned q/k/v views");
         return MMX_ENOTSUP;
     }
     if (attn_fwd_head_try(a, s, &rc)) return rc;    // short sequences: a wave owns 16 query rows, scores in registers
@@ -375,7 +379,32 @@ extern "C" int mmx_attn_capture_bwd(const void* q_dev, const void* k_dev, const 
                                    scale_mode, need_dqkv, workspace_dev, workspace_bytes, stream);
 }
 
-extern "C" int mmx_attn_capture_bwd_ex(const void* q_dev, const void* k_dev, const void* v_dev, int64_t q_sb,
+namespace mmx {
+namespace {
+// v_out[b][k] = v_in[b][k] + (1 / H) sum_j part[b][j][k]   (row-relevancy mode: the rows j are (head, query tile))
+__global__ __launch_bounds__(256) void rel_row_update_kernel(const float* __restrict__ v_in, const float* __restrict__ part,
+                                                             float* __restrict__ v_out, int J, int N, float inv_h) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const int64_t b = blockIdx.y;
+    const float* p = part + b * J * N + k;
+    float sum = 0.f;
+    for (int j = 0; j < J; ++j) sum += p[static_cast<int64_t>(j) * N];
+    v_out[b * N + k] = v_in[b * N + k] + sum * inv_h;
+}
+}  // namespace
+}  // namespace mmx
+
+static size_t rowrel_delta_bytes(int B, int H, int Nq) {
+    return (sizeof(float) * static_cast<size_t>(B) * H * Nq + 255) / 256 * 256;
+}
+
+extern "C" size_t mmx_attn_capture_bwd_rowrel_workspace_bytes(int B, int H, int Nq, int Nk) {
+    const size_t nrt = (static_cast<size_t>(Nq) + 63) / 64;
+    return rowrel_delta_bytes(B, H, Nq) + sizeof(float) * static_cast<size_t>(B) * H * nrt * Nk;
+}
+
+static int attn_bwd_impl(const void* q_dev, const void* k_dev, const void* v_dev, int64_t q_sb,
                                        int64_t q_sh, int64_t q_sn, int64_t k_sb, int64_t k_sh, int64_t k_sn, int64_t v_sb,
                                        int64_t v_sh, int64_t v_sn, const void* probs_dev, int64_t probs_sb, int slab_dtype,
                                        const void* do_dev, int64_t o_sb, int64_t o_sh, int64_t o_sn, const void* fwd_o_dev,
@@ -384,8 +413,20 @@ extern "C" int mmx_attn_capture_bwd_ex(const void* q_dev, const void* k_dev, con
                                        int64_t dq_sn, int64_t dk_sb, int64_t dk_sh, int64_t dk_sn, int64_t dv_sb,
                                        int64_t dv_sh, int64_t dv_sn, int B, int H, int Nq, int Nk, int D, float scale,
                                        int scale_mode, int need_dqkv, void* workspace_dev, size_t workspace_bytes,
-                                       void* stream) {
-    MMX_CHECK_ARG(v_dev && probs_dev && do_dev && dprobs_dev, "mmx_attn_capture_bwd: null pointer");
+                                       void* stream, const void* rel_in_dev, void* rel_out_dev) {
+    const bool rel = rel_in_dev != nullptr;
+    MMX_CHECK_ARG(v_dev && probs_dev && do_dev && (dprobs_dev || rel), "mmx_attn_capture_bwd: null pointer");
+    if (rel) {
+        MMX_CHECK_ARG(rel_out_dev && Nq == Nk, "mmx_attn_capture_bwd_rowrel: needs rel_out and self-attention (Nq == Nk)");
+        MMX_CHECK_ARG(slab_dtype & MMX_ATTN_MMA_BF16, "mmx_attn_capture_bwd_rowrel: MMX_ATTN_MMA_BF16 kernels only");
+        if (!workspace_dev || workspace_bytes < mmx_attn_capture_bwd_rowrel_workspace_bytes(B, H, Nq, Nk)) {
+            set_error("mmx_attn_capture_bwd_rowrel: workspace %zu < %zu", workspace_bytes,
+                      mmx_attn_capture_bwd_rowrel_workspace_bytes(B, H, Nq, Nk));
+            return MMX_EWORKSPACE;
+        }
+    }
+    const int mma_bf16 = (slab_dtype & MMX_ATTN_MMA_BF16) ? 1 : 0;
+    slab_dtype &= ~MMX_ATTN_MMA_BF16;
     MMX_CHECK_ARG(slab_dtype == MMX_F32 || slab_dtype == MMX_F16 || slab_dtype == MMX_BF16,
                   "mmx_attn_capture_bwd: slab dtype %d", slab_dtype);
     int rc = check_attn_dims("mmx_attn_capture_bwd", B, H, Nq, Nk, D, scale_mode);
@@ -411,10 +452,26 @@ extern "C" int mmx_attn_capture_bwd_ex(const void* q_dev, const void* k_dev, con
     a.delta = static_cast<float*>(workspace_dev);
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale; a.scale_mode = scale_mode; a.need_dqkv = need_dqkv;
     a.slab_dt = slab_dtype;
+    a.mma_bf16 = mma_bf16;
+    a.rel_v = static_cast<const float*>(rel_in_dev);
+    a.rel_part = rel ? reinterpret_cast<float*>(static_cast<char*>(workspace_dev) + rowrel_delta_bytes(B, H, Nq)) : nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (slab_dtype != MMX_F32) {
+    if (rel) {
+        if (!attn_bwd_stream_try(a, s, &rc)) {
+            set_error("mmx_attn_capture_bwd_rowrel: needs head_dim %% 4 == 0 (<= 64) and 16-byte aligned views");
+            return MMX_ENOTSUP;
+        }
+        if (rc) return rc;
+        const int J = H * ((Nq + 63) / 64);
+        rel_row_update_kernel<<<dim3((Nk + 255) / 256, B), 256, 0, s>>>(a.rel_v, a.rel_part,
+                                                                       static_cast<float*>(rel_out_dev), J, Nk, 1.0f / H);
+        MMX_LAUNCH_CHECK("rel_row_update_kernel");
+        return MMX_OK;
+    }
+    if (slab_dtype != MMX_F32 || mma_bf16) {
         if (attn_bwd_stream_try(a, s, &rc)) return rc;
-        set_error("mmx_attn_capture_bwd: fp16 / bf16 capture slabs need head_dim %% 4 == 0 and 16-byte aligned views");
+        set_error("mmx_attn_capture_bwd: fp16 / bf16 capture slabs and MMX_ATTN_MMA_BF16 need head_dim %% 4 == 0 "
+                  "(<= 64) and 16-byte aligned views");
         return MMX_ENOTSUP;
     }
     if (attn_bwd_head_try(a, s, &rc)) return rc;    // short sequences: a wave owns 16 query rows, scores in registers
@@ -432,4 +489,38 @@ extern "C" int mmx_attn_capture_bwd_ex(const void* q_dev, const void* k_dev, con
     }
     MMX_LAUNCH_CHECK("attn_capture_bwd_kv_kernel");
     return MMX_OK;
+}
+
+extern "C" int mmx_attn_capture_bwd_ex(const void* q_dev, const void* k_dev, const void* v_dev, int64_t q_sb,
+                                       int64_t q_sh, int64_t q_sn, int64_t k_sb, int64_t k_sh, int64_t k_sn, int64_t v_sb,
+                                       int64_t v_sh, int64_t v_sn, const void* probs_dev, int64_t probs_sb, int slab_dtype,
+                                       const void* do_dev, int64_t o_sb, int64_t o_sh, int64_t o_sn, const void* fwd_o_dev,
+                                       int64_t fo_sb, int64_t fo_sh, int64_t fo_sn, void* dprobs_dev,
+                                       void* dq_dev, void* dk_dev, void* dv_dev, int64_t dq_sb, int64_t dq_sh,
+                                       int64_t dq_sn, int64_t dk_sb, int64_t dk_sh, int64_t dk_sn, int64_t dv_sb,
+                                       int64_t dv_sh, int64_t dv_sn, int B, int H, int Nq, int Nk, int D, float scale,
+                                       int scale_mode, int need_dqkv, void* workspace_dev, size_t workspace_bytes,
+                                       void* stream) {
+    return attn_bwd_impl(q_dev, k_dev, v_dev, q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn, probs_dev, probs_sb,
+                         slab_dtype, do_dev, o_sb, o_sh, o_sn, fwd_o_dev, fo_sb, fo_sh, fo_sn, dprobs_dev, dq_dev, dk_dev,
+                         dv_dev, dq_sb, dq_sh, dq_sn, dk_sb, dk_sh, dk_sn, dv_sb, dv_sh, dv_sn, B, H, Nq, Nk, D, scale,
+                         scale_mode, need_dqkv, workspace_dev, workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int mmx_attn_capture_bwd_rowrel(const void* q_dev, const void* k_dev, const void* v_dev, int64_t q_sb,
+                                           int64_t q_sh, int64_t q_sn, int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                                           int64_t v_sb, int64_t v_sh, int64_t v_sn, const void* probs_dev,
+                                           int64_t probs_sb, int slab_dtype, const void* do_dev, int64_t o_sb,
+                                           int64_t o_sh, int64_t o_sn, const void* fwd_o_dev, int64_t fo_sb,
+                                           int64_t fo_sh, int64_t fo_sn, void* dprobs_dev, void* dq_dev, void* dk_dev,
+                                           void* dv_dev, int64_t dq_sb, int64_t dq_sh, int64_t dq_sn, int64_t dk_sb,
+                                           int64_t dk_sh, int64_t dk_sn, int64_t dv_sb, int64_t dv_sh, int64_t dv_sn,
+                                           int B, int H, int Nq, int Nk, int D, float scale, int scale_mode,
+                                           int need_dqkv, const void* rel_in_dev, void* rel_out_dev,
+                                           void* workspace_dev, size_t workspace_bytes, void* stream) {
+    MMX_CHECK_ARG(rel_in_dev && rel_out_dev, "mmx_attn_capture_bwd_rowrel: null relevancy row");
+    return attn_bwd_impl(q_dev, k_dev, v_dev, q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn, probs_dev, probs_sb,
+                         slab_dtype, do_dev, o_sb, o_sh, o_sn, fwd_o_dev, fo_sb, fo_sh, fo_sn, dprobs_dev, dq_dev, dk_dev,
+                         dv_dev, dq_sb, dq_sh, dq_sn, dk_sb, dk_sh, dk_sn, dv_sb, dv_sh, dv_sn, B, H, Nq, Nk, D, scale,
+                         scale_mode, need_dqkv, workspace_dev, workspace_bytes, stream, rel_in_dev, rel_out_dev);
 }

@@ -124,13 +124,65 @@ __device__ __forceinline__ void tile_wt(f32x4 (&acc)[2][DP / 16], const float* w
     }
 }
 
+// ---- the same two products on v_mfma_f32_16x16x32_bf16 (MMX_ATTN_MMA_BF16).  The LDS tiles stay fp32: an operand is
+// the 8 values of TWO of the b128 (or 2 x 4 b32) reads the fp32 form already makes, rounded to bf16 in registers
+// (4 v_cvt_pk_bf16_f32), so one bf16 MFMA replaces eight exact-fp32 ones on the same LDS traffic.
+// Contraction slot (g, j) of pair pr  <->  index 32 pr + 16 (j >> 2) + 4 g + (j & 3), for both operands.
+template <int DP>
+__device__ __forceinline__ void pack_a_rows(bf16x8 (&apk)[DP / 32], const f32x4 (&a)[DP / 16]) {
+#pragma unroll
+    for (int pr = 0; pr < DP / 32; ++pr) apk[pr] = pack_bf16(a[2 * pr], a[2 * pr + 1]);
+}
+
+// acc[t][4g + r][i] = sum_d  R[i or 4g+r ...]: SWAP = false: C[m][n] with m = the register operand's row (A = regs, B = LDS
+// rows 16 t + i);  SWAP = true: A = LDS rows 16 t + i (m), B = regs (n).
+template <int DP, bool SWAP>
+__device__ __forceinline__ void tile_abt4_bf16(f32x4 (&acc)[4], const bf16x8 (&a)[DP / 32], const float* tile, int i, int g) {
+    constexpr int LS = DP + 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* p = tile + i * LS + 4 * g;
+#pragma unroll
+    for (int pr = 0; pr < DP / 32; ++pr) {
+        bf16x8 b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            b[t] = pack_bf16(*reinterpret_cast<const f32x4*>(p + 16 * t * LS + 32 * pr),
+                             *reinterpret_cast<const f32x4*>(p + 16 * t * LS + 32 * pr + 16));
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            acc[t] = SWAP ? mfma16x16x32_bf16(b[t], a[pr], acc[t]) : mfma16x16x32_bf16(a[pr], b[t], acc[t]);
+    }
+}
+
+template <int DP>
+__device__ __forceinline__ void tile_wt_bf16(f32x4 (&acc)[2][DP / 16], const float* w, const float* tile, int i, int g) {
+    constexpr int LS = DP + 4;
+#pragma unroll
+    for (int pr = 0; pr < kTile / 32; ++pr) {
+        const bf16x8 av = pack_bf16(*reinterpret_cast<const f32x4*>(w + i * kPS + 32 * pr + 4 * g),
+                                    *reinterpret_cast<const f32x4*>(w + i * kPS + 32 * pr + 16 + 4 * g));
+        const float* row0 = tile + (32 * pr + 4 * g) * LS + i;
+#pragma unroll
+        for (int dt = 0; dt < DP / 16; ++dt) {
+            f32x4 lo, hi;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                lo[s2] = row0[s2 * LS + 16 * dt];
+                hi[s2] = row0[(16 + s2) * LS + 16 * dt];
+            }
+            acc[pr][dt] = mfma16x16x32_bf16(av, pack_bf16(lo, hi), acc[pr][dt]);
+        }
+    }
+}
+
 template <int DP>
 constexpr size_t stream_lds_bytes(int tiles) {
     return sizeof(float) * (static_cast<size_t>(tiles) * kTile * (DP + 4) + 4 * 16 * kPS);
 }
 
 // =============================================================================================== forward
-template <int DP, int DT>
+template <int DP, int DT, bool MM>
 __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_kernel(const AttnFwdArgs a) {
     typedef typename slab_elem<DT>::type slab_t;
     constexpr int LS = DP + 4, NB = DP / 16;
@@ -153,6 +205,12 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_ke
 
     f32x4 qa[NB];
     load_a_rows<DP>(qa, qb, a.qs.sn, min(rw + i, a.Nq - 1), a.D, g, q_first ? a.scale : 1.f);
+    bf16x8 qa_pk[DP / 32];
+    if constexpr (MM) pack_a_rows<DP>(qa_pk, qa);
+    auto s_tile = [&](f32x4 (&sacc)[4]) {
+        if constexpr (MM) tile_abt4_bf16<DP, false>(sacc, qa_pk, Ks, i, g);
+        else tile_abt4<DP>(sacc, qa, Ks, i, g);
+    };
 
     // per-lane row pointers (+ this lane's key column i): inside the sweeps only a wave-uniform key offset is added,
     // and rows beyond Nq simply have no output pointer
@@ -182,7 +240,7 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_ke
     float m[4] = {ninf, ninf, ninf, ninf}, l[4] = {0.f, 0.f, 0.f, 0.f};
     auto sweep1 = [&](int kt, auto edge) {
         f32x4 sacc[4];
-        tile_abt4<DP>(sacc, qa, Ks, i, g);
+        s_tile(sacc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float sv[4];
@@ -220,7 +278,7 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_ke
     auto sweep2 = [&](int kt, auto edge) {
         constexpr bool EDGE = decltype(edge)::value;
         f32x4 sacc[4];
-        tile_abt4<DP>(sacc, qa, Ks, i, g);
+        s_tile(sacc);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int k0 = kt * kTile + 16 * t;
@@ -232,7 +290,8 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_ke
                 Pw[(4 * g + r) * kPS + 16 * t + i] = p;
             }
         }
-        tile_wt<DP>(oacc, Pw, Vs, i, g);                   // same-wave LDS traffic is in order: no barrier needed
+        if constexpr (MM) tile_wt_bf16<DP>(oacc, Pw, Vs, i, g);
+        else tile_wt<DP>(oacc, Pw, Vs, i, g);               // same-wave LDS traffic is in order: no barrier needed
     };
     tile_fetch<DP>(kreg, kb, a.ks.sn, 0, a.Nk, a.D, tid);
     tile_fetch<DP>(vreg, vb, a.vs.sn, 0, a.Nk, a.D, tid);
@@ -258,7 +317,10 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_ke
 
 // =============================================================================================== backward, query side
 // dP = dO.V^T -> capture slab;  delta = rowsum(P * dP) -> workspace;  dS = P * (dP - delta);  dQ = dS.K
-template <int DP, int DT>
+// REL (row-relevancy mode, see AttnBwdArgs::rel_v): the product the relevancy rules need from this layer -- one ROW of
+// R + A_bar.R, i.e. v.A_bar with A_bar = mean_h clamp(dP * P, 0) -- is reduced here from the dP / P values the sweep
+// already holds, so dP is neither stored nor re-read and no A_bar matrix exists.
+template <int DP, int DT, bool MM, bool REL = false>
 __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_kernel(const AttnBwdArgs a) {
     typedef typename slab_elem<DT>::type slab_t;
     constexpr int LS = DP + 4, NB = DP / 16;
@@ -279,6 +341,12 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
 
     f32x4 doa[NB];
     load_a_rows<DP>(doa, dob, a.os.sn, min(rw + i, a.Nq - 1), a.D, g, 1.f);
+    bf16x8 doa_pk[DP / 32];
+    if constexpr (MM) pack_a_rows<DP>(doa_pk, doa);
+    auto dp_tile = [&](f32x4 (&dp)[4]) {
+        if constexpr (MM) tile_abt4_bf16<DP, false>(dp, doa_pk, Vs, i, g);
+        else tile_abt4<DP>(dp, doa, Vs, i, g);
+    };
 
     // per-lane row pointers incl. this lane's key column i; the sweeps add wave-uniform key offsets only
     int rows[4];
@@ -289,8 +357,25 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
         rows[r] = rw + 4 * g + r;
         prow[r] = reinterpret_cast<const slab_t*>(a.probs) + b * a.probs_sb +
                   (static_cast<int64_t>(h) * a.Nq + min(rows[r], a.Nq - 1)) * a.Nk + i;
-        dpout[r] = rows[r] < a.Nq ? reinterpret_cast<slab_t*>(a.dprobs) + (head * a.Nq + rows[r]) * a.Nk + i : nullptr;
+        dpout[r] = (rows[r] < a.Nq && a.dprobs) ? reinterpret_cast<slab_t*>(a.dprobs) + (head * a.Nq + rows[r]) * a.Nk + i
+                                                : nullptr;
     }
+    float vrow[4] = {0.f, 0.f, 0.f, 0.f};
+    float* relw = smem + 2 * kTile * LS + 4 * 16 * kPS;      // REL: [4 waves x 4 row groups][64 keys] partial sums
+    if constexpr (REL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vrow[r] = rows[r] < a.Nq ? a.rel_v[static_cast<int64_t>(b) * a.Nq + rows[r]] : 0.f;
+    }
+    // REL: keys of tile kt summed over the workgroup's 64 query rows (fixed order: deterministic) -> this workgroup's row
+    auto rel_flush = [&](int kt) {
+        const int kk = kt * kTile + tid;
+        if (tid < kTile && kk < a.Nk) {
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sum += relw[j * kTile + tid];
+            a.rel_part[(head * nrt + wg % nrt) * a.Nk + kk] = sum;
+        }
+    };
     const int ntiles = (a.Nk + kTile - 1) / kTile;
     f32x4 kreg[NB], vreg[NB];
     // this lane's 4 x 4 probabilities of a key tile.  EDGE = the tile may run past Nk (last tile only)
@@ -333,7 +418,7 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
             float p[4][4];
             load_p(p, kt, edge);
             f32x4 dp[4];
-            tile_abt4<DP>(dp, doa, Vs, i, g);
+            dp_tile(dp);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -362,9 +447,18 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
     auto sweep2 = [&](int kt, auto edge) {
         constexpr bool EDGE = decltype(edge)::value;
         float p[4][4];
-        if (a.need_dqkv) load_p(p, kt, edge);
+        if (a.need_dqkv || REL) load_p(p, kt, edge);
         f32x4 dp[4];
-        tile_abt4<DP>(dp, doa, Vs, i, g);
+        dp_tile(dp);
+        if constexpr (REL) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float c = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c += vrow[r] * relu_nan(p[t][r] * dp[t][r]);
+                relw[(wave * 4 + g) * kTile + 16 * t + i] = c;
+            }
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int k0 = kt * kTile + 16 * t;
@@ -374,12 +468,16 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
                 if (a.need_dqkv) Sw[(4 * g + r) * kPS + 16 * t + i] = p[t][r] * (dp[t][r] - delta[r]) * ds_mul;
             }
         }
-        if (a.need_dqkv) tile_wt<DP>(qacc, Sw, Ks, i, g);
+        if (a.need_dqkv) {
+            if constexpr (MM) tile_wt_bf16<DP>(qacc, Sw, Ks, i, g);
+            else tile_wt<DP>(qacc, Sw, Ks, i, g);
+        }
     };
     tile_fetch<DP>(vreg, vb, a.vs.sn, 0, a.Nk, a.D, tid);
     if (a.need_dqkv) tile_fetch<DP>(kreg, kb, a.ks.sn, 0, a.Nk, a.D, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         lds_barrier();
+        if constexpr (REL) { if (kt > 0) rel_flush(kt - 1); }
         tile_store<DP>(Vs, vreg, 1.f, tid);
         if (a.need_dqkv) tile_store<DP>(Ks, kreg, 1.f, tid);
         lds_barrier();
@@ -388,6 +486,10 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
             if (a.need_dqkv) tile_fetch<DP>(kreg, kb, a.ks.sn, (kt + 1) * kTile, a.Nk, a.D, tid);
         }
         if (kt + 1 < ntiles) sweep2(kt, std::false_type{}); else sweep2(kt, std::true_type{});
+    }
+    if constexpr (REL) {
+        lds_barrier();
+        rel_flush(ntiles - 1);
     }
     if (!a.need_dqkv) return;
     float* dqb = a.dq + b * a.dqs.sb + h * a.dqs.sh;
@@ -404,7 +506,9 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
 // per 64 keys (16 per wave): dV = P^T.dO, dK = dS^T.Q with dS rebuilt from the two capture slabs and delta.
 // The A operands (columns of P / dS) come straight from the slabs in MFMA layout: lane (key i, slot g) reads rows
 // 16 rb + 4 g + s of key column j0 + i -- 16 consecutive keys per row segment, no LDS staging.
-template <int DP, int DT>
+// MM (bf16 MFMA): dP of the tile is RECOMPUTED (dO tile from LDS . this wave's V rows held in registers -- two bf16
+// MFMAs per 16 queries) instead of being read back from the slab the query-side kernel just wrote: one N^2 read less.
+template <int DP, int DT, bool MM>
 __global__ __launch_bounds__(kThreads) void attn_bwd_kv_stream_kernel(const AttnBwdArgs a) {
     typedef typename slab_elem<DT>::type slab_t;
     constexpr int LS = DP + 4, NB = DP / 16;
@@ -431,6 +535,12 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_kv_stream_kernel(const Attn
 #pragma unroll
     for (int dt = 0; dt < NB; ++dt) kacc[dt] = vacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float ds_mul = q_first ? 1.f : 1.f / a.scale;
+    bf16x8 v_pk[DP / 32];
+    if constexpr (MM) {
+        f32x4 va[NB];
+        load_a_rows<DP>(va, a.v + b * a.vs.sb + h * a.vs.sh, a.vs.sn, keyc, a.D, g, 1.f);
+        pack_a_rows<DP>(v_pk, va);
+    }
 
     const int ntiles = (a.Nq + kTile - 1) / kTile;
     f32x4 qreg[NB], doreg[NB];
@@ -455,9 +565,12 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_kv_stream_kernel(const Attn
                 const int row = qt * kTile + 16 * rb + 4 * g + s;
                 const int64_t off = static_cast<int64_t>(min(row, a.Nq - 1)) * a.Nk;
                 const bool ok = key_ok && row < a.Nq;
-                const float pv = slab_load<DT>(pcol + off), dv = slab_load<DT>(dpcol + off);
+                const float pv = slab_load<DT>(pcol + off);
                 p[rb][s] = ok ? pv : 0.f;
-                dp[rb][s] = ok ? dv : 0.f;
+                if constexpr (!MM) {
+                    const float dv = slab_load<DT>(dpcol + off);
+                    dp[rb][s] = ok ? dv : 0.f;
+                }
             }
         lds_barrier();
         tile_store<DP>(Qs, qreg, q_first ? a.scale : 1.f, tid);
@@ -465,18 +578,50 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_kv_stream_kernel(const Attn
         if (tid < kTile) dl[tid] = dlreg;
         lds_barrier();
         if (qt + 1 < ntiles) fetch(qt + 1);
+        if constexpr (MM) {
+            f32x4 dpt[4];                                      // dpt[rb][r] = dP[16 rb + 4 g + r][key i]  (rows past Nq: dO = 0)
+            tile_abt4_bf16<DP, true>(dpt, v_pk, dOs, i, g);
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            const f32x4 dlv = *reinterpret_cast<const f32x4*>(dl + 16 * rb + 4 * g);
+            for (int pr = 0; pr < 2; ++pr) {
+                f32x4 dsv[2];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float ds = p[rb][s] * (dp[rb][s] - dlv[s]) * ds_mul;
-                const float* qrow = Qs + (16 * rb + 4 * g + s) * LS + i;
-                const float* drow = dOs + (16 * rb + 4 * g + s) * LS + i;
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int rb = 2 * pr + hh;
+                    const f32x4 dlv = *reinterpret_cast<const f32x4*>(dl + 16 * rb + 4 * g);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) dsv[hh][s] = p[rb][s] * (dpt[rb][s] - dlv[s]) * ds_mul;
+                }
+                const bf16x8 p_pk = pack_bf16(f32x4{p[2 * pr][0], p[2 * pr][1], p[2 * pr][2], p[2 * pr][3]},
+                                              f32x4{p[2 * pr + 1][0], p[2 * pr + 1][1], p[2 * pr + 1][2], p[2 * pr + 1][3]});
+                const bf16x8 ds_pk = pack_bf16(dsv[0], dsv[1]);
+                const float* qrow = Qs + (32 * pr + 4 * g) * LS + i;
+                const float* drow = dOs + (32 * pr + 4 * g) * LS + i;
 #pragma unroll
                 for (int dt = 0; dt < NB; ++dt) {
-                    vacc[dt] = mfma16x16x4(p[rb][s], drow[16 * dt], vacc[dt]);
-                    kacc[dt] = mfma16x16x4(ds, qrow[16 * dt], kacc[dt]);
+                    f32x4 qlo, qhi, dlo, dhi;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        qlo[s] = qrow[s * LS + 16 * dt]; qhi[s] = qrow[(16 + s) * LS + 16 * dt];
+                        dlo[s] = drow[s * LS + 16 * dt]; dhi[s] = drow[(16 + s) * LS + 16 * dt];
+                    }
+                    vacc[dt] = mfma16x16x32_bf16(p_pk, pack_bf16(dlo, dhi), vacc[dt]);
+                    kacc[dt] = mfma16x16x32_bf16(ds_pk, pack_bf16(qlo, qhi), kacc[dt]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const f32x4 dlv = *reinterpret_cast<const f32x4*>(dl + 16 * rb + 4 * g);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float ds = p[rb][s] * (dp[rb][s] - dlv[s]) * ds_mul;
+                    const float* qrow = Qs + (16 * rb + 4 * g + s) * LS + i;
+                    const float* drow = dOs + (16 * rb + 4 * g + s) * LS + i;
+#pragma unroll
+                    for (int dt = 0; dt < NB; ++dt) {
+                        vacc[dt] = mfma16x16x4(p[rb][s], drow[16 * dt], vacc[dt]);
+                        kacc[dt] = mfma16x16x4(ds, qrow[16 * dt], kacc[dt]);
+                    }
                 }
             }
         }
@@ -512,28 +657,56 @@ int launch_stream(K kern, const A& args, dim3 grid, size_t lds, hipStream_t s, c
     return MMX_OK;
 }
 
+template <int DT, bool MM>
+int launch_fwd_mm(const AttnFwdArgs& a, dim3 grid, hipStream_t s) {
+    return a.D <= 32
+        ? launch_stream(attn_fwd_stream_kernel<32, DT, MM>, a, grid, stream_lds_bytes<32>(2), s, "attn_fwd_stream_kernel<32>")
+        : launch_stream(attn_fwd_stream_kernel<64, DT, MM>, a, grid, stream_lds_bytes<64>(2), s, "attn_fwd_stream_kernel<64>");
+}
+
 template <int DT>
 int launch_fwd_dt(const AttnFwdArgs& a, dim3 grid, hipStream_t s) {
-    return a.D <= 32
-        ? launch_stream(attn_fwd_stream_kernel<32, DT>, a, grid, stream_lds_bytes<32>(2), s, "attn_fwd_stream_kernel<32>")
-        : launch_stream(attn_fwd_stream_kernel<64, DT>, a, grid, stream_lds_bytes<64>(2), s, "attn_fwd_stream_kernel<64>");
+    return a.mma_bf16 ? launch_fwd_mm<DT, true>(a, grid, s) : launch_fwd_mm<DT, false>(a, grid, s);
+}
+
+template <int DT, bool MM>
+int launch_bwd_mm(const AttnBwdArgs& a, dim3 gq, dim3 gk, hipStream_t s) {
+    const bool small_d = a.D <= 32;
+    int rc = small_d ? launch_stream(attn_bwd_q_stream_kernel<32, DT, MM>, a, gq, stream_lds_bytes<32>(2), s,
+                                     "attn_bwd_q_stream_kernel<32>")
+                     : launch_stream(attn_bwd_q_stream_kernel<64, DT, MM>, a, gq, stream_lds_bytes<64>(2), s,
+                                     "attn_bwd_q_stream_kernel<64>");
+    if (rc == MMX_OK && a.need_dqkv) {
+        // the key-side kernel's LDS: two operand tiles + 64 deltas (the 4 x 16 x 68 floats of the wave tiles cover it)
+        rc = small_d ? launch_stream(attn_bwd_kv_stream_kernel<32, DT, MM>, a, gk, stream_lds_bytes<32>(2), s,
+                                     "attn_bwd_kv_stream_kernel<32>")
+                     : launch_stream(attn_bwd_kv_stream_kernel<64, DT, MM>, a, gk, stream_lds_bytes<64>(2), s,
+                                     "attn_bwd_kv_stream_kernel<64>");
+    }
+    return rc;
+}
+
+template <int DT>
+int launch_bwd_rel(const AttnBwdArgs& a, dim3 gq, dim3 gk, hipStream_t s) {
+    const bool small_d = a.D <= 32;
+    constexpr size_t kRel = sizeof(float) * 16 * kTile;
+    int rc = small_d ? launch_stream(attn_bwd_q_stream_kernel<32, DT, true, true>, a, gq, stream_lds_bytes<32>(2) + kRel, s,
+                                     "attn_bwd_q_stream_kernel<32, rel>")
+                     : launch_stream(attn_bwd_q_stream_kernel<64, DT, true, true>, a, gq, stream_lds_bytes<64>(2) + kRel, s,
+                                     "attn_bwd_q_stream_kernel<64, rel>");
+    if (rc == MMX_OK && a.need_dqkv) {
+        rc = small_d ? launch_stream(attn_bwd_kv_stream_kernel<32, DT, true>, a, gk, stream_lds_bytes<32>(2), s,
+                                     "attn_bwd_kv_stream_kernel<32>")
+                     : launch_stream(attn_bwd_kv_stream_kernel<64, DT, true>, a, gk, stream_lds_bytes<64>(2), s,
+                                     "attn_bwd_kv_stream_kernel<64>");
+    }
+    return rc;
 }
 
 template <int DT>
 int launch_bwd_dt(const AttnBwdArgs& a, dim3 gq, dim3 gk, hipStream_t s) {
-    const bool small_d = a.D <= 32;
-    int rc = small_d ? launch_stream(attn_bwd_q_stream_kernel<32, DT>, a, gq, stream_lds_bytes<32>(2), s,
-                                     "attn_bwd_q_stream_kernel<32>")
-                     : launch_stream(attn_bwd_q_stream_kernel<64, DT>, a, gq, stream_lds_bytes<64>(2), s,
-                                     "attn_bwd_q_stream_kernel<64>");
-    if (rc == MMX_OK && a.need_dqkv) {
-        // the key-side kernel's LDS: two operand tiles + 64 deltas (the 4 x 16 x 68 floats of the wave tiles cover it)
-        rc = small_d ? launch_stream(attn_bwd_kv_stream_kernel<32, DT>, a, gk, stream_lds_bytes<32>(2), s,
-                                     "attn_bwd_kv_stream_kernel<32>")
-                     : launch_stream(attn_bwd_kv_stream_kernel<64, DT>, a, gk, stream_lds_bytes<64>(2), s,
-                                     "attn_bwd_kv_stream_kernel<64>");
-    }
-    return rc;
+    if (a.rel_v) return launch_bwd_rel<DT>(a, gq, gk, s);
+    return a.mma_bf16 ? launch_bwd_mm<DT, true>(a, gq, gk, s) : launch_bwd_mm<DT, false>(a, gq, gk, s);
 }
 
 }  // namespace
@@ -543,7 +716,7 @@ void attn_stream_enable(int on) { g_attn_stream = on & 1; }
 // returns 1 if the streaming kernel was launched (rc in *rc_out), 0 if the shape / layout is not eligible.
 // Slabs in fp16 / bf16 (slab_dt) exist on this path only: they ignore the "attn_stream" switch.
 int attn_fwd_stream_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out) {
-    if ((!g_attn_stream && a.slab_dt == MMX_F32) || a.D % 4 || a.D > 64) return 0;
+    if ((!g_attn_stream && a.slab_dt == MMX_F32 && !a.mma_bf16) || a.D % 4 || a.D > 64) return 0;
     if (!aligned16(a.q, a.qs) || !aligned16(a.k, a.ks) || !aligned16(a.v, a.vs)) return 0;
     dim3 grid(((a.Nq + kRows - 1) / kRows) * a.H * a.B);
     switch (a.slab_dt) {
@@ -556,7 +729,8 @@ int attn_fwd_stream_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out) {
 }
 
 int attn_bwd_stream_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out) {
-    if ((!g_attn_stream && a.slab_dt == MMX_F32) || a.D % 4 || a.D > 64) return 0;
+    if ((!g_attn_stream && a.slab_dt == MMX_F32 && !a.mma_bf16) || a.D % 4 || a.D > 64) return 0;
+    if (a.rel_v && !a.mma_bf16) return 0;
     if (!aligned16(a.v, a.vs) || !aligned16(a.dout, a.os)) return 0;
     if (a.need_dqkv && (!aligned16(a.q, a.qs) || !aligned16(a.k, a.ks))) return 0;
     dim3 gq(((a.Nq + kRows - 1) / kRows) * a.H * a.B), gk(((a.Nk + kRows - 1) / kRows) * a.H * a.B);

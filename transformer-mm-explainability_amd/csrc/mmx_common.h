@@ -143,6 +143,21 @@ __device__ __forceinline__ f32x4 mfma16x16x4(float a, float b, f32x4 acc) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
 }
 
+// bf16 MFMA, fp32 accumulate: D(16x16) += A(16x32) . B(32x16).  lane l holds A[l & 15][8 (l >> 4) + j] and
+// B[8 (l >> 4) + j][l & 15], j = 0..7; acc as for the fp32 form.  Both operands index the contraction the same way, so
+// any 8 values per lane may stand for slots j as long as A and B agree (the kernels pick the 8 that one b128 pair holds).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 pack_bf16(f32x4 lo, f32x4 hi) {     // round to nearest even (v_cvt_pk_bf16_f32)
+    bf16x8 r;
+    r[0] = static_cast<__bf16>(lo[0]); r[1] = static_cast<__bf16>(lo[1]); r[2] = static_cast<__bf16>(lo[2]);
+    r[3] = static_cast<__bf16>(lo[3]); r[4] = static_cast<__bf16>(hi[0]); r[5] = static_cast<__bf16>(hi[1]);
+    r[6] = static_cast<__bf16>(hi[2]); r[7] = static_cast<__bf16>(hi[3]);
+    return r;
+}
+__device__ __forceinline__ f32x4 mfma16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (its workgroup fence covers
 // global memory), which would serialise every in-flight global prefetch behind the barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

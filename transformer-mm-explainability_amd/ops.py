@@ -241,12 +241,7 @@ def layernorm_bwd_add(dy, x, mean, rstd, gamma, d_res=None):
 _GEMM_WEIGHTS = {}   # id(parameter) -> {dtype: (version, converted copy)}; the entry is dropped when the parameter dies
 
 
-def backward_gemm(x, weight, dtype=torch.float32):
-    """``x @ weight`` for the hand-written (shared-forward) backward passes.  ``dtype=torch.bfloat16`` (opt-in per tower /
-    body, ``backward_gemm_dtype``) runs it on the bf16 MFMA with fp32 accumulation and an fp32 result; the converted
-    weight is cached until the parameter is modified in place.  A plain library GEMM either way (hipBLASLt / rocBLAS)."""
-    if dtype == torch.float32:
-        return torch.matmul(x, weight)
+def _converted(weight, dtype):
     per_weight = _GEMM_WEIGHTS.get(id(weight))
     if per_weight is None:
         per_weight = _GEMM_WEIGHTS[id(weight)] = {}
@@ -254,7 +249,44 @@ def backward_gemm(x, weight, dtype=torch.float32):
     hit = per_weight.get(dtype)
     if hit is None or hit[0] != weight._version or hit[1].device != weight.device:
         hit = per_weight[dtype] = (weight._version, weight.detach().to(dtype))
-    return torch.matmul(x.to(dtype), hit[1]).float()
+    return hit[1]
+
+
+_MM_OUT_DTYPE = [None]      # does torch.mm(a, b, out_dtype=torch.float32) work on this build / device?  probed once
+
+
+def _mm_f32_out(a, b):
+    """``a @ b`` for 2-D half-precision operands with an fp32 result straight from the GEMM's fp32 accumulators
+    (``aten::mm.dtype``) -- no rounding of the result to bf16 and no conversion pass; falls back to ``.float()``."""
+    if _MM_OUT_DTYPE[0] is None:
+        try:
+            torch.mm(a[:1], b, out_dtype=torch.float32)
+            _MM_OUT_DTYPE[0] = True
+        except (RuntimeError, TypeError):
+            _MM_OUT_DTYPE[0] = False
+    if _MM_OUT_DTYPE[0]:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    return torch.mm(a, b).float()
+
+
+def backward_gemm(x, weight, dtype=torch.float32):
+    """``x @ weight`` for the hand-written (shared-forward) backward passes.  ``dtype=torch.bfloat16`` (opt-in per tower /
+    body, ``backward_gemm_dtype``) runs it on the bf16 MFMA with fp32 accumulation and an fp32 result; the converted
+    weight is cached until the parameter is modified in place.  A plain library GEMM either way (hipBLASLt / rocBLAS)."""
+    if dtype == torch.float32:
+        return torch.matmul(x, weight)
+    w = _converted(weight, dtype)
+    return _mm_f32_out(x.reshape(-1, x.shape[-1]).to(dtype), w).view(*x.shape[:-1], w.shape[-1])
+
+
+def linear(x, weight, bias=None, dtype=torch.float32):
+    """``F.linear`` for the tape forward passes; ``dtype=torch.bfloat16`` (a bf16 body, ``forward_gemm_dtype``) rounds
+    ``x`` and the (cached) weight to bf16, accumulates in fp32 and returns fp32."""
+    if dtype == torch.float32:
+        return torch.nn.functional.linear(x, weight, bias)
+    w = _converted(weight, dtype)
+    y = _mm_f32_out(x.reshape(-1, x.shape[-1]).to(dtype), w.t()).view(*x.shape[:-1], w.shape[0])
+    return y if bias is None else y.add_(bias)
 
 
 class ChainPlan:
@@ -449,9 +481,11 @@ def _bhnd_strides(t, layout):
     raise MMXError("layout %r" % layout)
 
 
-def attn_capture_fwd(q, k, v, probs_out, scale, scale_mode=_lib.SCALE_Q_FIRST, mask=None, layout="bnhd"):
+def attn_capture_fwd(q, k, v, probs_out, scale, scale_mode=_lib.SCALE_Q_FIRST, mask=None, layout="bnhd", mma_bf16=False):
     """``q``: ``[B, Nq, H, D]`` view (``layout='bnhd'``) or ``[B, H, Nq, D]``; writes P into ``probs_out``
-    (``[B, H, Nq, Nk]`` fp32 contiguous, caller-owned slab) and returns O in the same layout as q."""
+    (``[B, H, Nq, Nk]`` fp32 contiguous, caller-owned slab) and returns O in the same layout as q.
+    ``mma_bf16``: products on the bf16 matrix cores (``MMX_ATTN_MMA_BF16``: operands rounded to bf16, fp32 accumulate
+    and softmax; long-sequence streaming kernels only)."""
     _dev(q, k, v, probs_out, mask)
     if q.dtype != torch.float32 or k.dtype != torch.float32 or v.dtype != torch.float32:
         raise MMXError("attention capture op is fp32 in this ABI version")
@@ -476,21 +510,26 @@ def attn_capture_fwd(q, k, v, probs_out, scale, scale_mode=_lib.SCALE_Q_FIRST, m
             raise MMXError("mask must be [Nq,Nk] or [B,Nq|1,Nk]")
     check(lib().mmx_attn_capture_fwd_ex(_p(q), _p(k), _p(v), *_bhnd_strides(q, layout), *_bhnd_strides(k, layout),
                                         *_bhnd_strides(v, layout), _p(mask), msb, msq, _p(probs_out),
-                                        _DTYPES[probs_out.dtype], _p(o), *_bhnd_strides(o, layout), B, H, Nq, Nk, D,
+                                        _DTYPES[probs_out.dtype] | (_lib.MMX_ATTN_MMA_BF16 if mma_bf16 else 0),
+                                        _p(o), *_bhnd_strides(o, layout), B, H, Nq, Nk, D,
                                         float(scale), scale_mode, _stream()), "mmx_attn_capture_fwd")
     return o
 
 
 def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCALE_Q_FIRST, need_dqkv=True,
-                     layout="bnhd", out=None, batch=None, o=None):
+                     layout="bnhd", out=None, batch=None, o=None, mma_bf16=False, rel_row=None):
     """Writes dP into ``dprobs_out`` and returns ``(dq, dk, dv)`` (``None`` when ``need_dqkv`` is False).
     ``out=(dq, dk, dv)`` lets the caller hand in (strided) views, e.g. of one packed dqkv tensor.
     ``batch``: shared-forward mode -- q/k/v/probs come from ONE forward (batch 1) and are broadcast (stride 0) over the
     ``batch`` upstream gradients in ``d_o``; dq/dk/dv/dprobs are per sample.
-    ``o``: the forward's output (same layout as ``q``), optional: saves the long-sequence kernels a sweep over the keys."""
-    _dev(q, k, v, probs, d_o, dprobs_out)
-    if probs.dtype not in _DTYPES or probs.dtype != dprobs_out.dtype:
+    ``o``: the forward's output (same layout as ``q``), optional: saves the long-sequence kernels a sweep over the keys.
+    ``rel_row`` (``[B, N]`` fp32; row-relevancy mode, ``mmx_attn_capture_bwd_rowrel``): returns
+    ``(dq, dk, dv, rel_row + rel_row . mean_h clamp(dP * P, 0))``; ``dprobs_out`` may then be ``None`` (dP is not stored)."""
+    _dev(q, k, v, probs, d_o, dprobs_out, rel_row)
+    if probs.dtype not in _DTYPES or (dprobs_out is not None and probs.dtype != dprobs_out.dtype):
         raise MMXError("attn_capture_bwd: probs / dprobs slabs must share one of fp32 / fp16 / bf16")
+    if dprobs_out is None and rel_row is None:
+        raise MMXError("attn_capture_bwd: no dprobs slab (only the row-relevancy mode runs without one)")
     if layout == "bnhd":
         B, Nq, H, D = q.shape
         Nk = k.shape[1]
@@ -521,9 +560,26 @@ def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCA
     zero3 = (0, 0, 0)
     if o is not None and (o.dtype != torch.float32 or o.stride(-1) != 1):
         o = None                                               # only a hint: fall back to the two-sweep form
+    if rel_row is not None:
+        if not mma_bf16 or rel_row.dtype != torch.float32 or tuple(rel_row.shape) != (B, Nq) or Nq != Nk:
+            raise MMXError("attn_capture_bwd: rel_row must be fp32 [B, N] of a self-attention, with mma_bf16=True")
+        rel_row = rel_row.contiguous()
+        rel_out = torch.empty_like(rel_row)
+        need = lib().mmx_attn_capture_bwd_rowrel_workspace_bytes(B, H, Nq, Nk)
+        ws = _workspace(need, q.device, "attn_bwd")
+        check(lib().mmx_attn_capture_bwd_rowrel(
+            _p(q), _p(k), _p(v), *_bhnd_strides(q, layout), *_bhnd_strides(k, layout), *_bhnd_strides(v, layout),
+            _p(probs), probs_sb, _DTYPES[probs.dtype] | _lib.MMX_ATTN_MMA_BF16, _p(d_o), *_bhnd_strides(d_o, layout),
+            _p(o), *(_bhnd_strides(o, layout) if o is not None else zero3), _p(dprobs_out), _p(dq), _p(dk), _p(dv),
+            *(_bhnd_strides(dq, layout) if need_dqkv else zero3), *(_bhnd_strides(dk, layout) if need_dqkv else zero3),
+            *(_bhnd_strides(dv, layout) if need_dqkv else zero3),
+            B, H, Nq, Nk, D, float(scale), scale_mode, int(need_dqkv), _p(rel_row), _p(rel_out), _p(ws), need, _stream()),
+            "mmx_attn_capture_bwd_rowrel")
+        return dq, dk, dv, rel_out
     check(lib().mmx_attn_capture_bwd_ex(
         _p(q), _p(k), _p(v), *_bhnd_strides(q, layout), *_bhnd_strides(k, layout), *_bhnd_strides(v, layout),
-        _p(probs), probs_sb, _DTYPES[probs.dtype], _p(d_o), *_bhnd_strides(d_o, layout),
+        _p(probs), probs_sb, _DTYPES[probs.dtype] | (_lib.MMX_ATTN_MMA_BF16 if mma_bf16 else 0),
+        _p(d_o), *_bhnd_strides(d_o, layout),
         _p(o), *(_bhnd_strides(o, layout) if o is not None else zero3), _p(dprobs_out), _p(dq), _p(dk), _p(dv),
         *(_bhnd_strides(dq, layout) if need_dqkv else zero3), *(_bhnd_strides(dk, layout) if need_dqkv else zero3),
         *(_bhnd_strides(dv, layout) if need_dqkv else zero3),
