@@ -37,6 +37,9 @@ enum mmx_dtype { MMX_F32 = 0, MMX_F16 = 1, MMX_BF16 = 2 };
  * cores (v_mfma_f32_16x16x32_bf16: operands rounded to bf16 as they are read, fp32 accumulation, softmax / dS arithmetic in
  * fp32) instead of the exact-fp32 MFMA.  BASELINE config 5 (a bf16 CLIP body, CLIP/clip/model.py:381-402). */
 #define MMX_ATTN_MMA_BF16 0x100
+/* Backward only, together with MMX_ATTN_MMA_BF16: `do_dev` holds bf16 and dq / dk / dv are written as bf16 (the gradient
+ * stream between the bf16 GEMMs of a bf16 body needs no conversion passes); strides stay in elements, 16-byte aligned. */
+#define MMX_ATTN_IO_BF16 0x200
 
 enum mmx_status {
     MMX_OK = 0,
@@ -313,6 +316,13 @@ int mmx_quick_gelu_fwd(const void* x_dev, void* y_dev, int64_t n, void* stream);
 int mmx_quick_gelu_bwd(const void* x_dev, const void* dy_dev, void* dx_dev, int64_t n, void* stream);
 /* Same with x ([x_n] elements) broadcast over the leading dimension of dy / dx ([n] elements, n % x_n == 0, x_n % 4 == 0):
  * the shared-forward backward has ONE activation tensor for B upstream gradients. */
+/* bf16 gradient stream (BASELINE config 5's bf16 body): dy / dx bf16, x fp32 (broadcast over the batch as above; x_n % 8 == 0);
+ * LayerNorm backward + residual with a bf16 upstream gradient, written as fp32 (`dx_dev`, the next residual) and / or bf16
+ * (`dx_bf16_dev`, the next GEMM's operand) -- either may be NULL. */
+int mmx_quick_gelu_bwd_bcast_bf16(const void* x_dev, const void* dy_dev, void* dx_dev, int64_t n, int64_t x_n, void* stream);
+int mmx_layernorm_bwd_add_bf16(const void* dy_dev, const void* x_dev, const void* mean_dev, const void* rstd_dev,
+                               const void* gamma_dev, const void* d_res_dev, void* dx_dev, void* dx_bf16_dev,
+                               int64_t rows, int x_rows, int E, void* stream);
 int mmx_quick_gelu_bwd_bcast(const void* x_dev, const void* dy_dev, void* dx_dev, int64_t n, int64_t x_n, void* stream);
 
 /* LayerNorm input gradient + residual add with forward statistics shared by the batch (shared-forward backward of the

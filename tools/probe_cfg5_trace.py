@@ -11,7 +11,8 @@ dev = torch.device("cuda")
 model = clip_model.random_init("ViT-L/14@336", seed=0).to(dev)
 model.set_body_dtype(torch.bfloat16)
 image = torch.randn(1, 3, 336, 336, device=dev)
-texts = torch.zeros(32, 77, dtype=torch.long)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+texts = torch.zeros(B, 77, dtype=torch.long)
 texts[:, 0] = 49406
 texts[:, 1:6] = 1000
 texts[:, 6] = 49407

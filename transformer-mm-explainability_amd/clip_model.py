@@ -242,6 +242,12 @@ class Transformer(nn.Module):
         buffers = self.buffers
         top = self.layers - 1
         dx = dy
+        mma = bool(getattr(self, "attention_mma_bf16", False)) and N > 128
+        # bf16 body on the streaming kernels: the gradients BETWEEN the GEMMs are bf16 (what the bf16 GEMMs produce and
+        # consume; the elementwise kernels and the attention backward read / write bf16 directly -- no conversion
+        # passes), the residual gradient stream (dx, d_x1) stays fp32
+        stream16 = mma and getattr(self, "backward_gemm_dtype", torch.float32) == torch.bfloat16
+        dx_h = None
         for l in range(top, first_grad_layer - 1, -1):
             blk = self.resblocks[l]
             at = blk.attn
@@ -249,6 +255,16 @@ class Transformer(nn.Module):
             shared = x.shape[0] != B
             if l == top and dy_rows is not None:
                 d_x1, d_o = self._top_block_rows(blk, tape[l], dy, dy_rows, shared)
+                if stream16:
+                    d_o = d_o.to(torch.bfloat16)
+            elif stream16:
+                if dx_h is None:
+                    dx_h = dx.to(torch.bfloat16)
+                d_a = ops.backward_gemm_bf16(dx_h, blk.mlp.c_proj.weight)
+                d_m = ops.quick_gelu_bwd(m, d_a)
+                d_h2 = ops.backward_gemm_bf16(d_m, blk.mlp.c_fc.weight)
+                d_x1, d_x1_h = ops.layernorm_bwd_add_bf16(d_h2, x1, mean2, rstd2, blk.ln_2.weight, dx)
+                d_o = ops.backward_gemm_bf16(d_x1_h, at.out_proj.weight)
             else:
                 # MLP branch: x2 = x1 + c_proj(m * sigmoid(1.702 m)),  m = c_fc(ln_2(x1))
                 d_a = self._gemm(dx, blk.mlp.c_proj.weight)
@@ -259,20 +275,22 @@ class Transformer(nn.Module):
                 d_o = self._gemm(d_x1, at.out_proj.weight)
             d_o = d_o.view(B, N, at.num_heads, at.head_dim)
             need = l > first_grad_layer                                       # nothing below needs gradients
-            dqkv = torch.empty(B, N, 3, at.num_heads, at.head_dim, dtype=torch.float32, device=dy.device) if need else None
+            dqkv = torch.empty(B, N, 3, at.num_heads, at.head_dim, dtype=d_o.dtype, device=dy.device) if need else None
             out = (dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]) if need else None
             res = ops.attn_capture_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], buffers.probs[l], d_o,
                                        buffers.grads[l] if buffers.grads is not None else None,
                                        at.head_dim ** -0.5, _lib.SCALE_Q_FIRST, need_dqkv=need, layout="bnhd", out=out,
-                                       batch=B if shared else None, o=o_fwd,
-                                       mma_bf16=bool(getattr(self, "attention_mma_bf16", False)) and N > 128,
-                                       rel_row=rel_row)
+                                       batch=B if shared else None, o=o_fwd, mma_bf16=mma, rel_row=rel_row)
             if rel_row is not None:
                 rel_row = res[3]
             if not need:
                 break
-            d_h1 = self._gemm(dqkv.view(B, N, 3 * E), at.in_proj_weight)
-            dx = ops.layernorm_bwd_add(d_h1, x, mean1, rstd1, blk.ln_1.weight, d_x1)
+            if stream16:
+                d_h1 = ops.backward_gemm_bf16(dqkv.view(B, N, 3 * E), at.in_proj_weight)
+                dx, dx_h = ops.layernorm_bwd_add_bf16(d_h1, x, mean1, rstd1, blk.ln_1.weight, d_x1)
+            else:
+                d_h1 = self._gemm(dqkv.view(B, N, 3 * E), at.in_proj_weight)
+                dx = ops.layernorm_bwd_add(d_h1, x, mean1, rstd1, blk.ln_1.weight, d_x1)
         return rel_row
 
     def _top_block_rows(self, blk, entry, dy, rows, shared):

@@ -38,6 +38,9 @@ struct AttnBwdArgs {
     // its head into rel_part[b][h * nrt + row_tile][k]; rel_v == nullptr: off.
     const float* rel_v;
     float* rel_part;
+    // MMX_ATTN_IO_BF16 (bf16-MFMA streaming kernels only): `dout` is bf16 and dq / dk / dv are written as bf16 (the
+    // gradient stream between the bf16 GEMMs of a bf16 body); strides stay in elements.  q / k / v / o / delta: fp32.
+    int io_bf16;
 };
 
 int attn_fwd_head_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out);    // attention_head.hip (register-resident)

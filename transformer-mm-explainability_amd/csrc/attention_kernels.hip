@@ -416,6 +416,8 @@ static int attn_bwd_impl(const void* q_dev, const void* k_dev, const void* v_dev
                                        void* stream, const void* rel_in_dev, void* rel_out_dev) {
     const bool rel = rel_in_dev != nullptr;
     MMX_CHECK_ARG(v_dev && probs_dev && do_dev && (dprobs_dev || rel), "mmx_attn_capture_bwd: null pointer");
+    const int io_bf16 = (slab_dtype & MMX_ATTN_IO_BF16) ? 1 : 0;
+    MMX_CHECK_ARG(!io_bf16 || (slab_dtype & MMX_ATTN_MMA_BF16), "mmx_attn_capture_bwd: MMX_ATTN_IO_BF16 needs MMX_ATTN_MMA_BF16");
     if (rel) {
         MMX_CHECK_ARG(rel_out_dev && Nq == Nk, "mmx_attn_capture_bwd_rowrel: needs rel_out and self-attention (Nq == Nk)");
         MMX_CHECK_ARG(slab_dtype & MMX_ATTN_MMA_BF16, "mmx_attn_capture_bwd_rowrel: MMX_ATTN_MMA_BF16 kernels only");
@@ -426,7 +428,7 @@ static int attn_bwd_impl(const void* q_dev, const void* k_dev, const void* v_dev
         }
     }
     const int mma_bf16 = (slab_dtype & MMX_ATTN_MMA_BF16) ? 1 : 0;
-    slab_dtype &= ~MMX_ATTN_MMA_BF16;
+    slab_dtype &= ~(MMX_ATTN_MMA_BF16 | MMX_ATTN_IO_BF16);
     MMX_CHECK_ARG(slab_dtype == MMX_F32 || slab_dtype == MMX_F16 || slab_dtype == MMX_BF16,
                   "mmx_attn_capture_bwd: slab dtype %d", slab_dtype);
     int rc = check_attn_dims("mmx_attn_capture_bwd", B, H, Nq, Nk, D, scale_mode);
@@ -453,6 +455,7 @@ static int attn_bwd_impl(const void* q_dev, const void* k_dev, const void* v_dev
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale; a.scale_mode = scale_mode; a.need_dqkv = need_dqkv;
     a.slab_dt = slab_dtype;
     a.mma_bf16 = mma_bf16;
+    a.io_bf16 = io_bf16;
     a.rel_v = static_cast<const float*>(rel_in_dev);
     a.rel_part = rel ? reinterpret_cast<float*>(static_cast<char*>(workspace_dev) + rowrel_delta_bytes(B, H, Nq)) : nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -78,6 +78,67 @@ __device__ __forceinline__ void load_a_rows(f32x4 (&a)[DP / 16], const float* ba
     }
 }
 
+// ---- the same two loaders for a bf16 operand in global memory (MMX_ATTN_IO_BF16: dO): 8-byte loads, widened to fp32
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 widen_bf16x4(u32x2 r) {
+    return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+                 __uint_as_float(r[1] & 0xffff0000u)};
+}
+template <int DP>
+__device__ __forceinline__ void tile_fetch_h(f32x4 (&reg)[DP / 16], const unsigned short* base, int64_t sn, int row0,
+                                             int rows_total, int D, int tid) {
+    constexpr int C4 = DP / 4;
+#pragma unroll
+    for (int e = 0; e < DP / 16; ++e) {
+        const int f = tid + kThreads * e;
+        const int row = row0 + f / C4, c = (f % C4) * 4;
+        const bool ok = row < rows_total && c < D;
+        const u32x2 v = *reinterpret_cast<const u32x2*>(base + (ok ? static_cast<int64_t>(row) * sn + c : 0));
+        reg[e] = ok ? widen_bf16x4(v) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+template <int DP>
+__device__ __forceinline__ void load_a_rows_h(f32x4 (&a)[DP / 16], const unsigned short* base, int64_t sn, int row, int D,
+                                              int g) {
+#pragma unroll
+    for (int blk = 0; blk < DP / 16; ++blk) {
+        const int d0 = 16 * blk + 4 * g;
+        const bool ok = d0 < D;
+        const u32x2 v = *reinterpret_cast<const u32x2*>(base + static_cast<int64_t>(row) * sn + (ok ? d0 : 0));
+        a[blk] = ok ? widen_bf16x4(v) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// bf16 epilogue of a C-layout accumulator (lane (i, g): rows 4g + r, column 16 dt + i).  Element-wise that is one 2-byte
+// store per value; here lanes i and i ^ 1 swap one value per row pair (DPP quad_perm, no LDS), so the even lane owns rows
+// r = 0, 2 and the odd lane rows r = 1, 3 as (column, column + 1) PAIRS: 4-byte stores, half as many.
+__device__ __forceinline__ float dpp_swap1(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));   // quad_perm:[1,0,3,2]
+}
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    bf2 r;
+    r[0] = static_cast<__bf16>(lo);
+    r[1] = static_cast<__bf16>(hi);
+    return __builtin_bit_cast(unsigned, r);
+}
+// v[r]: this lane's 4 row values of column `col`; row_ok(r) / row_idx(r) describe row r.  All lanes must call it.
+template <typename RowOk, typename RowIdx>
+__device__ __forceinline__ void store_rows_bf16_pairs(float* base, int64_t off0, int64_t sn, int col, int D, const f32x4& v,
+                                                      int i, RowOk row_ok, RowIdx row_idx) {
+    const bool odd = i & 1;
+    unsigned short* out = reinterpret_cast<unsigned short*>(base);
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {
+        const float mine = odd ? v[2 * rp + 1] : v[2 * rp];              // the value of the row this lane will write
+        const float recv = dpp_swap1(odd ? v[2 * rp] : v[2 * rp + 1]);   // the partner's value of that same row
+        const int r = 2 * rp + (odd ? 1 : 0);
+        const int c0 = col - (odd ? 1 : 0);                               // even column of the pair
+        if (row_ok(r) && c0 < D)
+            *reinterpret_cast<unsigned*>(out + off0 + row_idx(r) * sn + c0) = odd ? pack2_bf16(recv, mine) : pack2_bf16(mine, recv);
+    }
+}
+
 // C_t[16 x 16] = A_regs[16 x D] . T_t^T for the four 16-row sub-tiles t of the LDS tile ([row][d], contiguous in d).
 // The four accumulator chains are issued round-robin: a dependent v_mfma_f32_16x16x4_f32 has 40 cycles of latency
 // against a 32-cycle issue rate, and anything the compiler slips between two MFMAs on the SAME accumulator costs a
@@ -320,7 +381,7 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_ke
 // REL (row-relevancy mode, see AttnBwdArgs::rel_v): the product the relevancy rules need from this layer -- one ROW of
 // R + A_bar.R, i.e. v.A_bar with A_bar = mean_h clamp(dP * P, 0) -- is reduced here from the dP / P values the sweep
 // already holds, so dP is neither stored nor re-read and no A_bar matrix exists.
-template <int DP, int DT, bool MM, bool REL = false>
+template <int DP, int DT, bool MM, bool REL = false, bool IOH = false>
 __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_kernel(const AttnBwdArgs a) {
     typedef typename slab_elem<DT>::type slab_t;
     constexpr int LS = DP + 4, NB = DP / 16;
@@ -340,7 +401,11 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
     const int64_t head = static_cast<int64_t>(b) * a.H + h;
 
     f32x4 doa[NB];
-    load_a_rows<DP>(doa, dob, a.os.sn, min(rw + i, a.Nq - 1), a.D, g, 1.f);
+    if constexpr (IOH)
+        load_a_rows_h<DP>(doa, reinterpret_cast<const unsigned short*>(a.dout) + b * a.os.sb + h * a.os.sh, a.os.sn,
+                          min(rw + i, a.Nq - 1), a.D, g);
+    else
+        load_a_rows<DP>(doa, dob, a.os.sn, min(rw + i, a.Nq - 1), a.D, g, 1.f);
     bf16x8 doa_pk[DP / 32];
     if constexpr (MM) pack_a_rows<DP>(doa_pk, doa);
     auto dp_tile = [&](f32x4 (&dp)[4]) {
@@ -492,14 +557,22 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
         rel_flush(ntiles - 1);
     }
     if (!a.need_dqkv) return;
-    float* dqb = a.dq + b * a.dqs.sb + h * a.dqs.sh;
+    const int64_t dq0 = b * a.dqs.sb + h * a.dqs.sh;
     const float mul = q_first ? a.scale : 1.f;
+    if constexpr (IOH) {
 #pragma unroll
-    for (int dt = 0; dt < NB; ++dt)
+        for (int dt = 0; dt < NB; ++dt)
+            store_rows_bf16_pairs(a.dq, dq0, a.dqs.sn, 16 * dt + i, a.D, (qacc[0][dt] + qacc[1][dt]) * mul, i,
+                                  [&](int r) { return rw + 4 * g + r < a.Nq; },
+                                  [&](int r) { return static_cast<int64_t>(rw + 4 * g + r); });
+    } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (rows[r] < a.Nq && 16 * dt + i < a.D)
-                dqb[static_cast<int64_t>(rows[r]) * a.dqs.sn + 16 * dt + i] = (qacc[0][dt][r] + qacc[1][dt][r]) * mul;
+        for (int dt = 0; dt < NB; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (rows[r] < a.Nq && 16 * dt + i < a.D)
+                    a.dq[dq0 + static_cast<int64_t>(rows[r]) * a.dqs.sn + 16 * dt + i] = (qacc[0][dt][r] + qacc[1][dt][r]) * mul;
+    }
 }
 
 // =============================================================================================== backward, key side
@@ -508,7 +581,7 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
 // 16 rb + 4 g + s of key column j0 + i -- 16 consecutive keys per row segment, no LDS staging.
 // MM (bf16 MFMA): dP of the tile is RECOMPUTED (dO tile from LDS . this wave's V rows held in registers -- two bf16
 // MFMAs per 16 queries) instead of being read back from the slab the query-side kernel just wrote: one N^2 read less.
-template <int DP, int DT, bool MM>
+template <int DP, int DT, bool MM, bool IOH = false>
 __global__ __launch_bounds__(kThreads) void attn_bwd_kv_stream_kernel(const AttnBwdArgs a) {
     typedef typename slab_elem<DT>::type slab_t;
     constexpr int LS = DP + 4, NB = DP / 16;
@@ -547,7 +620,11 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_kv_stream_kernel(const Attn
     float dlreg = 0.f;
     auto fetch = [&](int qt) {
         tile_fetch<DP>(qreg, qb, a.qs.sn, qt * kTile, a.Nq, a.D, tid);
-        tile_fetch<DP>(doreg, dob, a.os.sn, qt * kTile, a.Nq, a.D, tid);
+        if constexpr (IOH)
+            tile_fetch_h<DP>(doreg, reinterpret_cast<const unsigned short*>(a.dout) + b * a.os.sb + h * a.os.sh, a.os.sn,
+                             qt * kTile, a.Nq, a.D, tid);
+        else
+            tile_fetch<DP>(doreg, dob, a.os.sn, qt * kTile, a.Nq, a.D, tid);
         if (tid < kTile) {
             const int row = qt * kTile + tid;
             const float v = a.delta[head * a.Nq + min(row, a.Nq - 1)];
@@ -626,18 +703,27 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_kv_stream_kernel(const Attn
             }
         }
     }
-    float* dkb = a.dk + b * a.dks.sb + h * a.dks.sh;
-    float* dvb = a.dv + b * a.dvs.sb + h * a.dvs.sh;
+    const int64_t dk0 = b * a.dks.sb + h * a.dks.sh, dv0 = b * a.dvs.sb + h * a.dvs.sh;
+    if constexpr (IOH) {
+        auto ok = [&](int r) { return kw + 4 * g + r < a.Nk; };
+        auto idx = [&](int r) { return static_cast<int64_t>(kw + 4 * g + r); };
 #pragma unroll
-    for (int dt = 0; dt < NB; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = kw + 4 * g + r, d = 16 * dt + i;
-            if (j < a.Nk && d < a.D) {
-                dkb[static_cast<int64_t>(j) * a.dks.sn + d] = kacc[dt][r];
-                dvb[static_cast<int64_t>(j) * a.dvs.sn + d] = vacc[dt][r];
-            }
+        for (int dt = 0; dt < NB; ++dt) {
+            store_rows_bf16_pairs(a.dk, dk0, a.dks.sn, 16 * dt + i, a.D, kacc[dt], i, ok, idx);
+            store_rows_bf16_pairs(a.dv, dv0, a.dvs.sn, 16 * dt + i, a.D, vacc[dt], i, ok, idx);
         }
+    } else {
+#pragma unroll
+        for (int dt = 0; dt < NB; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = kw + 4 * g + r, d = 16 * dt + i;
+                if (j < a.Nk && d < a.D) {
+                    a.dk[dk0 + static_cast<int64_t>(j) * a.dks.sn + d] = kacc[dt][r];
+                    a.dv[dv0 + static_cast<int64_t>(j) * a.dvs.sn + d] = vacc[dt][r];
+                }
+            }
+    }
 }
 
 bool aligned16(const float* p, const Strides& s) {
@@ -686,27 +772,29 @@ int launch_bwd_mm(const AttnBwdArgs& a, dim3 gq, dim3 gk, hipStream_t s) {
     return rc;
 }
 
-template <int DT>
-int launch_bwd_rel(const AttnBwdArgs& a, dim3 gq, dim3 gk, hipStream_t s) {
+// bf16-MFMA kernels with the optional modes: REL (row relevancy) and IOH (bf16 gradient stream)
+template <int DT, bool REL, bool IOH>
+int launch_bwd_bf16(const AttnBwdArgs& a, dim3 gq, dim3 gk, hipStream_t s) {
     const bool small_d = a.D <= 32;
-    constexpr size_t kRel = sizeof(float) * 16 * kTile;
-    int rc = small_d ? launch_stream(attn_bwd_q_stream_kernel<32, DT, true, true>, a, gq, stream_lds_bytes<32>(2) + kRel, s,
-                                     "attn_bwd_q_stream_kernel<32, rel>")
-                     : launch_stream(attn_bwd_q_stream_kernel<64, DT, true, true>, a, gq, stream_lds_bytes<64>(2) + kRel, s,
-                                     "attn_bwd_q_stream_kernel<64, rel>");
+    constexpr size_t kRel = REL ? sizeof(float) * 16 * kTile : 0;
+    int rc = small_d ? launch_stream(attn_bwd_q_stream_kernel<32, DT, true, REL, IOH>, a, gq, stream_lds_bytes<32>(2) + kRel, s,
+                                     "attn_bwd_q_stream_kernel<32, bf16>")
+                     : launch_stream(attn_bwd_q_stream_kernel<64, DT, true, REL, IOH>, a, gq, stream_lds_bytes<64>(2) + kRel, s,
+                                     "attn_bwd_q_stream_kernel<64, bf16>");
     if (rc == MMX_OK && a.need_dqkv) {
-        rc = small_d ? launch_stream(attn_bwd_kv_stream_kernel<32, DT, true>, a, gk, stream_lds_bytes<32>(2), s,
-                                     "attn_bwd_kv_stream_kernel<32>")
-                     : launch_stream(attn_bwd_kv_stream_kernel<64, DT, true>, a, gk, stream_lds_bytes<64>(2), s,
-                                     "attn_bwd_kv_stream_kernel<64>");
+        rc = small_d ? launch_stream(attn_bwd_kv_stream_kernel<32, DT, true, IOH>, a, gk, stream_lds_bytes<32>(2), s,
+                                     "attn_bwd_kv_stream_kernel<32, bf16>")
+                     : launch_stream(attn_bwd_kv_stream_kernel<64, DT, true, IOH>, a, gk, stream_lds_bytes<64>(2), s,
+                                     "attn_bwd_kv_stream_kernel<64, bf16>");
     }
     return rc;
 }
 
 template <int DT>
 int launch_bwd_dt(const AttnBwdArgs& a, dim3 gq, dim3 gk, hipStream_t s) {
-    if (a.rel_v) return launch_bwd_rel<DT>(a, gq, gk, s);
-    return a.mma_bf16 ? launch_bwd_mm<DT, true>(a, gq, gk, s) : launch_bwd_mm<DT, false>(a, gq, gk, s);
+    if (!a.mma_bf16) return launch_bwd_mm<DT, false>(a, gq, gk, s);
+    if (a.rel_v) return a.io_bf16 ? launch_bwd_bf16<DT, true, true>(a, gq, gk, s) : launch_bwd_bf16<DT, true, false>(a, gq, gk, s);
+    return a.io_bf16 ? launch_bwd_bf16<DT, false, true>(a, gq, gk, s) : launch_bwd_bf16<DT, false, false>(a, gq, gk, s);
 }
 
 }  // namespace
@@ -730,7 +818,7 @@ int attn_fwd_stream_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out) {
 
 int attn_bwd_stream_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out) {
     if ((!g_attn_stream && a.slab_dt == MMX_F32 && !a.mma_bf16) || a.D % 4 || a.D > 64) return 0;
-    if (a.rel_v && !a.mma_bf16) return 0;
+    if ((a.rel_v || a.io_bf16) && !a.mma_bf16) return 0;
     if (!aligned16(a.v, a.vs) || !aligned16(a.dout, a.os)) return 0;
     if (a.need_dqkv && (!aligned16(a.q, a.qs) || !aligned16(a.k, a.ks))) return 0;
     dim3 gq(((a.Nq + kRows - 1) / kRows) * a.H * a.B), gk(((a.Nk + kRows - 1) / kRows) * a.H * a.B);

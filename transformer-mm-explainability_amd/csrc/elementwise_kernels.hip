@@ -241,3 +241,116 @@ extern "C" int mmx_add_layernorm_fwd(const void* x_dev, const void* y_dev, const
     MMX_LAUNCH_CHECK("add_layernorm_fwd_kernel");
     return MMX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 gradient stream of a bf16 body (BASELINE config 5): the upstream gradients between the backward's GEMMs are bf16
+// (what the bf16 GEMMs produce and consume -- no conversion passes), the residual gradient stream stays fp32.
+//   * quick_gelu_bwd_bcast_bf16:  dx(bf16) = dy(bf16) * QuickGELU'(x),  x fp32 broadcast over the batch;
+//   * layernorm_bwd_add_bf16:     dx = d_res + LN'(dy), dy bf16, written as fp32 (the next residual) AND bf16 (the
+//                                 operand of the next GEMM).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace mmx {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ unsigned bf_pack(float a, float b) {        // round to nearest even (v_cvt_pk_bf16_f32)
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    bf2 r;
+    r[0] = static_cast<__bf16>(a);
+    r[1] = static_cast<__bf16>(b);
+    return __builtin_bit_cast(unsigned, r);
+}
+
+__global__ __launch_bounds__(256) void quick_gelu_bwd_bf16_kernel(const f32x4* __restrict__ x, const u32x4* __restrict__ dy,
+                                                                  u32x4* __restrict__ dx, int64_t n8, int64_t x_n8) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n8; i += static_cast<int64_t>(gridDim.x) * 256) {
+        const int64_t xi = (x_n8 == n8 ? i : i % x_n8) * 2;
+        const f32x4 v0 = x[xi], v1 = x[xi + 1];
+        const u32x4 g = dy[i];
+        float gv[8], xv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gv[2 * e] = bf_lo(g[e]); gv[2 * e + 1] = bf_hi(g[e]); }
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sg = sigmoid_f(1.702f * xv[e]);
+            o[e] = gv[e] * (sg + 1.702f * xv[e] * sg * (1.f - sg));
+        }
+        dx[i] = u32x4{bf_pack(o[0], o[1]), bf_pack(o[2], o[3]), bf_pack(o[4], o[5]), bf_pack(o[6], o[7])};
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_add_bf16_kernel(const unsigned short* __restrict__ dy,
+                                                                     const float* __restrict__ x, const float* __restrict__ mean,
+                                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                     const float* d_res, float* __restrict__ dx,
+                                                                     unsigned short* __restrict__ dx_h, int64_t rows, int x_rows,
+                                                                     int E) {
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int m = static_cast<int>(r % x_rows);
+    const u32x2* dyr = reinterpret_cast<const u32x2*>(dy + r * E);
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + static_cast<int64_t>(m) * E);
+    const f32x4* gm = reinterpret_cast<const f32x4*>(gamma);
+    const float mu = mean[m], rs = rstd[m];
+    const int n4 = E >> 2;
+    float a = 0.f, b = 0.f;
+    for (int i = lane; i < n4; i += 64) {
+        const u32x2 raw = dyr[i];
+        const f32x4 g = f32x4{bf_lo(raw[0]), bf_hi(raw[0]), bf_lo(raw[1]), bf_hi(raw[1])} * gm[i];
+        const f32x4 xh = (xr[i] - mu) * rs;
+        a += g[0] + g[1] + g[2] + g[3];
+        b += g[0] * xh[0] + g[1] * xh[1] + g[2] * xh[2] + g[3] * xh[3];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    a /= static_cast<float>(E);
+    b /= static_cast<float>(E);
+    const f32x4* dr = d_res ? reinterpret_cast<const f32x4*>(d_res + r * E) : nullptr;
+    f32x4* out = dx ? reinterpret_cast<f32x4*>(dx + r * E) : nullptr;
+    u32x2* out_h = dx_h ? reinterpret_cast<u32x2*>(dx_h + r * E) : nullptr;
+    for (int i = lane; i < n4; i += 64) {
+        const u32x2 raw = dyr[i];
+        const f32x4 g = f32x4{bf_lo(raw[0]), bf_hi(raw[0]), bf_lo(raw[1]), bf_hi(raw[1])} * gm[i];
+        const f32x4 xh = (xr[i] - mu) * rs;
+        f32x4 o = (g - a - xh * b) * rs;
+        if (dr) o = o + dr[i];
+        if (out) out[i] = o;
+        if (out_h) out_h[i] = u32x2{bf_pack(o[0], o[1]), bf_pack(o[2], o[3])};
+    }
+}
+
+}  // namespace mmx
+
+extern "C" int mmx_quick_gelu_bwd_bcast_bf16(const void* x_dev, const void* dy_dev, void* dx_dev, int64_t n, int64_t x_n,
+                                             void* stream) {
+    MMX_CHECK_ARG(x_dev && dy_dev && dx_dev && n > 0 && x_n > 0, "mmx_quick_gelu_bwd_bcast_bf16: bad argument");
+    MMX_CHECK_ARG(n % x_n == 0 && x_n % 8 == 0, "mmx_quick_gelu_bwd_bcast_bf16: n=%ld must be a multiple of x_n=%ld, x_n %% 8 == 0",
+                  static_cast<long>(n), static_cast<long>(x_n));
+    MMX_CHECK_ARG(((reinterpret_cast<uintptr_t>(x_dev) | reinterpret_cast<uintptr_t>(dy_dev) |
+                    reinterpret_cast<uintptr_t>(dx_dev)) & 15u) == 0, "mmx_quick_gelu_bwd_bcast_bf16: pointers must be 16-byte aligned");
+    const int64_t n8 = n / 8;
+    quick_gelu_bwd_bf16_kernel<<<gelu_grid(n8), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const f32x4*>(x_dev), static_cast<const u32x4*>(dy_dev), static_cast<u32x4*>(dx_dev), n8, x_n / 8);
+    MMX_LAUNCH_CHECK("quick_gelu_bwd_bf16_kernel");
+    return MMX_OK;
+}
+
+extern "C" int mmx_layernorm_bwd_add_bf16(const void* dy_dev, const void* x_dev, const void* mean_dev, const void* rstd_dev,
+                                          const void* gamma_dev, const void* d_res_dev, void* dx_dev, void* dx_bf16_dev,
+                                          int64_t rows, int x_rows, int E, void* stream) {
+    MMX_CHECK_ARG(dy_dev && x_dev && mean_dev && rstd_dev && gamma_dev && (dx_dev || dx_bf16_dev),
+                  "mmx_layernorm_bwd_add_bf16: null pointer");
+    MMX_CHECK_ARG(rows > 0 && x_rows > 0 && E > 0 && E % 4 == 0, "mmx_layernorm_bwd_add_bf16: rows=%ld x_rows=%d E=%d (E %% 4 must be 0)",
+                  static_cast<long>(rows), x_rows, E);
+    mmx::layernorm_bwd_add_bf16_kernel<<<static_cast<unsigned>((rows + 3) / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const unsigned short*>(dy_dev), static_cast<const float*>(x_dev), static_cast<const float*>(mean_dev),
+        static_cast<const float*>(rstd_dev), static_cast<const float*>(gamma_dev), static_cast<const float*>(d_res_dev),
+        static_cast<float*>(dx_dev), static_cast<unsigned short*>(dx_bf16_dev), rows, x_rows, E);
+    MMX_LAUNCH_CHECK("layernorm_bwd_add_bf16_kernel");
+    return MMX_OK;
+}

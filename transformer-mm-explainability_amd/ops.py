@@ -192,6 +192,14 @@ def quick_gelu_bwd(x, dy):
     """``dy * QuickGELU'(x)`` in one pass.  ``x`` has ``dy``'s shape, or batch 1 where ``dy`` has batch B (shared-forward
     mode: the ONE activation tensor is broadcast over the B upstream gradients inside the kernel)."""
     _dev(x, dy)
+    if dy.dtype == torch.bfloat16:             # bf16 gradient stream: dy / dx bf16, x fp32 (broadcast over the batch)
+        x, dy = _f32c(x), dy.contiguous()
+        if dy.numel() % x.numel() or x.numel() % 8:
+            raise MMXError("quick_gelu_bwd (bf16): x %s does not tile dy %s" % (tuple(x.shape), tuple(dy.shape)))
+        dx = torch.empty_like(dy)
+        check(lib().mmx_quick_gelu_bwd_bcast_bf16(_p(x), _p(dy), _p(dx), dy.numel(), x.numel(), _stream()),
+              "mmx_quick_gelu_bwd_bcast_bf16")
+        return dx
     x, dy = _f32c(x), _f32c(dy)
     dx = torch.empty_like(dy)
     if x.shape == dy.shape:
@@ -238,6 +246,23 @@ def layernorm_bwd_add(dy, x, mean, rstd, gamma, d_res=None):
     return dx
 
 
+def layernorm_bwd_add_bf16(dy, x, mean, rstd, gamma, d_res=None, want_f32=True):
+    """``layernorm_bwd_add`` for a bf16 upstream gradient ``dy``: returns ``(dx fp32 or None, dx bf16)`` -- the fp32 result
+    is the next residual gradient, the bf16 copy the operand of the next bf16 GEMM (one pass writes both)."""
+    _dev(dy, x, mean, rstd, gamma, d_res)
+    if dy.dtype != torch.bfloat16:
+        raise MMXError("layernorm_bwd_add_bf16: dy must be bf16")
+    dy, x = dy.contiguous(), _f32c(x)
+    E = dy.shape[-1]
+    rows, x_rows = dy.numel() // E, x.numel() // E
+    dx = torch.empty(dy.shape, dtype=torch.float32, device=dy.device) if want_f32 else None
+    dx_h = torch.empty_like(dy)
+    check(lib().mmx_layernorm_bwd_add_bf16(_p(dy), _p(x), _p(_f32c(mean)), _p(_f32c(rstd)), _p(_f32c(gamma)),
+                                           _p(_f32c(d_res)) if d_res is not None else _p(None), _p(dx), _p(dx_h), rows,
+                                           x_rows, E, _stream()), "mmx_layernorm_bwd_add_bf16")
+    return dx, dx_h
+
+
 _GEMM_WEIGHTS = {}   # id(parameter) -> {dtype: (version, converted copy)}; the entry is dropped when the parameter dies
 
 
@@ -267,6 +292,13 @@ def _mm_f32_out(a, b):
     if _MM_OUT_DTYPE[0]:
         return torch.mm(a, b, out_dtype=torch.float32)
     return torch.mm(a, b).float()
+
+
+def backward_gemm_bf16(x, weight):
+    """``x (bf16) @ weight`` -> bf16: a GEMM of the bf16 gradient stream (fp32 accumulation inside the library kernel,
+    result rounded once); the bf16 copy of ``weight`` is cached like ``backward_gemm``'s."""
+    w = _converted(weight, torch.bfloat16)
+    return torch.mm(x.reshape(-1, x.shape[-1]), w).view(*x.shape[:-1], w.shape[-1])
 
 
 def backward_gemm(x, weight, dtype=torch.float32):
@@ -547,6 +579,10 @@ def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCA
     probs_sb = 0 if shared else H * Nq * Nk
     if d_o.stride(-1) != 1:
         d_o = d_o.contiguous()
+    io_bf16 = d_o.dtype == torch.bfloat16            # bf16 gradient stream: dq / dk / dv come back as bf16 too
+    if io_bf16 and not mma_bf16:
+        raise MMXError("attn_capture_bwd: a bf16 d_o needs mma_bf16=True (MMX_ATTN_IO_BF16)")
+    flags = (_lib.MMX_ATTN_MMA_BF16 if mma_bf16 else 0) | (_lib.MMX_ATTN_IO_BF16 if io_bf16 else 0)
     dq = dk = dv = None
     ws = None
     need = 0
@@ -554,7 +590,7 @@ def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCA
         if out is not None:
             dq, dk, dv = out
         else:
-            dq, dk, dv = (torch.empty(tuple(t.shape), dtype=torch.float32, device=t.device) for t in (q, k, v))
+            dq, dk, dv = (torch.empty(tuple(t.shape), dtype=d_o.dtype, device=t.device) for t in (q, k, v))
         need = lib().mmx_attn_capture_bwd_workspace_bytes(B, H, Nq)
         ws = _workspace(need, q.device, "attn_bwd")
     zero3 = (0, 0, 0)
@@ -569,7 +605,7 @@ def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCA
         ws = _workspace(need, q.device, "attn_bwd")
         check(lib().mmx_attn_capture_bwd_rowrel(
             _p(q), _p(k), _p(v), *_bhnd_strides(q, layout), *_bhnd_strides(k, layout), *_bhnd_strides(v, layout),
-            _p(probs), probs_sb, _DTYPES[probs.dtype] | _lib.MMX_ATTN_MMA_BF16, _p(d_o), *_bhnd_strides(d_o, layout),
+            _p(probs), probs_sb, _DTYPES[probs.dtype] | flags, _p(d_o), *_bhnd_strides(d_o, layout),
             _p(o), *(_bhnd_strides(o, layout) if o is not None else zero3), _p(dprobs_out), _p(dq), _p(dk), _p(dv),
             *(_bhnd_strides(dq, layout) if need_dqkv else zero3), *(_bhnd_strides(dk, layout) if need_dqkv else zero3),
             *(_bhnd_strides(dv, layout) if need_dqkv else zero3),
@@ -578,8 +614,7 @@ def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCA
         return dq, dk, dv, rel_out
     check(lib().mmx_attn_capture_bwd_ex(
         _p(q), _p(k), _p(v), *_bhnd_strides(q, layout), *_bhnd_strides(k, layout), *_bhnd_strides(v, layout),
-        _p(probs), probs_sb, _DTYPES[probs.dtype] | (_lib.MMX_ATTN_MMA_BF16 if mma_bf16 else 0),
-        _p(d_o), *_bhnd_strides(d_o, layout),
+        _p(probs), probs_sb, _DTYPES[probs.dtype] | flags, _p(d_o), *_bhnd_strides(d_o, layout),
         _p(o), *(_bhnd_strides(o, layout) if o is not None else zero3), _p(dprobs_out), _p(dq), _p(dk), _p(dv),
         *(_bhnd_strides(dq, layout) if need_dqkv else zero3), *(_bhnd_strides(dk, layout) if need_dqkv else zero3),
         *(_bhnd_strides(dv, layout) if need_dqkv else zero3),
