@@ -39,29 +39,50 @@ int g_attn_stream = 1;
 // ~15: PMC showed these kernels issue-bound on VALU work around the MFMAs, not HBM-bound.
 __device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
-// ---- streamed [64 x D] operand tile: global -> registers (prefetch) -> LDS, row stride DP + 4 floats
-template <int DP>
-__device__ __forceinline__ void tile_fetch(f32x4 (&reg)[DP / 16], const float* base, int64_t sn, int row0,
-                                           int rows_total, int D, int tid) {
+// ---- streamed [64 x D] operand tile: global -> registers (prefetch) -> LDS, row stride DP + 4 floats.
+// The prefetch registers hold the RAW loaded words: masking (rows past the end, d >= D), the bf16 -> fp32 widening of a
+// bf16 operand and the scale all happen in tile_store, one iteration later.  Any ALU op on the loaded value at fetch time
+// makes the compiler wait for the load right there (s_waitcnt vmcnt(0) before the tile's MFMAs): PMC showed the bf16-input
+// variant, which widened at fetch time, parked 48 % of its wave cycles against 33 %.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 widen_bf16x4(u32x2 r) {
+    return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+                 __uint_as_float(r[1] & 0xffff0000u)};
+}
+template <int DP, bool HALF = false>
+struct TileRegs {
+    typename std::conditional<HALF, u32x2, f32x4>::type raw[DP / 16];
+    int row0;
+};
+template <int DP, bool HALF, typename T>
+__device__ __forceinline__ void tile_fetch(TileRegs<DP, HALF>& reg, const T* base, int64_t sn, int row0, int rows_total,
+                                           int D, int tid) {
+    static_assert(sizeof(T) == (HALF ? 2 : 4), "operand type");
     constexpr int C4 = DP / 4;
+    reg.row0 = row0;
 #pragma unroll
     for (int e = 0; e < DP / 16; ++e) {
         const int f = tid + kThreads * e;
         const int row = row0 + f / C4, c = (f % C4) * 4;
         const bool ok = row < rows_total && c < D;
-        // unconditional (clamped) load + select: a conditional load would serialise on vmcnt(0) per element
-        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (ok ? static_cast<int64_t>(row) * sn + c : 0));
-        reg[e] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        // unconditional (clamped) load: a conditional load would serialise on vmcnt(0) per element
+        const T* src = base + (ok ? static_cast<int64_t>(row) * sn + c : 0);
+        if constexpr (HALF) reg.raw[e] = *reinterpret_cast<const u32x2*>(src);
+        else reg.raw[e] = *reinterpret_cast<const f32x4*>(src);
     }
 }
 
-template <int DP>
-__device__ __forceinline__ void tile_store(float* lds, const f32x4 (&reg)[DP / 16], float mul, int tid) {
+template <int DP, bool HALF>
+__device__ __forceinline__ void tile_store(float* lds, const TileRegs<DP, HALF>& reg, float mul, int rows_total, int D, int tid) {
     constexpr int C4 = DP / 4, LS = DP + 4;
 #pragma unroll
     for (int e = 0; e < DP / 16; ++e) {
         const int f = tid + kThreads * e;
-        *reinterpret_cast<f32x4*>(lds + (f / C4) * LS + (f % C4) * 4) = reg[e] * mul;
+        const bool ok = reg.row0 + f / C4 < rows_total && (f % C4) * 4 < D;
+        f32x4 v;
+        if constexpr (HALF) v = widen_bf16x4(reg.raw[e]);
+        else v = reg.raw[e];
+        *reinterpret_cast<f32x4*>(lds + (f / C4) * LS + (f % C4) * 4) = ok ? v * mul : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -78,25 +99,7 @@ __device__ __forceinline__ void load_a_rows(f32x4 (&a)[DP / 16], const float* ba
     }
 }
 
-// ---- the same two loaders for a bf16 operand in global memory (MMX_ATTN_IO_BF16: dO): 8-byte loads, widened to fp32
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x4 widen_bf16x4(u32x2 r) {
-    return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
-                 __uint_as_float(r[1] & 0xffff0000u)};
-}
-template <int DP>
-__device__ __forceinline__ void tile_fetch_h(f32x4 (&reg)[DP / 16], const unsigned short* base, int64_t sn, int row0,
-                                             int rows_total, int D, int tid) {
-    constexpr int C4 = DP / 4;
-#pragma unroll
-    for (int e = 0; e < DP / 16; ++e) {
-        const int f = tid + kThreads * e;
-        const int row = row0 + f / C4, c = (f % C4) * 4;
-        const bool ok = row < rows_total && c < D;
-        const u32x2 v = *reinterpret_cast<const u32x2*>(base + (ok ? static_cast<int64_t>(row) * sn + c : 0));
-        reg[e] = ok ? widen_bf16x4(v) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-}
+// ---- load_a_rows for a bf16 operand in global memory (MMX_ATTN_IO_BF16: dO): 8-byte loads, widened to fp32
 template <int DP>
 __device__ __forceinline__ void load_a_rows_h(f32x4 (&a)[DP / 16], const unsigned short* base, int64_t sn, int row, int D,
                                               int g) {
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_ke
     };
 
     const int ntiles = (a.Nk + kTile - 1) / kTile;
-    f32x4 kreg[NB], vreg[NB];
+    TileRegs<DP> kreg, vreg;
 
     // ---- sweep 1: lane-local running max m and sum l of exp(s - m) over this lane's keys
     float m[4] = {ninf, ninf, ninf, ninf}, l[4] = {0.f, 0.f, 0.f, 0.f};
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_ke
     tile_fetch<DP>(kreg, kb, a.ks.sn, 0, a.Nk, a.D, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         lds_barrier();
-        tile_store<DP>(Ks, kreg, 1.f, tid);
+        tile_store<DP>(Ks, kreg, 1.f, a.Nk, a.D, tid);
         lds_barrier();
         if (kt + 1 < ntiles) tile_fetch<DP>(kreg, kb, a.ks.sn, (kt + 1) * kTile, a.Nk, a.D, tid);
         if (kt + 1 < ntiles) sweep1(kt, std::false_type{}); else sweep1(kt, std::true_type{});
@@ -358,8 +361,8 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_ke
     tile_fetch<DP>(vreg, vb, a.vs.sn, 0, a.Nk, a.D, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
         lds_barrier();
-        tile_store<DP>(Ks, kreg, 1.f, tid);
-        tile_store<DP>(Vs, vreg, 1.f, tid);
+        tile_store<DP>(Ks, kreg, 1.f, a.Nk, a.D, tid);
+        tile_store<DP>(Vs, vreg, 1.f, a.Nk, a.D, tid);
         lds_barrier();
         if (kt + 1 < ntiles) {
             tile_fetch<DP>(kreg, kb, a.ks.sn, (kt + 1) * kTile, a.Nk, a.D, tid);
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
         }
     };
     const int ntiles = (a.Nk + kTile - 1) / kTile;
-    f32x4 kreg[NB], vreg[NB];
+    TileRegs<DP> kreg, vreg;
     // this lane's 4 x 4 probabilities of a key tile.  EDGE = the tile may run past Nk (last tile only)
     auto load_p = [&](float (&p)[4][4], int kt, auto edge) {
         constexpr bool EDGE = decltype(edge)::value;
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
         tile_fetch<DP>(vreg, vb, a.vs.sn, 0, a.Nk, a.D, tid);
         for (int kt = 0; kt < ntiles; ++kt) {
             lds_barrier();
-            tile_store<DP>(Vs, vreg, 1.f, tid);
+            tile_store<DP>(Vs, vreg, 1.f, a.Nk, a.D, tid);
             lds_barrier();
             if (kt + 1 < ntiles) tile_fetch<DP>(vreg, vb, a.vs.sn, (kt + 1) * kTile, a.Nk, a.D, tid);
             if (kt + 1 < ntiles) sweep1(kt, std::false_type{}); else sweep1(kt, std::true_type{});
@@ -509,10 +512,8 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
 #pragma unroll
     for (int dt = 0; dt < NB; ++dt) qacc[0][dt] = qacc[1][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float ds_mul = q_first ? 1.f : 1.f / a.scale;      // exact for the power-of-two sqrt(d) of d = 16, 64
-    auto sweep2 = [&](int kt, auto edge) {
+    auto sweep2 = [&](int kt, const float (&p)[4][4], auto edge) {
         constexpr bool EDGE = decltype(edge)::value;
-        float p[4][4];
-        if (a.need_dqkv || REL) load_p(p, kt, edge);
         f32x4 dp[4];
         dp_tile(dp);
         if constexpr (REL) {
@@ -543,14 +544,18 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_bwd_q_stream_
     for (int kt = 0; kt < ntiles; ++kt) {
         lds_barrier();
         if constexpr (REL) { if (kt > 0) rel_flush(kt - 1); }
-        tile_store<DP>(Vs, vreg, 1.f, tid);
-        if (a.need_dqkv) tile_store<DP>(Ks, kreg, 1.f, tid);
+        tile_store<DP>(Vs, vreg, 1.f, a.Nk, a.D, tid);
+        if (a.need_dqkv) tile_store<DP>(Ks, kreg, 1.f, a.Nk, a.D, tid);
         lds_barrier();
+        // this tile's probabilities first, the next tile's K / V after them: vmcnt retires in order, so the wait in front
+        // of the first use of p then leaves the prefetch in flight (issued the other way round it drained everything)
+        float p[4][4];
+        if (a.need_dqkv || REL) { if (kt + 1 < ntiles) load_p(p, kt, std::false_type{}); else load_p(p, kt, std::true_type{}); }
         if (kt + 1 < ntiles) {
             tile_fetch<DP>(vreg, vb, a.vs.sn, (kt + 1) * kTile, a.Nk, a.D, tid);
             if (a.need_dqkv) tile_fetch<DP>(kreg, kb, a.ks.sn, (kt + 1) * kTile, a.Nk, a.D, tid);
         }
-        if (kt + 1 < ntiles) sweep2(kt, std::false_type{}); else sweep2(kt, std::true_type{});
+        if (kt + 1 < ntiles) sweep2(kt, p, std::false_type{}); else sweep2(kt, p, std::true_type{});
     }
     if constexpr (REL) {
         lds_barrier();
@@ -616,13 +621,14 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_kv_stream_kernel(const Attn
     }
 
     const int ntiles = (a.Nq + kTile - 1) / kTile;
-    f32x4 qreg[NB], doreg[NB];
+    TileRegs<DP> qreg;
+    TileRegs<DP, IOH> doreg;
     float dlreg = 0.f;
     auto fetch = [&](int qt) {
         tile_fetch<DP>(qreg, qb, a.qs.sn, qt * kTile, a.Nq, a.D, tid);
         if constexpr (IOH)
-            tile_fetch_h<DP>(doreg, reinterpret_cast<const unsigned short*>(a.dout) + b * a.os.sb + h * a.os.sh, a.os.sn,
-                             qt * kTile, a.Nq, a.D, tid);
+            tile_fetch<DP>(doreg, reinterpret_cast<const unsigned short*>(a.dout) + b * a.os.sb + h * a.os.sh, a.os.sn,
+                           qt * kTile, a.Nq, a.D, tid);
         else
             tile_fetch<DP>(doreg, dob, a.os.sn, qt * kTile, a.Nq, a.D, tid);
         if (tid < kTile) {
@@ -650,8 +656,8 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_kv_stream_kernel(const Attn
                 }
             }
         lds_barrier();
-        tile_store<DP>(Qs, qreg, q_first ? a.scale : 1.f, tid);
-        tile_store<DP>(dOs, doreg, 1.f, tid);
+        tile_store<DP>(Qs, qreg, q_first ? a.scale : 1.f, a.Nq, a.D, tid);
+        tile_store<DP>(dOs, doreg, 1.f, a.Nq, a.D, tid);
         if (tid < kTile) dl[tid] = dlreg;
         lds_barrier();
         if (qt + 1 < ntiles) fetch(qt + 1);
