@@ -18,4 +18,8 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OU
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --headline-only > /dev/null 2> $OUT/pmc_write.log
 python tools/pmc_summary.py $OUT/pmc_fetch/bench_counter_collection.csv mmx:: > $OUT/pmc_fetch.txt; python tools/pmc_summary.py $OUT/pmc_write/bench_counter_collection.csv mmx:: > $OUT/pmc_write.txt
 cat $OUT/pmc_fetch.txt $OUT/pmc_write.txt
-rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/trace
+# trace of the DEFAULT command's legs (headline + variants + the stand-alone chain launches the roofline is measured on): the chain
+# kernels' min / avg there include the 2 x 21 stand-alone launches, which do not overlap with the other tower's kernels
+timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/trace_full -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/trace_full.log
+python tools/prof_summary.py $OUT/trace_full/bench_results.db "self_chain" --by-grid > $OUT/chain_kernel_trace.txt 2>&1; cat $OUT/chain_kernel_trace.txt | cut -c1-200
+rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/trace $OUT/trace_full
