@@ -496,3 +496,32 @@ def test_detr_graph_replay_after_unrelated_eager_work():
     scale = float(want.abs().max())
     assert float((got - want).abs().max()) <= 1e-6 * max(scale, 1e-6) + 1e-9
     assert float((got[:, :, 3:4] - one).abs().max()) <= 1e-4 * scale
+
+
+@pytest.mark.gpu
+def test_detr_rows_only_rules_equal_the_matrix_route(golden):
+    """``generate_ours_multi(rows_only=True)`` -- rules 6 / 7 / 10 applied to one row vector per sample, no ``R_i_i`` --
+    vs the matrix route (itself pinned on the reference generator): the golden-sized body and the full-size DETR-R50
+    head (950 image tokens), incl. a NaN-poisoned gradient slab (the reference's ``R_sq_addition[isnan] = 0``)."""
+    from transformer_mm_explainability_amd import detr_model
+    from transformer_mm_explainability_amd.detr_explainability import Generator
+    g = golden("detr_transformer")
+    model = _detr_from_golden(g)
+    feats = cu(g["features"])
+    t = torch.tensor([4, 0, 6, 2], device="cuda")
+    want = Generator(model).generate_ours_multi(feats, t)
+    got = Generator(model).generate_ours_multi(feats, t, rows_only=True)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-5 * scale
+    torch.manual_seed(0)
+    big = detr_model.detr_resnet50_head().cuda().eval()
+    f = torch.randn(1, 2048, 25, 38, device="cuda") * 0.5
+    tt = torch.tensor([25, 33, 46, 49, 53], device="cuda")
+    gen_m, gen_r = Generator(big), Generator(big)
+    want = gen_m.generate_ours_multi(f, tt)
+    got = gen_r.generate_ours_multi(f, tt, rows_only=True)
+    assert gen_r.R_i_i is None and float(gen_r.diag_min) >= 0
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-5 * scale
+    one = Generator(big).generate_ours(f, tt[2:3], use_lrp=False)             # the reference's per-query call
+    assert float((got[:, :, 2:3] - one).abs().max()) <= 1e-4 * scale

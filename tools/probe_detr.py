@@ -45,13 +45,18 @@ for K in (1, 5, 10, 20):
     print("generate_ours_multi K=%-2d %.2f ms  (%.2f ms/query, %.0f queries/s)" % (K, ms, ms / K, K / ms * 1e3))
 
 from transformer_mm_explainability_amd.detr_explainability import GraphedGenerateOursMulti, MaskGenerator  # noqa: E402
-for K in (10, 16, 20):
-    run = GraphedGenerateOursMulti(model, feats, K=K)
+for rows_only in (False, True):
+    for K in (10, 16, 20):
+        run = GraphedGenerateOursMulti(model, feats, K=K, rows_only=rows_only)
+        t = torch.arange(K, device="cuda") * 3
+        ms = timed(lambda: run(feats, t), n=10, warm=2)
+        print("generate_ours_multi hipGraph K=%-2d %s %.2f ms  (%.2f ms/query, %.0f queries/s; one deferred diag read per call)"
+              % (K, "row-vector rules" if rows_only else "matrix rules    ", ms, ms / K, K / ms * 1e3))
+        del run
+for K in (10, 20):
     t = torch.arange(K, device="cuda") * 3
-    ms = timed(lambda: run(feats, t), n=10, warm=2)
-    print("generate_ours_multi hipGraph K=%-2d %.2f ms  (%.2f ms/query, %.0f queries/s; one deferred diag read per call)"
-          % (K, ms, ms / K, K / ms * 1e3))
-    del run
+    ms = timed(lambda: gen.generate_ours_multi(feats, t, rows_only=True), n=5, warm=2)
+    print("generate_ours_multi eager, row-vector rules K=%-2d %.2f ms  (%.2f ms/query)" % (K, ms, ms / K))
 
 for K in (5, 10, 20):
     t = torch.arange(K, device="cuda") * 3

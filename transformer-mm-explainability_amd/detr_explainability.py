@@ -124,8 +124,66 @@ class Generator:
         aggregated = self.R_q_i.unsqueeze_(0)
         return aggregated[:, target_index, :].unsqueeze_(0).detach()
 
+    def _rows_only_rules(self, encoder_blocks, decoder_blocks, targets, K, shared, pair, check_diag):
+        """Rules 6 / 7 / 10 of ``generate_ours`` (DETR/modules/ExplanationGenerator.py:110-140) for ONE row per sample.
+
+        With ``A_l`` the head-averaged encoder maps, ``B_l`` the decoder self-attention ones, ``C_l`` the cross-attention
+        ones and ``N(.)`` = ``handle_residual``:   ``R_ii = (I+A_6)...(I+A_1)``,  ``R_qq^(l) = (I+B_l) R_qq^(l-1)``,
+        ``R_qi^(l) = (I+B_l) R_qi^(l-1) + scrub( N(R_qq^(l))^T C_l N(R_ii) )``.  Row t of the final ``R_qi`` is therefore
+
+            sum_l  u_l N(R_qq^(l))^T C_l  N(R_ii),      u_l = e_t^T (I+B_L)...(I+B_(l+1))   (a row vector, top-down)
+          =  s N(R_ii)  with  s = sum_l u_l N(R_qq^(l))^T C_l,
+          =  (s / rho) R_ii - s / rho + s,               rho = R_ii 1 - 1   (the row sums eq. 8-9 divides by),
+
+        and both ``R_ii 1`` (bottom-up) and ``v R_ii`` (top-down) are chains of mat-vecs with the ``A_l``: the 950^3 products
+        and the ``[Q, Ni]`` state never exist.  NaN policy of the reference (``R_sq_addition[isnan] = 0``): an addition
+        holding one NaN holds only NaNs (every element sums over the offending row), so a layer whose factors contain a
+        NaN contributes nothing, and a sample whose ``N(R_ii)`` is not finite (an all-zero row of ``R_ii - I``) returns
+        zeros.  ``diag(R_ii - I) >= 0`` cannot be read without ``R_ii``; its entries are sums of products of clamped
+        (>= 0) maps, so the assert can only fire on NaN, which ``min(rho) >= 0`` detects as well: that word stands in."""
+        if not (self.apply_self_in_rule_10 and self.normalize_self_attention):
+            raise NotImplementedError("rows_only covers the default rule set (normalize_self_attention, apply_self_in_rule_10)")
+        dev = targets.device
+        A = [ops.avg_heads(*pair(blk.self_attn), batch_size=K, shared_attn=shared) for blk in encoder_blocks]      # [K, Ni, Ni]
+        n_img = A[0].shape[-1]
+        y = torch.ones(K, n_img, 1, device=dev)
+        for a in A:                                                    # R_ii 1, bottom-up
+            y = torch.baddbmm(y, a, y)
+        rho = (y - 1.0).reshape(K, 1, n_img)
+        Bq = [ops.avg_heads(*pair(blk.self_attn), batch_size=K, shared_attn=shared) for blk in decoder_blocks]      # [K, Q, Q]
+        n_q = Bq[0].shape[-1]
+        R_qq = torch.eye(n_q, device=dev).repeat(K, 1, 1)
+        R_hat, words = [], []
+        for b in Bq:
+            R_qq = torch.baddbmm(R_qq, b, R_qq)
+            hat, word = ops.handle_residual(R_qq, check_diag="defer")
+            R_hat.append(hat)
+            words.append(word)
+        u = torch.zeros(K, 1, n_q, device=dev)
+        u.scatter_(2, targets.reshape(K, 1, 1), 1.0)                   # e_t, one per sample
+        s = torch.zeros(K, 1, n_img, device=dev)
+        for l in range(len(decoder_blocks) - 1, -1, -1):
+            w = torch.bmm(u, R_hat[l].transpose(1, 2))                                             # u_l N(R_qq^(l))^T
+            cam = ops.avg_heads(*pair(decoder_blocks[l].multihead_attn), batch_size=K, shared_attn=shared)      # [K, Q, Ni]
+            z = torch.bmm(w, cam)
+            clean = ~(torch.isnan(R_hat[l]).flatten(1).any(1) | torch.isnan(cam).flatten(1).any(1))
+            s = s + torch.where(clean.reshape(K, 1, 1), z, torch.zeros_like(z))
+            u = torch.baddbmm(u, u, Bq[l])                                                          # u_(l-1) = u_l (I + B_l)
+        v = s / rho
+        x = v
+        for a in reversed(A):                                          # v R_ii, top-down
+            x = torch.baddbmm(x, x, a)
+        out = x - v + s
+        finite = torch.isfinite(v).flatten(1).all(1).reshape(K, 1, 1)
+        out = torch.where(finite & ~torch.isnan(out), out, torch.zeros_like(out))
+        self.R_i_i = self.R_q_q = self.R_q_i = None
+        self.diag_min = torch.cat(words + [rho.min().reshape(1)]).min()
+        if check_diag is True:
+            assert self.diag_min.item() >= 0
+        return out.reshape(1, 1, K, n_img).detach()
+
     def generate_ours_multi(self, img, target_indices, index=None, normalize_self_attention=True,
-                            apply_self_in_rule_10=True, share_forward=True, check_diag=True):
+                            apply_self_in_rule_10=True, share_forward=True, check_diag=True, rows_only=False):
         """All kept queries of one image in ONE pass.
 
         Equal to ``torch.cat([generate_ours(img, t, index, use_lrp=False, ...) for t in target_indices], dim=2)`` --
@@ -145,6 +203,11 @@ class Generator:
         ``check_diag``: the reference asserts ``diag(R - I) >= 0`` inside every ``handle_residual`` (a device->host
         read each, 7 per call here).  ``True``: the 7 device words are reduced and asserted ONCE at the end; ``"defer"``:
         the reduced word is left in ``self.diag_min`` and nothing synchronises (``GraphedGenerateOursMulti``).
+
+        ``rows_only=True``: the call returns ROW ``targets[k]`` of sample k's ``R_q_i`` and nothing else reads the
+        matrices, so the rules are applied to row VECTORS (``_rows_only_rules``): no ``R_i_i`` (6 products of 950^3 per
+        sample), no ``[Q, Ni]`` state, no rule-10 matmuls -- mat-vecs with the head-averaged maps instead.  Same result
+        up to fp32 summation order; ``self.R_i_i`` / ``R_q_q`` / ``R_q_i`` are then ``None``.
         """
         self.use_lrp = False
         self.normalize_self_attention = normalize_self_attention
@@ -186,6 +249,8 @@ class Generator:
         def pair(mod):
             return mod.get_attn().detach(), mod.get_attn_gradients().detach()
 
+        if rows_only:
+            return self._rows_only_rules(encoder_blocks, decoder_blocks, targets, K, shared, pair, check_diag)
         enc = [pair(blk.self_attn) for blk in encoder_blocks]
         self.R_i_i = ops.relevancy_self_chain([a for a, _ in enc], [g for _, g in enc], K, shared_attn=shared)   # [K, Ni, Ni]
         n_img = self.R_i_i.shape[-1]
@@ -399,7 +464,8 @@ class GraphedGenerateOursMulti:
         maps = run(features, kept_query_indices)        # [1, 1, len(kept), Ni], == Generator(model).generate_ours_multi(...)
     """
 
-    def __init__(self, model, example_img, K=16, normalize_self_attention=True, apply_self_in_rule_10=True, warmup=2):
+    def __init__(self, model, example_img, K=16, normalize_self_attention=True, apply_self_in_rule_10=True, warmup=2,
+                 rows_only=None):
         if not hasattr(model, "forward_shared"):
             raise ValueError("GraphedGenerateOursMulti needs a body with forward_shared / backward_shared (detr_model)")
         self.K = K
@@ -410,8 +476,11 @@ class GraphedGenerateOursMulti:
         # round differently (library GEMM selection inside / outside a capture) and flip a near-tie between classes.
         self.index = torch.full((K,), -1, dtype=torch.long, device=example_img.device)
         self.gen = Generator(model)
+        # only rows are returned: the row-vector form of the rules (no 950^3 products) whenever the default rules are on
+        if rows_only is None:
+            rows_only = bool(normalize_self_attention and apply_self_in_rule_10)
         kw = dict(normalize_self_attention=normalize_self_attention, apply_self_in_rule_10=apply_self_in_rule_10,
-                  check_diag="defer")
+                  check_diag="defer", rows_only=rows_only)
         self._call = lambda: self.gen.generate_ours_multi(self.img, self.targets, index=self.index, **kw)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
