@@ -484,7 +484,7 @@ def test_detr_graph_replay_after_unrelated_eager_work():
     from transformer_mm_explainability_amd.detr_explainability import Generator, GraphedGenerateOursMulti
     torch.manual_seed(0)
     model = detr_model.detr_resnet50_head().cuda().eval()
-    run = GraphedGenerateOursMulti(model, torch.randn(1, 2048, 25, 38, device="cuda") * 0.5, K=8)
+    run = GraphedGenerateOursMulti(model, torch.randn(1, 2048, 25, 38, device="cuda") * 0.5, K=8, rows_only=False)
     gen = torch.Generator().manual_seed(5000)
     feats = (torch.randn(1, 2048, 25, 38, generator=gen) * 0.5).cuda()
     t = torch.tensor([25, 33, 46, 49, 53, 60, 89, 95], device="cuda")
@@ -496,6 +496,10 @@ def test_detr_graph_replay_after_unrelated_eager_work():
     scale = float(want.abs().max())
     assert float((got - want).abs().max()) <= 1e-6 * max(scale, 1e-6) + 1e-9
     assert float((got[:, :, 3:4] - one).abs().max()) <= 1e-4 * scale
+    run_rows = GraphedGenerateOursMulti(model, feats, K=8)           # default: row-vector rules (other summation order)
+    with torch.no_grad():
+        model(feats)
+    assert float((run_rows(feats, t) - want).abs().max()) <= 1e-5 * scale
 
 
 @pytest.mark.gpu

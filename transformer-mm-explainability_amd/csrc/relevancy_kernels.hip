@@ -723,6 +723,104 @@ extern "C" int mmx_handle_residual(const void* R_dev, void* out_dev, int batch, 
                        static_cast<hipStream_t>(stream));
 }
 
+// ----------------------------------------------------------------------------------------- chain on vectors
+// One ROW / COLUMN of the chain instead of the matrix (DETR rows-only rules, detr_explainability._rows_only_rules):
+//   matvec:  y_out[b] = y[b] + A[b] . y[b]        (R 1 carried bottom-up: the row sums eq. 8-9 divides by)
+//   vecmat:  x_out[b] = x[b] + x[b] . A[b]        (a row of R carried top-down)
+// A: [B, N, N] fp32 (the head-averaged map of a layer).  Both read A once: N^2 bytes instead of the 2 N^3 flops of
+// R <- R + A.R.  matvec: one wave per row.  vecmat: a workgroup reduces a 32-row chunk for all columns into a partial
+// row, a second pass adds the chunks in a fixed order (deterministic; no atomics).
+namespace mmx {
+
+__global__ __launch_bounds__(256) void chain_matvec_kernel(const float* __restrict__ A, const float* __restrict__ y,
+                                                           float* __restrict__ out, int rows_total, int N) {
+    const int row_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row_g >= rows_total) return;
+    const int b = row_g / N;
+    const float* a = A + static_cast<int64_t>(row_g) * N;
+    const float* yb = y + static_cast<int64_t>(b) * N;
+    float s = 0.f;
+    const int n4 = N >> 2;
+    for (int j = lane; j < n4; j += 64) {
+        const f32x4 av = ldg4_u(a + 4 * j), yv = ldg4_u(yb + 4 * j);
+        s += av[0] * yv[0] + av[1] * yv[1] + av[2] * yv[2] + av[3] * yv[3];
+    }
+    for (int j = 4 * n4 + lane; j < N; j += 64) s += a[j] * yb[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) out[row_g] = yb[row_g - b * N] + s;
+}
+
+constexpr int kVecmatRows = 32;
+
+__global__ __launch_bounds__(256) void chain_vecmat_partial_kernel(const float* __restrict__ A, const float* __restrict__ x,
+                                                                   float* __restrict__ part, int N, int chunks) {
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int r0 = chunk * kVecmatRows, r1 = min(N, r0 + kVecmatRows);
+    const float* xb = x + static_cast<int64_t>(b) * N;
+    const float* Ab = A + static_cast<int64_t>(b) * N * N;
+    float* pb = part + (static_cast<int64_t>(b) * chunks + chunk) * N;
+    for (int c = threadIdx.x * 4; c < N; c += 256 * 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (c + 3 < N) {
+            for (int r = r0; r < r1; ++r) acc += ldg4_u(Ab + static_cast<int64_t>(r) * N + c) * xb[r];
+            pb[c] = acc[0]; pb[c + 1] = acc[1]; pb[c + 2] = acc[2]; pb[c + 3] = acc[3];
+        } else {
+            for (int e = 0; c + e < N; ++e) {
+                float sacc = 0.f;
+                for (int r = r0; r < r1; ++r) sacc += Ab[static_cast<int64_t>(r) * N + c + e] * xb[r];
+                pb[c + e] = sacc;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void chain_vecmat_reduce_kernel(const float* __restrict__ part, const float* __restrict__ x,
+                                                                  float* __restrict__ out, int N, int chunks) {
+    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (c >= N) return;
+    const float* pb = part + static_cast<int64_t>(b) * chunks * N + c;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += pb[static_cast<int64_t>(k) * N];
+    out[static_cast<int64_t>(b) * N + c] = x[static_cast<int64_t>(b) * N + c] + s;
+}
+
+}  // namespace mmx
+
+extern "C" int mmx_chain_matvec(const void* A_dev, const void* y_dev, void* out_dev, int B, int N, void* stream) {
+    MMX_CHECK_ARG(A_dev && y_dev && out_dev && B > 0 && N > 0 && y_dev != out_dev, "mmx_chain_matvec: bad argument");
+    const int rows = B * N;
+    mmx::chain_matvec_kernel<<<(rows + 3) / 4, 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const float*>(A_dev), static_cast<const float*>(y_dev), static_cast<float*>(out_dev), rows, N);
+    MMX_LAUNCH_CHECK("chain_matvec_kernel");
+    return MMX_OK;
+}
+
+extern "C" size_t mmx_chain_vecmat_workspace_bytes(int B, int N) {
+    const size_t chunks = (static_cast<size_t>(N) + mmx::kVecmatRows - 1) / mmx::kVecmatRows;
+    return sizeof(float) * static_cast<size_t>(B) * chunks * N;
+}
+
+extern "C" int mmx_chain_vecmat(const void* A_dev, const void* x_dev, void* out_dev, int B, int N, void* workspace_dev,
+                                size_t workspace_bytes, void* stream) {
+    MMX_CHECK_ARG(A_dev && x_dev && out_dev && B > 0 && N > 0, "mmx_chain_vecmat: bad argument");
+    if (!workspace_dev || workspace_bytes < mmx_chain_vecmat_workspace_bytes(B, N)) {
+        mmx::set_error("mmx_chain_vecmat: workspace %zu < %zu", workspace_bytes, mmx_chain_vecmat_workspace_bytes(B, N));
+        return MMX_EWORKSPACE;
+    }
+    const int chunks = (N + mmx::kVecmatRows - 1) / mmx::kVecmatRows;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(workspace_dev);
+    mmx::chain_vecmat_partial_kernel<<<dim3(chunks, B), 256, 0, s>>>(static_cast<const float*>(A_dev),
+                                                                    static_cast<const float*>(x_dev), part, N, chunks);
+    MMX_LAUNCH_CHECK("chain_vecmat_partial_kernel");
+    mmx::chain_vecmat_reduce_kernel<<<dim3((N + 255) / 256, B), 256, 0, s>>>(part, static_cast<const float*>(x_dev),
+                                                                             static_cast<float*>(out_dev), N, chunks);
+    MMX_LAUNCH_CHECK("chain_vecmat_reduce_kernel");
+    return MMX_OK;
+}
+
 // ----------------------------------------------------------------------------------------- rules 10/11
 __global__ void copy_scrub_kernel(const float* __restrict__ in, float* __restrict__ out, long n, int nan_to_zero) {
     const long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x;

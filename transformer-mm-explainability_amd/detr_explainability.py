@@ -146,9 +146,9 @@ class Generator:
         dev = targets.device
         A = [ops.avg_heads(*pair(blk.self_attn), batch_size=K, shared_attn=shared) for blk in encoder_blocks]      # [K, Ni, Ni]
         n_img = A[0].shape[-1]
-        y = torch.ones(K, n_img, 1, device=dev)
+        y = torch.ones(K, n_img, device=dev)
         for a in A:                                                    # R_ii 1, bottom-up
-            y = torch.baddbmm(y, a, y)
+            y = ops.chain_matvec(a, y)
         rho = (y - 1.0).reshape(K, 1, n_img)
         Bq = [ops.avg_heads(*pair(blk.self_attn), batch_size=K, shared_attn=shared) for blk in decoder_blocks]      # [K, Q, Q]
         n_q = Bq[0].shape[-1]
@@ -170,10 +170,10 @@ class Generator:
             s = s + torch.where(clean.reshape(K, 1, 1), z, torch.zeros_like(z))
             u = torch.baddbmm(u, u, Bq[l])                                                          # u_(l-1) = u_l (I + B_l)
         v = s / rho
-        x = v
+        x = v.reshape(K, n_img)
         for a in reversed(A):                                          # v R_ii, top-down
-            x = torch.baddbmm(x, x, a)
-        out = x - v + s
+            x = ops.chain_vecmat(x, a)
+        out = x.reshape(K, 1, n_img) - v + s
         finite = torch.isfinite(v).flatten(1).all(1).reshape(K, 1, 1)
         out = torch.where(finite & ~torch.isnan(out), out, torch.zeros_like(out))
         self.R_i_i = self.R_q_q = self.R_q_i = None

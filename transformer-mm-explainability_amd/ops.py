@@ -384,6 +384,28 @@ def matmul(a, b, add_to=None, trans_a=False, nan_to_zero=False):
     return out[0] if squeeze else out
 
 
+def chain_matvec(A, y):
+    """``y + A @ y`` for ``A [B, N, N]``, ``y [B, N]`` (fp32): one column of the chain ``R <- R + A R`` (``R 1``)."""
+    _dev(A, y)
+    A, y = _f32c(A), _f32c(y)
+    B, N = y.shape
+    out = torch.empty_like(y)
+    check(lib().mmx_chain_matvec(_p(A), _p(y), _p(out), B, N, _stream()), "mmx_chain_matvec")
+    return out
+
+
+def chain_vecmat(x, A):
+    """``x + x @ A`` for ``x [B, N]``, ``A [B, N, N]`` (fp32): one row of the chain carried top-down."""
+    _dev(A, x)
+    A, x = _f32c(A), _f32c(x)
+    B, N = x.shape
+    out = torch.empty_like(x)
+    need = lib().mmx_chain_vecmat_workspace_bytes(B, N)
+    ws = _workspace(need, x.device, "vecmat")
+    check(lib().mmx_chain_vecmat(_p(A), _p(x), _p(out), B, N, _p(ws), need, _stream()), "mmx_chain_vecmat")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- eq. 8-9
 def handle_residual(R, check_diag=True):
     """Eq. 8-9 on ``[.., N, N]``.  ``check_diag``: ``True`` asserts ``min diag(R - I) >= 0`` now, like the reference's
