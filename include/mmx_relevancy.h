@@ -132,12 +132,13 @@ int mmx_bmm_f32(const void* A_dev, const void* B_dev, const void* Cin_dev, void*
 /* The chain on VECTORS (rows-only DETR rules): when a caller returns single rows of R_q_i (`aggregated[:, target_index, :]`,
  * DETR/modules/ExplanationGenerator.py:180-182) the encoder product R_ii = (I + A_6) ... (I + A_1) (`:110-118`) is needed only
  * as  R_ii . 1  (the row sums `handle_residual` divides by, `:26-31`) and as  v . R_ii : mat-vecs with the head-averaged maps.
- *   mmx_chain_matvec:  out[b] = y[b] + A[b] . y[b]      mmx_chain_vecmat:  out[b] = x[b] + x[b] . A[b]
- * A [B, N, N], vectors [B, N], fp32; out may not alias the input vector; vecmat needs mmx_chain_vecmat_workspace_bytes. */
-int mmx_chain_matvec(const void* A_dev, const void* y_dev, void* out_dev, int B, int N, void* stream);
+ *   mmx_chain_matvec:  out[b] = base[b] + A[b] . y[b]      mmx_chain_vecmat:  out[b] = base[b] + x[b] . A[b]
+ * A [B, N, N], vectors [B, N], fp32; `base` separate from the multiplied vector so the caller can carry the deviation from
+ * the start vector (no cancellation at the end); out may not alias y / x; vecmat needs mmx_chain_vecmat_workspace_bytes. */
+int mmx_chain_matvec(const void* A_dev, const void* y_dev, const void* base_dev, void* out_dev, int B, int N, void* stream);
 size_t mmx_chain_vecmat_workspace_bytes(int B, int N);
-int mmx_chain_vecmat(const void* A_dev, const void* x_dev, void* out_dev, int B, int N, void* workspace_dev,
-                     size_t workspace_bytes, void* stream);
+int mmx_chain_vecmat(const void* A_dev, const void* x_dev, const void* base_dev, void* out_dev, int B, int N,
+                     void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * eq. 8-9: out = (R - I) / rowsum(R - I) + I  (0/0 rows -> NaN like the reference).

@@ -215,3 +215,34 @@ def test_detr_ni950_rules_vs_oracle():
     both = torch.tensor([3, 57], device="cuda")
     multi = Generator(model).generate_ours_multi(feats, both)
     close(multi[:, :, 1:2], want, atol=1e-5)
+    # the row-vector form of the same rules (``rows_only``: no R_i_i, mat-vecs only) vs the oracle, and both routes vs an
+    # fp64 evaluation of the schedule on the captured slabs (referee only): the vector form carries rho = R_ii 1 - 1 as a
+    # deviation, the matrix form gets it through diag(R_ii) - 1 and loses 2-3 digits there
+    rows = Generator(model).generate_ours_multi(feats, both, rows_only=True)
+    close(rows[:, :, 1:2], want, atol=1e-5)
+    gen2 = Generator(model)
+    gen2.generate_ours_multi(feats, both, share_forward=False)              # per-sample slabs of sample 1 (query 57)
+    dd = lambda t: t.double()
+    H = 8
+    avg = lambda m: (dd(m.get_attn().reshape(2, H, *m.get_attn().shape[-2:])[1]) *
+                     dd(m.get_attn_gradients().reshape(2, H, *m.get_attn().shape[-2:])[1])).clamp(min=0).mean(0)
+
+    def residual(R):
+        n = R.shape[-1]
+        eye = torch.eye(n, dtype=R.dtype, device=R.device)
+        return (R - eye) / (R - eye).sum(-1, keepdim=True) + eye
+
+    R_ii = torch.eye(950, dtype=torch.float64, device="cuda")
+    for b in enc:
+        R_ii = R_ii + avg(b.self_attn) @ R_ii
+    R_qq = torch.eye(100, dtype=torch.float64, device="cuda")
+    R_qi = torch.zeros(100, 950, dtype=torch.float64, device="cuda")
+    for b in dec:
+        cam = avg(b.self_attn)
+        R_qq, R_qi = R_qq + cam @ R_qq, R_qi + cam @ R_qi
+        R_qi = R_qi + residual(R_qq).T @ (avg(b.multihead_attn) @ residual(R_ii))
+    exact = R_qi[57].float()
+    scale = float(exact.abs().max())
+    err_rows = float((rows[0, 0, 1] - exact).abs().max()) / scale
+    err_matrix = float((multi[0, 0, 1] - exact).abs().max()) / scale
+    assert err_rows <= 2e-5 and err_matrix <= 2e-3, (err_rows, err_matrix)

@@ -725,15 +725,19 @@ extern "C" int mmx_handle_residual(const void* R_dev, void* out_dev, int batch, 
 
 // ----------------------------------------------------------------------------------------- chain on vectors
 // One ROW / COLUMN of the chain instead of the matrix (DETR rows-only rules, detr_explainability._rows_only_rules):
-//   matvec:  y_out[b] = y[b] + A[b] . y[b]        (R 1 carried bottom-up: the row sums eq. 8-9 divides by)
-//   vecmat:  x_out[b] = x[b] + x[b] . A[b]        (a row of R carried top-down)
+//   matvec:  out[b] = base[b] + A[b] . y[b]       (R 1 carried bottom-up: the row sums eq. 8-9 divides by)
+//   vecmat:  out[b] = base[b] + x[b] . A[b]       (a row of R carried top-down)
+// `base` is separate from the multiplied vector so that a caller can carry the DEVIATION from the start vector
+// (e <- e + A (1 + e) for R 1 - 1, d <- d + (v + d) A for v R - v): subtracting the start vector at the end instead would
+// cancel 2-3 digits, because R - I is small against I.
 // A: [B, N, N] fp32 (the head-averaged map of a layer).  Both read A once: N^2 bytes instead of the 2 N^3 flops of
 // R <- R + A.R.  matvec: one wave per row.  vecmat: a workgroup reduces a 32-row chunk for all columns into a partial
 // row, a second pass adds the chunks in a fixed order (deterministic; no atomics).
 namespace mmx {
 
 __global__ __launch_bounds__(256) void chain_matvec_kernel(const float* __restrict__ A, const float* __restrict__ y,
-                                                           float* __restrict__ out, int rows_total, int N) {
+                                                           const float* __restrict__ base, float* __restrict__ out,
+                                                           int rows_total, int N) {
     const int row_g = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row_g >= rows_total) return;
@@ -749,7 +753,7 @@ __global__ __launch_bounds__(256) void chain_matvec_kernel(const float* __restri
     for (int j = 4 * n4 + lane; j < N; j += 64) s += a[j] * yb[j];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) out[row_g] = yb[row_g - b * N] + s;
+    if (lane == 0) out[row_g] = base[row_g] + s;
 }
 
 constexpr int kVecmatRows = 32;
@@ -776,23 +780,25 @@ __global__ __launch_bounds__(256) void chain_vecmat_partial_kernel(const float* 
     }
 }
 
-__global__ __launch_bounds__(256) void chain_vecmat_reduce_kernel(const float* __restrict__ part, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void chain_vecmat_reduce_kernel(const float* __restrict__ part, const float* __restrict__ base,
                                                                   float* __restrict__ out, int N, int chunks) {
     const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
     if (c >= N) return;
     const float* pb = part + static_cast<int64_t>(b) * chunks * N + c;
     float s = 0.f;
     for (int k = 0; k < chunks; ++k) s += pb[static_cast<int64_t>(k) * N];
-    out[static_cast<int64_t>(b) * N + c] = x[static_cast<int64_t>(b) * N + c] + s;
+    out[static_cast<int64_t>(b) * N + c] = base[static_cast<int64_t>(b) * N + c] + s;
 }
 
 }  // namespace mmx
 
-extern "C" int mmx_chain_matvec(const void* A_dev, const void* y_dev, void* out_dev, int B, int N, void* stream) {
-    MMX_CHECK_ARG(A_dev && y_dev && out_dev && B > 0 && N > 0 && y_dev != out_dev, "mmx_chain_matvec: bad argument");
+extern "C" int mmx_chain_matvec(const void* A_dev, const void* y_dev, const void* base_dev, void* out_dev, int B, int N,
+                                void* stream) {
+    MMX_CHECK_ARG(A_dev && y_dev && base_dev && out_dev && B > 0 && N > 0 && y_dev != out_dev, "mmx_chain_matvec: bad argument");
     const int rows = B * N;
     mmx::chain_matvec_kernel<<<(rows + 3) / 4, 256, 0, static_cast<hipStream_t>(stream)>>>(
-        static_cast<const float*>(A_dev), static_cast<const float*>(y_dev), static_cast<float*>(out_dev), rows, N);
+        static_cast<const float*>(A_dev), static_cast<const float*>(y_dev), static_cast<const float*>(base_dev),
+        static_cast<float*>(out_dev), rows, N);
     MMX_LAUNCH_CHECK("chain_matvec_kernel");
     return MMX_OK;
 }
@@ -802,9 +808,9 @@ extern "C" size_t mmx_chain_vecmat_workspace_bytes(int B, int N) {
     return sizeof(float) * static_cast<size_t>(B) * chunks * N;
 }
 
-extern "C" int mmx_chain_vecmat(const void* A_dev, const void* x_dev, void* out_dev, int B, int N, void* workspace_dev,
-                                size_t workspace_bytes, void* stream) {
-    MMX_CHECK_ARG(A_dev && x_dev && out_dev && B > 0 && N > 0, "mmx_chain_vecmat: bad argument");
+extern "C" int mmx_chain_vecmat(const void* A_dev, const void* x_dev, const void* base_dev, void* out_dev, int B, int N,
+                                void* workspace_dev, size_t workspace_bytes, void* stream) {
+    MMX_CHECK_ARG(A_dev && x_dev && base_dev && out_dev && B > 0 && N > 0, "mmx_chain_vecmat: bad argument");
     if (!workspace_dev || workspace_bytes < mmx_chain_vecmat_workspace_bytes(B, N)) {
         mmx::set_error("mmx_chain_vecmat: workspace %zu < %zu", workspace_bytes, mmx_chain_vecmat_workspace_bytes(B, N));
         return MMX_EWORKSPACE;
@@ -815,7 +821,7 @@ extern "C" int mmx_chain_vecmat(const void* A_dev, const void* x_dev, void* out_
     mmx::chain_vecmat_partial_kernel<<<dim3(chunks, B), 256, 0, s>>>(static_cast<const float*>(A_dev),
                                                                     static_cast<const float*>(x_dev), part, N, chunks);
     MMX_LAUNCH_CHECK("chain_vecmat_partial_kernel");
-    mmx::chain_vecmat_reduce_kernel<<<dim3((N + 255) / 256, B), 256, 0, s>>>(part, static_cast<const float*>(x_dev),
+    mmx::chain_vecmat_reduce_kernel<<<dim3((N + 255) / 256, B), 256, 0, s>>>(part, static_cast<const float*>(base_dev),
                                                                              static_cast<float*>(out_dev), N, chunks);
     MMX_LAUNCH_CHECK("chain_vecmat_reduce_kernel");
     return MMX_OK;

@@ -146,10 +146,12 @@ class Generator:
         dev = targets.device
         A = [ops.avg_heads(*pair(blk.self_attn), batch_size=K, shared_attn=shared) for blk in encoder_blocks]      # [K, Ni, Ni]
         n_img = A[0].shape[-1]
-        y = torch.ones(K, n_img, device=dev)
-        for a in A:                                                    # R_ii 1, bottom-up
-            y = ops.chain_matvec(a, y)
-        rho = (y - 1.0).reshape(K, 1, n_img)
+        # rho = R_ii 1 - 1 carried as the deviation e from 1 (e <- e + A (1 + e)): forming R_ii 1 and subtracting 1 at the
+        # end would cancel 2-3 digits of rho (the matrix route has that noise in diag(R_ii) - 1 as well)
+        e = torch.zeros(K, n_img, device=dev)
+        for a in A:                                                    # bottom-up
+            e = ops.chain_matvec(a, e + 1.0, base=e)
+        rho = e.reshape(K, 1, n_img)
         Bq = [ops.avg_heads(*pair(blk.self_attn), batch_size=K, shared_attn=shared) for blk in decoder_blocks]      # [K, Q, Q]
         n_q = Bq[0].shape[-1]
         R_qq = torch.eye(n_q, device=dev).repeat(K, 1, 1)
@@ -170,10 +172,11 @@ class Generator:
             s = s + torch.where(clean.reshape(K, 1, 1), z, torch.zeros_like(z))
             u = torch.baddbmm(u, u, Bq[l])                                                          # u_(l-1) = u_l (I + B_l)
         v = s / rho
-        x = v.reshape(K, n_img)
-        for a in reversed(A):                                          # v R_ii, top-down
-            x = ops.chain_vecmat(x, a)
-        out = x.reshape(K, 1, n_img) - v + s
+        v2 = v.reshape(K, n_img)
+        d = torch.zeros_like(v2)                                       # d = v R_ii - v, top-down: d <- d + (v + d) A
+        for a in reversed(A):
+            d = ops.chain_vecmat(v2 + d, a, base=d)
+        out = d.reshape(K, 1, n_img) + s
         finite = torch.isfinite(v).flatten(1).all(1).reshape(K, 1, 1)
         out = torch.where(finite & ~torch.isnan(out), out, torch.zeros_like(out))
         self.R_i_i = self.R_q_q = self.R_q_i = None

@@ -384,25 +384,29 @@ def matmul(a, b, add_to=None, trans_a=False, nan_to_zero=False):
     return out[0] if squeeze else out
 
 
-def chain_matvec(A, y):
-    """``y + A @ y`` for ``A [B, N, N]``, ``y [B, N]`` (fp32): one column of the chain ``R <- R + A R`` (``R 1``)."""
-    _dev(A, y)
+def chain_matvec(A, y, base=None):
+    """``base + A @ y`` for ``A [B, N, N]``, ``y`` / ``base [B, N]`` (fp32; ``base`` defaults to ``y``): one column of
+    the chain ``R <- R + A R``."""
+    _dev(A, y, base)
     A, y = _f32c(A), _f32c(y)
+    base = y if base is None else _f32c(base)
     B, N = y.shape
     out = torch.empty_like(y)
-    check(lib().mmx_chain_matvec(_p(A), _p(y), _p(out), B, N, _stream()), "mmx_chain_matvec")
+    check(lib().mmx_chain_matvec(_p(A), _p(y), _p(base), _p(out), B, N, _stream()), "mmx_chain_matvec")
     return out
 
 
-def chain_vecmat(x, A):
-    """``x + x @ A`` for ``x [B, N]``, ``A [B, N, N]`` (fp32): one row of the chain carried top-down."""
-    _dev(A, x)
+def chain_vecmat(x, A, base=None):
+    """``base + x @ A`` for ``x`` / ``base [B, N]``, ``A [B, N, N]`` (fp32; ``base`` defaults to ``x``): one row of the
+    chain carried top-down."""
+    _dev(A, x, base)
     A, x = _f32c(A), _f32c(x)
+    base = x if base is None else _f32c(base)
     B, N = x.shape
     out = torch.empty_like(x)
     need = lib().mmx_chain_vecmat_workspace_bytes(B, N)
     ws = _workspace(need, x.device, "vecmat")
-    check(lib().mmx_chain_vecmat(_p(A), _p(x), _p(out), B, N, _p(ws), need, _stream()), "mmx_chain_vecmat")
+    check(lib().mmx_chain_vecmat(_p(A), _p(x), _p(base), _p(out), B, N, _p(ws), need, _stream()), "mmx_chain_vecmat")
     return out
 
 
