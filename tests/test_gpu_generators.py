@@ -530,4 +530,4 @@ def test_detr_rows_only_rules_equal_the_matrix_route(golden):
     scale = float(want.abs().max())
     assert float((got - want).abs().max()) <= 1e-3 * scale                    # see the note in the graph-replay test
     one = Generator(big).generate_ours(f, tt[2:3], use_lrp=False)             # the reference's per-query call
-    assert float((got[:, :, 2:3] - one).abs().max()) <= 1e-4 * scale
+    assert float((got[:, :, 2:3] - one).abs().max()) <= 1e-3 * scale
