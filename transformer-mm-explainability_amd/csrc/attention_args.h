@@ -49,5 +49,7 @@ int attn_fwd_small_try(AttnFwdArgs& a, hipStream_t s, int* rc_out);
 int attn_bwd_small_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);
 int attn_fwd_stream_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out);   // attention_stream.hip
 int attn_bwd_stream_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);
+int attn_bwd_bf16_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);     // attention_bf16.hip (2nd-generation bf16 MFMA backward)
+void attn_bf16_v2_enable(int on);
 
 }  // namespace mmx

@@ -825,6 +825,7 @@ int attn_fwd_stream_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out) {
 int attn_bwd_stream_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out) {
     if ((!g_attn_stream && a.slab_dt == MMX_F32 && !a.mma_bf16) || a.D % 4 || a.D > 64) return 0;
     if ((a.rel_v || a.io_bf16) && !a.mma_bf16) return 0;
+    if (a.mma_bf16 && attn_bwd_bf16_try(a, s, rc_out)) return 1;      // second-generation bf16 kernels (attention_bf16.hip)
     if (!aligned16(a.v, a.vs) || !aligned16(a.dout, a.os)) return 0;
     if (a.need_dqkv && (!aligned16(a.q, a.qs) || !aligned16(a.k, a.ks))) return 0;
     dim3 gq(((a.Nq + kRows - 1) / kRows) * a.H * a.B), gk(((a.Nk + kRows - 1) / kRows) * a.H * a.B);

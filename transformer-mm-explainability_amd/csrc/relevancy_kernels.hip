@@ -964,6 +964,10 @@ extern "C" int mmx_set_option(const char* key, int value) {
         attn_head_enable(value);
         return MMX_OK;
     }
+    if (key && strcmp(key, "attn_bf16_v2") == 0) {
+        attn_bf16_v2_enable(value);
+        return MMX_OK;
+    }
     if (key && strcmp(key, "attn_stream") == 0) {
         attn_stream_enable(value);
         return MMX_OK;
