@@ -282,24 +282,29 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_q_bf16_kernel(const AttnBwdAr
             }
         }
     };
-    // Interior tiles: the lane's 4 consecutive probabilities per 16 keys are ONE (possibly 2-byte aligned) load, issued
-    // before the dP^T MFMAs and converted after them; the last tile may run past Nk: clamped element loads.
+    // Interior tiles: the lane's 4 consecutive probabilities per 16 keys are ONE (possibly 2-byte aligned) load.  They are
+    // fetched ONE TILE AHEAD as raw words (p_cur was issued during the previous iteration, before that iteration's K / V
+    // prefetch; converted here): a load consumed inside the iteration that issues it waits behind the prefetch it was queued
+    // with -- vmcnt retires in order -- and that exposed a full memory round trip per tile (3 us of a 3.2 us tile step).
+    // The last tile may run past Nk: clamped element loads, issued and consumed in place (one tile of ~10).
+    const bool want_p = need_ds || REL;
+    stream_raw<DT> p_cur[4], p_nxt[4];
+    auto p_issue = [&](stream_raw<DT> (&raw)[4], int kt) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) raw[t] = load4_stream_raw<DT>(a.probs, prow_idx + kt * kT + 16 * t + 4 * g);
+    };
     auto tile_compute = [&](int kt, auto edge) {
         constexpr bool EDGE = decltype(edge)::value;
         const bf16_t* Vcur = Vt + (kt & 1) * kT * kLR;
-        const bool want_p = need_ds || REL;
         f32x4 p[4], dpT[4];
         if (!want_p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) p[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             tile_x_regs<true>(dpT, Vcur, dob, i, g);
         } else if constexpr (!EDGE) {
-            stream_raw<DT> raw[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) raw[t] = load4_stream_raw<DT>(a.probs, prow_idx + kt * kT + 16 * t + 4 * g);
             tile_x_regs<true>(dpT, Vcur, dob, i, g);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) p[t] = stream_cvt<DT>(raw[t], prow_idx + kt * kT + 16 * t + 4 * g);
+            for (int t = 0; t < 4; ++t) p[t] = stream_cvt<DT>(p_cur[t], prow_idx + kt * kT + 16 * t + 4 * g);
         } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -316,15 +321,23 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_q_bf16_kernel(const AttnBwdAr
 
     fetch(0);
     stage(0);
-    if (ntiles > 1) fetch(1);
+    if (ntiles > 1) {
+        if (want_p) p_issue(p_cur, 0);
+        fetch(1);
+    }
     __syncthreads();
     for (int kt = 0; kt < ntiles; ++kt) {
         if constexpr (REL) { if (kt > 0) rel_flush(kt - 1); }
         if (kt + 1 < ntiles) {
             stage((kt + 1) & 1);                                   // the tile fetched during the previous iteration
+            if (want_p && kt + 2 < ntiles) p_issue(p_nxt, kt + 1);  // (tile kt + 1 is interior)
             if (kt + 2 < ntiles) fetch(kt + 2);
         }
         if (kt + 1 < ntiles) tile_compute(kt, std::false_type{}); else tile_compute(kt, std::true_type{});
+        if (want_p && kt + 2 < ntiles) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) p_cur[t] = p_nxt[t];
+        }
         lds_barrier();
     }
     if constexpr (REL) rel_flush(ntiles - 1);
@@ -399,26 +412,39 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_kv_bf16_kernel(const AttnBwdA
         store_transposed(Qt + buf * kDP * kLT, rows, tid);
         if (tid < kT) dl[buf * kT + tid] = dlreg;
     };
+    // this lane's probability column segments of a query tile (lane = key, 16 query rows): raw words, fetched one tile
+    // ahead like the query side's (and ahead of the Q / dO prefetch in issue order)
+    slab_t p_cur[4][4], p_nxt[4][4];
+    auto p_issue = [&](slab_t (&raw)[4][4], int qt) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                raw[t][r] = pcol[static_cast<int64_t>(min(qt * kT + 16 * t + 4 * g + r, a.Nq - 1)) * a.Nk];
+    };
     fetch(0);
     stage(0);
+    p_issue(p_cur, 0);
     if (ntiles > 1) fetch(1);
     __syncthreads();
     for (int qt = 0; qt < ntiles; ++qt) {
         const int cur = qt & 1;
-        // this tile's probability column segments (lane = key, 16 query rows per lane): issued first, used after the dP MFMAs
+        if (qt + 1 < ntiles) {
+            stage(cur ^ 1);
+            p_issue(p_nxt, qt + 1);
+            if (qt + 2 < ntiles) fetch(qt + 2);
+        }
         float p[4][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = qt * kT + 16 * t + 4 * g + r;
-                const float v = slab_load<DT>(pcol + static_cast<int64_t>(min(row, a.Nq - 1)) * a.Nk);
-                p[t][r] = (key_ok && row < a.Nq) ? v : 0.f;
+                float v;
+                if constexpr (DT == MMX_F32) v = p_cur[t][r];
+                else if constexpr (DT == MMX_BF16) v = bf16_bits_to_f32(p_cur[t][r]);
+                else v = f16_bits_to_f32(p_cur[t][r]);
+                p[t][r] = (key_ok && qt * kT + 16 * t + 4 * g + r < a.Nq) ? v : 0.f;
             }
-        if (qt + 1 < ntiles) {
-            stage(cur ^ 1);
-            if (qt + 2 < ntiles) fetch(qt + 2);
-        }
         f32x4 dp[4];                                                   // dp[t][r] = dP[16 t + 4 g + r][key i]
         tile_x_regs<true>(dp, dOr + cur * kT * kLR, vop, i, g);
         const bf16_t* dOtc = dOt + cur * kDP * kLT;
@@ -439,6 +465,12 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_kv_bf16_kernel(const AttnBwdA
                 vacc[dt] = mfma16x16x32_bf16(p_op, transposed_operand(dOtc, dt, pp, i, g), vacc[dt]);
                 kacc[dt] = mfma16x16x32_bf16(ds_op, transposed_operand(Qtc, dt, pp, i, g), kacc[dt]);
             }
+        }
+        if (qt + 1 < ntiles) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p_cur[t][r] = p_nxt[t][r];
         }
         lds_barrier();
     }
