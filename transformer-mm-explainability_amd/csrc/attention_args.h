@@ -38,6 +38,7 @@ struct AttnBwdArgs {
     // its head into rel_part[b][h * nrt + row_tile][k]; rel_v == nullptr: off.
     const float* rel_v;
     float* rel_part;
+    float* rel_out;   // rel_v + (1 / H) sum of the partial rows: written by the path that ran (it knows how many rows it made)
     // MMX_ATTN_IO_BF16 (bf16-MFMA streaming kernels only): `dout` is bf16 and dq / dk / dv are written as bf16 (the
     // gradient stream between the bf16 GEMMs of a bf16 body); strides stay in elements.  q / k / v / o / delta: fp32.
     int io_bf16;
@@ -49,6 +50,8 @@ int attn_fwd_small_try(AttnFwdArgs& a, hipStream_t s, int* rc_out);
 int attn_bwd_small_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);
 int attn_fwd_stream_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out);   // attention_stream.hip
 int attn_bwd_stream_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);
+// out[b][k] = v_in[b][k] + inv_h * sum_{j < J} part[b][j][k]   (row-relevancy mode, second pass; attention_kernels.hip)
+int rel_row_update(const float* v_in, const float* part, float* out, int B, int J, int N, float inv_h, hipStream_t s);
 int attn_bwd_bf16_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);     // attention_bf16.hip (2nd-generation bf16 MFMA backward)
 void attn_bf16_v2_enable(int on);
 

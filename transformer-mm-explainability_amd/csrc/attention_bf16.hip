@@ -153,15 +153,16 @@ __device__ __forceinline__ bf16x8 transposed_operand(const bf16_t* tile, int dt,
 }
 
 // ===================================================================================================== query side
-// dP (-> capture slab and / or the row-relevancy reduction), delta = rowsum(dO * O), dS, dQ = dS.K
-template <int DT, bool REL, bool IOH>
+// dP (-> capture slab), delta = rowsum(dO * O), dS, dQ = dS.K.  (The row-relevancy reduction lives on the KEY side: there
+// a lane owns a key and 16 query rows, so the sum over queries is an in-lane sum -- here it was 16 DPP row reductions per
+// tile, a third of the kernel's VALU work.)
+template <int DT, bool IOH>
 __global__ __launch_bounds__(kTh, 2) void attn_bwd_q_bf16_kernel(const AttnBwdArgs a) {
     typedef typename slab_elem<DT>::type slab_t;
     constexpr int NB = kDP / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* Vt = reinterpret_cast<bf16_t*>(smem_raw);                 // [2][kT][kLR]   V rows (row-major)
     bf16_t* Kt = Vt + 2 * kT * kLR;                                   // [2][kDP][kLT]  K transposed
-    float* relw = reinterpret_cast<float*>(Kt + 2 * kDP * kLT);       // [2][4][kT]     REL: per-wave partial sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
     const int nrt = (a.Nq + kR - 1) / kR;
     const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
@@ -214,7 +215,6 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_q_bf16_kernel(const AttnBwdAr
         delta = q_ok ? part : 0.f;
         if (need_ds && g == 0 && q_ok) a.delta[head * a.Nq + q] = delta;
     }
-    const float vq = (REL && q_ok) ? a.rel_v[static_cast<int64_t>(b) * a.Nq + q] : 0.f;
     const slab_t* prow = reinterpret_cast<const slab_t*>(a.probs) + b * a.probs_sb + (static_cast<int64_t>(h) * a.Nq + qc) * a.Nk;
     const int64_t prow_idx = b * a.probs_sb + (static_cast<int64_t>(h) * a.Nq + qc) * a.Nk;     // element index of the row start
     slab_t* dprow = (a.dprobs && q_ok) ? reinterpret_cast<slab_t*>(a.dprobs) + (head * a.Nq + q) * a.Nk : nullptr;
@@ -239,27 +239,10 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_q_bf16_kernel(const AttnBwdAr
             store_transposed(Kt + buf * kDP * kLT, rows, tid);
         }
     };
-    auto rel_flush = [&](int kt) {      // keys of tile kt: the 4 waves' partial sums, fixed order -> this workgroup's row
-        const int kk = kt * kT + tid;
-        if (tid < kT && kk < a.Nk) {
-            const float* w = relw + (kt & 1) * 4 * kT + tid;
-            a.rel_part[(head * nrt + rt) * a.Nk + kk] = (w[0] + w[kT]) + (w[2 * kT] + w[3 * kT]);
-        }
-    };
 
     // everything that follows dP^T of a tile: p[t][r], dpT[t][r] <-> key 16 t + 4 g + r of this lane's query row
     auto tile_tail = [&](const f32x4 (&p)[4], const f32x4 (&dpT)[4], int kt, bool edge) {
         const bf16_t* Kcur = Kt + (kt & 1) * kDP * kLT;
-        if constexpr (REL) {
-            float* w = relw + ((kt & 1) * 4 + wave) * kT;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float c = group16_sum(vq * relu_nan(p[t][r] * dpT[t][r]));     // over the wave's 16 query rows
-                    if (i == 0) w[16 * t + 4 * g + r] = c;
-                }
-        }
         if (dprow) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -287,7 +270,7 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_q_bf16_kernel(const AttnBwdAr
     // prefetch; converted here): a load consumed inside the iteration that issues it waits behind the prefetch it was queued
     // with -- vmcnt retires in order -- and that exposed a full memory round trip per tile (3 us of a 3.2 us tile step).
     // The last tile may run past Nk: clamped element loads, issued and consumed in place (one tile of ~10).
-    const bool want_p = need_ds || REL;
+    const bool want_p = need_ds;
     stream_raw<DT> p_cur[4], p_nxt[4];
     auto p_issue = [&](stream_raw<DT> (&raw)[4], int kt) {
 #pragma unroll
@@ -327,7 +310,6 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_q_bf16_kernel(const AttnBwdAr
     }
     __syncthreads();
     for (int kt = 0; kt < ntiles; ++kt) {
-        if constexpr (REL) { if (kt > 0) rel_flush(kt - 1); }
         if (kt + 1 < ntiles) {
             stage((kt + 1) & 1);                                   // the tile fetched during the previous iteration
             if (want_p && kt + 2 < ntiles) p_issue(p_nxt, kt + 1);  // (tile kt + 1 is interior)
@@ -340,7 +322,6 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_q_bf16_kernel(const AttnBwdAr
         }
         lds_barrier();
     }
-    if constexpr (REL) rel_flush(ntiles - 1);
     if (!need_ds || !q_ok) return;
     // dQ^T accumulators: lane (q = column i), rows d = 16 dt + 4 g + r: 4 consecutive d of one query row
     const float mul = q_first ? a.scale : 1.f;
@@ -359,8 +340,11 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_q_bf16_kernel(const AttnBwdAr
 }
 
 // ===================================================================================================== key side
-// per 64 keys (16 per wave): dP recomputed, dV = P^T.dO, dK = dS^T.Q
-template <int DT, bool IOH>
+// per 64 keys (16 per wave): dP recomputed, dV = P^T.dO, dK = dS^T.Q (DKV), and / or the row-relevancy product of this head
+// (REL):  rel_part[b][h][key] = sum_q rel_v[b][q] * clamp(dP * P, 0)[q][key] -- the lane owns the key, its 16 query rows of a
+// tile are registers, so the sum over ALL queries is one running register, two cross-row shuffles at the very end and ONE
+// partial row per head (fixed order: deterministic).  DKV = false (the lowest explained layer) runs only that.
+template <int DT, bool IOH, bool REL, bool DKV>
 __global__ __launch_bounds__(kTh, 2) void attn_bwd_kv_bf16_kernel(const AttnBwdArgs a) {
     typedef typename slab_elem<DT>::type slab_t;
     constexpr int NB = kDP / 16;
@@ -369,6 +353,7 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_kv_bf16_kernel(const AttnBwdA
     bf16_t* dOt = dOr + 2 * kT * kLR;                                 // [2][kDP][kLT]  dO transposed
     bf16_t* Qt = dOt + 2 * kDP * kLT;                                 // [2][kDP][kLT]  Q transposed (pre-scaled)
     float* dl = reinterpret_cast<float*>(Qt + 2 * kDP * kLT);         // [2][kT]        delta of the staged query rows
+    float* vl = dl + 2 * kT;                                          // [2][kT]        REL: rel_v of the staged query rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
     const int nkt = (a.Nk + kR - 1) / kR;
     const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
@@ -393,24 +378,33 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_kv_bf16_kernel(const AttnBwdA
     const int ntiles = (a.Nq + kT - 1) / kT;
     Block4x4<false> qreg;
     Block4x4<IOH> doreg;
-    float dlreg = 0.f;
+    float dlreg = 0.f, vlreg = 0.f, racc = 0.f;
     auto fetch = [&](int qt) {
-        block_fetch<false>(qreg, qb, a.qs.sn, qt * kT, a.Nq, a.D, tid);
+        if constexpr (DKV) block_fetch<false>(qreg, qb, a.qs.sn, qt * kT, a.Nq, a.D, tid);
         if constexpr (IOH)
             block_fetch<true>(doreg, reinterpret_cast<const bf16_t*>(a.dout) + b * a.os.sb + h * a.os.sh, a.os.sn, qt * kT, a.Nq,
                               a.D, tid);
         else
             block_fetch<false>(doreg, a.dout + b * a.os.sb + h * a.os.sh, a.os.sn, qt * kT, a.Nq, a.D, tid);
-        if (tid < kT) dlreg = a.delta[head * a.Nq + min(qt * kT + tid, a.Nq - 1)];
+        if (tid < kT) {
+            const int row = min(qt * kT + tid, a.Nq - 1);
+            if constexpr (DKV) dlreg = a.delta[head * a.Nq + row];
+            if constexpr (REL) vlreg = a.rel_v[static_cast<int64_t>(b) * a.Nq + row];
+        }
     };
     auto stage = [&](int buf) {
         u32x2v rows[4];
         block_rows<IOH>(rows, doreg, 1.f, a.Nq, a.D, tid);
         store_row_major(dOr + buf * kT * kLR, rows, tid);
-        store_transposed(dOt + buf * kDP * kLT, rows, tid);
-        block_rows<false>(rows, qreg, q_first ? a.scale : 1.f, a.Nq, a.D, tid);
-        store_transposed(Qt + buf * kDP * kLT, rows, tid);
-        if (tid < kT) dl[buf * kT + tid] = dlreg;
+        if constexpr (DKV) {
+            store_transposed(dOt + buf * kDP * kLT, rows, tid);
+            block_rows<false>(rows, qreg, q_first ? a.scale : 1.f, a.Nq, a.D, tid);
+            store_transposed(Qt + buf * kDP * kLT, rows, tid);
+        }
+        if (tid < kT) {
+            if constexpr (DKV) dl[buf * kT + tid] = dlreg;
+            if constexpr (REL) vl[buf * kT + tid] = vlreg;      // (rows past Nq: p is masked to 0 below)
+        }
     };
     // this lane's probability column segments of a query tile (lane = key, 16 query rows): raw words, fetched one tile
     // ahead like the query side's (and ahead of the Q / dO prefetch in issue order)
@@ -447,8 +441,17 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_kv_bf16_kernel(const AttnBwdA
             }
         f32x4 dp[4];                                                   // dp[t][r] = dP[16 t + 4 g + r][key i]
         tile_x_regs<true>(dp, dOr + cur * kT * kLR, vop, i, g);
+        if constexpr (REL) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(vl + cur * kT + 16 * t + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) racc += vv[r] * relu_nan(p[t][r] * dp[t][r]);
+            }
+        }
         const bf16_t* dOtc = dOt + cur * kDP * kLT;
         const bf16_t* Qtc = Qt + cur * kDP * kLT;
+        if constexpr (DKV) {
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             f32x4 ds[2], pv[2];
@@ -466,6 +469,7 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_kv_bf16_kernel(const AttnBwdA
                 kacc[dt] = mfma16x16x32_bf16(ds_op, transposed_operand(Qtc, dt, pp, i, g), kacc[dt]);
             }
         }
+        }
         if (qt + 1 < ntiles) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -474,6 +478,12 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_kv_bf16_kernel(const AttnBwdA
         }
         lds_barrier();
     }
+    if constexpr (REL) {
+        racc += __shfl_xor(racc, 16);
+        racc += __shfl_xor(racc, 32);                              // the 4 row groups of the tile rows: all queries of key i
+        if (g == 0 && key_ok) a.rel_part[head * a.Nk + key] = racc;
+    }
+    if constexpr (!DKV) return;
     // accumulators: lane (d = 16 dt + i), rows key = kw + 4 g + r
     const int64_t dk0 = b * a.dks.sb + h * a.dks.sh, dv0 = b * a.dvs.sb + h * a.dvs.sh;
     const bool odd = i & 1;
@@ -512,8 +522,8 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_kv_bf16_kernel(const AttnBwdA
     }
 }
 
-constexpr size_t kQLds = sizeof(bf16_t) * (2 * kT * kLR + 2 * kDP * kLT) + sizeof(float) * 2 * 4 * kT;
-constexpr size_t kKvLds = sizeof(bf16_t) * (2 * kT * kLR + 4 * kDP * kLT) + sizeof(float) * 2 * kT;
+constexpr size_t kQLds = sizeof(bf16_t) * (2 * kT * kLR + 2 * kDP * kLT);
+constexpr size_t kKvLds = sizeof(bf16_t) * (2 * kT * kLR + 4 * kDP * kLT) + sizeof(float) * 4 * kT;
 
 template <typename K>
 int launch_v2(K kern, const AttnBwdArgs& a, dim3 grid, size_t lds, hipStream_t s, const char* name) {
@@ -530,10 +540,17 @@ int launch_v2(K kern, const AttnBwdArgs& a, dim3 grid, size_t lds, hipStream_t s
 
 template <int DT, bool IOH>
 int launch_dt_io(const AttnBwdArgs& a, dim3 gq, dim3 gk, hipStream_t s) {
-    int rc = a.rel_v ? launch_v2(attn_bwd_q_bf16_kernel<DT, true, IOH>, a, gq, kQLds, s, "attn_bwd_q_bf16_kernel<rel>")
-                     : launch_v2(attn_bwd_q_bf16_kernel<DT, false, IOH>, a, gq, kQLds, s, "attn_bwd_q_bf16_kernel");
-    if (rc == MMX_OK && a.need_dqkv)
-        rc = launch_v2(attn_bwd_kv_bf16_kernel<DT, IOH>, a, gk, kKvLds, s, "attn_bwd_kv_bf16_kernel");
+    int rc = MMX_OK;
+    // the query side: dQ (and delta for the key side), the dP slab when one is wanted
+    if (a.need_dqkv || a.dprobs) rc = launch_v2(attn_bwd_q_bf16_kernel<DT, IOH>, a, gq, kQLds, s, "attn_bwd_q_bf16_kernel");
+    if (rc) return rc;
+    if (a.rel_v) {
+        rc = a.need_dqkv ? launch_v2(attn_bwd_kv_bf16_kernel<DT, IOH, true, true>, a, gk, kKvLds, s, "attn_bwd_kv_bf16_kernel<rel>")
+                         : launch_v2(attn_bwd_kv_bf16_kernel<DT, IOH, true, false>, a, gk, kKvLds, s, "attn_bwd_kv_bf16_kernel<rel only>");
+        if (rc) return rc;
+        return rel_row_update(a.rel_v, a.rel_part, a.rel_out, a.B, a.H, a.Nk, 1.0f / a.H, s);     // one partial row per head
+    }
+    if (a.need_dqkv) rc = launch_v2(attn_bwd_kv_bf16_kernel<DT, IOH, false, true>, a, gk, kKvLds, s, "attn_bwd_kv_bf16_kernel");
     return rc;
 }
 

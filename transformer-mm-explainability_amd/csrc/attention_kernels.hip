@@ -395,6 +395,14 @@ __global__ __launch_bounds__(256) void rel_row_update_kernel(const float* __rest
 }  // namespace
 }  // namespace mmx
 
+namespace mmx {
+int rel_row_update(const float* v_in, const float* part, float* out, int B, int J, int N, float inv_h, hipStream_t s) {
+    rel_row_update_kernel<<<dim3((N + 255) / 256, B), 256, 0, s>>>(v_in, part, out, J, N, inv_h);
+    MMX_LAUNCH_CHECK("rel_row_update_kernel");
+    return MMX_OK;
+}
+}  // namespace mmx
+
 static size_t rowrel_delta_bytes(int B, int H, int Nq) {
     return (sizeof(float) * static_cast<size_t>(B) * H * Nq + 255) / 256 * 256;
 }
@@ -458,18 +466,14 @@ static int attn_bwd_impl(const void* q_dev, const void* k_dev, const void* v_dev
     a.io_bf16 = io_bf16;
     a.rel_v = static_cast<const float*>(rel_in_dev);
     a.rel_part = rel ? reinterpret_cast<float*>(static_cast<char*>(workspace_dev) + rowrel_delta_bytes(B, H, Nq)) : nullptr;
+    a.rel_out = static_cast<float*>(rel_out_dev);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (rel) {
         if (!attn_bwd_stream_try(a, s, &rc)) {
             set_error("mmx_attn_capture_bwd_rowrel: needs head_dim %% 4 == 0 (<= 64) and 16-byte aligned views");
             return MMX_ENOTSUP;
         }
-        if (rc) return rc;
-        const int J = H * ((Nq + 63) / 64);
-        rel_row_update_kernel<<<dim3((Nk + 255) / 256, B), 256, 0, s>>>(a.rel_v, a.rel_part,
-                                                                       static_cast<float*>(rel_out_dev), J, Nk, 1.0f / H);
-        MMX_LAUNCH_CHECK("rel_row_update_kernel");
-        return MMX_OK;
+        return rc;      // (the path that ran has also launched rel_row_update over the partial rows it made)
     }
     if (slab_dtype != MMX_F32 || mma_bf16) {
         if (attn_bwd_stream_try(a, s, &rc)) return rc;

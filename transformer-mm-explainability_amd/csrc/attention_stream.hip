@@ -799,7 +799,11 @@ int launch_bwd_bf16(const AttnBwdArgs& a, dim3 gq, dim3 gk, hipStream_t s) {
 template <int DT>
 int launch_bwd_dt(const AttnBwdArgs& a, dim3 gq, dim3 gk, hipStream_t s) {
     if (!a.mma_bf16) return launch_bwd_mm<DT, false>(a, gq, gk, s);
-    if (a.rel_v) return a.io_bf16 ? launch_bwd_bf16<DT, true, true>(a, gq, gk, s) : launch_bwd_bf16<DT, true, false>(a, gq, gk, s);
+    if (a.rel_v) {
+        int rc = a.io_bf16 ? launch_bwd_bf16<DT, true, true>(a, gq, gk, s) : launch_bwd_bf16<DT, true, false>(a, gq, gk, s);
+        if (rc) return rc;
+        return rel_row_update(a.rel_v, a.rel_part, a.rel_out, a.B, a.H * ((a.Nq + kRows - 1) / kRows), a.Nk, 1.0f / a.H, s);
+    }
     return a.io_bf16 ? launch_bwd_bf16<DT, false, true>(a, gq, gk, s) : launch_bwd_bf16<DT, false, false>(a, gq, gk, s);
 }
 
