@@ -30,8 +30,14 @@ constexpr int kR = 64;        // query rows (query side) / keys (key side) per w
 constexpr int kT = 64;        // rows of the streamed operand per step
 constexpr int kTh = 256;
 constexpr int kDP = 64;       // padded head dim (D <= 64, D % 8 == 0)
-constexpr int kLR = kDP + 8;  // bf16 elements per row of a row-major tile  [row][d]   (144 B: 16-B aligned rows)
-constexpr int kLT = kT + 8;   // bf16 elements per row of a transposed tile [d][row]   (144 B)
+// LDS layouts, bank-conflict free for every access below under the lane-group rules of MI355X_MICROARCH.md (searched by
+// brute force over row strides / swizzles; the first version -- 72-element rows, no swizzle -- spent 22 % of its wave cycles
+// in SQ_LDS_BANK_CONFLICT: the transposed ds_write_b64 of 16 lanes hit 2 bank positions):
+//   row-major tile  [row][d]:  80-element (160 B) rows, no swizzle   (ds_write_b64 by (row, 4 d), ds_read_b128 by (row i, 8 g))
+//   transposed tile [d][row]:  80-element rows; the 4-row group index of a row is XOR-ed with (d / 4) & 15
+//                              (ds_write_b64 of 4 consecutive rows by 16 lanes of different d; ds_read_b64 by (d = i, group g))
+constexpr int kLR = kDP + 16;
+constexpr int kLT = kT + 16;
 
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
@@ -95,14 +101,14 @@ __device__ __forceinline__ void store_row_major(bf16_t* tile, const u32x2v (&row
 }
 // transposed copy: element (row r4 + e, column c + dd) -> tile[c + dd][r4 + e]; 4 consecutive rows = one 8-byte store
 __device__ __forceinline__ void store_transposed(bf16_t* tile, const u32x2v (&rows)[4], int tid) {
-    const int r4 = 4 * (tid >> 4), c = 4 * (tid & 15);
+    const int c = 4 * (tid & 15);
 #pragma unroll
     for (int dd = 0; dd < 4; ++dd) {
         const int w = dd >> 1;
         const unsigned sel = (dd & 1) ? 0x07060302u : 0x05040100u;     // high / low halves of (row e+1, row e)
         const unsigned lo = __builtin_amdgcn_perm(rows[1][w], rows[0][w], sel);
         const unsigned hi = __builtin_amdgcn_perm(rows[3][w], rows[2][w], sel);
-        *reinterpret_cast<u32x2v*>(tile + (c + dd) * kLT + r4) = u32x2v{lo, hi};
+        *reinterpret_cast<u32x2v*>(tile + (c + dd) * kLT + 4 * ((tid >> 4) ^ (tid & 15))) = u32x2v{lo, hi};   // (c + dd) / 4 == tid & 15
     }
 }
 
@@ -147,8 +153,10 @@ __device__ __forceinline__ void tile_x_regs(f32x4 (&acc)[4], const bf16_t* tile,
 // one operand of the "contract over the tile's row index" products, from a TRANSPOSED tile [d][row]: row-slots (g, j) of
 // tile pair p (rows 32 p + 16 (j >> 2) + 4 g + (j & 3)) for d = 16 dt + i
 __device__ __forceinline__ bf16x8 transposed_operand(const bf16_t* tile, int dt, int p, int i, int g) {
-    const bf16_t* src = tile + (16 * dt + i) * kLT + 32 * p + 4 * g;
-    const u32x2v lo = *reinterpret_cast<const u32x2v*>(src), hi = *reinterpret_cast<const u32x2v*>(src + 16);
+    const int sw = (4 * dt + (i >> 2)) & 15;                          // (d / 4) & 15 of d = 16 dt + i
+    const bf16_t* row = tile + (16 * dt + i) * kLT;
+    const u32x2v lo = *reinterpret_cast<const u32x2v*>(row + 4 * ((8 * p + g) ^ sw));
+    const u32x2v hi = *reinterpret_cast<const u32x2v*>(row + 4 * ((8 * p + 4 + g) ^ sw));
     return as_bf16x8(u32x4v{lo[0], lo[1], hi[0], hi[1]});
 }
 
