@@ -33,16 +33,13 @@ constexpr int kDP = 64;       // padded head dim (D <= 64, D % 8 == 0)
 // LDS layouts, bank-conflict free for every access below under the lane-group rules of MI355X_MICROARCH.md (searched by
 // brute force over row strides / swizzles; the first version -- 72-element rows, no swizzle -- spent 22 % of its wave cycles
 // in SQ_LDS_BANK_CONFLICT: the transposed ds_write_b64 of 16 lanes hit 2 bank positions):
-//   row-major tile  [row][d]:  64-element rows, the 8-element (16 B) chunk index XOR-ed with row & 7: conflict-free for the
-//                              ds_write_b64 by (row, 4 d) and the ds_read_b128 by (row i, chunk g)
-//   transposed tile [d][row]:  64-element rows, the 4-row group index XOR-ed with (d / 4 + d) & 15: conflict-free ds_write_b64
-//                              (4 consecutive rows, 16 lanes of different d), 2-way ds_read_b64 by (d = i, group g)
-// (80-element rows reach "conflict-free" for every access as well, without / with a simpler swizzle, but cost 25 % more
-//  LDS: with unpadded rows THREE workgroups fit a CU -- the kernels are latency-bound, occupancy is what they need.)
-constexpr int kLR = kDP;
-constexpr int kLT = kT;
-__device__ __forceinline__ int rm_off(int row, int d) { return row * kLR + ((((d >> 3) ^ row) & 7) << 3) + (d & 7); }
-__device__ __forceinline__ int tr_sw(int d) { return ((d >> 2) + d) & 15; }
+//   row-major tile  [row][d]:  80-element (160 B) rows, no swizzle   (ds_write_b64 by (row, 4 d), ds_read_b128 by (row i, 8 g))
+//   transposed tile [d][row]:  80-element rows; the 4-row group index of a row is XOR-ed with (d / 4) & 15
+//                              (ds_write_b64 of 4 consecutive rows by 16 lanes of different d; ds_read_b64 by (d = i, group g))
+// (Unpadded 64-element rows with XOR swizzles are conflict-free too and would let THREE workgroups fit a CU, but the
+//  kernels need 162-184 VGPRs: under __launch_bounds__(256, 3) they spill 60-128 registers and run 4 x slower.)
+constexpr int kLR = kDP + 16;
+constexpr int kLT = kT + 16;
 
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
@@ -102,7 +99,7 @@ __device__ __forceinline__ void block_rows(u32x2v (&rows)[4], const Block4x4<HAL
 __device__ __forceinline__ void store_row_major(bf16_t* tile, const u32x2v (&rows)[4], int tid) {
     const int r4 = 4 * (tid >> 4), c = 4 * (tid & 15);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) *reinterpret_cast<u32x2v*>(tile + rm_off(r4 + e, c)) = rows[e];
+    for (int e = 0; e < 4; ++e) *reinterpret_cast<u32x2v*>(tile + (r4 + e) * kLR + c) = rows[e];
 }
 // transposed copy: element (row r4 + e, column c + dd) -> tile[c + dd][r4 + e]; 4 consecutive rows = one 8-byte store
 __device__ __forceinline__ void store_transposed(bf16_t* tile, const u32x2v (&rows)[4], int tid) {
@@ -113,7 +110,7 @@ __device__ __forceinline__ void store_transposed(bf16_t* tile, const u32x2v (&ro
         const unsigned sel = (dd & 1) ? 0x07060302u : 0x05040100u;     // high / low halves of (row e+1, row e)
         const unsigned lo = __builtin_amdgcn_perm(rows[1][w], rows[0][w], sel);
         const unsigned hi = __builtin_amdgcn_perm(rows[3][w], rows[2][w], sel);
-        *reinterpret_cast<u32x2v*>(tile + (c + dd) * kLT + 4 * ((tid >> 4) ^ tr_sw(c + dd))) = u32x2v{lo, hi};
+        *reinterpret_cast<u32x2v*>(tile + (c + dd) * kLT + 4 * ((tid >> 4) ^ (tid & 15))) = u32x2v{lo, hi};   // (c + dd) / 4 == tid & 15
     }
 }
 
@@ -148,7 +145,7 @@ __device__ __forceinline__ void tile_x_regs(f32x4 (&acc)[4], const bf16_t* tile,
     for (int pr = 0; pr < kDP / 32; ++pr) {
         bf16x8 op[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) op[t] = *reinterpret_cast<const bf16x8*>(tile + rm_off(16 * t + i, 32 * pr + 8 * g));
+        for (int t = 0; t < 4; ++t) op[t] = *reinterpret_cast<const bf16x8*>(tile + (16 * t + i) * kLR + 32 * pr + 8 * g);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
             acc[t] = TILE_IS_A ? mfma16x16x32_bf16(op[t], reg[pr], acc[t]) : mfma16x16x32_bf16(reg[pr], op[t], acc[t]);
@@ -158,7 +155,7 @@ __device__ __forceinline__ void tile_x_regs(f32x4 (&acc)[4], const bf16_t* tile,
 // one operand of the "contract over the tile's row index" products, from a TRANSPOSED tile [d][row]: row-slots (g, j) of
 // tile pair p (rows 32 p + 16 (j >> 2) + 4 g + (j & 3)) for d = 16 dt + i
 __device__ __forceinline__ bf16x8 transposed_operand(const bf16_t* tile, int dt, int p, int i, int g) {
-    const int sw = tr_sw(16 * dt + i);
+    const int sw = (4 * dt + (i >> 2)) & 15;                          // (d / 4) & 15 of d = 16 dt + i
     const bf16_t* row = tile + (16 * dt + i) * kLT;
     const u32x2v lo = *reinterpret_cast<const u32x2v*>(row + 4 * ((8 * p + g) ^ sw));
     const u32x2v hi = *reinterpret_cast<const u32x2v*>(row + 4 * ((8 * p + 4 + g) ^ sw));
@@ -170,7 +167,7 @@ __device__ __forceinline__ bf16x8 transposed_operand(const bf16_t* tile, int dt,
 // a lane owns a key and 16 query rows, so the sum over queries is an in-lane sum -- here it was 16 DPP row reductions per
 // tile, a third of the kernel's VALU work.)
 template <int DT, bool IOH>
-__global__ __launch_bounds__(kTh, 3) void attn_bwd_q_bf16_kernel(const AttnBwdArgs a) {
+__global__ __launch_bounds__(kTh, 2) void attn_bwd_q_bf16_kernel(const AttnBwdArgs a) {
     typedef typename slab_elem<DT>::type slab_t;
     constexpr int NB = kDP / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -358,7 +355,7 @@ __global__ __launch_bounds__(kTh, 3) void attn_bwd_q_bf16_kernel(const AttnBwdAr
 // tile are registers, so the sum over ALL queries is one running register, two cross-row shuffles at the very end and ONE
 // partial row per head (fixed order: deterministic).  DKV = false (the lowest explained layer) runs only that.
 template <int DT, bool IOH, bool REL, bool DKV>
-__global__ __launch_bounds__(kTh, 3) void attn_bwd_kv_bf16_kernel(const AttnBwdArgs a) {
+__global__ __launch_bounds__(kTh, 2) void attn_bwd_kv_bf16_kernel(const AttnBwdArgs a) {
     typedef typename slab_elem<DT>::type slab_t;
     constexpr int NB = kDP / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
