@@ -422,3 +422,23 @@ def test_self_chain_big_shared_attn_and_bf16(ops):
         close(ops.relevancy_self_chain([a.cuda() for a in a16], [x.cuda() for x in g16], B), want16)
     finally:
         ops.set_option("self_chain_big", 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,B,shared", [(197, 3, False), (197, 4, True), (77, 2, False), (300, 1, False)])
+def test_relevancy_chain_row_equals_the_matrix_chain(N, B, shared):
+    """``ops.relevancy_chain_row`` (one row of R carried top-down as a vector: head average + mat-vec per layer) vs the
+    rows of ``relevancy_self_chain`` (itself held against the oracle above), per-sample row indices, shared probabilities."""
+    from transformer_mm_explainability_amd import ops
+    g = torch.Generator().manual_seed(N + B)
+    L, H = 4, 3
+    attn = [torch.rand((1 if shared else B) * H, N, N, generator=g).softmax(-1).cuda() for _ in range(L)]
+    grad = [(torch.randn(B * H, N, N, generator=g) * 0.05).cuda() for _ in range(L)]
+    rows = torch.randint(0, N, (B,), generator=g).cuda()
+    R = ops.relevancy_self_chain(attn, grad, B, shared_attn=shared)
+    want = R[torch.arange(B, device="cuda"), rows]
+    got = ops.relevancy_chain_row(attn, grad, B, rows, shared_attn=shared)
+    assert got.shape == want.shape == (B, N)
+    assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    got0 = ops.relevancy_chain_row(attn, grad, B, 0, shared_attn=shared)
+    assert float((got0 - R[:, 0]).abs().max()) <= 2e-6 * float(R[:, 0].abs().max())

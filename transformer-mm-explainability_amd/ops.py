@@ -153,6 +153,26 @@ def relevancy_self_chain(attn_layers, grad_layers, batch_size, R_init=None, R_sq
     return (R_out, sq_out) if sq_out is not None else R_out
 
 
+def relevancy_chain_row(attn_layers, grad_layers, batch_size, rows, shared_attn=False):
+    """Row ``rows[b]`` of sample b's ``relevancy_self_chain`` result, ``[B, N]`` -- what the ViT / VisualBERT generators
+    return (``R[0, 1:]``, ViT notebook cell 7:34; ``R[cls_index]``, VisualBERT/.../ExplanationGenerator.py:95-97).
+
+    ``R = (I + A_L) ... (I + A_1)``, so ``e_r^T R`` is a row vector carried from the TOP layer down,
+    ``x <- x + x A_l`` (``mmx_chain_vecmat``): per layer one head-average pass over the slabs and one mat-vec, instead of
+    the N^3 product the long-sequence split path runs.  N <= 128 keeps the one-launch fused kernel (all layers, R in
+    registers) and picks the row afterwards -- that is faster there.  Same result up to fp32 summation order."""
+    n = grad_layers[0].shape[-1]
+    rows = torch.as_tensor(rows, device=grad_layers[0].device).reshape(-1).expand(batch_size)
+    if n <= 128:
+        R = relevancy_self_chain(attn_layers, grad_layers, batch_size, shared_attn=shared_attn)
+        return R[torch.arange(batch_size, device=R.device), rows]
+    x = torch.zeros(batch_size, n, dtype=torch.float32, device=rows.device)
+    x.scatter_(1, rows.reshape(batch_size, 1), 1.0)
+    for a, g in zip(reversed(list(attn_layers)), reversed(list(grad_layers))):
+        x = chain_vecmat(x, avg_heads(a, g, batch_size=batch_size, shared_attn=shared_attn))
+    return x
+
+
 class _QuickGELU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -50,9 +50,8 @@ class SelfAttentionGenerator:
         blocks = self._blocks()
         attn = [blk.attention.self.get_attn()[0] for blk in blocks]            # cam[0] -> [H, N, N]
         grad = [blk.attention.self.get_attn_gradients()[0] for blk in blocks]
-        R = ops.relevancy_self_chain(attn, grad, 1)[0]
         cls_index = input["input_mask"].sum(1) - 2
-        cls_per_token_score = R[cls_index]
+        cls_per_token_score = ops.relevancy_chain_row(attn, grad, 1, cls_index)          # R[cls_index], [1, N]
         cls_per_token_score[:, cls_index] = 0
         return cls_per_token_score
 
@@ -82,10 +81,9 @@ class SelfAttentionGenerator:
         self.model.zero_grad()
         torch.sum(one_hot * output).backward(retain_graph=True)
         blocks = self._blocks()
-        R = ops.relevancy_self_chain([blk.attention.self.get_attn() for blk in blocks],
-                                     [blk.attention.self.get_attn_gradients() for blk in blocks], B)          # [B, N, N]
         cls_index = n_text - 2
-        scores = R[:, cls_index, :].clone()
+        scores = ops.relevancy_chain_row([blk.attention.self.get_attn() for blk in blocks],
+                                         [blk.attention.self.get_attn_gradients() for blk in blocks], B, cls_index)    # [B, N]
         scores[:, cls_index] = 0
         return scores
 

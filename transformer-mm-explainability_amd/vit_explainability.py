@@ -28,5 +28,4 @@ def generate_relevance(model, input, index=None):
     loss.backward(retain_graph=True)
     attn = [blk.attn.get_attention_map().detach() for blk in model.blocks]
     grad = [blk.attn.get_attn_gradients().detach() for blk in model.blocks]
-    R = ops.relevancy_self_chain(attn, grad, 1)[0]
-    return R[0, 1:]
+    return ops.relevancy_chain_row(attn, grad, 1, 0)[0, 1:]          # row 0 of R only: carried as a row vector (N = 197 > 128)

@@ -237,9 +237,9 @@ def generate_relevance_multi(model, input, indices=None, top_k=None):
     d_logits.scatter_(1, idx.reshape(K, 1), 1.0)                     # one one-hot per target (capturable: no host sync)
     model.backward_shared(state, d_logits)
     buf = model.buffers_
-    R = ops.relevancy_self_chain([buf.probs[l] for l in range(model.depth)], [buf.grads[l] for l in range(model.depth)],
-                                 K, shared_attn=K > 1)
-    return R[:, 0, 1:]
+    row = ops.relevancy_chain_row([buf.probs[l] for l in range(model.depth)], [buf.grads[l] for l in range(model.depth)],
+                                  K, 0, shared_attn=K > 1)           # R[:, 0, :] carried as row vectors: no 197^3 products
+    return row[:, 1:]
 
 
 class GraphedRelevance:
