@@ -162,12 +162,18 @@ def relevancy_chain_row(attn_layers, grad_layers, batch_size, rows, shared_attn=
     the N^3 product the long-sequence split path runs.  N <= 128 keeps the one-launch fused kernel (all layers, R in
     registers) and picks the row afterwards -- that is faster there.  Same result up to fp32 summation order."""
     n = grad_layers[0].shape[-1]
-    rows = torch.as_tensor(rows, device=grad_layers[0].device).reshape(-1).expand(batch_size)
+    dev = grad_layers[0].device
+    fixed = isinstance(rows, int)               # (a Python int needs no host -> device copy: capturable into a hipGraph)
+    if not fixed:
+        rows = torch.as_tensor(rows, device=dev).reshape(-1).expand(batch_size)
     if n <= 128:
         R = relevancy_self_chain(attn_layers, grad_layers, batch_size, shared_attn=shared_attn)
-        return R[torch.arange(batch_size, device=R.device), rows]
-    x = torch.zeros(batch_size, n, dtype=torch.float32, device=rows.device)
-    x.scatter_(1, rows.reshape(batch_size, 1), 1.0)
+        return R[:, rows].contiguous() if fixed else R[torch.arange(batch_size, device=dev), rows]
+    x = torch.zeros(batch_size, n, dtype=torch.float32, device=dev)
+    if fixed:
+        x[:, rows] = 1.0
+    else:
+        x.scatter_(1, rows.reshape(batch_size, 1), 1.0)
     for a, g in zip(reversed(list(attn_layers)), reversed(list(grad_layers))):
         x = chain_vecmat(x, avg_heads(a, g, batch_size=batch_size, shared_attn=shared_attn))
     return x
