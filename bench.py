@@ -77,6 +77,117 @@ def step_flops(batch):
     return out
 
 
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix-core peak (AMD's 5 PF figure is 2:1 sparse)
+CFG5_BATCH = 128
+CFG5_MODEL = "ViT-L/14@336"
+
+
+def cfg5_step_flops(batch):
+    """Matrix FLOPs of one cfg-5 step (CLIP ViT-L/14@336 bf16 body: image tower 24 x 1024 x 16 heads x 577 tokens with a shared
+    forward and row-relevancy backward, text tower 12 x 768 x 12 x 77), as ``step_flops`` counts them for cfg 2."""
+    def tower(L, E, N, H, m_fwd, m_bwd, attn_products):
+        gemm_fwd = L * 2 * m_fwd * 12 * E * E
+        full, top, low = 2 * m_bwd * 12 * E * E, 2 * m_bwd * 3 * E * E + 2 * batch * 9 * E * E, 2 * m_bwd * 9 * E * E
+        d = E // H
+        attn = L * 4 * (m_fwd // N) * H * N * N * d + (L - 1) * attn_products * 2 * (m_bwd // N) * H * N * N * d \
+            + 2 * (m_bwd // N) * H * N * N * d
+        return gemm_fwd + (L - 2) * full + top + low, attn
+    g_img, a_img = tower(24, 1024, 577, 16, 577, batch * 577, 5)       # dP (twice: both kernels), dQ, dK, dV
+    g_txt, a_txt = tower(12, 768, 77, 12, batch * 77, batch * 77, 4)
+    return {"gemm": g_img + g_txt, "attention": a_img + a_txt, "total": g_img + g_txt + a_img + a_txt}
+
+
+def main_cfg5(args):
+    """Optional leg (``--workload cfg5``; NOT the driver's default): BASELINE.json config 5's shape on this GPU -- CLIP
+    ViT-L/14@336 with the bf16 body of ``clip_model.CLIP.set_body_dtype``, batch 128 per GPU, all layers, eager."""
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    from transformer_mm_explainability_amd import clip_model, ops
+    model = clip_model.random_init(CFG5_MODEL, seed=0).to(device)
+    model.set_body_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(1 + rank)
+    image = torch.randn(1, 3, 336, 336, generator=g).to(device)
+    _, texts = synthetic_inputs(CFG5_BATCH, device, seed=rank)
+    n_img = 576
+    row = n_img + 77 * 77
+    gathered = torch.empty(world * CFG5_BATCH, row, device=device) if world > 1 else None
+    packed = torch.empty(CFG5_BATCH, row, device=device) if world > 1 else None
+
+    def step():
+        R_text, R_image = ce.interpret(image, texts, model, device, start_layer=0, start_layer_text=0)
+        if world > 1:
+            packed[:, :n_img] = R_image
+            packed[:, n_img:] = R_text.reshape(CFG5_BATCH, -1)
+            dist.all_gather_into_tensor(gathered, packed)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    torch.cuda.reset_peak_memory_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms = elapsed / args.steps * 1e3
+    fl = cfg5_step_flops(CFG5_BATCH)
+    # our dominant kernel pair of this step: the bf16 attention backward of one image-tower layer (stand-alone launches)
+    H, N, D = 16, 577, 64
+    qkv = torch.randn(1, N, 3, H, D, device=device)
+    d_o = (torch.randn(CFG5_BATCH, N, H, D, device=device) * 1e-2).to(torch.bfloat16)
+    probs = torch.empty(1, H, N, N, device=device, dtype=torch.bfloat16)
+    o = ops.attn_capture_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], probs, D ** -0.5, mma_bf16=True)
+    out = torch.empty(CFG5_BATCH, N, 3, H, D, device=device, dtype=torch.bfloat16)
+    rel = torch.zeros(CFG5_BATCH, N, device=device)
+    rel[:, 0] = 1
+
+    def attn_layer():
+        ops.attn_capture_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], probs, d_o, None, D ** -0.5, batch=CFG5_BATCH, o=o,
+                             out=(out[:, :, 0], out[:, :, 1], out[:, :, 2]), mma_bf16=True, rel_row=rel)
+    us = kernel_time_us(attn_layer, 5, torch.cuda.current_stream())
+    attn_flops = 5 * 2 * CFG5_BATCH * H * N * N * D
+    if rank == 0:
+        print(json.dumps({
+            "metric": "relevancy maps/sec (fwd+bwd+rollout), CLIP ViT-L/14@336", "value": round(world * CFG5_BATCH / (ms * 1e-3), 2),
+            "unit": "maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE config 5 shape: CLIP ViT-L/14@336 (577 image tokens) image<->text relevancy, batch=128 "
+                                   "per GPU, all 24+12 layers; bf16 body (GEMMs + image attention on the bf16 matrix cores, fp32 "
+                                   "accumulation / LayerNorm / softmax / relevancy); random-init weights, synthetic inputs; eager",
+                       "global_batch": world * CFG5_BATCH, "parallelism": "dp%d (independent batches, all-gather of maps)" % world,
+                       "resident_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
+            "roofline": {"bound": "mfma", "kernel": "attn_bwd_q_bf16_kernel + attn_bwd_kv_bf16_kernel (one image-tower layer, "
+                                                    "row-relevancy mode)", "achieved": round(attn_flops / us / 1e6, 1),
+                         "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(attn_flops / us / 1e6 / BF16_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None, "us_per_launch": round(us, 1),
+                         "note": "latency- / VALU-bound, not matrix-core bound: see profiles/r02_cfg5_probe.txt (SQ counters)"},
+            "roofline_step": {"bound": "mfma", "achieved": round(fl["total"] / (ms * 1e-3) / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": round(fl["total"] / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                              "flop_per_step": fl},
+            "cpu_baseline": None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def synthetic_inputs(batch, device, seed):
     g = torch.Generator().manual_seed(1 + seed)
     image = torch.randn(1, 3, 224, 224, generator=g)
@@ -168,9 +279,16 @@ def main():
                     help="skip the variant rates (eager, distinct images, last layer, trimmed): what the rocprofv3 "
                          "kernel-split run uses, so that the trace holds headline steps only")
     ap.add_argument("--cpu-baseline-worker", nargs=2, type=int, metavar=("BATCH", "REPS"), help=argparse.SUPPRESS)
+    ap.add_argument("--workload", default="cfg2", choices=("cfg2", "cfg5"),
+                    help="cfg2 (default, BASELINE.json's metric configuration) or the optional cfg-5 shape (ViT-L/14@336 bf16 body)")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(*args.cpu_baseline_worker)
+        return
+    if args.workload == "cfg5":
+        if args.steps == 100:
+            args.steps = 5          # 120 ms per step
+        main_cfg5(args)
         return
 
     rank = int(os.environ.get("RANK", 0))
