@@ -8,6 +8,10 @@ sys.path.insert(0, ".")
 from transformer_mm_explainability_amd import detr_model  # noqa: E402
 from transformer_mm_explainability_amd.detr_explainability import Generator  # noqa: E402
 
+import os as _os
+if _os.environ.get("MMX_TUNED", "1") == "1":
+    from transformer_mm_explainability_amd import tuned_gemms
+    print("tuned GEMM selection loaded:", tuned_gemms.enable("detr"))
 torch.manual_seed(0)
 model = detr_model.detr_resnet50_head().cuda().eval()
 feats = torch.randn(1, 2048, 25, 38, device="cuda") * 0.5

@@ -18,5 +18,5 @@ for _ in range(n):
     if K == 1:
         gen.generate_ours(feats, tgt, use_lrp=False)
     else:
-        gen.generate_ours_multi(feats, tgt)
+        gen.generate_ours_multi(feats, tgt, rows_only=len(sys.argv) > 3)
 torch.cuda.synchronize()

@@ -1,0 +1,61 @@
+"""Make ``tuning/tunableop_gfx950_<workload>.csv`` on an MI355X: run a workload's passes eagerly with PyTorch TunableOp
+tuning ON (every distinct GEMM shape is timed against the hipBLASLt / rocBLAS solutions once), write the selection.
+
+    python tools/tune_gemms.py detr|lxmert|cfg5 <out.csv>
+"""
+import os
+import sys
+
+work, out = sys.argv[1], sys.argv[2]
+os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
+os.environ["PYTORCH_TUNABLEOP_TUNING"] = "1"
+os.environ["PYTORCH_TUNABLEOP_FILENAME"] = out
+os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS", "15")
+os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS", "5")
+os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
+import torch  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+torch.manual_seed(0)
+if work == "detr":
+    from transformer_mm_explainability_amd import detr_model
+    from transformer_mm_explainability_amd.detr_explainability import Generator
+    model = detr_model.detr_resnet50_head().cuda().eval()
+    feats = torch.randn(1, 2048, 25, 38, device="cuda") * 0.5
+    with torch.no_grad():
+        model(feats)
+    gen = Generator(model)
+    for K in (8, 10, 16, 20):
+        gen.generate_ours_multi(feats, torch.arange(K, device="cuda") * 3, rows_only=True)
+    gen.generate_ours(feats, torch.tensor([3], device="cuda"), use_lrp=False)
+elif work == "lxmert":
+    from transformer_mm_explainability_amd import lxmert_explainability as le
+    from transformer_mm_explainability_amd import lxmert_model as lm
+    from transformer_mm_explainability_amd import lxmert_perturbation as lp
+    cfg = lm.LxmertConfig()
+    model = lm.LxmertForQuestionAnswering(cfg).cuda().eval()
+    gen = le.GeneratorOurs(type("Usage", (), {"model": model})())
+    pert = lp.LxmertPerturbation(model)
+    for B in (8, 32):
+        T = 20
+        batch = dict(input_ids=torch.randint(1, cfg.vocab_size, (B, T), device="cuda"), attention_mask=torch.ones(B, T, device="cuda"),
+                     token_type_ids=torch.zeros(B, T, dtype=torch.long, device="cuda"),
+                     visual_feats=torch.randn(B, 36, cfg.visual_feat_dim, device="cuda"), visual_pos=torch.rand(B, 36, 4, device="cuda"))
+        R_t_t, R_t_i = gen.generate_ours_batch(batch)
+        cam_image, cam_text = lp.normalize_cams_batch(R_t_t, R_t_i, batch["attention_mask"])
+        pert.perturbation_image(batch, cam_image, False)
+        pert.perturbation_text(batch, cam_text, False)
+elif work == "cfg5":
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    from transformer_mm_explainability_amd import clip_model
+    import bench
+    model = clip_model.random_init("ViT-L/14@336", seed=0).cuda()
+    model.set_body_dtype(torch.bfloat16)
+    image = torch.randn(1, 3, 336, 336, device="cuda")
+    _, texts = bench.synthetic_inputs(128, "cuda", 0)
+    ce.interpret(image, texts, model, "cuda", 0, 0)
+else:
+    raise SystemExit("unknown workload " + work)
+torch.cuda.synchronize()
+torch.cuda.tunable.write_file(out) if hasattr(torch.cuda, "tunable") else None
+print("wrote", out)

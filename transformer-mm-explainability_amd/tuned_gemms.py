@@ -1,0 +1,32 @@
+"""Pre-tuned library-GEMM selections (PyTorch-ROCm TunableOp) for the model bodies of this package on gfx950.
+
+The bodies' GEMMs are plain library GEMMs (hipBLASLt / rocBLAS); for the small and skinny shapes of the explainability
+passes (DETR decoder at 100 queries, LXMERT at 20 + 36 tokens, batch-1 shared forwards) the default heuristic often picks
+a solution that runs on ONE workgroup (e.g. ``MT256x112x32`` for a ``[100, 256] x [256, 256]`` product: 31 us on 1 of 256
+CUs).  ``tuning/*.csv`` hold the solutions TunableOp selected on an MI355X for each workload (made by
+``tools/tune_gemms.py``); ``enable(workload)`` turns TunableOp on with tuning OFF and loads that file, so shapes that are
+in it use the tuned solution and everything else the default.  PyTorch ignores a file whose validators (ROCm / hipBLASLt
+version, architecture) do not match the box.  Process-wide (it changes every GEMM of the process), hence opt-in.
+"""
+import os
+
+import torch
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning")
+WORKLOADS = {"clip_vitb32_b64": "tunableop_gfx950_clip_vitb32_b64.csv", "detr": "tunableop_gfx950_detr_r50.csv",
+             "lxmert": "tunableop_gfx950_lxmert_base.csv", "clip_vitl14_336_bf16": "tunableop_gfx950_clip_vitl14_336_bf16.csv"}
+
+
+def available(workload):
+    return workload in WORKLOADS and os.path.exists(os.path.join(_DIR, WORKLOADS[workload]))
+
+
+def enable(workload):
+    """Returns True if the tuned selection for ``workload`` was loaded (False: no file for it, nothing changed)."""
+    if not available(workload):
+        return False
+    tun = torch.cuda.tunable
+    tun.enable(True)
+    tun.tuning_enable(False)
+    tun.record_untuned_enable(False) if hasattr(tun, "record_untuned_enable") else None
+    return bool(tun.read_file(os.path.join(_DIR, WORKLOADS[workload])))
