@@ -8,6 +8,10 @@ import torch
 sys.path.insert(0, ".")
 from transformer_mm_explainability_amd import clip_explainability as ce  # noqa: E402
 from transformer_mm_explainability_amd import clip_model  # noqa: E402
+import os as _os  # noqa: E402
+if _os.environ.get("MMX_TUNED", "1") == "1":
+    from transformer_mm_explainability_amd import tuned_gemms  # noqa: E402
+    print("tuned GEMM selection loaded:", tuned_gemms.enable("clip_vitl14_336_bf16"))
 
 dev = torch.device("cuda")
 model = clip_model.random_init("ViT-L/14@336", seed=0).to(dev)
