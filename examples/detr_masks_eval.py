@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--graph-slots", type=int, default=16, help="target slots of the captured explain pass (0: eager)")
     ap.add_argument("--keep-top", type=int, default=8, help="random-init logits are flat: keep this many queries per image")
     ap.add_argument("--resume-dir", default=None)
+    ap.add_argument("--no-tuned-gemms", action="store_true", help="keep the default hipBLASLt / rocBLAS heuristic for the body's GEMMs")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
@@ -65,9 +66,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    from transformer_mm_explainability_amd import detr_model
+    from transformer_mm_explainability_amd import detr_model, tuned_gemms
     from transformer_mm_explainability_amd.detr_explainability import MaskGenerator
 
+    if not args.no_tuned_gemms:
+        tuned_gemms.enable("detr")     # pre-tuned library-GEMM selection for the 100-query decoder shapes (tuning stays off)
     torch.manual_seed(0)
     model = detr_model.detr_resnet50_head().to(dev).eval()
     mg = MaskGenerator(model, threshold=0.5, graph_slots=args.graph_slots or None)

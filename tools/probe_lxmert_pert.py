@@ -47,10 +47,6 @@ print("text  test, batched               : %.2f ms / sample" % timed(lambda: per
 import types  # noqa: E402
 
 from transformer_mm_explainability_amd import lxmert_explainability as le  # noqa: E402
-import os as _os  # noqa: E402
-if _os.environ.get("MMX_TUNED", "1") == "1":
-    from transformer_mm_explainability_amd import tuned_gemms  # noqa: E402
-    print("tuned GEMM selection loaded:", tuned_gemms.enable("lxmert"))
 
 usage = types.SimpleNamespace(model=model, text_len=T, image_boxes_len=I, forward=lambda item: model(**inputs))
 gen = le.GeneratorOurs(usage)

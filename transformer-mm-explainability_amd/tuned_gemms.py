@@ -13,8 +13,10 @@ import os
 import torch
 
 _DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning")
+# (LXMERT: a selection was made too, but with it the capture of GraphedGenerateOursBatch died with
+#  hipErrorStreamCaptureUnsupported inside a library call -- not shipped; `tools/tune_gemms.py lxmert` reproduces it.)
 WORKLOADS = {"clip_vitb32_b64": "tunableop_gfx950_clip_vitb32_b64.csv", "detr": "tunableop_gfx950_detr_r50.csv",
-             "lxmert": "tunableop_gfx950_lxmert_base.csv", "clip_vitl14_336_bf16": "tunableop_gfx950_clip_vitl14_336_bf16.csv"}
+             "clip_vitl14_336_bf16": "tunableop_gfx950_clip_vitl14_336_bf16.csv"}
 
 
 def available(workload):
