@@ -112,6 +112,8 @@ def main_cfg5(args):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     from transformer_mm_explainability_amd import clip_explainability as ce
     from transformer_mm_explainability_amd import clip_model, ops
+    from transformer_mm_explainability_amd import tuned_gemms
+    tuned_gemms.enable("clip_vitl14_336_bf16")      # pre-tuned selection for this body's GEMM shapes (tuning off)
     model = clip_model.random_init(CFG5_MODEL, seed=0).to(device)
     model.set_body_dtype(torch.bfloat16)
     g = torch.Generator().manual_seed(1 + rank)
