@@ -169,6 +169,20 @@ def self_chain(attn_layers, grad_layers, batch_size, start_layer=0):
     return R
 
 
+def self_chain_row(attn_layers, grad_layers, batch_size, row, start_layer=0):
+    """Row ``row`` of ``self_chain``'s result as a row VECTOR carried from the TOP layer down (``x <- x + x A_bar_l``):
+    ``R = (I + A_L) ... (I + A_start)``, so ``e_row^T R = ((e_row^T (I + A_L)) (I + A_(L-1))) ...``.  The algebra behind the
+    product path's row modes (``mmx_attn_capture_bwd_rowrel`` for CLIP's ``R[:, 0, 1:]``, cell 6:57; ``ops.relevancy_chain_row``
+    for the ViT notebook's ``R[0, 1:]``, cell 7:34, and VisualBERT's ``R[cls_index]``, ExplanationGenerator.py:95-97).
+    Returns ``[B, N]``."""
+    n = attn_layers[0].shape[-1]
+    x = np.zeros((batch_size, 1, n), dtype=F32)
+    x[:, 0, row] = 1.0
+    for i in range(len(attn_layers) - 1, start_layer - 1, -1):
+        x = x + np.matmul(x, avg_heads_batched(attn_layers[i], grad_layers[i], batch_size))
+    return x[:, 0]
+
+
 def clip_interpret_chain(img_attn, img_grad, txt_attn, txt_grad, batch_size,
                          start_layer=-1, start_layer_text=-1):
     """Rule part of the notebook ``interpret`` (model forward/backward excluded).
@@ -230,6 +244,55 @@ def detr_generate_ours_chain(enc_attn, enc_grad, dec_self_attn, dec_self_grad,
             apply_self_in_rule_10=apply_self_in_rule_10)
     agg = R_q_i[None]
     return agg[:, target_index, :][None]
+
+
+def detr_generate_ours_rows(enc_attn, enc_grad, dec_self_attn, dec_self_grad, dec_cross_attn, dec_cross_grad,
+                            target_index):
+    """The same schedule as ``detr_generate_ours_chain`` (default flags), restated for the ROWS it returns -- the algebra
+    behind ``Generator._rows_only_rules`` / ``mmx_chain_matvec`` / ``mmx_chain_vecmat`` (the product path never forms
+    ``R_i_i`` or the ``[Q, Ni]`` state; this restatement shows the two forms give the same rows).
+
+    Reference: DETR/modules/ExplanationGenerator.py:26-43 (``handle_residual``, rule 10 with ``R_sq_addition[isnan] = 0``),
+    :110-140, :180-182 (``aggregated[:, target_index, :]``).  With ``A_l`` / ``B_l`` / ``C_l`` the head-averaged encoder /
+    decoder-self / cross maps and ``N(.)`` = ``handle_residual``:
+        row t of R_q_i  =  sum_l u_l N(R_qq^(l))^T C_l N(R_ii),   u_l = e_t^T (I + B_L) ... (I + B_(l+1)),
+                        =  (s / rho) R_ii - s / rho + s,            s = sum_l u_l N(R_qq^(l))^T C_l,  rho = R_ii 1 - 1,
+    where ``R_ii 1`` and ``v R_ii`` are chains of mat-vecs with the ``A_l``.  fp64 inside (a referee, not a timing baseline).
+    """
+    f8 = np.float64
+    A = [avg_heads(a, g).astype(f8) for a, g in zip(enc_attn, enc_grad)]
+    B = [avg_heads(a, g).astype(f8) for a, g in zip(dec_self_attn, dec_self_grad)]
+    Cs = [avg_heads(a, g).astype(f8) for a, g in zip(dec_cross_attn, dec_cross_grad)]
+    n_i, n_q = A[0].shape[-1], B[0].shape[-1]
+    e = np.zeros(n_i, dtype=f8)                       # rho = R_ii 1 - 1, carried as the deviation from 1 (bottom-up)
+    for a in A:
+        e = e + a @ (1.0 + e)
+    R_qq = np.eye(n_q, dtype=f8)
+    hats = []
+    for b in B:
+        R_qq = R_qq + b @ R_qq
+        d = R_qq - np.eye(n_q)
+        hats.append(d / d.sum(axis=-1, keepdims=True) + np.eye(n_q))
+    rows = []
+    for t in np.atleast_1d(target_index):
+        u = np.zeros(n_q, dtype=f8)
+        u[int(t)] = 1.0
+        s_vec = np.zeros(n_i, dtype=f8)
+        for l in range(len(B) - 1, -1, -1):           # top-down
+            z = (u @ hats[l].T) @ Cs[l]
+            if not (np.isnan(hats[l]).any() or np.isnan(Cs[l]).any()):
+                s_vec = s_vec + z                     # a rule-10 addition holding one NaN holds only NaNs -> scrubbed to 0
+            u = u + u @ B[l]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            v = s_vec / e
+        dev = np.zeros(n_i, dtype=f8)                 # v R_ii - v, top-down: dev <- dev + (v + dev) A
+        for a in reversed(A):
+            dev = dev + (v + dev) @ a
+        out = dev + s_vec
+        if not np.isfinite(v).all():
+            out = np.zeros(n_i, dtype=f8)
+        rows.append(np.where(np.isnan(out), 0.0, out))
+    return np.stack(rows)[None, None].astype(F32)
 
 
 def lxmert_generate_ours_chain(lang_attn, lang_grad, vis_attn, vis_grad, x_layers,

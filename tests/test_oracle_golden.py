@@ -217,3 +217,31 @@ def test_lrp_route_is_the_same_schedule_on_cams(golden):
                                                   list(g["vis_cam"]), list(g["vis_grad"]), x_layers)
     close(R_t_t, g["R_t_t"], atol=1e-5)
     close(R_t_i, g["R_t_i"], atol=1e-5)
+
+
+def test_detr_row_vector_rules_equal_the_reference_rows(golden):
+    """The row-vector form of the DETR rules (what ``Generator.generate_ours_multi(rows_only=True)`` runs on mat-vec
+    kernels: no ``R_i_i``, no ``[Q, Ni]`` state) against the rows the REFERENCE generator returned (``detr_chain.npz`` is
+    made by ``DETR/modules/ExplanationGenerator.Generator.generate_ours`` on fake slots)."""
+    g = golden("detr_chain")
+    out = onp.detr_generate_ours_rows(list(g["enc_attn"]), list(g["enc_grad"]), list(g["dself_attn"]), list(g["dself_grad"]),
+                                      list(g["dcross_attn"]), list(g["dcross_grad"]), g["target_index"])
+    assert out.shape == g["out"].shape
+    close(out, g["out"], atol=1e-6)
+
+
+def test_row_vector_chain_equals_the_reference_rows(golden):
+    """``oracle.self_chain_row`` (the row carried top-down: what the product path's row modes compute) against rows the
+    REFERENCE code returned: the ViT notebook's ``R[0, 1:]`` (vit_chain.npz), VisualBERT's ``R[cls_index]``
+    (visualbert_chain.npz) and CLIP ``interpret``'s ``R[:, 0, 1:]`` for three ``start_layer`` settings (clip_tiny.npz)."""
+    g = golden("vit_chain")
+    close(onp.self_chain_row([a[0] for a in g["attn"]], [x[0] for x in g["grad"]], 1, 0)[0, 1:], g["out"], atol=1e-6)
+    g = golden("visualbert_chain")
+    cls_index = int(g["input_mask"].sum(1)[0]) - 2
+    row = onp.self_chain_row([a[0] for a in g["attn"]], [x[0] for x in g["grad"]], 1, cls_index).copy()
+    row[:, cls_index] = 0
+    close(row, g["out"], atol=1e-6)
+    g = golden("clip_tiny")
+    B = g["texts"].shape[0]
+    for tag, sl in (("last", len(g["img_attn"]) - 1), ("all", 0), ("mid", 1)):
+        close(onp.self_chain_row(list(g["img_attn"]), list(g["img_grad"]), B, 0, sl)[:, 1:], g["R_image_" + tag], atol=1e-6)
