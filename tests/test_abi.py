@@ -52,3 +52,16 @@ def test_no_cpu_fallback():
         if name.endswith(".py"):
             src = open(os.path.join(pkg, name)).read()
             assert "import oracle" not in src and "from oracle" not in src, name
+
+
+def test_tuned_gemm_files_are_tunableop_selections():
+    """``tuned_gemms.WORKLOADS`` files: present, TunableOp CSVs for gfx950 (validator rows first, then op,shape,solution,time)."""
+    import importlib
+    tg = importlib.import_module("transformer_mm_explainability_amd.tuned_gemms")
+    for workload, name in tg.WORKLOADS.items():
+        assert tg.available(workload), workload
+        rows = [l.strip().split(",") for l in open(os.path.join(os.path.dirname(tg.__file__), "tuning", name)) if l.strip()]
+        validators = [r for r in rows if r[0] == "Validator"]
+        assert any(r[1] == "GCN_ARCH_NAME" and r[2].startswith("gfx950") for r in validators), name
+        entries = [r for r in rows if r[0] != "Validator"]
+        assert entries and all(len(r) >= 4 and "TunableOp" in r[0] and float(r[-1]) > 0 for r in entries), name
