@@ -80,9 +80,10 @@ def main():
     def masks_of(k):
         feats = synthetic_features(k, device=dev)
         with torch.no_grad():       # the 0.5 confidence cut of mask_generator.py:50 keeps nothing on random weights
-            conf = model(feats)["pred_logits"].softmax(-1)[0, :, :-1].max(-1).values
+            outputs = model(feats)
+            conf = outputs["pred_logits"].softmax(-1)[0, :, :-1].max(-1).values
         mg.threshold = float(conf.sort().values[-args.keep_top - 1])
-        masks, keep = mg.get_masks(feats, args.method)
+        masks, keep = mg.get_masks(feats, args.method, outputs=outputs)          # (one forward per image, not two)
         queries[0] += int(keep.sum())
         return masks.cpu(), keep.cpu()
 

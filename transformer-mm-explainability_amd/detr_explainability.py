@@ -429,10 +429,13 @@ class MaskGenerator:
                              % (method,))
         return fn(img, idx)
 
-    def get_masks(self, img, method="ours_no_lrp"):
+    def get_masks(self, img, method="ours_no_lrp", outputs=None):
+        """``outputs``: the body's output dict for ``img`` when the caller has already run the forward (an evaluator
+        that looks at the confidences first); default: run it here, like ``mask_generator.py:47``."""
         from . import postprocess
-        with torch.no_grad():
-            outputs = self.model(img)
+        if outputs is None:
+            with torch.no_grad():
+                outputs = self.model(img)
         h, w = self.model.spatial_dim
         probas = outputs["pred_logits"].softmax(-1)[0, :, :-1]
         keep = probas.max(-1).values > self.threshold
