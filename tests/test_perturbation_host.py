@@ -148,3 +148,42 @@ def test_backward_gemm_cache_follows_the_parameter():
     del w, cached
     gc.collect()
     assert len(ops._GEMM_WEIGHTS) == n - 1
+
+
+def test_bf16_body_gemm_helpers():
+    """The GEMM helpers of the bf16 body (``CLIP.set_body_dtype``): ``ops.linear`` rounds activations and the (cached)
+    weight to bf16 and returns fp32 -- through ``aten::mm.dtype`` where the build has it, else by widening the bf16 result;
+    ``backward_gemm_bf16`` keeps the gradient stream in bf16; fp32 stays the plain library call."""
+    from transformer_mm_explainability_amd import ops
+    lin = torch.nn.Linear(32, 24)
+    x = torch.randn(5, 7, 32)
+    assert torch.equal(ops.linear(x, lin.weight, lin.bias), torch.nn.functional.linear(x, lin.weight, lin.bias))
+    y = ops.linear(x, lin.weight, lin.bias, torch.bfloat16)
+    want = torch.nn.functional.linear(x.bfloat16().float(), lin.weight.detach().bfloat16().float(), lin.bias)
+    assert y.dtype == torch.float32 and y.shape == (5, 7, 24)
+    assert torch.allclose(y, want, rtol=2e-2, atol=2e-2)           # (bf16-rounded result on builds without mm.dtype)
+    g = torch.randn(5, 7, 24).bfloat16()
+    d = ops.backward_gemm_bf16(g, lin.weight)
+    assert d.dtype == torch.bfloat16 and d.shape == (5, 7, 32)
+    assert torch.allclose(d.float(), g.float() @ lin.weight.detach().bfloat16().float(), rtol=3e-2, atol=3e-2)
+    assert ops._GEMM_WEIGHTS[id(lin.weight)][torch.bfloat16][1].dtype == torch.bfloat16     # one cached copy serves both
+
+
+def test_clip_body_dtype_switch():
+    """``CLIP.set_body_dtype``: image tower -> bf16 slabs + GEMMs + attention products, text tower -> bf16 GEMMs only (its
+    77-token attention stays on the exact-fp32 register-resident kernels); back to fp32 restores everything."""
+    from transformer_mm_explainability_amd import clip_model
+    m = clip_model.CLIP(32, 32, 2, 128, 8, 12, 64, 64, 2, 2)
+    vis, txt = m.visual.transformer, m.transformer
+    assert (vis.capture_dtype, vis.forward_gemm_dtype, vis.attention_mma_bf16) == (torch.float32, torch.float32, False)
+    m.set_body_dtype(torch.bfloat16)
+    assert (vis.capture_dtype, vis.forward_gemm_dtype, vis.backward_gemm_dtype, vis.attention_mma_bf16) == \
+        (torch.bfloat16, torch.bfloat16, torch.bfloat16, True)
+    assert (txt.capture_dtype, txt.forward_gemm_dtype, txt.backward_gemm_dtype) == (torch.float32, torch.bfloat16, torch.bfloat16)
+    assert not m.visual.row_relevancy_ok()          # 17 tokens: the whole-head kernels, no row mode
+    m.set_body_dtype(torch.float32)
+    assert (vis.capture_dtype, vis.forward_gemm_dtype, vis.attention_mma_bf16, txt.forward_gemm_dtype) == \
+        (torch.float32, torch.float32, False, torch.float32)
+    import pytest
+    with pytest.raises(ValueError):
+        m.set_body_dtype(torch.float16)
