@@ -282,8 +282,9 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_q_bf16_kernel(const AttnBwdAr
     // The last tile may run past Nk: clamped element loads, issued and consumed in place (one tile of ~10).
     // NOTE (16-bit slabs): load4_stream_raw covers up to 5 elements past the 4 it needs.  For the LAST row of the slab and
     // Nk % 64 == 1 (577) the second-to-last tile's load therefore touches one element (2 bytes) past the tensor -- inside the
-    // allocator's 512-byte granule for every slab torch hands out, never used; a caller with a hand-carved slab that ends on a
-    // page boundary should leave 4 bytes of slack (include/mmx_relevancy.h says so).  TODO next round: element-wise path for
+    // allocator's 512-byte granule for every slab torch hands out, never used; capture.CaptureBuffers allocates 16-bit slabs
+    // with 8 elements of slack anyway, and a caller with a hand-carved slab that ends on a mapping boundary should leave 4
+    // bytes (include/mmx_relevancy.h says so).  TODO next round: element-wise path for
     // that one workgroup's tile (needs a GPU run to validate).
     const bool want_p = need_ds;
     stream_raw<DT> p_cur[4], p_nxt[4];
