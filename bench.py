@@ -110,15 +110,9 @@ def main_cfg5(args):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    from tools import bench_legs
     from transformer_mm_explainability_amd import clip_explainability as ce
-    from transformer_mm_explainability_amd import clip_model, ops
-    from transformer_mm_explainability_amd import tuned_gemms
-    tuned_gemms.enable("clip_vitl14_336_bf16")      # pre-tuned selection for this body's GEMM shapes (tuning off)
-    model = clip_model.random_init(CFG5_MODEL, seed=0).to(device)
-    model.set_body_dtype(torch.bfloat16)
-    g = torch.Generator().manual_seed(1 + rank)
-    image = torch.randn(1, 3, 336, 336, generator=g).to(device)
-    _, texts = synthetic_inputs(CFG5_BATCH, device, seed=rank)
+    model, image, texts, attn_layer, attn_flops = bench_legs.cfg5_setup(CFG5_BATCH, device, rank)
     n_img = 576
     row = n_img + 77 * 77
     gathered = torch.empty(world * CFG5_BATCH, row, device=device) if world > 1 else None
@@ -152,20 +146,7 @@ def main_cfg5(args):
     ms = elapsed / args.steps * 1e3
     fl = cfg5_step_flops(CFG5_BATCH)
     # our dominant kernel pair of this step: the bf16 attention backward of one image-tower layer (stand-alone launches)
-    H, N, D = 16, 577, 64
-    qkv = torch.randn(1, N, 3, H, D, device=device)
-    d_o = (torch.randn(CFG5_BATCH, N, H, D, device=device) * 1e-2).to(torch.bfloat16)
-    probs = torch.empty(1, H, N, N, device=device, dtype=torch.bfloat16)
-    o = ops.attn_capture_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], probs, D ** -0.5, mma_bf16=True)
-    out = torch.empty(CFG5_BATCH, N, 3, H, D, device=device, dtype=torch.bfloat16)
-    rel = torch.zeros(CFG5_BATCH, N, device=device)
-    rel[:, 0] = 1
-
-    def attn_layer():
-        ops.attn_capture_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], probs, d_o, None, D ** -0.5, batch=CFG5_BATCH, o=o,
-                             out=(out[:, :, 0], out[:, :, 1], out[:, :, 2]), mma_bf16=True, rel_row=rel)
     us = kernel_time_us(attn_layer, 5, torch.cuda.current_stream())
-    attn_flops = 5 * 2 * CFG5_BATCH * H * N * N * D
     if rank == 0:
         print(json.dumps({
             "metric": "relevancy maps/sec (fwd+bwd+rollout), CLIP ViT-L/14@336", "value": round(world * CFG5_BATCH / (ms * 1e-3), 2),
@@ -180,7 +161,7 @@ def main_cfg5(args):
                                                     "row-relevancy mode)", "achieved": round(attn_flops / us / 1e6, 1),
                          "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(attn_flops / us / 1e6 / BF16_MFMA_PEAK_TFLOPS, 4),
                          "traffic": None, "us_per_launch": round(us, 1),
-                         "note": "latency- / VALU-bound, not matrix-core bound: see profiles/r02_cfg5_probe.txt (SQ counters)"},
+                         "note": "see profiles/ (newest rNN_cfg5_probe.txt) for the SQ counters of this pair"},
             "roofline_step": {"bound": "mfma", "achieved": round(fl["total"] / (ms * 1e-3) / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(fl["total"] / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
                               "flop_per_step": fl},
@@ -280,6 +261,9 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the variant rates (eager, distinct images, last layer, trimmed): what the rocprofv3 "
                          "kernel-split run uses, so that the trace holds headline steps only")
+    ap.add_argument("--no-config-legs", action="store_true",
+                    help="skip the cfg 1 / 3 / 4 / 5 legs (tools/bench_legs.py) reported under \"configs\"")
+    ap.add_argument("--legs", default=None, help="comma-separated subset of the config legs, e.g. cfg3,cfg5")
     ap.add_argument("--cpu-baseline-worker", nargs=2, type=int, metavar=("BATCH", "REPS"), help=argparse.SUPPRESS)
     ap.add_argument("--workload", default="cfg2", choices=("cfg2", "cfg5"),
                     help="cfg2 (default, BASELINE.json's metric configuration) or the optional cfg-5 shape (ViT-L/14@336 bf16 body)")
@@ -455,6 +439,21 @@ def main():
                      "kernel_time_split": json.load(open(split_file)) if split_file else None,
                      "kernel_time_split_source": os.path.relpath(split_file, ROOT) if split_file else None}
 
+    configs = None
+    if world == 1 and not args.headline_only and not args.no_config_legs:
+        # the other BASELINE.json configurations, each a bounded leg of its own (tools/bench_legs.py); the headline's graph
+        # and slabs are released first (cfg 5 wants ~12 GB)
+        import gc
+        from tools import bench_legs
+        del run
+        for tr in (model.visual.transformer, model.transformer):
+            tr.buffers = None
+        model = None
+        gc.collect()
+        torch.cuda.empty_cache()
+        log("config legs (cfg 1 / 3 / 4 / 5)")
+        configs = bench_legs.run_all(kernel_time_us, log, only=args.legs.split(",") if args.legs else None)
+
     if rank == 0:
         line = {
             "metric": "relevancy maps/sec (fwd+bwd+rollout), CLIP ViT-B/32", "value": round(value, 2),
@@ -470,6 +469,7 @@ def main():
                        "variants": variants},
             "roofline": roofline,
             "roofline_step": roofline_step,
+            "configs": configs,
         }
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (child process, <= 240 s)")

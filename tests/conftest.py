@@ -24,3 +24,13 @@ def golden():
     def load(name):
         return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
     return load
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Largest absolute error every ``tests/parity.close`` comparison saw (GPU suites) -> gpurun_out/parity_errors.json."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import parity
+        parity.dump(os.path.join(ROOT, "gpurun_out", "parity_errors.json"))
+    except Exception:           # a read-only tree must not fail the session
+        pass

@@ -1,0 +1,44 @@
+"""Shared parity helper of the ``-m gpu`` suites: absolute tolerance only for relevancy maps (north star: 1e-5, fp32), and
+a record of the LARGEST absolute error every comparison saw, per test, written at session end to
+``gpurun_out/parity_errors.json`` (copied to ``profiles/rNN_parity.json`` by the round script) so the tolerance in a test
+is backed by a measured number, not by a constant."""
+import json
+import os
+
+import numpy as np
+
+RECORD = {}
+
+
+def _np(x):
+    return x.detach().float().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+
+
+def note(label, value, bound=None):
+    """Remember ``value`` (max over repeated notes) under the running test's id + ``label``."""
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    key = test + ("::" + label if label else "")
+    prev = RECORD.get(key)
+    entry = {"max_abs_err": float(value)}
+    if bound is not None:
+        entry["atol"] = float(bound)
+    if prev is None or prev["max_abs_err"] < entry["max_abs_err"]:
+        RECORD[key] = entry
+
+
+def close(a, b, atol=1e-5, rtol=0.0, what=""):
+    """|a - b| <= atol + rtol |b| elementwise; ``rtol`` defaults to ZERO (relevancy maps are judged on the absolute 1e-5)."""
+    a, b = _np(a), _np(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    fin = ~np.isnan(b)
+    err = float(np.abs(a[fin] - b[fin]).max()) if fin.any() else 0.0
+    note(what, err, atol if rtol == 0.0 else None)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
+
+
+def dump(path):
+    if RECORD:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(dict(sorted(RECORD.items())), f, indent=1)

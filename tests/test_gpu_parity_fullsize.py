@@ -16,11 +16,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def close(a, b, atol=1e-5, rtol=1e-4):
-    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
-    assert a.shape == b.shape, (a.shape, b.shape)
-    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+from parity import close  # noqa: E402  (atol only: rtol = 0)
 
 
 def bench_inputs(batch, seed=0, context=77, vocab_hi=49405, sot=49406, eot=49407, res=224):
@@ -52,16 +48,16 @@ def test_cfg2_batch64_vs_oracle():
     image, texts = image.cuda(), texts.cuda()
     for share in (True, False):
         R_text, R_image = ce.interpret(image, texts, model, "cuda", 0, 0, share_image_forward=share)
-        close(R_text, want_text)
-        close(R_image, want_img)
+        close(R_text, want_text, what="R_text")
+        close(R_image, want_img, what="R_image")
     run = ce.GraphedInterpret(model, image, texts, start_layer=0, start_layer_text=0)
     R_text, R_image = run()
-    close(R_text, want_text)
-    close(R_image, want_img)
+    close(R_text, want_text, what="R_text")
+    close(R_image, want_img, what="R_image")
     run_ns = ce.GraphedInterpret(model, image, texts, start_layer=0, start_layer_text=0, share_image_forward=False)
     R_text, R_image = run_ns()
-    close(R_text, want_text)
-    close(R_image, want_img)
+    close(R_text, want_text, what="R_text")
+    close(R_image, want_img, what="R_image")
 
 
 def test_cfg5_token_count_vs_oracle():
@@ -78,8 +74,8 @@ def test_cfg5_token_count_vs_oracle():
     model = model.cuda()
     for share in (True, False):
         R_text, R_image = ce.interpret(image.cuda(), texts.cuda(), model, "cuda", 0, 0, share_image_forward=share)
-        close(R_text, want_text)
-        close(R_image, want_img)
+        close(R_text, want_text, what="R_text")
+        close(R_image, want_img, what="R_image")
 
 
 def test_cfg5_bf16_body_vs_oracle():
@@ -124,6 +120,90 @@ def test_cfg5_bf16_body_vs_oracle():
     assert torch.equal(R_graph, row)
 
 
+def _cfg5_model(vision_layers, text_layers=12, seed=0):
+    from transformer_mm_explainability_amd import clip_model
+    torch.manual_seed(seed)
+    return clip_model.CLIP(768, 336, vision_layers, 1024, 14, 77, 49408, 768, 12, text_layers).float().eval()
+
+
+_CFG5_ORACLE = {}
+
+
+def _cfg5_oracle(vision_layers, text_layers, batch):
+    """fp32 CPU oracle maps of the ViT-L/14@336 architecture at the given depth (cached per session: the fp32 and the
+    bf16 test of one depth share it)."""
+    from oracle import clip_torch
+    key = (vision_layers, text_layers, batch)
+    if key not in _CFG5_ORACLE:
+        model = _cfg5_model(vision_layers, text_layers)
+        image, texts = bench_inputs(batch, res=336)
+        torch.set_num_threads(min(32, torch.get_num_threads()))
+        sd = clip_torch.prepare_state_dict(model.state_dict(), 12)
+        _CFG5_ORACLE[key] = clip_torch.interpret(sd, image, texts, 0, 0)
+    return _CFG5_ORACLE[key]
+
+
+def test_cfg5_full_depth_fp32_vs_oracle():
+    """BASELINE config 5's architecture at its REAL depth --
+    ``CLIP(768, 336, 24, 1024, 14, 77, 49408, 768, 12, 12)`` (CLIP/clip/model.py:405-428 sizes), B = 2, all 24 + 12 layers --
+    on the exact fp32 path (streaming attention kernels at N = 577, split chain) vs ``oracle/clip_torch.interpret`` at the
+    north star's 1e-5 absolute, shared image forward and B copies."""
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    want_text, want_img = _cfg5_oracle(24, 12, 2)
+    model = _cfg5_model(24, 12).cuda()
+    image, texts = bench_inputs(2, res=336)
+    for share in (True, False):
+        R_text, R_image = ce.interpret(image.cuda(), texts.cuda(), model, "cuda", 0, 0, share_image_forward=share)
+        close(R_text, want_text, what="R_text")
+        close(R_image, want_img, what="R_image")
+
+
+# measured on an MI355X (profiles/r03_parity.json, keys ``...bf16_error_by_depth[L]::R_image_rel``): the bf16 body's error
+# relative to max |map| grows with depth; the bound per depth is ~2x the measured value, NOT a constant picked at L = 3
+CFG5_BF16_REL_BOUND = {3: 3e-2, 6: 6e-2, 12: 1.2e-1, 24: 2.5e-1}
+
+
+@pytest.mark.parametrize("depth", [3, 6, 12, 24])
+def test_cfg5_bf16_error_by_depth(depth):
+    """the bf16 body (what ``bench.py --workload cfg5`` times) vs the fp32 oracle as a CURVE over the
+    image tower's depth (text tower at its real 12 layers, B = 2): per sample max |diff| / max |map| and the cosine
+    similarity are recorded per depth (``parity.note``) and bounded by ``CFG5_BF16_REL_BOUND``."""
+    from parity import note
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    want_text, want_img = _cfg5_oracle(depth, 12, 2)
+    model = _cfg5_model(depth, 12).cuda()
+    model.set_body_dtype(torch.bfloat16)
+    image, texts = bench_inputs(2, res=336)
+    R_text, R_image = ce.interpret(image.cuda(), texts.cuda(), model, "cuda", 0, 0)
+    off = torch.eye(77, dtype=torch.bool).logical_not()
+    worst = {}
+    for name, got, want in (("R_image", R_image.float().cpu(), want_img), ("R_text", R_text.float().cpu()[:, off], want_text[:, off])):
+        got, want = got.reshape(got.shape[0], -1), want.reshape(want.shape[0], -1)
+        rel = max(float((got[b] - want[b]).abs().max() / want[b].abs().max()) for b in range(got.shape[0]))
+        cos = min(float(torch.nn.functional.cosine_similarity(got[b], want[b], dim=0)) for b in range(got.shape[0]))
+        note(name + "_rel", rel)
+        note(name + "_one_minus_cos", 1.0 - cos)
+        worst[name] = (rel, cos)
+    assert worst["R_image"][0] <= CFG5_BF16_REL_BOUND[depth] and worst["R_image"][1] >= 0.98, worst
+    assert worst["R_text"][0] <= CFG5_BF16_REL_BOUND[12] and worst["R_text"][1] >= 0.98, worst
+
+
+def test_cfg5_graph_replay_after_other_interpret():
+    """a captured row-relevancy graph (bf16 body: probabilities-only buffers, ``grads is None``) must
+    re-install its pinned slabs when another interpret() with a different batch replaced them in between."""
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    model = _cfg5_model(2, 2).cuda()
+    model.set_body_dtype(torch.bfloat16)
+    image, texts = bench_inputs(3, res=336)
+    image, texts = image.cuda(), texts.cuda()
+    run = ce.GraphedInterpret(model, image, texts, start_layer=0, start_layer_text=0)
+    first = [t.clone() for t in run()]
+    ce.interpret(image, texts[:2], model, "cuda", 0, 0)                 # another batch size: new slabs on both towers
+    again = run()
+    assert torch.equal(again[0], first[0]) and torch.equal(again[1], first[1])
+    assert model.visual.transformer.resblocks[0].attn_grad is None      # probabilities-only buffers: no gradient view
+
+
 @pytest.mark.parametrize("Nq,Nk", [(950, 950), (100, 950), (577, 577)])
 def test_capture_op_at_size_vs_oracle(Nq, Nk):
     """The capture op at the DETR-encoder / DETR-cross / ViT-L token counts vs the oracle's hooked attention core."""
@@ -138,13 +218,13 @@ def test_capture_op_at_size_vs_oracle(Nq, Nk):
     dprobs = torch.empty_like(probs)
     qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
     o = ops.attn_capture_fwd(qc, kc, vc, probs, D ** -0.5)
-    close(probs, P, atol=2e-6)
-    close(bh(o), O)
+    close(probs, P, atol=2e-6, rtol=1e-4, what="intermediate")
+    close(bh(o), O, rtol=1e-4, what="intermediate")
     gq, gk, gv = ops.attn_capture_bwd(qc, kc, vc, probs, d_o.cuda(), dprobs, D ** -0.5, o=o)
-    close(dprobs, dP, atol=2e-5)
-    close(bh(gq), dq, atol=2e-5)
-    close(bh(gk), dk, atol=2e-5)
-    close(bh(gv), dv, atol=2e-5)
+    close(dprobs, dP, atol=2e-5, rtol=1e-4, what="intermediate")
+    close(bh(gq), dq, atol=2e-5, rtol=1e-4, what="intermediate")
+    close(bh(gk), dk, atol=2e-5, rtol=1e-4, what="intermediate")
+    close(bh(gv), dv, atol=2e-5, rtol=1e-4, what="intermediate")
 
 
 @pytest.mark.parametrize("Nq,Nk,slab", [(577, 577, torch.bfloat16), (577, 577, torch.float32), (100, 950, torch.bfloat16),

@@ -7,11 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def close(a, b, atol=1e-5, rtol=1e-4):
-    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
-    assert a.shape == b.shape, (a.shape, b.shape)
-    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+from parity import close  # noqa: E402  (atol only: rtol = 0)
 
 
 def build(img, patch, dim, depth, heads, classes, seed=0):
@@ -43,7 +39,7 @@ def test_generate_relevance_and_batched_targets(img, patch, dim, depth, heads):
     model = model.cuda()
     xc = x.cuda()
     logits = model(xc, register_hook=True)
-    close(logits, logits_ref, atol=2e-5)
+    close(logits, logits_ref, atol=2e-5, rtol=1e-4, what="logits")
     for idx in (None, 3, 7):
         close(ve.generate_relevance(model, xc, index=idx), want[idx])
     blk = model.blocks[0].attn

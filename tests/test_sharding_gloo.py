@@ -111,3 +111,21 @@ def test_partial_scores_header_guards_against_stale_rows(tmp_path):
         sharding.PartialScores(str(tmp_path), 0)                             # header present, caller states none
     with pytest.raises(ValueError, match="empty id list"):
         sharding.PartialScores(str(tmp_path / "x"), 0).table([])
+
+
+def test_partial_scores_torn_first_line_still_gets_a_header(tmp_path):
+    """A run killed during its very FIRST write leaves a non-empty file with nothing parseable in it: the next start must
+    still write the config header (it used to key on the file size), or the resume after that refuses its own rows."""
+    import torch
+    from transformer_mm_explainability_amd.sharding import PartialScores
+    cfg = {"method": "ours_no_lrp", "steps": 9}
+    path = tmp_path / "scores_rank0.jsonl"
+    path.write_text('{"config": {"method": "ours_no')             # torn header, no newline
+    ps = PartialScores(str(tmp_path), 0, cfg)
+    ps.add([3, 4], torch.ones(2, 9))
+    ps.close()
+    again = PartialScores(str(tmp_path), 0, cfg)                   # legitimate resume of the same run
+    assert again.done() == {3, 4}
+    again.close()
+    with pytest.raises(ValueError):
+        PartialScores(str(tmp_path), 0, {"method": "rollout", "steps": 9})

@@ -58,6 +58,9 @@ class CaptureBuffers:
         return self.probs[l].view(-1, nq, nk)      # [B*H, Nq, Nk] ([H, Nq, Nk] when the forward is shared)
 
     def layer_grads(self, l):
+        """``[B*H, Nq, Nk]`` view of layer ``l``'s gradient slab; ``None`` for probabilities-only buffers (``grads=False``)."""
+        if self.grads is None:
+            return None
         _, b, h, nq, nk = self.shape
         return self.grads[l].view(b * h, nq, nk)
 

@@ -86,7 +86,7 @@ def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, 
     txt_feat, txt_state = model.encode_text_tape(texts, n_text, slt)
     main.wait_stream(side)
     with torch.enable_grad():
-        image_features = img_feat.expand(batch_size, -1).contiguous().requires_grad_(True)   # per-sample leaves
+        image_features = img_feat.detach().expand(batch_size, -1).contiguous().requires_grad_(True)   # per-sample leaves
         text_features = txt_feat.detach().requires_grad_(True)
         logits_per_image, _ = model.logits(image_features, text_features)
         # one_hot = sum_i logits_per_image[i, i]  (cell 6:6-10)  ->  d one_hot / d logits = I

@@ -209,7 +209,7 @@ class Transformer(nn.Module):
             m = self._linear(h2, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
             mlp_out = self._linear(ops.quick_gelu_fwd(m), blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
             tape.append((x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o) if l >= first_grad_layer else None)
-            blk.attn_probs, blk.attn_grad = buffers.layer_probs(l), (buffers.layer_grads(l) if grads else None)
+            blk.attn_probs, blk.attn_grad = buffers.layer_probs(l), buffers.layer_grads(l)
             if l + 1 < len(blocks):
                 nxt = blocks[l + 1].ln_1
                 x, h1, mean1, rstd1 = ops.add_layernorm(x1, mlp_out, nxt.weight, nxt.bias, nxt.eps)
@@ -373,13 +373,13 @@ class VisualTransformer(nn.Module):
         x = self.ln_post(x[:, 0, :])
         return x @ self.proj if self.proj is not None else x
 
-    @torch.no_grad()
     def row_relevancy_ok(self):
         """Can ``backward_tape(..., cls_row=True)`` run?  (bf16-body tower on the long-sequence streaming kernels.)"""
         t = self.transformer
         n_tokens = self.positional_embedding.shape[0]
         return bool(getattr(t, "attention_mma_bf16", False)) and n_tokens > 128
 
+    @torch.no_grad()
     def forward_tape(self, image, batch=None, first_grad_layer=0, grads=True):
         """``image [Bx, 3, R, R]`` -> ``(features [Bx, output_dim], state)``; ``Bx == 1 < batch``: shared-forward mode
         (see ``Transformer.forward_tape``)."""

@@ -18,6 +18,8 @@ raise ``NotImplementedError`` naming the missing method.
 """
 from __future__ import annotations
 
+import collections
+
 import torch
 
 from . import ops, rules
@@ -408,16 +410,20 @@ class MaskGenerator:
     _BATCHED = {"ours_no_lrp": {}, "ablation_no_self_in_10": {"apply_self_in_rule_10": False},
                 "ours_no_lrp_no_norm": {"normalize_self_attention": False}}
 
-    def __init__(self, model, threshold=0.5, graph_slots=None):
+    def __init__(self, model, threshold=0.5, graph_slots=None, max_graphs=4):
         """``graph_slots`` (e.g. 16): run the batched methods through ``GraphedGenerateOursMulti`` with that many target
         slots (captured on the first image of a given feature-map size; the evaluator's images are resized to a common
-        size per batch, ``DETR/datasets/coco.py:138-140``)."""
+        size per batch, ``DETR/datasets/coco.py:138-140``).  Each captured pass owns a private memory pool and its pinned
+        slabs, so at most ``max_graphs`` (method, feature-map size) pairs are kept, least recently used evicted."""
         self.gen = Generator(model)
         self.abl = GeneratorAlbationNoAgg(model)
         self.model = model
         self.threshold = threshold
+        if graph_slots is not None and graph_slots < 2:
+            raise ValueError("graph_slots must be >= 2 (the K-slot pass shares ONE forward between its slots)")
         self.graph_slots = graph_slots
-        self._graphs = {}
+        self.max_graphs = max_graphs
+        self._graphs = collections.OrderedDict()     # (method, feature shape) -> captured pass, least recently used first
 
     def _per_query(self, img, idx, method):
         if method == "ablation_no_aggregation":
@@ -449,7 +455,10 @@ class MaskGenerator:
         if method in self._BATCHED and self.graph_slots and hasattr(self.model, "forward_shared"):
             key = (method, tuple(img.shape))
             if key not in self._graphs:
+                while len(self._graphs) >= self.max_graphs:
+                    self._graphs.popitem(last=False)
                 self._graphs[key] = GraphedGenerateOursMulti(self.model, img, self.graph_slots, **self._BATCHED[method])
+            self._graphs.move_to_end(key)
             cams = self._graphs[key](img, kept, index=classes)[0, 0]
         elif method in self._BATCHED:
             cams = self.gen.generate_ours_multi(img, kept, index=classes, **self._BATCHED[method])[0, 0]   # [K, Ni]
@@ -474,6 +483,9 @@ class GraphedGenerateOursMulti:
                  rows_only=None):
         if not hasattr(model, "forward_shared"):
             raise ValueError("GraphedGenerateOursMulti needs a body with forward_shared / backward_shared (detr_model)")
+        if K < 2:
+            raise ValueError("GraphedGenerateOursMulti: K >= 2 target slots (one forward is shared between the slots; a "
+                             "single slot would capture the autograd route, which does not replay)")
         self.K = K
         self.img = example_img.clone()
         self.targets = torch.zeros(K, dtype=torch.long, device=example_img.device)

@@ -148,7 +148,9 @@ class PartialScores:
         if (self.rows or header is not None) and header != config:
             raise ValueError("%s holds rows of another run (%r), not of %r: use a fresh directory" %
                              (self.path, header, config))
-        fresh = not os.path.exists(self.path) or os.path.getsize(self.path) == 0
+        # header wanted whenever the file has neither a header nor rows yet -- also when all it holds is the torn first
+        # line of a run killed during its very first write (non-empty file, nothing parsed)
+        fresh = header is None and not self.rows
         torn = os.path.exists(self.path) and os.path.getsize(self.path) > 0 and \
             open(self.path, "rb").read()[-1:] != b"\n"
         self._f = open(self.path, "a")
