@@ -321,6 +321,27 @@ int mmx_attn_capture_bwd_rowrel(const void* q_dev, const void* k_dev, const void
                                 void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * LRP relevance through the attention core: the two `einsum` relprops inside the reference's
+ * MultiheadAttention.relprop (DETR/modules/layers.py:770-781; einsum = RelPropSimple, layers.py:54-66, each result halved;
+ * softmax / dropout relprops are the identity, layers.py:170-186), which the reference evaluates by re-running the einsums
+ * and calling torch.autograd.grad.  With S = safe_divide(cam_O, O) (layers.py:11-14) and Z = (scale q).k^T:
+ *   cam_P = P * (S.V^T) / 2   (-> cam_probs_dev, what the reference stores with save_attn_cam, layers.py:776)
+ *   cam_V = V * (P^T.S) / 2,   S1 = safe_divide(cam_P, Z),   cam_Q = (scale q) * (S1.k) / 2,   cam_K = k * (S1^T.(scale q)) / 2
+ * q / k / v / o / cam_o and the three outputs use the (batch, head, token) element strides of the capture op; probs and
+ * cam_probs are [B, H, Nq, Nk] fp32 contiguous.  MMX_SCALE_Q_FIRST: q is multiplied by `scale` first (DETR, layers.py:741);
+ * MMX_SCALE_SCORES: Z is the raw q.k^T product (BERT-style modules divide afterwards).  head_dim <= 64.  Two launches
+ * (query side, then key side) on `stream`; no workspace.
+ */
+int mmx_attn_relprop(const void* q_dev, const void* k_dev, const void* v_dev, const void* o_dev, const void* cam_o_dev,
+                     int64_t q_sb, int64_t q_sh, int64_t q_sn, int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                     int64_t v_sb, int64_t v_sh, int64_t v_sn, int64_t o_sb, int64_t o_sh, int64_t o_sn,
+                     int64_t co_sb, int64_t co_sh, int64_t co_sn,
+                     const void* probs_dev, void* cam_probs_dev, void* cam_q_dev, void* cam_k_dev, void* cam_v_dev,
+                     int64_t cq_sb, int64_t cq_sh, int64_t cq_sn, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn,
+                     int64_t cv_sb, int64_t cv_sh, int64_t cv_sn,
+                     int B, int H, int Nq, int Nk, int D, float scale, int scale_mode, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused QuickGELU of the CLIP body's MLP, y = x * sigmoid(1.702 x) (CLIP/clip/model.py:162-164): one HBM pass forward,
  * one backward (dx from x and dy; nothing saved but x) instead of PyTorch's 3 + 5 elementwise kernels.
  * fp32, contiguous, 16-byte aligned, n elements.

@@ -526,6 +526,75 @@ def gen_detr_transformer():
     save("detr_transformer", **arrays)
 
 
+def gen_detr_transformer_lrp():
+    """The reference's REAL LRP pass: ``DETR/models/transformer.py`` (every ``relprop`` of the
+    encoder / decoder stack) over the LRP layer library ``DETR/modules/layers.py`` (``Linear`` / ``Add`` / ``Clone`` /
+    ``einsum`` / ``IndexSelect`` / ``MultiheadAttention.relprop``, :770-801), entered through ``DETR.relprop``
+    (``DETR/models/detr.py:79-92``, its source exec'd unchanged: ``detr.py`` itself needs torchvision to import).
+    ``DETR.forward`` after the backbone (``detr.py:61-70``) is restated below (flagged glue): input projection,
+    transformer, ``class_embed`` (an LRP ``Linear``), ``index_select`` of the LAST decoder level (the reference hard-codes
+    level 5 of 6).  Recorded: every attention module's ``attn_cam`` after ``Generator.generate_ours(img, t)`` with its
+    DEFAULT arguments (``use_lrp=True``), the outputs of the three LRP methods, and the relevance ``relprop`` returns."""
+    detr_tr = load_by_path("detr_transformer_ref", os.path.join(REF, "DETR/models/transformer.py"))
+    torch.manual_seed(21)
+    d, heads, Le, Ld, ff, Q, n_cls, Cb, h, w = 32, 4, 2, 3, 64, 7, 5, 24, 3, 5
+
+    class Body(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.transformer = detr_tr.Transformer(d_model=d, nhead=heads, num_encoder_layers=Le,
+                                                   num_decoder_layers=Ld, dim_feedforward=ff, dropout=0.0,
+                                                   return_intermediate_dec=True)
+            self.class_embed = detr_layers.Linear(d, n_cls + 1)
+            self.query_embed = nn.Embedding(Q, d)
+            self.input_proj = nn.Conv2d(Cb, d, kernel_size=1)
+            self.index_select = detr_layers.IndexSelect()
+
+        def forward(self, feats):                                     # detr.py:61-70 after the backbone (restated glue)
+            mask = torch.zeros(feats.shape[0], h, w, dtype=torch.bool)
+            hs, memory = self.transformer(self.input_proj(feats), mask, self.query_embed.weight, self.pos)
+            self.memory_shape = memory.shape
+            outputs_class = self.class_embed(hs)
+            a = self.index_select(outputs_class, 0, torch.tensor([Ld - 1])).squeeze(0)
+            return {"pred_logits": a}
+
+    Body.relprop = reference_function("DETR/models/detr.py", "DETR", "relprop", {"torch": torch})
+    body = Body().eval()
+    g = torch.Generator().manual_seed(22)
+    feats = torch.randn(1, Cb, h, w, generator=g)
+    body.pos = torch.randn(1, d, h, w, generator=g)
+    tgt = torch.tensor([1, 4])
+    gen = detr_eg.Generator(body)
+    out = gen.generate_ours(feats, tgt)                               # DEFAULT arguments: use_lrp=True
+    enc, dec = body.transformer.encoder.layers, body.transformer.decoder.layers
+    arrays = dict(features=feats, pos=body.pos, target_index=tgt, out_default=out, R_i_i=gen.R_i_i, R_q_q=gen.R_q_q,
+                  pred_logits=body(feats)["pred_logits"],
+                  enc_cam=torch.stack([b.self_attn.get_attn_cam() for b in enc]),
+                  dself_cam=torch.stack([b.self_attn.get_attn_cam() for b in dec]),
+                  dcross_cam=torch.stack([b.multihead_attn.get_attn_cam() for b in dec]),
+                  enc_attn=torch.stack([b.self_attn.get_attn() for b in enc]),
+                  enc_grad=torch.stack([b.self_attn.get_attn_gradients() for b in enc]),
+                  dims=np.array([d, heads, Le, Ld, ff, Q, n_cls, Cb, h, w]))
+    # the relevance the pass hands back for the transformer input (conservation check + end-to-end pin of every relprop)
+    outputs = body(feats)["pred_logits"]
+    index = outputs[0, tgt, :-1].max(1)[1]
+    one_hot = torch.zeros_like(outputs)
+    one_hot[0, tgt, index] = 1
+    body.zero_grad()
+    torch.sum(one_hot * outputs).backward(retain_graph=True)
+    arrays["cam_src"] = body.relprop(one_hot.clone(), alpha=1, target_index=tgt, target_class=index)
+    arrays["target_class"] = index
+    arrays["transformer_att_out"] = detr_eg.Generator(body).generate_transformer_att(feats, tgt)
+    arrays["partial_lrp_out"] = detr_eg.Generator(body).generate_partial_lrp(feats, tgt)
+    arrays["abl_lrp_out"] = detr_eg.GeneratorAlbationNoAgg(body).generate_ours_abl(feats, tgt, use_lrp=True)
+    single = torch.tensor([4])
+    arrays["out_default_single"] = detr_eg.Generator(body).generate_ours(feats, single)
+    for name, p in body.state_dict().items():
+        arrays["w__" + name] = p
+    save("detr_transformer_lrp", **arrays)
+
+
+
 def _build_lxmert_ref():
     """The REAL reference LXMERT body (lxmert/lxmert/src/lxmert_lrp.py: embeddings, encoder with hooked attention,
     pooler, answer head) driven by the reference GeneratorOurs / GeneratorBaselines.  ``LxmertModel`` itself derives
@@ -858,6 +927,8 @@ def main(which):
         "detr_chain_lrp": gen_detr_chain_lrp, "lxmert_chain_lrp": gen_lxmert_chain_lrp,
         "visualbert_chain_lrp": gen_visualbert_chain_lrp,
         "lxmert_perturbation": gen_lxmert_perturbation, "visualbert_perturbation": gen_visualbert_perturbation,
+        # round 3
+        "detr_transformer_lrp": gen_detr_transformer_lrp,
     }
     for name in (which or list(todo)):
         todo[name]()

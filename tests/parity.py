@@ -14,14 +14,18 @@ def _np(x):
     return x.detach().float().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
 
-def note(label, value, bound=None):
-    """Remember ``value`` (max over repeated notes) under the running test's id + ``label``."""
+def note(label, value, bound=None, scale=None):
+    """Remember ``value`` (max over repeated notes) under the running test's id + ``label``; ``scale`` = max |reference|
+    of the compared tensor, so the record also says what the absolute error means relative to the map."""
     test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
     key = test + ("::" + label if label else "")
     prev = RECORD.get(key)
     entry = {"max_abs_err": float(value)}
     if bound is not None:
         entry["atol"] = float(bound)
+    if scale:
+        entry["max_abs_ref"] = float(scale)
+        entry["err_over_max_ref"] = float(value) / float(scale)
     if prev is None or prev["max_abs_err"] < entry["max_abs_err"]:
         RECORD[key] = entry
 
@@ -33,7 +37,7 @@ def close(a, b, atol=1e-5, rtol=0.0, what=""):
     assert np.array_equal(np.isnan(a), np.isnan(b))
     fin = ~np.isnan(b)
     err = float(np.abs(a[fin] - b[fin]).max()) if fin.any() else 0.0
-    note(what, err, atol if rtol == 0.0 else None)
+    note(what, err, atol if rtol == 0.0 else None, float(np.abs(b[fin]).max()) if fin.any() else None)
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
 
 

@@ -158,9 +158,11 @@ def test_cfg5_full_depth_fp32_vs_oracle():
         close(R_image, want_img, what="R_image")
 
 
-# measured on an MI355X (profiles/r03_parity.json, keys ``...bf16_error_by_depth[L]::R_image_rel``): the bf16 body's error
-# relative to max |map| grows with depth; the bound per depth is ~2x the measured value, NOT a constant picked at L = 3
-CFG5_BF16_REL_BOUND = {3: 3e-2, 6: 6e-2, 12: 1.2e-1, 24: 2.5e-1}
+# measured on an MI355X (profiles/r03_parity.json, keys ``...bf16_error_by_depth[L]::R_image_rel`` / ``R_text_rel``): the bf16
+# body's error relative to max |map| is 5.3e-3 / 4.0e-3 / 2.8e-3 / 2.3e-3 at L = 3 / 6 / 12 / 24 image-tower layers (text
+# tower: 3.4e-3 .. 4.2e-3) -- it does NOT grow with depth on these inputs (the map is dominated by the top layers, whose
+# gradients have passed through the fewest bf16 roundings); cosine distance <= 4.2e-6.  Bound = ~3x the measured value.
+CFG5_BF16_REL_BOUND = {3: 1.5e-2, 6: 1.2e-2, 12: 1.0e-2, 24: 1.0e-2}
 
 
 @pytest.mark.parametrize("depth", [3, 6, 12, 24])
@@ -184,8 +186,8 @@ def test_cfg5_bf16_error_by_depth(depth):
         note(name + "_rel", rel)
         note(name + "_one_minus_cos", 1.0 - cos)
         worst[name] = (rel, cos)
-    assert worst["R_image"][0] <= CFG5_BF16_REL_BOUND[depth] and worst["R_image"][1] >= 0.98, worst
-    assert worst["R_text"][0] <= CFG5_BF16_REL_BOUND[12] and worst["R_text"][1] >= 0.98, worst
+    assert worst["R_image"][0] <= CFG5_BF16_REL_BOUND[depth] and worst["R_image"][1] >= 0.9999, worst
+    assert worst["R_text"][0] <= 1.2e-2 and worst["R_text"][1] >= 0.9999, worst
 
 
 def test_cfg5_graph_replay_after_other_interpret():

@@ -672,3 +672,30 @@ def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCA
         *(_bhnd_strides(dv, layout) if need_dqkv else zero3),
         B, H, Nq, Nk, D, float(scale), scale_mode, int(need_dqkv), _p(ws), need, _stream()), "mmx_attn_capture_bwd")
     return dq, dk, dv
+
+
+def attn_relprop(q, k, v, probs, o, cam_o, scale, scale_mode=_lib.SCALE_Q_FIRST, layout="bnhd"):
+    """LRP relevance through the attention core (``mmx_attn_relprop``; the two halved ``einsum`` relprops of
+    DETR/modules/layers.py:770-781).  ``q [B, Nq, H, D]``, ``k`` / ``v [B, Nk, H, D]``, ``o`` / ``cam_o [B, Nq, H, D]``
+    (strided views ok), ``probs [B, H, Nq, Nk]`` fp32 contiguous.  Returns ``(cam_probs [B, H, Nq, Nk], cam_q, cam_k, cam_v)``
+    with the cams of q / k / v contiguous in ``layout``."""
+    _dev(q, k, v, probs, o, cam_o)
+    if any(t.dtype != torch.float32 for t in (q, k, v, probs, o, cam_o)):
+        raise MMXError("attn_relprop: fp32 operands only")
+    if layout == "bnhd":
+        B, Nq, H, D = q.shape
+        Nk = k.shape[1]
+    else:
+        B, H, Nq, D = q.shape
+        Nk = k.shape[2]
+    if not probs.is_contiguous() or probs.numel() != B * H * Nq * Nk:
+        raise MMXError("attn_relprop: probs must be a contiguous [B,H,Nq,Nk] slab")
+    if cam_o.stride(-1) != 1:
+        cam_o = cam_o.contiguous()
+    cam_probs = torch.empty(B, H, Nq, Nk, dtype=torch.float32, device=q.device)
+    cam_q, cam_k, cam_v = (torch.empty(tuple(t.shape), dtype=torch.float32, device=q.device) for t in (q, k, v))
+    st = lambda t: _bhnd_strides(t, layout)                                   # noqa: E731
+    check(lib().mmx_attn_relprop(_p(q), _p(k), _p(v), _p(o), _p(cam_o), *st(q), *st(k), *st(v), *st(o), *st(cam_o),
+                                 _p(probs), _p(cam_probs), _p(cam_q), _p(cam_k), _p(cam_v), *st(cam_q), *st(cam_k), *st(cam_v),
+                                 B, H, Nq, Nk, D, float(scale), scale_mode, _stream()), "mmx_attn_relprop")
+    return cam_probs, cam_q, cam_k, cam_v
