@@ -595,6 +595,55 @@ def gen_detr_transformer_lrp():
 
 
 
+def gen_lrp_layers():
+    """The LRP layer library itself (DETR/modules/layers.py): ``Linear`` / ``Add`` / ``Clone`` / ``IndexSelect`` relprops and the
+    whole ``MultiheadAttention.relprop`` (:770-801) on seeded inputs -- pins ``lrp.py``'s closed forms (CPU suite) and the HIP
+    attention-core kernels (GPU suite).  Two MHA cases: a generic one, and one whose value stream is all zeros (decoder
+    layer 0 of DETR: ``tgt = 0``), which takes the q / k rescale branch (:791-799)."""
+    L = detr_layers
+    g = torch.Generator().manual_seed(31)
+    arrays = {}
+    lin = L.Linear(12, 7)
+    x = torch.randn(5, 3, 12, generator=g)
+    lin(x)
+    r = torch.randn(5, 3, 7, generator=g)
+    arrays.update(lin_w=lin.weight, lin_x=x, lin_r=r, lin_out=lin.relprop(r, 1))
+    add = L.Add()
+    a, b = torch.randn(4, 6, generator=g), torch.randn(4, 6, generator=g)
+    add([a, b])
+    r = torch.randn(4, 6, generator=g)
+    ra, rb = add.relprop(r, 1)
+    arrays.update(add_a=a, add_b=b, add_r=r, add_out_a=ra, add_out_b=rb)
+    clone = L.Clone()
+    x = torch.randn(4, 6, generator=g)
+    x[0, 0] = 0.0                                                        # safe_divide's zero branch
+    clone(x, 3)
+    rs = [torch.randn(4, 6, generator=g) for _ in range(3)]
+    arrays.update(clone_x=x, clone_r=torch.stack(rs), clone_out=clone.relprop(rs, 1))
+    sel = L.IndexSelect()
+    x = torch.randn(3, 2, 5, generator=g)
+    idx = torch.tensor([2])
+    sel(x, 0, idx)
+    r = torch.randn(1, 2, 5, generator=g)
+    arrays.update(sel_x=x, sel_r=r, sel_out=sel.relprop(r, 1))
+    for tag, zero_value, (E, H, T, S, B) in (("mha", False, (64, 4, 6, 15, 2)), ("mha0", True, (32, 2, 5, 5, 1))):
+        torch.manual_seed(32 + zero_value)
+        mha = L.MultiheadAttention(E, H, dropout=0.0).eval()
+        q = torch.randn(T, B, E, generator=g)
+        k = torch.randn(S, B, E, generator=g)
+        v = torch.zeros(S, B, E) if zero_value else torch.randn(S, B, E, generator=g)
+        out = mha(q, k, v)
+        cam_out = torch.randn(T, B, E, generator=g) * 0.1
+        cam_q, cam_k, cam_v = mha.relprop(cam_out, 1)
+        arrays.update({tag + "_query": q, tag + "_key": k, tag + "_value": v, tag + "_out": out, tag + "_cam_out": cam_out,
+                       tag + "_cam_q": cam_q, tag + "_cam_k": cam_k, tag + "_cam_v": cam_v,
+                       tag + "_attn_cam": mha.get_attn_cam(), tag + "_attn": mha.get_attn(),
+                       tag + "_heads": np.int64(H)})
+        for name, p_ in mha.state_dict().items():
+            arrays[tag + "_w__" + name] = p_
+    save("lrp_layers", **arrays)
+
+
 def _build_lxmert_ref():
     """The REAL reference LXMERT body (lxmert/lxmert/src/lxmert_lrp.py: embeddings, encoder with hooked attention,
     pooler, answer head) driven by the reference GeneratorOurs / GeneratorBaselines.  ``LxmertModel`` itself derives
@@ -928,7 +977,7 @@ def main(which):
         "visualbert_chain_lrp": gen_visualbert_chain_lrp,
         "lxmert_perturbation": gen_lxmert_perturbation, "visualbert_perturbation": gen_visualbert_perturbation,
         # round 3
-        "detr_transformer_lrp": gen_detr_transformer_lrp,
+        "detr_transformer_lrp": gen_detr_transformer_lrp, "lrp_layers": gen_lrp_layers,
     }
     for name in (which or list(todo)):
         todo[name]()

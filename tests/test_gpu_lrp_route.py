@@ -4,7 +4,7 @@
 the cam comes from ``get_attn_cam()`` (filled by the body's ``relprop``).  These tests plug a body that supplies
 ``attn_cam`` slabs + a ``relprop`` and compare every LRP-route entry point with what the REFERENCE's generator classes
 returned on the same tensors (``tests/golden/*_chain_lrp.npz``, made by ``make_golden.py`` from the reference code).
-A body without ``relprop`` (the ones in this package) must fail loudly, before any work is done.
+A body without ``relprop`` must fail loudly, before any work is done.
 """
 import types
 
@@ -152,8 +152,9 @@ def test_visualbert_lrp_route(golden):
 
 
 def test_bodies_without_relprop_fail_before_any_work(golden):
-    """The package's own bodies have no LRP pass: the default-argument call names what is missing (and does not run a
-    forward / backward first); the cam slot of the hooked modules is a plain slot an external LRP pass can fill."""
+    """A body WITHOUT an LRP pass (``detr_model`` has one since round 3, tests/test_gpu_lrp.py): the default-argument call
+    names what is missing (and does not run a forward / backward first); the cam slot of the hooked modules is a plain
+    slot an external LRP pass can fill."""
     from transformer_mm_explainability_amd import detr_explainability as de
     from transformer_mm_explainability_amd.attention_modules import MultiheadAttention
 

@@ -13,8 +13,10 @@ forward hook and a tensor backward hook.  These classes keep that surface but th
     inputs ``[B, N, E]``, ``get_attn()`` -> ``[B, H, Nq, Nk]`` (captured before dropout; eval mode => identical).
 
 ``save_attn_cam`` / ``get_attn_cam`` are the plain slot of the reference (DETR/modules/layers.py:699-703): an LRP pass
-supplied by the caller (``model.relprop``) stores its per-head relevance there and the rule kernels read it like any other
-cam.  Producing the cam (the ``relprop`` of layers.py:770-801) is not done here; reading an empty slot raises.
+(``model.relprop``) stores its per-head relevance there and the rule kernels read it like any other cam.
+``MultiheadAttention.relprop`` (layers.py:770-801) produces it: closed-form Linear rules (``lrp.py``) around the HIP
+attention-core kernels (``csrc/attention_lrp.hip``).  The BERT-style module has no ``relprop`` yet (a caller-supplied LRP
+pass may still fill the slot); reading an empty slot raises.
 """
 from __future__ import annotations
 
@@ -104,8 +106,34 @@ class MultiheadAttention(_SlabOwner):
         o = attention_capture(q, k, v, probs, grads, float(D) ** -0.5, mask=None, scale_mode=_lib.SCALE_Q_FIRST)
         self.save_attn(probs.view(B * H, T, S))
         self.save_attn_gradients(grads.view(B * H, T, S))   # filled by the backward kernel
+        # what an LRP pass needs of this forward (references only; the reference keeps the same tensors alive through its
+        # forward hooks, DETR/modules/layers.py:17-30): inference under no_grad does not pin them
+        self._lrp_tape = None
+        if torch.is_grad_enabled():
+            bf = lambda t: t.detach().permute(1, 0, 2)                          # noqa: E731  [N, B, E] -> [B, N, E]
+            self._lrp_tape = dict(query=bf(query), key=bf(key), value=bf(value), q=q.detach(), k=k.detach(), v=v.detach(),
+                                  o=o.detach(), probs=probs, scale=float(D) ** -0.5)
         o = o.permute(1, 0, 2, 3).reshape(T, B, E)
         return self.out_proj(o)
+
+    def relprop(self, cam_attn_output, alpha=1, **kwargs):
+        """``MultiheadAttention.relprop`` (DETR/modules/layers.py:770-801): ``cam_attn_output [T, B, E]`` -> ``(cam_q [T, B, E],
+        cam_k [S, B, E], cam_v [S, B, E])``; the per-head relevance of the probabilities is stored with ``save_attn_cam``
+        (``[B*H, T, S]``, layers.py:776).  The Linear rules are closed-form matrix products (``lrp.py``), the attention core
+        (both ``einsum`` relprops) runs in the HIP kernels of ``csrc/attention_lrp.hip``."""
+        from . import lrp
+        t = getattr(self, "_lrp_tape", None)
+        if t is None:
+            raise _lib.MMXError("relprop needs the activations of a forward run with gradients enabled")
+        core = lambda cam_o: ops.attn_relprop(t["q"], t["k"], t["v"], t["probs"], t["o"], cam_o, t["scale"],   # noqa: E731
+                                              _lib.SCALE_Q_FIRST, layout="bnhd")
+        with torch.no_grad():
+            cam_q, cam_k, cam_v, cam_p = lrp.mha_relprop(
+                cam_attn_output.permute(1, 0, 2), t,
+                (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.out_proj.weight), core)
+        B, H, T, S = cam_p.shape
+        self.save_attn_cam(cam_p.view(B * H, T, S))
+        return cam_q.permute(1, 0, 2), cam_k.permute(1, 0, 2), cam_v.permute(1, 0, 2)
 
 
     # ---- shared-forward mode (one forward at batch 1, K upstream gradients): batch-first tensors

@@ -9,12 +9,13 @@ them straight from the capture slabs).
 
 What changes underneath: the 6-layer encoder chain is ONE ``relevancy_self_chain`` call, each decoder self-attention
 block is one call carrying both right-hand sides (rules 6+7), rule 10 runs on the MFMA matmul + row-normalise kernels.
-LRP variants (``use_lrp=True``, ``generate_transformer_att``, ``generate_partial_lrp``): the rule kernels take any cam, so
-these run exactly the reference's schedule on ``get_attn_cam()`` instead of ``get_attn()`` -- PROVIDED the body brings its
-own LRP pass (``model.relprop(one_hot, alpha=1, target_index=..., target_class=...)`` filling ``save_attn_cam`` on every
-attention module, as the reference's LRP layer library does, DETR/modules/layers.py:770-801).  The bodies in this package
-(``detr_model``) have no ``relprop`` (producing the LRP cams is SURVEY section 8f row 4): with them these entry points
-raise ``NotImplementedError`` naming the missing method.
+LRP variants (``use_lrp=True`` -- the reference's DEFAULT --, ``generate_transformer_att``, ``generate_partial_lrp``): the
+rule kernels take any cam, so these run exactly the reference's schedule on ``get_attn_cam()`` instead of ``get_attn()`` after
+the body's LRP pass (``model.relprop(one_hot, alpha=1, target_index=..., target_class=...)`` filling ``save_attn_cam`` on
+every attention module, as the reference's LRP layer library does, DETR/modules/layers.py:770-801).  ``detr_model``'s body
+has that pass (``DETRFromFeatures.relprop``: closed-form layer rules + HIP attention-core kernels, ``lrp.py`` /
+``csrc/attention_lrp.hip``), so ``Generator(detr_model).generate_ours(img, t)`` runs with its default arguments; a body
+without ``relprop`` makes these entry points raise ``NotImplementedError`` naming the missing method, before any work.
 """
 from __future__ import annotations
 

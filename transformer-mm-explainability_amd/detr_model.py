@@ -11,7 +11,8 @@ Differences from the reference that a caller can observe:
   * every attention block is ``attention_modules.MultiheadAttention`` -- P and dL/dP land in device slabs written by
     the HIP kernels, ``get_attn()`` / ``get_attn_gradients()`` return views of them, there are no Python hooks;
   * padding masks are accepted and ignored, exactly like the reference's hooked MHA (``DETR/modules/layers.py:728-756``);
-  * eval mode only (dropout is the identity), no ``relprop`` (LRP is out of scope, DESIGN.md section 8);
+  * eval mode only (dropout is the identity); ``relprop`` (the LRP pass of ``DETR/models/detr.py:79-92`` / ``transformer.py``) is
+    closed-form matrix products + HIP attention-core kernels instead of autograd-in-autograd (``lrp.py``), post-norm layers;
   * the reference hard-codes decoder layer index 5 for ``pred_logits`` (``detr.py:64``); here it is the last layer.
 """
 from __future__ import annotations
@@ -22,8 +23,22 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import lrp, ops
 from .attention_modules import MultiheadAttention
+
+
+def _detached(*tensors):
+    """Activations an LRP pass (``relprop``) reads, kept as detached references when the forward runs in grad mode (the
+    explainability pass); ``None`` under ``torch.no_grad()`` so that plain inference pins nothing."""
+    return tuple(t.detach() for t in tensors) if torch.is_grad_enabled() else None
+
+
+def _lrp_tape(module):
+    tape = getattr(module, "_lrp", None)
+    if tape is None:
+        raise RuntimeError("%s.relprop needs the activations of a forward pass run with gradients enabled (the generators' "
+                           "explainability pass); run model(img) first" % type(module).__name__)
+    return tape
 
 
 def _with_pos(x, pos):
@@ -85,9 +100,25 @@ class TransformerEncoderLayer(nn.Module, _FeedForward):
             src = src + self.self_attn(qk, qk, h, attn_mask=src_mask, key_padding_mask=src_key_padding_mask)
             return src + self._ffn(self.norm2(src))
         qk = _with_pos(src, pos)           # transformer.py:236-256 forward_post
-        src = self.norm1(src + self.self_attn(qk, qk, src, attn_mask=src_mask,
-                                              key_padding_mask=src_key_padding_mask))
-        return self.norm2(src + self._ffn(src))
+        a = self.self_attn(qk, qk, src, attn_mask=src_mask, key_padding_mask=src_key_padding_mask)
+        src1 = self.norm1(src + a)
+        r = self.activation(self.linear1(src1))
+        ff = self.linear2(r)
+        self._lrp = _detached(src, qk, a, src1, r, ff)       # layer inputs of the LRP pass (references, grad mode only)
+        return self.norm2(src1 + ff)
+
+    def relprop(self, cam, alpha=1, **kwargs):
+        """``forward_post_relprop`` (DETR/models/transformer.py:256-275); LayerNorm / ReLU / dropout / WithPosEmbd pass
+        relevance through unchanged (DETR/modules/layers.py:46-47, 110-111)."""
+        src, qk, a, src1, r, ff = _lrp_tape(self)
+        cam_src_2, cam_ff = lrp.add_relprop(cam, src1, ff)                               # add2([src_2, src2])
+        cam_1 = lrp.linear_relprop(cam_ff, r, self.linear2.weight, alpha)
+        cam_1 = lrp.linear_relprop(cam_1, src1, self.linear1.weight, alpha)
+        cam = lrp.clone_relprop([cam_1, cam_src_2], src1)                                # clone3
+        cam_src_3, cam_drop = lrp.add_relprop(cam, src, a)                               # add1([src_3, src_drop])
+        cam_q, cam_k, cam_v = self.self_attn.relprop(cam_drop, alpha, **kwargs)
+        cam_w = lrp.clone_relprop([cam_q, cam_k], qk)                                    # clone2 (X = src + pos)
+        return lrp.clone_relprop([cam_w, cam_v, cam_src_3], src)                         # clone1
 
     # ---- shared-forward mode (post-norm): tensors are batch-first, ``[1, N, E]`` forward / ``[K, N, E]`` backward
     def forward_shared(self, src, pos, batch):
@@ -132,12 +163,31 @@ class TransformerDecoderLayer(nn.Module, _FeedForward):
                                             attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask)
             return tgt + self._ffn(self.norm3(tgt))
         qk = _with_pos(tgt, query_pos)     # transformer.py:371-407 forward_post
-        tgt = self.norm1(tgt + self.self_attn(qk, qk, tgt, attn_mask=tgt_mask,
-                                              key_padding_mask=tgt_key_padding_mask))
-        tgt = self.norm2(tgt + self.multihead_attn(_with_pos(tgt, query_pos), _with_pos(memory, pos), memory,
-                                                   attn_mask=memory_mask,
-                                                   key_padding_mask=memory_key_padding_mask))
-        return self.norm3(tgt + self._ffn(tgt))
+        a = self.self_attn(qk, qk, tgt, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)
+        tgt1 = self.norm1(tgt + a)
+        c = self.multihead_attn(_with_pos(tgt1, query_pos), _with_pos(memory, pos), memory, attn_mask=memory_mask,
+                                key_padding_mask=memory_key_padding_mask)
+        tgt2 = self.norm2(tgt1 + c)
+        r = self.activation(self.linear1(tgt2))
+        ff = self.linear2(r)
+        self._lrp = _detached(tgt, qk, a, tgt1, memory, c, tgt2, r, ff)
+        return self.norm3(tgt2 + ff)
+
+    def relprop(self, cam, alpha=1, **kwargs):
+        """``forward_post_relprop`` (DETR/models/transformer.py:410-436) -> ``(cam_tgt, cam_memory)``."""
+        tgt, qk, a, tgt1, memory, c, tgt2, r, ff = _lrp_tape(self)
+        cam_tgt_2, cam_ff = lrp.add_relprop(cam, tgt2, ff)                               # add3([tgt_2, tgt2])
+        cam_ff = lrp.linear_relprop(cam_ff, r, self.linear2.weight, alpha)
+        cam_tgt_1 = lrp.linear_relprop(cam_ff, tgt2, self.linear1.weight, alpha)
+        cam = lrp.clone_relprop([cam_tgt_1, cam_tgt_2], tgt2)                            # clone5
+        cam_tgt_2, cam_drop = lrp.add_relprop(cam, tgt1, c)                              # add2([tgt_2, tgt_drop])
+        cam_q, cam_k, cam_mem_2 = self.multihead_attn.relprop(cam_drop, alpha, **kwargs)
+        cam_mem = lrp.clone_relprop([cam_k, cam_mem_2], memory)                          # clone4 (wembd3 / wembd2: identity)
+        cam = lrp.clone_relprop([cam_q, cam_tgt_2], tgt1)                                # clone3
+        cam_tgt_3, cam_drop = lrp.add_relprop(cam, tgt, a)                               # add1([tgt_3, tgt_drop])
+        cam_q, cam_k, cam_tgt_2 = self.self_attn.relprop(cam_drop, alpha, **kwargs)
+        cam_tgt_1 = lrp.clone_relprop([cam_q, cam_k], qk)                                # clone2 (X = tgt + query_pos)
+        return cam_tgt_1 + cam_tgt_2 + cam_tgt_3, cam_mem                                # transformer.py:434: a plain sum
 
 
     # ---- shared-forward mode (post-norm), batch-first tensors
@@ -176,6 +226,12 @@ class TransformerEncoder(nn.Module):
             src = layer(src, src_mask=mask, src_key_padding_mask=src_key_padding_mask, pos=pos)
         return src if self.norm is None else self.norm(src)
 
+    def relprop(self, cam, alpha=1, **kwargs):
+        """DETR/models/transformer.py:104-111 (the final norm, if any, passes relevance through)."""
+        for layer in reversed(self.layers):
+            cam = layer.relprop(cam, alpha, **kwargs)
+        return cam
+
 
 class TransformerDecoder(nn.Module):
     def __init__(self, make_layer, num_layers, norm=None, return_intermediate=False):
@@ -187,16 +243,33 @@ class TransformerDecoder(nn.Module):
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None, pos=None, query_pos=None):
-        out, stack = tgt, []
+        out, stack, outs = tgt, [], []
         for layer in self.layers:
             out = layer(out, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
                         tgt_key_padding_mask=tgt_key_padding_mask,
                         memory_key_padding_mask=memory_key_padding_mask, pos=pos, query_pos=query_pos)
+            outs.append(out)
             if self.return_intermediate:
                 stack.append(self.norm(out))     # transformer.py:148-153: every level is normed by the shared LN
+        self._lrp = _detached(memory, *outs)
         if self.return_intermediate:
             return torch.stack(stack)
         return (out if self.norm is None else self.norm(out)).unsqueeze(0)
+
+    def relprop(self, cam_list, alpha=1, **kwargs):
+        """DETR/models/transformer.py:166-199 for ``return_intermediate=True`` (what DETR builds): ``cam_list [levels, Q, B,
+        C]`` (relevance of every normed level) -> ``(cam_tgt, cam_memory)``.  Level ``j < last`` joins the stream through the
+        ``Clone`` that fed both the next layer and that level's norm (``clone_list[j]``)."""
+        if not self.return_intermediate:
+            raise NotImplementedError("relprop covers return_intermediate_dec=True (the reference's other branch is marked "
+                                      "FIXME there, transformer.py:167-172)")
+        memory, *outs = _lrp_tape(self)
+        cam, cam_mems = None, []
+        for j in range(self.num_layers - 1, -1, -1):
+            cam = cam_list[j] if j == self.num_layers - 1 else lrp.clone_relprop([cam, cam_list[j]], outs[j])
+            cam, cam_mem = self.layers[j].relprop(cam, alpha, **kwargs)
+            cam_mems.append(cam_mem)
+        return cam, lrp.clone_relprop(cam_mems, memory)
 
 
 class Transformer(nn.Module):
@@ -225,7 +298,21 @@ class Transformer(nn.Module):
         memory = self.encoder(tokens, src_key_padding_mask=key_padding, pos=pos)
         hs = self.decoder(torch.zeros_like(query_pos), memory, memory_key_padding_mask=key_padding, pos=pos,
                           query_pos=query_pos)
+        self._lrp = _detached(memory)
+        self._lrp_src_shape = (bs, c, h, w)
         return hs.transpose(1, 2), memory.permute(1, 2, 0).reshape(bs, c, h, w)
+
+    def relprop(self, cam, alpha=1, **kwargs):
+        """DETR/models/transformer.py:68-79: ``cam = [cam_hs [levels, B, Q, C], cam_memory [B, C, h, w]]`` -> relevance of the
+        projected feature map ``[B, C, h, w]``."""
+        (memory,) = _lrp_tape(self)
+        bs, c, h, w = self._lrp_src_shape
+        cam_hs = cam[0].transpose(1, 2)
+        cam_mem1 = cam[1].reshape(bs, c, h * w).permute(2, 0, 1)
+        cam_tgt, cam_mem2 = self.decoder.relprop(cam_hs, alpha, **kwargs)
+        cam_memory = lrp.clone_relprop([cam_mem1, cam_mem2], memory)
+        cam_src = self.encoder.relprop(cam_memory, alpha, **kwargs)
+        return cam_src.permute(1, 2, 0).reshape(bs, c, h, w)
 
 
     # ---- shared-forward mode: ONE forward at batch 1, the backward at batch K (K upstream gradients)
@@ -344,7 +431,31 @@ class DETRFromFeatures(nn.Module):
         proj = F.linear(features.permute(0, 2, 3, 1), self.input_proj.weight.flatten(1), self.input_proj.bias)
         hs, memory = self.transformer(proj.permute(0, 3, 1, 2), mask, self.query_embed.weight, pos)
         self.memory_shape = memory.shape
-        return {"pred_logits": self.class_embed(hs[-1]), "pred_boxes": self.bbox_embed(hs[-1]).sigmoid()}
+        logits = self.class_embed(hs[-1])
+        self._lrp = _detached(hs, logits)
+        return {"pred_logits": logits, "pred_boxes": self.bbox_embed(hs[-1]).sigmoid()}
+
+    @torch.no_grad()
+    def relprop(self, cam=None, alpha=1, **kwargs):
+        """``DETR.relprop`` (DETR/models/detr.py:79-92): the LRP pass of the whole head.  ``target_index`` (kept queries) and
+        ``target_class`` (``None``: arg-max over all classes, as there) select the relevance seeds; ``cam`` is ignored, as in
+        the reference.  Afterwards every attention module holds its ``attn_cam`` (``save_attn_cam``).  Returns the relevance
+        of the projected feature map ``[B, C, h, w]`` (the reference stops there too).  The decoder level that feeds
+        ``pred_logits`` is the last one here (the reference hard-codes ``index_select(..., [5])`` of its 6 levels)."""
+        hs, logits = _lrp_tape(self)
+        target_index, target_class = kwargs["target_index"], kwargs.get("target_class")
+        if target_class is None:
+            target_class = logits.max(dim=-1)[1][0, target_index]
+        seed = torch.zeros_like(logits)
+        seed[0, target_index, target_class] = 1
+        # index_select.relprop (DETR/modules/layers.py:232-244): only the selected level carries relevance -- X * (R / X)
+        cam_logits = logits * lrp.safe_divide(seed, logits)
+        levels_logits = torch.zeros(hs.shape[0], *logits.shape, dtype=logits.dtype, device=logits.device)
+        levels_logits[-1] = cam_logits
+        # class_embed.relprop on ALL levels at once, as the reference does (its R.sum() / Z cover the whole stack)
+        cam_hs = lrp.linear_relprop(levels_logits, hs, self.class_embed.weight, alpha)
+        mem_zero = torch.zeros(self.memory_shape, dtype=hs.dtype, device=hs.device)
+        return self.transformer.relprop([cam_hs, mem_zero], alpha, **kwargs)
 
 
     def forward_shared(self, features, batch, mask=None):
