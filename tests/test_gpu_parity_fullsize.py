@@ -328,3 +328,40 @@ def test_detr_ni950_rules_vs_oracle():
     err_rows = float((rows[0, 0, 1] - exact).abs().max()) / scale
     err_matrix = float((multi[0, 0, 1] - exact).abs().max()) / scale
     assert err_rows <= 2e-5 and err_matrix <= 2e-3, (err_rows, err_matrix)
+
+
+@pytest.mark.parametrize("N,B,need", [(577, 3, True), (197, 2, True), (577, 2, False), (64, 2, True), (130, 1, True)])
+def test_bf16_backward_third_generation_equals_second(N, B, need):
+    """``attention_bf16_v3.hip`` (shared forward + bf16 gradient stream + row-relevancy mode: the cfg-5 path; bf16 images of
+    the shared operands prepared once per call, padded / transposed probability images, 4 waves per SIMD) runs the SAME
+    tile arithmetic in the SAME order as the second generation (``attention_bf16.hip``, pinned on the oracle above), so dq /
+    dk / dv and the carried relevancy row must agree to the last bit -- both workgroup shapes (``attn_bf16_v3`` = 1 / 2)."""
+    from transformer_mm_explainability_amd import ops
+    H, D = 4, 64
+    g = torch.Generator().manual_seed(N * 7 + B)
+    qkv = torch.randn(1, N, 3, H, D, generator=g).cuda()
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    probs = torch.empty(1, H, N, N, device="cuda", dtype=torch.bfloat16)
+    o = ops.attn_capture_fwd(q, k, v, probs, D ** -0.5, mma_bf16=True)
+    d_o = (torch.randn(B, N, H, D, generator=g) * 1e-2).to(torch.bfloat16).cuda()
+    rel = torch.rand(B, N, generator=g).cuda()
+    results = {}
+    try:
+        for mode in (0, 1, 2):
+            ops.set_option("attn_bf16_v3", mode)
+            out = torch.full((B, N, 3, H, D), float("nan"), device="cuda", dtype=torch.bfloat16) if need else None
+            res = ops.attn_capture_bwd(q, k, v, probs, d_o, None, D ** -0.5, batch=B, o=o, need_dqkv=need, mma_bf16=True,
+                                       rel_row=rel, out=(out[:, :, 0], out[:, :, 1], out[:, :, 2]) if need else None)
+            torch.cuda.synchronize()
+            results[mode] = (out, res[3])
+    finally:
+        ops.set_option("attn_bf16_v3", 2)
+    want_out, want_rel = results[0]
+    assert torch.isfinite(want_rel).all()
+    for mode in (1, 2):
+        got_out, got_rel = results[mode]
+        if need:
+            assert torch.isfinite(got_out.float()).all()
+            assert torch.equal(got_out, want_out), (mode, float((got_out.float() - want_out.float()).abs().max()))
+        # (the relevancy sum is fp32 VALU work: same terms, but the compiler may contract / order the fmas differently)
+        assert float((got_rel - want_rel).abs().max()) <= 1e-6 * float(want_rel.abs().max()), mode

@@ -54,5 +54,9 @@ int attn_bwd_stream_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);
 int rel_row_update(const float* v_in, const float* part, float* out, int B, int J, int N, float inv_h, hipStream_t s);
 int attn_bwd_bf16_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);     // attention_bf16.hip (2nd-generation bf16 MFMA backward)
 void attn_bf16_v2_enable(int on);
+// attention_bf16_v3.hip: third generation, shared-forward + bf16 gradient stream + row-relevancy mode only (BASELINE config 5)
+int attn_bwd_bf16_v3_try(const AttnBwdArgs& a, void* prep, size_t prep_bytes, hipStream_t s, int* rc_out);
+size_t attn_bwd_bf16_v3_prep_bytes(int H, int N);
+void attn_bf16_v3_enable(int mode);
 
 }  // namespace mmx

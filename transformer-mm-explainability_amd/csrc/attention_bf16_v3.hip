@@ -1,0 +1,535 @@
+// Third generation of the bf16-matrix-core attention BACKWARD, for the configuration BASELINE config 5 runs (CLIP
+// ViT-L/14@336, 577 tokens x 64, batch 128 per GPU): SHARED forward (q / k / v / P of ONE image, batch stride 0), bf16 gradient
+// stream (dO in, dq / dk / dv out), row-relevancy mode (no dP slab), q * d^-0.5 first.  Everything else stays on the
+// second generation (attention_bf16.hip), whose tile arithmetic this file keeps.
+//
+// What the second generation paid per workgroup and per tile although the operands are the same for all B samples
+// (profiles/r02_cfg5_probe.txt: 21-26 % of the wave cycles in VALU at 2 waves / SIMD, 36-51 % parked):
+//   * K, V (query side) and Q (key side) were fetched as fp32 and rounded / transposed in registers by every workgroup --
+//     B x (N / 64) times per head;
+//   * the probabilities were 12-byte unaligned loads + funnel shifts (query side) and SIXTEEN 2-byte loads with a clamped
+//     64-bit address each (key side: a lane owns a key, its 16 query rows are a strided column of the slab).
+// Here two small PREP kernels run once per call on the shared operands (a few MB, L2-resident afterwards):
+//   Vb  [H][Np][64]  V rows, bf16                     KbT / QbT [H][64][Np]  K / (scale q) transposed, bf16
+//   Pq  [H][Np][Np]  P rows, zero padded to Np = 64 ceil(N / 64)             PT [H][Np][Np]  P transposed (row = key)
+// so that in the main kernels every LDS tile is a raw 8-byte copy of its global image (no ALU, no masks: the padding is
+// zero), a lane's probabilities of a tile are four ALIGNED 8-byte loads on both sides, and on the key side those raw words
+// ARE the bf16 A operand of dV = P^T . dO.  The padded row images also end the over-read of the 16-bit slab the second
+// generation needed slack for: no load of this file touches the caller's slab outside the prep kernel,
+// which reads it element-wise.  The tile loop is written in two 32-row halves so that only half of the score-shaped
+// registers are live at a time (the second generation's 162-184 VGPRs capped it at 2 waves per SIMD).
+#include "mmx_common.h"
+#include "attention_args.h"
+
+namespace mmx {
+namespace {
+
+constexpr int kT = 64;        // rows of the streamed operand per step
+constexpr int kD = 64;        // head dim (exactly)
+constexpr int kLR = kD + 16;  // row-major LDS tile [row][d]: 80-element rows (conflict-free, see attention_bf16.hip)
+constexpr int kLT = kT + 16;  // transposed LDS tile [d][row]: 80-element rows, 4-row group index XOR (d / 4) & 15
+
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;
+
+int g_attn_bf16_v3 = 2;       // 0: off (second generation), 1: 4-wave workgroups, 2: 8-wave workgroups (4 waves / SIMD on both kernels)
+
+struct V3Images {
+    const bf16_t *Vb, *KbT, *QbT, *Pq, *PT;
+    int Np;
+};
+
+__device__ __forceinline__ unsigned pk2(float lo, float hi) {      // two fp32 -> packed bf16 pair, round to nearest even
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    bf2 r;
+    r[0] = static_cast<__bf16>(lo);
+    r[1] = static_cast<__bf16>(hi);
+    return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4v v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
+    return as_bf16x8(u32x4v{pk2(lo[0], lo[1]), pk2(lo[2], lo[3]), pk2(hi[0], hi[1]), pk2(hi[2], hi[3])});
+}
+__device__ __forceinline__ float bflo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bfhi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ f32x4 unpack4(u32x2v w) { return f32x4{bflo(w[0]), bfhi(w[0]), bflo(w[1]), bfhi(w[1])}; }
+
+// 4 rows x 4 columns of bf16 (rows[e] = columns c, c+1 | c+2, c+3 of row e) -> column dd as 4 consecutive rows (8 bytes)
+__device__ __forceinline__ u32x2v column_of(const u32x2v (&rows)[4], int dd) {
+    const int w = dd >> 1;
+    const unsigned sel = (dd & 1) ? 0x07060302u : 0x05040100u;
+    return u32x2v{__builtin_amdgcn_perm(rows[1][w], rows[0][w], sel), __builtin_amdgcn_perm(rows[3][w], rows[2][w], sel)};
+}
+
+// ======================================================================================================= prep kernels
+// which = 0: Vb (row-major), 1: KbT, 2: QbT (times scale).  One workgroup per (64-row tile, head, which); fp32 in, 16-byte
+// aligned rows (checked by the caller), rows >= N are written as zeros.
+__global__ __launch_bounds__(256) void prep_qkv_kernel(const AttnBwdArgs a, bf16_t* Vb, bf16_t* KbT, bf16_t* QbT, int Np) {
+    const int tid = threadIdx.x, row0 = blockIdx.x * kT, h = blockIdx.y, which = blockIdx.z;
+    const int r4 = 4 * (tid >> 4), c = 4 * (tid & 15);
+    const float* base = which == 0 ? a.v + h * a.vs.sh : which == 1 ? a.k + h * a.ks.sh : a.q + h * a.qs.sh;
+    const int64_t sn = which == 0 ? a.vs.sn : which == 1 ? a.ks.sn : a.qs.sn;
+    const float mul = which == 2 ? a.scale : 1.f;
+    u32x2v rows[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = row0 + r4 + e;
+        rows[e] = u32x2v{0u, 0u};
+        if (row < a.Nk) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(row) * sn + c);
+            rows[e] = u32x2v{pk2(x[0] * mul, x[1] * mul), pk2(x[2] * mul, x[3] * mul)};
+        }
+    }
+    if (which == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            *reinterpret_cast<u32x2v*>(Vb + (static_cast<int64_t>(h) * Np + row0 + r4 + e) * kD + c) = rows[e];
+    } else {
+        bf16_t* out = which == 1 ? KbT : QbT;
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd)
+            *reinterpret_cast<u32x2v*>(out + (static_cast<int64_t>(h) * kD + c + dd) * Np + row0 + r4) = column_of(rows, dd);
+    }
+}
+
+// P slab [H][N][N] (16-bit elements, any alignment) -> Pq [H][Np][Np] (zero padded rows) and PT (its transpose)
+__global__ __launch_bounds__(256) void prep_p_kernel(const bf16_t* __restrict__ P, bf16_t* __restrict__ Pq, bf16_t* __restrict__ PT,
+                                                     int N, int Np) {
+    __shared__ bf16_t tile[kT][kT + 2];
+    const int tid = threadIdx.x, k0 = blockIdx.x * kT, q0 = blockIdx.y * kT, h = blockIdx.z;
+    const bf16_t* src = P + static_cast<int64_t>(h) * N * N;
+    for (int idx = tid; idx < kT * kT; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        bf16_t v = 0;
+        if (q0 + r < N && k0 + c < N) v = src[static_cast<int64_t>(q0 + r) * N + k0 + c];
+        tile[r][c] = v;
+        Pq[(static_cast<int64_t>(h) * Np + q0 + r) * Np + k0 + c] = v;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < kT * kT; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;                              // r: key within the tile, c: query within the tile
+        PT[(static_cast<int64_t>(h) * Np + k0 + r) * Np + q0 + c] = tile[c][r];
+    }
+}
+
+// ======================================================================================================= shared pieces
+// the wave's 16 rows of a bf16 operand as MFMA operand registers: lane (i, g) holds row `row`, d = 32 pr + 8 g .. + 7
+__device__ __forceinline__ void load_rows8(bf16x8 (&op)[kD / 32], const bf16_t* base, int64_t sn, int row, bool row_ok, int g) {
+#pragma unroll
+    for (int pr = 0; pr < kD / 32; ++pr) {
+        const u32x4v v = *reinterpret_cast<const u32x4v*>(base + static_cast<int64_t>(row) * sn + 32 * pr + 8 * g);
+        op[pr] = as_bf16x8(row_ok ? v : u32x4v{0u, 0u, 0u, 0u});
+    }
+}
+
+// one operand of the "contract over the tile's row index" products, from a TRANSPOSED tile [d][row]: row-slots (g, j) of
+// tile pair p (rows 32 p + 16 (j >> 2) + 4 g + (j & 3)) for d = 16 dt + i.  The swizzled 4-row group index
+// (8 p + 4 hi + g) ^ ((4 dt + (i >> 2)) & 15) splits into a per-lane part (g ^ (i >> 2), bits 0-1) and a compile-time part
+// (dt ^ (2 p + hi), bits 2-3), so ONE lane address (transposed_lane_base) + immediate offsets serve all 16 reads of a tile
+// (written with the XOR on the whole index the compiler kept 16-32 address registers live across the loop).
+__device__ __forceinline__ int transposed_lane_base(int i, int g) { return i * kLT + 4 * (g ^ (i >> 2)); }
+__device__ __forceinline__ bf16x8 transposed_operand(const bf16_t* tile_lane, int dt, int p) {
+    const u32x2v lo = *reinterpret_cast<const u32x2v*>(tile_lane + 16 * dt * kLT + 16 * (dt ^ (2 * p)));
+    const u32x2v hi = *reinterpret_cast<const u32x2v*>(tile_lane + 16 * dt * kLT + 16 * (dt ^ (2 * p + 1)));
+    return as_bf16x8(u32x4v{lo[0], lo[1], hi[0], hi[1]});
+}
+
+// a [64 x 64] bf16 tile of a row-major image (row stride `sn` elements): thread st (0..255) owns a 4 x 4 block
+struct RawBlock { u32x2v raw[4]; };
+__device__ __forceinline__ void fetch_row_major(RawBlock& blk, const bf16_t* img, int64_t sn, int row0, int st) {
+    const int r4 = 4 * (st >> 4), c = 4 * (st & 15);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) blk.raw[e] = *reinterpret_cast<const u32x2v*>(img + static_cast<int64_t>(row0 + r4 + e) * sn + c);
+}
+__device__ __forceinline__ void store_row_major(bf16_t* tile, const u32x2v (&rows)[4], int st) {
+    const int r4 = 4 * (st >> 4), c = 4 * (st & 15);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) *reinterpret_cast<u32x2v*>(tile + (r4 + e) * kLR + c) = rows[e];
+}
+// the same block of a TRANSPOSED image [d][row] (row stride Np): raw[dd] = rows row0 + r4 .. + 3 of d = c + dd
+__device__ __forceinline__ void fetch_transposed(RawBlock& blk, const bf16_t* imgT, int Np, int row0, int st) {
+    const int r4 = 4 * (st >> 4), c = 4 * (st & 15);
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd)
+        blk.raw[dd] = *reinterpret_cast<const u32x2v*>(imgT + static_cast<int64_t>(c + dd) * Np + row0 + r4);
+}
+__device__ __forceinline__ void store_transposed_raw(bf16_t* tile, const u32x2v (&cols)[4], int st) {
+    const int c = 4 * (st & 15);
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd)
+        *reinterpret_cast<u32x2v*>(tile + (c + dd) * kLT + 4 * ((st >> 4) ^ (st & 15))) = cols[dd];
+}
+
+// ===================================================================================================== query side
+// delta = rowsum(dO * O), dP^T = V . dO^T, dS, dQ = dS . K  (orientation and accumulator layouts: attention_bf16.hip)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 4) void attn_bwd_q_v3_kernel(const AttnBwdArgs a, const V3Images im) {
+    constexpr int NB = kD / 16, R = 16 * NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* Vt = reinterpret_cast<bf16_t*>(smem_raw);                 // [2][kT][kLR]   V rows (row-major)
+    bf16_t* Kt = Vt + 2 * kT * kLR;                                   // [2][kD][kLT]   K transposed
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int st = tid & 255;
+    const bool stage_v = NW == 4 || tid < 256;
+    const int nrt = (a.Nq + R - 1) / R;
+    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int rt = wg % nrt, h = (wg / nrt) % a.H, b = wg / (nrt * a.H);
+    const int q = rt * R + wave * 16 + i;
+    const bool q_ok = q < a.Nq;
+    const int qc = min(q, a.Nq - 1);
+    const int64_t head = static_cast<int64_t>(b) * a.H + h;
+
+    // the wave's dO rows as the B operand of dP^T, and delta = rowsum(dO * O) of this lane's row
+    bf16x8 dob[kD / 32];
+    float delta;
+    {
+        const bf16_t* src = reinterpret_cast<const bf16_t*>(a.dout) + b * a.os.sb + h * a.os.sh;
+        load_rows8(dob, src, a.os.sn, qc, q_ok, g);
+        const float* ob = a.o + h * a.oos.sh + static_cast<int64_t>(qc) * a.oos.sn;
+        float part = 0.f;
+#pragma unroll
+        for (int pr = 0; pr < kD / 32; ++pr) {
+            const int d0 = 32 * pr + 8 * g;
+            const u32x4v w = __builtin_bit_cast(u32x4v, dob[pr]);
+            const f32x4 o0 = *reinterpret_cast<const f32x4*>(ob + d0), o1 = *reinterpret_cast<const f32x4*>(ob + d0 + 4);
+            part += bflo(w[0]) * o0[0] + bfhi(w[0]) * o0[1] + bflo(w[1]) * o0[2] + bfhi(w[1]) * o0[3] +
+                    bflo(w[2]) * o1[0] + bfhi(w[2]) * o1[1] + bflo(w[3]) * o1[2] + bfhi(w[3]) * o1[3];
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        delta = q_ok ? part : 0.f;
+        if (g == 0 && q_ok) a.delta[head * a.Nq + q] = delta;
+    }
+    const bf16_t* prow = im.Pq + (static_cast<int64_t>(h) * im.Np + qc) * im.Np;     // zero padded beyond Nk
+    const bf16_t* vimg = im.Vb + static_cast<int64_t>(h) * im.Np * kD;
+    const bf16_t* kimg = im.KbT + static_cast<int64_t>(h) * kD * im.Np;
+    const int ntiles = (a.Nk + kT - 1) / kT;
+    const int tlane = transposed_lane_base(i, g);
+
+    f32x4 qacc[NB];
+#pragma unroll
+    for (int dt = 0; dt < NB; ++dt) qacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // NW == 4: every thread stages a block of V and one of K; NW == 8: waves 0-3 stage V, waves 4-7 K (ONE register block)
+    RawBlock r0, r1;
+    auto fetch = [&](int kt) {
+        if constexpr (NW == 4) {
+            fetch_row_major(r0, vimg, kD, kt * kT, st);
+            fetch_transposed(r1, kimg, im.Np, kt * kT, st);
+        } else {
+            if (stage_v) fetch_row_major(r0, vimg, kD, kt * kT, st);
+            else fetch_transposed(r0, kimg, im.Np, kt * kT, st);
+        }
+    };
+    auto stage = [&](int buf) {
+        if constexpr (NW == 4) {
+            store_row_major(Vt + buf * kT * kLR, r0.raw, st);
+            store_transposed_raw(Kt + buf * kD * kLT, r1.raw, st);
+        } else {
+            if (stage_v) store_row_major(Vt + buf * kT * kLR, r0.raw, st);
+            else store_transposed_raw(Kt + buf * kD * kLT, r0.raw, st);
+        }
+    };
+    u32x2v p_cur[4], p_nxt[4];
+    auto p_issue = [&](u32x2v (&raw)[4], int kt) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) raw[t] = *reinterpret_cast<const u32x2v*>(prow + kt * kT + 16 * t + 4 * g);
+    };
+
+    fetch(0);
+    stage(0);
+    p_issue(p_cur, 0);
+    if (ntiles > 1) fetch(1);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        if (kt + 1 < ntiles) {
+            stage((kt + 1) & 1);                                   // the tile fetched during the previous iteration
+            p_issue(p_nxt, kt + 1);
+            if (kt + 2 < ntiles) fetch(kt + 2);
+        }
+        const bf16_t* Vcur = Vt + (kt & 1) * kT * kLR;
+        const bf16_t* Kcur = Kt + (kt & 1) * kD * kLT + tlane;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {                           // keys 32 pp .. + 31 of the tile
+            f32x4 dpT[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int pr = 0; pr < kD / 32; ++pr)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const bf16x8 op = *reinterpret_cast<const bf16x8*>(Vcur + (16 * (2 * pp + hh) + i) * kLR + 32 * pr + 8 * g);
+                    dpT[hh] = mfma16x16x32_bf16(op, dob[pr], dpT[hh]);
+                }
+            // dS[q][key] = P * (dP - delta) for keys 16 t + 4 g + r, t = 2 pp + hh (scale_mode Q_FIRST: no further factor)
+            const f32x4 ds0 = unpack4(p_cur[2 * pp]) * (dpT[0] - delta);
+            const f32x4 ds1 = unpack4(p_cur[2 * pp + 1]) * (dpT[1] - delta);
+            const bf16x8 dsb = pack8(ds0, ds1);
+#pragma unroll
+            for (int dt = 0; dt < NB; ++dt) qacc[dt] = mfma16x16x32_bf16(transposed_operand(Kcur, dt, pp), dsb, qacc[dt]);
+            __builtin_amdgcn_sched_barrier(0);                    // keep the two halves apart: bounds the live registers
+        }
+        if (kt + 1 < ntiles) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) p_cur[t] = p_nxt[t];
+        }
+        lds_barrier();
+    }
+    if (!q_ok) return;
+    // dQ^T accumulators: lane (q = column i), rows d = 16 dt + 4 g + r: 4 consecutive d of one query row
+    const int64_t off = b * a.dqs.sb + h * a.dqs.sh + static_cast<int64_t>(q) * a.dqs.sn;
+#pragma unroll
+    for (int dt = 0; dt < NB; ++dt) {
+        const f32x4 v = qacc[dt] * a.scale;
+        *reinterpret_cast<u32x2v*>(reinterpret_cast<bf16_t*>(a.dq) + off + 16 * dt + 4 * g) = u32x2v{pk2(v[0], v[1]), pk2(v[2], v[3])};
+    }
+}
+
+// ===================================================================================================== key side
+// per 16 NW keys: dP recomputed, dV = P^T . dO, dK = dS^T . Q (DKV), and the row-relevancy partial of this head
+// rel_part[b][h][key] = sum_q rel_v[b][q] * clamp(dP * P, 0)[q][key]
+template <int NW, bool DKV>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kernel(const AttnBwdArgs a, const V3Images im) {
+    constexpr int NB = kD / 16, R = 16 * NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* dOr = reinterpret_cast<bf16_t*>(smem_raw);                // [2][kT][kLR]   dO rows (row-major)
+    bf16_t* dOt = dOr + 2 * kT * kLR;                                 // [2][kD][kLT]   dO transposed
+    bf16_t* Qt = dOt + 2 * kD * kLT;                                  // [2][kD][kLT]   (scale q) transposed
+    float* dl = reinterpret_cast<float*>(Qt + 2 * kD * kLT);          // [2][kT]        delta of the staged query rows
+    float* vl = dl + 2 * kT;                                          // [2][kT]        rel_v of the staged query rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int st = tid & 255;
+    const bool stage_do = NW == 4 || tid < 256, stage_q = DKV && (NW == 4 || tid >= 256);
+    const int nkt = (a.Nk + R - 1) / R;
+    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int h = (wg / nkt) % a.H, b = wg / (nkt * a.H);
+    const int kw = (wg % nkt) * R + wave * 16;                        // first key of this wave
+    const int key = kw + i;
+    const bool key_ok = key < a.Nk;
+    const int keyc = min(key, a.Nk - 1);
+    const int64_t head = static_cast<int64_t>(b) * a.H + h;
+    const bf16_t* pcol = im.PT + (static_cast<int64_t>(h) * im.Np + keyc) * im.Np;   // this key's column of P: queries contiguous
+    const bf16_t* qimg = im.QbT + static_cast<int64_t>(h) * kD * im.Np;
+    const bf16_t* dobase = reinterpret_cast<const bf16_t*>(a.dout) + b * a.os.sb + h * a.os.sh;
+
+    bf16x8 vop[kD / 32];                                              // this wave's V rows: B operand of dP = dO . V^T
+    load_rows8(vop, im.Vb + static_cast<int64_t>(h) * im.Np * kD, kD, keyc, key_ok, g);
+
+    f32x4 kacc[NB], vacc[NB];
+#pragma unroll
+    for (int dt = 0; dt < NB; ++dt) kacc[dt] = vacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = (a.Nq + kT - 1) / kT;
+    const int tlane = transposed_lane_base(i, g);
+    RawBlock doreg, qreg_;
+    RawBlock& qreg = NW == 4 ? qreg_ : doreg;                        // NW == 8: waves 4-7 stage Q, ONE register block per thread
+    int do_row0 = 0;
+    float dlreg = 0.f, vlreg = 0.f, racc = 0.f;
+    auto fetch = [&](int qt) {
+        if (stage_do) {                                               // per-sample operand: clamped rows, masked at the store
+            const int r4 = 4 * (st >> 4), c = 4 * (st & 15);
+            do_row0 = qt * kT;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                doreg.raw[e] = *reinterpret_cast<const u32x2v*>(dobase + static_cast<int64_t>(min(qt * kT + r4 + e, a.Nq - 1)) * a.os.sn + c);
+        }
+        if (stage_q) fetch_transposed(qreg, qimg, im.Np, qt * kT, st);
+        if (tid < kT) {
+            const int row = min(qt * kT + tid, a.Nq - 1);
+            if constexpr (DKV) dlreg = a.delta[head * a.Nq + row];
+            vlreg = a.rel_v[static_cast<int64_t>(b) * a.Nq + row];
+        }
+    };
+    auto stage = [&](int buf) {
+        if (stage_do) {
+            const int r4 = 4 * (st >> 4);
+            u32x2v rows[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rows[e] = do_row0 + r4 + e < a.Nq ? doreg.raw[e] : u32x2v{0u, 0u};
+            store_row_major(dOr + buf * kT * kLR, rows, st);
+            if constexpr (DKV) {
+                u32x2v cols[4];
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd) cols[dd] = column_of(rows, dd);
+                store_transposed_raw(dOt + buf * kD * kLT, cols, st);
+            }
+        }
+        if (stage_q) store_transposed_raw(Qt + buf * kD * kLT, qreg.raw, st);
+        if (tid < kT) {
+            if constexpr (DKV) dl[buf * kT + tid] = dlreg;
+            vl[buf * kT + tid] = vlreg;                                // (rows past Nq: p is zero there)
+        }
+    };
+    u32x2v p_cur[4], p_nxt[4];
+    auto p_issue = [&](u32x2v (&raw)[4], int qt) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) raw[t] = *reinterpret_cast<const u32x2v*>(pcol + qt * kT + 16 * t + 4 * g);
+    };
+    fetch(0);
+    stage(0);
+    p_issue(p_cur, 0);
+    if (ntiles > 1) fetch(1);
+    __syncthreads();
+    for (int qt = 0; qt < ntiles; ++qt) {
+        const int cur = qt & 1;
+        if (qt + 1 < ntiles) {
+            stage(cur ^ 1);
+            p_issue(p_nxt, qt + 1);
+            if (qt + 2 < ntiles) fetch(qt + 2);
+        }
+        const bf16_t* dOrc = dOr + cur * kT * kLR;
+        const bf16_t* dOtc = dOt + cur * kD * kLT + tlane;
+        const bf16_t* Qtc = Qt + cur * kD * kLT + tlane;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {                               // query rows 32 pp .. + 31 of the tile
+            f32x4 dp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // dp[hh][r] = dP[16 t + 4 g + r][key i]
+#pragma unroll
+            for (int pr = 0; pr < kD / 32; ++pr)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const bf16x8 op = *reinterpret_cast<const bf16x8*>(dOrc + (16 * (2 * pp + hh) + i) * kLR + 32 * pr + 8 * g);
+                    dp[hh] = mfma16x16x32_bf16(op, vop[pr], dp[hh]);
+                }
+            f32x4 ds[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int t = 2 * pp + hh;
+                const f32x4 p = unpack4(p_cur[t]);
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(vl + cur * kT + 16 * t + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) racc += vv[r] * relu_nan(p[r] * dp[hh][r]);
+                if constexpr (DKV) {
+                    const f32x4 dlv = *reinterpret_cast<const f32x4*>(dl + cur * kT + 16 * t + 4 * g);
+                    ds[hh] = p * (dp[hh] - dlv);
+                }
+            }
+            if constexpr (DKV) {
+                // the raw probability words of the two sub-tiles ARE the bf16 A operand of dV = P^T . dO
+                const bf16x8 p_op = as_bf16x8(u32x4v{p_cur[2 * pp][0], p_cur[2 * pp][1], p_cur[2 * pp + 1][0], p_cur[2 * pp + 1][1]});
+                const bf16x8 ds_op = pack8(ds[0], ds[1]);
+#pragma unroll
+                for (int dt = 0; dt < NB; ++dt) {
+                    vacc[dt] = mfma16x16x32_bf16(p_op, transposed_operand(dOtc, dt, pp), vacc[dt]);
+                    kacc[dt] = mfma16x16x32_bf16(ds_op, transposed_operand(Qtc, dt, pp), kacc[dt]);
+                }
+            }
+            // pin this half's share of the relevancy sum here: left alone the compiler sinks all 16 multiply / clamp / fma
+            // triples of a tile behind the second half and keeps both halves' p, dP and rel_v registers live until then
+            asm volatile("" : "+v"(racc));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (qt + 1 < ntiles) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) p_cur[t] = p_nxt[t];
+        }
+        lds_barrier();
+    }
+    racc += __shfl_xor(racc, 16);
+    racc += __shfl_xor(racc, 32);                                  // the 4 row groups of the tile rows: all queries of key i
+    if (g == 0 && key_ok) a.rel_part[head * a.Nk + key] = racc;
+    if constexpr (!DKV) return;
+    // accumulators: lane (d = 16 dt + i), rows key = kw + 4 g + r; lanes i / i ^ 1 pair up so that every store is 4 bytes
+    const int64_t dk0 = b * a.dks.sb + h * a.dks.sh, dv0 = b * a.dvs.sb + h * a.dvs.sh;
+    const bool odd = i & 1;
+#pragma unroll
+    for (int dt = 0; dt < NB; ++dt) {
+        const int d = 16 * dt + i;
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+            const int r = 2 * rp + (odd ? 1 : 0);
+            const int j = kw + 4 * g + r, c0 = d - (odd ? 1 : 0);
+            const float km = odd ? kacc[dt][2 * rp + 1] : kacc[dt][2 * rp];
+            const float vm = odd ? vacc[dt][2 * rp + 1] : vacc[dt][2 * rp];
+            const float ko = __int_as_float(__builtin_amdgcn_update_dpp(
+                0, __float_as_int(odd ? kacc[dt][2 * rp] : kacc[dt][2 * rp + 1]), 0xB1, 0xF, 0xF, false));
+            const float vo = __int_as_float(__builtin_amdgcn_update_dpp(
+                0, __float_as_int(odd ? vacc[dt][2 * rp] : vacc[dt][2 * rp + 1]), 0xB1, 0xF, 0xF, false));
+            if (j < a.Nk) {
+                bf16_t* dk = reinterpret_cast<bf16_t*>(a.dk) + dk0 + static_cast<int64_t>(j) * a.dks.sn + c0;
+                bf16_t* dv = reinterpret_cast<bf16_t*>(a.dv) + dv0 + static_cast<int64_t>(j) * a.dvs.sn + c0;
+                *reinterpret_cast<unsigned*>(dk) = odd ? pk2(ko, km) : pk2(km, ko);
+                *reinterpret_cast<unsigned*>(dv) = odd ? pk2(vo, vm) : pk2(vm, vo);
+            }
+        }
+    }
+}
+
+constexpr size_t kQLds = sizeof(bf16_t) * (2 * kT * kLR + 2 * kD * kLT);
+constexpr size_t kKvLds = sizeof(bf16_t) * (2 * kT * kLR + 4 * kD * kLT) + sizeof(float) * 4 * kT;
+
+template <typename K>
+int launch_v3(K kern, const AttnBwdArgs& a, const V3Images& im, dim3 grid, int threads, size_t lds, hipStream_t s, const char* name) {
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds));
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    kern<<<grid, threads, lds, s>>>(a, im);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, name);
+    return MMX_OK;
+}
+
+template <int NW>
+int run_v3(const AttnBwdArgs& a, const V3Images& im, hipStream_t s) {
+    constexpr int R = 16 * NW;
+    dim3 gq(((a.Nq + R - 1) / R) * a.H * a.B), gk(((a.Nk + R - 1) / R) * a.H * a.B);
+    int rc = MMX_OK;
+    if (a.need_dqkv) {
+        rc = launch_v3(attn_bwd_q_v3_kernel<NW>, a, im, gq, 64 * NW, kQLds, s, "attn_bwd_q_v3_kernel");
+        if (rc) return rc;
+        rc = launch_v3(attn_bwd_kv_v3_kernel<NW, true>, a, im, gk, 64 * NW, kKvLds, s, "attn_bwd_kv_v3_kernel");
+    } else {
+        rc = launch_v3(attn_bwd_kv_v3_kernel<NW, false>, a, im, gk, 64 * NW, kKvLds, s, "attn_bwd_kv_v3_kernel<rel only>");
+    }
+    if (rc) return rc;
+    return rel_row_update(a.rel_v, a.rel_part, a.rel_out, a.B, a.H, a.Nk, 1.0f / a.H, s);     // one partial row per head
+}
+
+bool al16(const void* p, const Strides& s, int elem) {
+    return reinterpret_cast<uintptr_t>(p) % 16 == 0 && (s.sh * elem) % 16 == 0 && (s.sn * elem) % 16 == 0;
+}
+
+}  // namespace
+
+void attn_bf16_v3_enable(int mode) { g_attn_bf16_v3 = mode; }
+
+// bytes of the prep images (independent of the batch): appended to the row-relevancy workspace
+size_t attn_bwd_bf16_v3_prep_bytes(int H, int N) {
+    const size_t Np = (static_cast<size_t>(N) + kT - 1) / kT * kT;
+    return sizeof(bf16_t) * (3 * H * Np * kD + 2 * H * Np * Np) + 256;
+}
+
+// returns 1 if the third-generation kernels were launched (rc in *rc_out), 0 if the call is not eligible (see the header
+// comment): shared forward, bf16 slab + bf16 gradient stream, row-relevancy mode, head_dim 64, q * scale first.
+int attn_bwd_bf16_v3_try(const AttnBwdArgs& a, void* prep, size_t prep_bytes, hipStream_t s, int* rc_out) {
+    if (!g_attn_bf16_v3 || !a.mma_bf16 || !a.io_bf16 || !a.rel_v || !a.o || a.dprobs) return 0;
+    if (a.D != kD || a.slab_dt != MMX_BF16 || a.scale_mode != MMX_SCALE_Q_FIRST || a.Nq != a.Nk) return 0;
+    if (a.probs_sb != 0 || a.vs.sb != 0 || a.oos.sb != 0 || (a.need_dqkv && (a.qs.sb != 0 || a.ks.sb != 0))) return 0;
+    if (!prep || prep_bytes < attn_bwd_bf16_v3_prep_bytes(a.H, a.Nk)) return 0;
+    if (!al16(a.v, a.vs, 4) || !al16(a.o, a.oos, 4) || !al16(a.dout, a.os, 2) || (a.os.sb * 2) % 16) return 0;
+    if (a.need_dqkv) {
+        if (!al16(a.q, a.qs, 4) || !al16(a.k, a.ks, 4)) return 0;
+        if (!al16(a.dq, a.dqs, 2) || (a.dqs.sb * 2) % 8 || reinterpret_cast<uintptr_t>(a.dk) % 4 || reinterpret_cast<uintptr_t>(a.dv) % 4 ||
+            (a.dks.sn * 2) % 4 || (a.dvs.sn * 2) % 4 || (a.dks.sh * 2) % 4 || (a.dvs.sh * 2) % 4 || (a.dks.sb * 2) % 4 ||
+            (a.dvs.sb * 2) % 4)
+            return 0;
+    }
+    const int Np = (a.Nk + kT - 1) / kT * kT;
+    bf16_t* base = reinterpret_cast<bf16_t*>((reinterpret_cast<uintptr_t>(prep) + 255) / 256 * 256);
+    bf16_t* Vb = base;
+    bf16_t* KbT = Vb + static_cast<size_t>(a.H) * Np * kD;
+    bf16_t* QbT = KbT + static_cast<size_t>(a.H) * Np * kD;
+    bf16_t* Pq = QbT + static_cast<size_t>(a.H) * Np * kD;
+    bf16_t* PT = Pq + static_cast<size_t>(a.H) * Np * Np;
+    prep_qkv_kernel<<<dim3(Np / kT, a.H, a.need_dqkv ? 3 : 1), 256, 0, s>>>(a, Vb, KbT, QbT, Np);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { *rc_out = hip_fail(e, "prep_qkv_kernel"); return 1; }
+    prep_p_kernel<<<dim3(Np / kT, Np / kT, a.H), 256, 0, s>>>(reinterpret_cast<const bf16_t*>(a.probs), Pq, PT, a.Nk, Np);
+    e = hipGetLastError();
+    if (e != hipSuccess) { *rc_out = hip_fail(e, "prep_p_kernel"); return 1; }
+    const V3Images im{Vb, KbT, QbT, Pq, PT, Np};
+    *rc_out = g_attn_bf16_v3 == 2 ? run_v3<8>(a, im, s) : run_v3<4>(a, im, s);
+    return 1;
+}
+
+}  // namespace mmx

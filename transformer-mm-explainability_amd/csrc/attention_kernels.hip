@@ -407,9 +407,14 @@ static size_t rowrel_delta_bytes(int B, int H, int Nq) {
     return (sizeof(float) * static_cast<size_t>(B) * H * Nq + 255) / 256 * 256;
 }
 
-extern "C" size_t mmx_attn_capture_bwd_rowrel_workspace_bytes(int B, int H, int Nq, int Nk) {
+static size_t rowrel_part_bytes(int B, int H, int Nq, int Nk) {
     const size_t nrt = (static_cast<size_t>(Nq) + 63) / 64;
-    return rowrel_delta_bytes(B, H, Nq) + sizeof(float) * static_cast<size_t>(B) * H * nrt * Nk;
+    return (sizeof(float) * static_cast<size_t>(B) * H * nrt * Nk + 255) / 256 * 256;
+}
+
+extern "C" size_t mmx_attn_capture_bwd_rowrel_workspace_bytes(int B, int H, int Nq, int Nk) {
+    // delta | partial relevancy rows | bf16 images of the shared operands (third-generation kernels, attention_bf16_v3.hip)
+    return rowrel_delta_bytes(B, H, Nq) + rowrel_part_bytes(B, H, Nq, Nk) + mmx::attn_bwd_bf16_v3_prep_bytes(H, Nk);
 }
 
 static int attn_bwd_impl(const void* q_dev, const void* k_dev, const void* v_dev, int64_t q_sb,
@@ -469,6 +474,8 @@ static int attn_bwd_impl(const void* q_dev, const void* k_dev, const void* v_dev
     a.rel_out = static_cast<float*>(rel_out_dev);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (rel) {
+        const size_t used = rowrel_delta_bytes(B, H, Nq) + rowrel_part_bytes(B, H, Nq, Nk);
+        if (attn_bwd_bf16_v3_try(a, static_cast<char*>(workspace_dev) + used, workspace_bytes - used, s, &rc)) return rc;
         if (!attn_bwd_stream_try(a, s, &rc)) {
             set_error("mmx_attn_capture_bwd_rowrel: needs head_dim %% 4 == 0 (<= 64) and 16-byte aligned views");
             return MMX_ENOTSUP;

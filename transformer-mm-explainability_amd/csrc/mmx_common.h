@@ -201,6 +201,7 @@ int self_chain_big_try(const void* const* attn_layers, const void* const* grad_l
                        size_t workspace_bytes, hipStream_t s, int* rc_out);
 void attn_stream_enable(int on);
 void attn_bf16_v2_enable(int on);
+void attn_bf16_v3_enable(int mode);
 int hip_fail(hipError_t e, const char* what);
 // Fill kernels instead of hipMemsetAsync: a memset NODE of a captured hipGraph was observed (ROCm 7.2, gfx950) to replay
 // with a corrupted 64-bit pattern once other work had run between capture and replay (every second fp32 word garbage);
