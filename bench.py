@@ -379,12 +379,15 @@ def main():
         last_only_graph = rate(run_last, reps)
         run_trim = ce.GraphedInterpret(model, image, texts, 0, 0, trim_text_padding=True)          # opt-in, exact
         trimmed_graph = rate(run_trim, reps)
-        del run_last, run_trim
+        run_order = ce.GraphedInterpret(model, image, texts, 0, 0, image_chain_on_main=True)
+        chain_on_main_graph = rate(run_order, reps)
+        del run_last, run_trim, run_order
         variants = {"eager_maps_per_s": round(eager, 2),
                     "eager_B_image_copies_maps_per_s": round(no_share, 2),
                     "distinct_images_hipgraph_maps_per_s": round(distinct_graph, 2),
                     "last_layer_only_maps_per_s": {"eager": round(last_only, 2), "hipgraph": round(last_only_graph, 2)},
-                    "trim_text_padding_hipgraph_maps_per_s": round(trimmed_graph, 2)}
+                    "trim_text_padding_hipgraph_maps_per_s": round(trimmed_graph, 2),
+                    "image_chain_on_main_stream_hipgraph_maps_per_s": round(chain_on_main_graph, 2)}
 
     roofline = None
     if not args.headline_only:

@@ -54,7 +54,11 @@ def evaluate(image_ids, masks_of, store=None, device="cpu"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--num-images", type=int, default=64)
-    ap.add_argument("--method", default="ours_no_lrp")
+    # the reference's flag (DETR/main.py:102-107), same name, choices and default
+    ap.add_argument("--method", type=str, default="ours_no_lrp",
+                    choices=["ours_with_lrp", "rollout", "partial_lrp", "transformer_att", "raw_attn", "attn_gradcam",
+                             "ours_no_normalization", "ours_no_lrp", "ours_no_lrp_no_norm", "ablation_no_aggregation",
+                             "ablation_no_self_in_10"])
     ap.add_argument("--graph-slots", type=int, default=16, help="target slots of the captured explain pass (0: eager)")
     ap.add_argument("--keep-top", type=int, default=8, help="random-init logits are flat: keep this many queries per image")
     ap.add_argument("--resume-dir", default=None)

@@ -35,17 +35,41 @@ def synthetic_item(k, regions, feat_dim, vocab, answers):
                 visual_pos=torch.rand(regions, 4, generator=g), label=label)
 
 
+# methods of the reference's --method flag this batched evaluator runs (rule flags of GeneratorOurs.generate_ours_batch);
+# the others exist per item on the generator classes (lxmert_explainability.GeneratorBaselines / ...AblationNoAggregation,
+# LRP ones need a body with relprop) and are not batched here
+BATCHED_METHODS = {"ours_no_lrp": {}, "ours_no_lrp_no_norm": {"normalize_self_attention": False},
+                   "ablation_no_self_in_10": {"apply_self_in_rule_10": False}}
+OTHER_METHODS = {"ours_with_lrp", "rollout", "partial_lrp", "transformer_att", "raw_attn", "attn_gradcam",
+                 "ours_with_lrp_no_normalization", "ablation_no_aggregation"}
+
+
+def ref_bool(text):
+    """The reference declares these flags with ``type=bool`` (any non-empty string is True there, even "False"); here
+    "false" / "0" / "no" / "" mean False."""
+    return str(text).strip().lower() not in ("", "0", "false", "no", "off")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--num-samples", type=int, default=512)
     ap.add_argument("--dataset-len", type=int, default=20000)
     ap.add_argument("--max-batch", type=int, default=32)
-    ap.add_argument("--text", action="store_true", help="text perturbation test instead of the image one")
-    ap.add_argument("--positive", action="store_true")
+    # the reference evaluator's own flags (lxmert/lxmert/src/param.py:93-107), same names and defaults
+    ap.add_argument("--method", type=str, default="ours_no_lrp", choices=sorted(BATCHED_METHODS) + sorted(OTHER_METHODS))
+    ap.add_argument("--is-positive-pert", type=ref_bool, default=False, help="positive perturbation test (default: negative)")
+    ap.add_argument("--is-text-pert", type=ref_bool, default=False, help="text perturbation test (default: image)")
+    ap.add_argument("--text", dest="is_text_pert", action="store_true", help="alias of --is-text-pert True")
+    ap.add_argument("--positive", dest="is_positive_pert", action="store_true", help="alias of --is-positive-pert True")
     ap.add_argument("--resume-dir", default=None, help="per-rank partial score files; finished samples are skipped on restart")
     ap.add_argument("--bucket-by-length", action="store_true",
                     help="round-1 behaviour: group items by question length, eager explain pass per group")
     args = ap.parse_args()
+    if args.method not in BATCHED_METHODS:
+        raise SystemExit("--method %s is a per-item method of the generator classes; this batched evaluator runs %s"
+                         % (args.method, sorted(BATCHED_METHODS)))
+    args.text, args.positive = args.is_text_pert, args.is_positive_pert
+    rule_flags = BATCHED_METHODS[args.method]
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
     torch.cuda.set_device(dev)
@@ -60,7 +84,7 @@ def main():
     indices = sharding.perturbation_sample_indices(args.dataset_len, args.num_samples)      # same list on every rank
     gen = le.GeneratorOurs(type("Usage", (), {"model": model})())
     pert = lp.LxmertPerturbation(model)
-    run_cfg = {"evaluator": "lxmert_perturbation", "method": "ours_no_lrp", "test": "text" if args.text else "image",
+    run_cfg = {"evaluator": "lxmert_perturbation", "method": args.method, "test": "text" if args.text else "image",
                "positive": bool(args.positive), "steps": list(lp.PERT_STEPS), "dataset_len": args.dataset_len}
     store = sharding.PartialScores(args.resume_dir, rank, config=run_cfg) if args.resume_dir else None
     cache = {}
@@ -92,10 +116,10 @@ def main():
                      visual_feats=torch.stack([it["visual_feats"] for it in items]).to(dev),
                      visual_pos=torch.stack([it["visual_pos"] for it in items]).to(dev))
         if args.bucket_by_length:
-            R_t_t, R_t_i = gen.generate_ours_batch(batch)
+            R_t_t, R_t_i = gen.generate_ours_batch(batch, **rule_flags)
         else:
             if "run" not in graphed:           # captured once; serves every later batch whatever its question lengths
-                graphed["run"] = le.GraphedGenerateOursBatch(model, batch)
+                graphed["run"] = le.GraphedGenerateOursBatch(model, batch, **rule_flags)
             R_t_t, R_t_i = graphed["run"](batch)
         cam_image, cam_text = lp.normalize_cams_batch(R_t_t, R_t_i, batch["attention_mask"])
         scores = pert.perturbation_text(batch, cam_text, args.positive) if args.text else \
@@ -118,6 +142,7 @@ def main():
     if rank == 0:
         print(json.dumps({"samples": len(indices), "n_gpus": world, "seconds": round(elapsed, 3),
                           "samples_per_s": round(len(indices) / elapsed, 1), "test": "text" if args.text else "image",
+                          "method": args.method, "positive": bool(args.positive),
                           "step_accuracy_percent": [round(float(a), 2) for a in acc]}))
     if world > 1:
         dist.barrier()

@@ -51,15 +51,27 @@ def evaluate(sample_ids, step_accuracies_of, num_samples, reference_exact=False,
     return table, table.double().sum(dim=0) / num_samples * 100.0
 
 
+def ref_bool(text):
+    """The reference declares these flags with ``type=bool`` (any non-empty string is True there, even "False"); here
+    "false" / "0" / "no" / "" mean False."""
+    return str(text).strip().lower() not in ("", "0", "false", "no", "off")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--num-samples", type=int, default=256)
     ap.add_argument("--dataset-len", type=int, default=20000)
-    ap.add_argument("--text", action="store_true", help="text perturbation test instead of the image one")
-    ap.add_argument("--positive", action="store_true")
+    # the reference's own flags (VisualBERT/mmf/utils/flags.py:29-46), same names, choices and defaults
+    ap.add_argument("--method", type=str, default="ours_no_lrp",
+                    choices=["ours_no_lrp", "transformer_attribution", "partial_lrp", "raw_attn", "attn_gradcam", "rollout"])
+    ap.add_argument("--is-positive-pert", type=ref_bool, default=False)
+    ap.add_argument("--is-text-pert", type=ref_bool, default=False)
+    ap.add_argument("--text", dest="is_text_pert", action="store_true", help="alias of --is-text-pert True")
+    ap.add_argument("--positive", dest="is_positive_pert", action="store_true", help="alias of --is-positive-pert True")
     ap.add_argument("--reference-exact", action="store_true")
     ap.add_argument("--resume-dir", default=None)
     args = ap.parse_args()
+    args.text, args.positive = args.is_text_pert, args.is_positive_pert
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
     torch.cuda.set_device(dev)
@@ -76,13 +88,18 @@ def main():
     gen = vb.SelfAttentionGenerator(model)
     pert = vp.VisualBertPerturbation(model)
 
+    # evaluation_loop.py:82-87: the method table of the reference (the LRP ones need a body with relprop and raise otherwise)
+    method_expl = {"transformer_attribution": gen.generate_transformer_att, "ours_no_lrp": gen.generate_ours,
+                   "partial_lrp": gen.generate_partial_lrp, "raw_attn": gen.generate_raw_attn,
+                   "attn_gradcam": gen.generate_attn_gradcam, "rollout": gen.generate_rollout}[args.method]
+
     def step_accuracies_of(k):
         item = {name: t.to(dev) for name, t in synthetic_item(k).items()}
-        cam = gen.generate_ours(dict(item)).detach()
+        cam = method_expl(dict(item)).detach()
         run = pert.perturbation_text if args.text else pert.perturbation_image
         return pert.accuracy(run(item, cam, args.positive), item["targets"][0])
 
-    cfg = {"evaluator": "visualbert_pert", "method": "ours_no_lrp", "test": "text" if args.text else "image",
+    cfg = {"evaluator": "visualbert_pert", "method": args.method, "test": "text" if args.text else "image",
            "positive": bool(args.positive), "reference_exact": bool(args.reference_exact)}
     store = sharding.PartialScores(args.resume_dir, rank, config=cfg) if args.resume_dir else None
     ids = list(range(args.dataset_len))         # the loader order (mmf's sampler is sequential for evaluation)

@@ -321,6 +321,25 @@ int mmx_attn_capture_bwd_rowrel(const void* q_dev, const void* k_dev, const void
                                 void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K2-DETR: the decoder half of DETR's rule schedule for ROWS of R_q_i -- rules 5, 6, 7 and 10 with
+ * eq. 8-9 and the NaN policy of DETR/modules/ExplanationGenerator.py:19-53 (rule functions), :120-140 (handle_co_attn_*) --
+ * in three launches for all decoder layers.  For sample k and explained query t_k = targets[k]:
+ *     s[k][:] = sum_l clean_l ? u_l . N(R_qq^(l))^T . C_l : 0,     u_l = e_t^T (I + B_L) ... (I + B_(l+1)),
+ * B_l / C_l = mean_h clamp(grad * attn, 0) of decoder layer l's self- / cross-attention, R_qq^(l) = (I + B_l) ... (I + B_1),
+ * N = handle_residual; clean_l = no NaN in N(R_qq^(l)) nor in C_l (the reference zeroes the NaNs of the rule-10 addition,
+ * :42).  The caller finishes row t_k of R_q_i as s . N(R_ii) (mmx_chain_vecmat over the encoder maps).
+ * Layer tables are HOST arrays of device pointers: self_* [K | 1, H, Q, Q], cross_* [K | 1, H, Q, Ni] fp32 contiguous;
+ * *_attn_bstride = batch stride of the probability slabs in elements, 0 when ONE forward is shared by the K samples; the
+ * gradient slabs are always per sample.  targets_dev: int64 [K].  s_out_dev: fp32 [K, Ni].  diag_min_dev (may be NULL):
+ * min over samples and layers of diag(R_qq^(l) - I), the value handle_residual asserts to be >= 0.  Q <= 128.
+ */
+size_t mmx_detr_decoder_rows_workspace_bytes(int n_layers, int K, int Q, int Ni);
+int mmx_detr_decoder_rows(const void* const* self_attn, const void* const* self_grad, const void* const* cross_attn,
+                          const void* const* cross_grad, int n_layers, int K, int H, int Q, int Ni,
+                          int64_t self_attn_bstride, int64_t cross_attn_bstride, const void* targets_dev,
+                          void* s_out_dev, void* diag_min_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * LRP relevance through the attention core: the two `einsum` relprops inside the reference's
  * MultiheadAttention.relprop (DETR/modules/layers.py:770-781; einsum = RelPropSimple, layers.py:54-66, each result halved;
  * softmax / dropout relprops are the identity, layers.py:170-186), which the reference evaluates by re-running the einsums

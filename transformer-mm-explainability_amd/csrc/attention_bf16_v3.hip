@@ -21,6 +21,8 @@
 #include "mmx_common.h"
 #include "attention_args.h"
 
+#include <type_traits>
+
 namespace mmx {
 namespace {
 
@@ -147,12 +149,20 @@ __device__ __forceinline__ void store_row_major(bf16_t* tile, const u32x2v (&row
 #pragma unroll
     for (int e = 0; e < 4; ++e) *reinterpret_cast<u32x2v*>(tile + (r4 + e) * kLR + c) = rows[e];
 }
-// the same block of a TRANSPOSED image [d][row] (row stride Np): raw[dd] = rows row0 + r4 .. + 3 of d = c + dd
+// the same block of a TRANSPOSED image [d][row] (row stride Np): raw[dd] = rows row0 + r4 .. + 3 of d = c + dd.  The image
+// pointer is wave-uniform: written as (uniform base of row d) + (ONE 32-bit lane offset) the four loads share a single address
+// VGPR (scalar-base addressing); as four 64-bit lane pointers they cost 8 registers that the kernel spilled inside the loop.
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {      // tell the compiler the pointer is wave-uniform (SGPRs)
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(u));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(u >> 32));
+    return reinterpret_cast<const char*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
 __device__ __forceinline__ void fetch_transposed(RawBlock& blk, const bf16_t* imgT, int Np, int row0, int st) {
-    const int r4 = 4 * (st >> 4), c = 4 * (st & 15);
+    const unsigned voff = (4u * (st & 15) * static_cast<unsigned>(Np) + 4u * (st >> 4)) * 2u;      // bytes
 #pragma unroll
     for (int dd = 0; dd < 4; ++dd)
-        blk.raw[dd] = *reinterpret_cast<const u32x2v*>(imgT + static_cast<int64_t>(c + dd) * Np + row0 + r4);
+        blk.raw[dd] = *reinterpret_cast<const u32x2v*>(uniform_ptr(imgT + row0 + static_cast<int64_t>(dd) * Np) + voff);
 }
 __device__ __forceinline__ void store_transposed_raw(bf16_t* tile, const u32x2v (&cols)[4], int st) {
     const int c = 4 * (st & 15);
@@ -163,43 +173,52 @@ __device__ __forceinline__ void store_transposed_raw(bf16_t* tile, const u32x2v 
 
 // ===================================================================================================== query side
 // delta = rowsum(dO * O), dP^T = V . dO^T, dS, dQ = dS . K  (orientation and accumulator layouts: attention_bf16.hip)
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 4) void attn_bwd_q_v3_kernel(const AttnBwdArgs a, const V3Images im) {
-    constexpr int NB = kD / 16, R = 16 * NW;
+//
+// A workgroup owns 16 NW query rows of NS consecutive SAMPLES of one head: the V / K tiles, the probabilities and every LDS
+// operand read of a tile are the same for all samples (shared forward), so they are fetched ONCE and used NS times -- the
+// shared operands were 3.3 GB of L2 -> CU traffic per launch at one sample per workgroup (4.7 TB/s, i.e. what bounded it).
+// Loads run TWO tiles ahead of their use (two register sets, loop unrolled by two): with one set the fetch of tile t + 2 could
+// only be issued after the wait for tile t + 1, so at most one tile per workgroup was ever in flight.
+template <int NW, int NS>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_q_v3_kernel(const AttnBwdArgs a, const V3Images im) {
+    constexpr int NB = kD / 16, R = 16 * NW, NOP = NW == 4 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* Vt = reinterpret_cast<bf16_t*>(smem_raw);                 // [2][kT][kLR]   V rows (row-major)
     bf16_t* Kt = Vt + 2 * kT * kLR;                                   // [2][kD][kLT]   K transposed
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
     const int st = tid & 255;
     const bool stage_v = NW == 4 || tid < 256;
-    const int nrt = (a.Nq + R - 1) / R;
+    const int nrt = (a.Nq + R - 1) / R, nbg = (a.B + NS - 1) / NS;
     const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
-    const int rt = wg % nrt, h = (wg / nrt) % a.H, b = wg / (nrt * a.H);
+    // row tile fastest, then the sample group, the head slowest: the workgroups an XCD runs at a time (a contiguous id range)
+    // share one or two heads' K / V / P images (L2-resident, ~1 MB per head)
+    const int rt = wg % nrt, b0 = ((wg / nrt) % nbg) * NS, h = wg / (nrt * nbg);
     const int q = rt * R + wave * 16 + i;
     const bool q_ok = q < a.Nq;
     const int qc = min(q, a.Nq - 1);
-    const int64_t head = static_cast<int64_t>(b) * a.H + h;
 
-    // the wave's dO rows as the B operand of dP^T, and delta = rowsum(dO * O) of this lane's row
-    bf16x8 dob[kD / 32];
-    float delta;
-    {
+    // per sample: the wave's dO rows as the B operand of dP^T, and delta = rowsum(dO * O) of this lane's row
+    bf16x8 dob[NS][kD / 32];
+    float delta[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int b = min(b0 + s, a.B - 1);                            // (a ragged last group recomputes the last sample; not stored)
         const bf16_t* src = reinterpret_cast<const bf16_t*>(a.dout) + b * a.os.sb + h * a.os.sh;
-        load_rows8(dob, src, a.os.sn, qc, q_ok, g);
+        load_rows8(dob[s], src, a.os.sn, qc, q_ok, g);
         const float* ob = a.o + h * a.oos.sh + static_cast<int64_t>(qc) * a.oos.sn;
         float part = 0.f;
 #pragma unroll
         for (int pr = 0; pr < kD / 32; ++pr) {
             const int d0 = 32 * pr + 8 * g;
-            const u32x4v w = __builtin_bit_cast(u32x4v, dob[pr]);
+            const u32x4v w = __builtin_bit_cast(u32x4v, dob[s][pr]);
             const f32x4 o0 = *reinterpret_cast<const f32x4*>(ob + d0), o1 = *reinterpret_cast<const f32x4*>(ob + d0 + 4);
             part += bflo(w[0]) * o0[0] + bfhi(w[0]) * o0[1] + bflo(w[1]) * o0[2] + bfhi(w[1]) * o0[3] +
                     bflo(w[2]) * o1[0] + bfhi(w[2]) * o1[1] + bflo(w[3]) * o1[2] + bfhi(w[3]) * o1[3];
         }
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);
-        delta = q_ok ? part : 0.f;
-        if (g == 0 && q_ok) a.delta[head * a.Nq + q] = delta;
+        delta[s] = q_ok ? part : 0.f;
+        if (g == 0 && q_ok && b0 + s < a.B) a.delta[(static_cast<int64_t>(b) * a.H + h) * a.Nq + q] = delta[s];
     }
     const bf16_t* prow = im.Pq + (static_cast<int64_t>(h) * im.Np + qc) * im.Np;     // zero padded beyond Nk
     const bf16_t* vimg = im.Vb + static_cast<int64_t>(h) * im.Np * kD;
@@ -207,80 +226,98 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_q_v3_kernel(const AttnBwd
     const int ntiles = (a.Nk + kT - 1) / kT;
     const int tlane = transposed_lane_base(i, g);
 
-    f32x4 qacc[NB];
+    f32x4 qacc[NS][NB];
 #pragma unroll
-    for (int dt = 0; dt < NB; ++dt) qacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int dt = 0; dt < NB; ++dt) qacc[s][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // NW == 4: every thread stages a block of V and one of K; NW == 8: waves 0-3 stage V, waves 4-7 K (ONE register block)
-    RawBlock r0, r1;
-    auto fetch = [&](int kt) {
+    // NW == 4: every thread stages a block of V and one of K; NW == 8: waves 0-3 stage V, waves 4-7 K (ONE block per set)
+    RawBlock rs[2][NOP];
+    u32x2v ps[2][4];
+    auto fetch = [&](int kt, auto set) {
+        constexpr int S = decltype(set)::value;
         if constexpr (NW == 4) {
-            fetch_row_major(r0, vimg, kD, kt * kT, st);
-            fetch_transposed(r1, kimg, im.Np, kt * kT, st);
+            fetch_row_major(rs[S][0], vimg, kD, kt * kT, st);
+            fetch_transposed(rs[S][1], kimg, im.Np, kt * kT, st);
         } else {
-            if (stage_v) fetch_row_major(r0, vimg, kD, kt * kT, st);
-            else fetch_transposed(r0, kimg, im.Np, kt * kT, st);
+            if (stage_v) fetch_row_major(rs[S][0], vimg, kD, kt * kT, st);
+            else fetch_transposed(rs[S][0], kimg, im.Np, kt * kT, st);
         }
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int buf, auto set) {
+        constexpr int S = decltype(set)::value;
         if constexpr (NW == 4) {
-            store_row_major(Vt + buf * kT * kLR, r0.raw, st);
-            store_transposed_raw(Kt + buf * kD * kLT, r1.raw, st);
+            store_row_major(Vt + buf * kT * kLR, rs[S][0].raw, st);
+            store_transposed_raw(Kt + buf * kD * kLT, rs[S][1].raw, st);
         } else {
-            if (stage_v) store_row_major(Vt + buf * kT * kLR, r0.raw, st);
-            else store_transposed_raw(Kt + buf * kD * kLT, r0.raw, st);
+            if (stage_v) store_row_major(Vt + buf * kT * kLR, rs[S][0].raw, st);
+            else store_transposed_raw(Kt + buf * kD * kLT, rs[S][0].raw, st);
         }
     };
-    u32x2v p_cur[4], p_nxt[4];
     auto p_issue = [&](u32x2v (&raw)[4], int kt) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) raw[t] = *reinterpret_cast<const u32x2v*>(prow + kt * kT + 16 * t + 4 * g);
     };
-
-    fetch(0);
-    stage(0);
-    p_issue(p_cur, 0);
-    if (ntiles > 1) fetch(1);
-    __syncthreads();
-    for (int kt = 0; kt < ntiles; ++kt) {
-        if (kt + 1 < ntiles) {
-            stage((kt + 1) & 1);                                   // the tile fetched during the previous iteration
-            p_issue(p_nxt, kt + 1);
-            if (kt + 2 < ntiles) fetch(kt + 2);
+    // tile kt: LDS buffer / register set / probability set kt & 1 (= PAR)
+    auto body = [&](int kt, auto par) {
+        constexpr int PAR = decltype(par)::value;
+        if (kt + 2 < ntiles) fetch(kt + 2, par);                       // this set's tile kt went to LDS one iteration ago
+        if (kt + 1 < ntiles) stage(1 - PAR, std::integral_constant<int, 1 - PAR>{});   // waits for THAT set only
+        const bf16_t* Vcur = Vt + PAR * kT * kLR;
+        const bf16_t* Kcur = Kt + PAR * kD * kLT + tlane;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {                               // keys 32 pp .. + 31 of the tile
+            bf16x8 dsb[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                f32x4 dpT[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int pr = 0; pr < kD / 32; ++pr)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const bf16x8 op = *reinterpret_cast<const bf16x8*>(Vcur + (16 * (2 * pp + hh) + i) * kLR + 32 * pr + 8 * g);
+                        dpT[hh] = mfma16x16x32_bf16(op, dob[s][pr], dpT[hh]);
+                    }
+                // dS[q][key] = P * (dP - delta) for keys 16 t + 4 g + r, t = 2 pp + hh (scale_mode Q_FIRST: no further factor)
+                dsb[s] = pack8(unpack4(ps[PAR][2 * pp]) * (dpT[0] - delta[s]), unpack4(ps[PAR][2 * pp + 1]) * (dpT[1] - delta[s]));
+                // the V operands are RE-READ from LDS for the next sample (16 registers the budget of 4 waves / SIMD does not
+                // have): the clobber keeps the compiler from carrying them over
+                asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int dt = 0; dt < NB; ++dt) {
+                const bf16x8 kop = transposed_operand(Kcur, dt, pp);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) qacc[s][dt] = mfma16x16x32_bf16(kop, dsb[s], qacc[s][dt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);                        // keep the two halves apart: bounds the live registers
         }
-        const bf16_t* Vcur = Vt + (kt & 1) * kT * kLR;
-        const bf16_t* Kcur = Kt + (kt & 1) * kD * kLT + tlane;
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {                           // keys 32 pp .. + 31 of the tile
-            f32x4 dpT[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int pr = 0; pr < kD / 32; ++pr)
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const bf16x8 op = *reinterpret_cast<const bf16x8*>(Vcur + (16 * (2 * pp + hh) + i) * kLR + 32 * pr + 8 * g);
-                    dpT[hh] = mfma16x16x32_bf16(op, dob[pr], dpT[hh]);
-                }
-            // dS[q][key] = P * (dP - delta) for keys 16 t + 4 g + r, t = 2 pp + hh (scale_mode Q_FIRST: no further factor)
-            const f32x4 ds0 = unpack4(p_cur[2 * pp]) * (dpT[0] - delta);
-            const f32x4 ds1 = unpack4(p_cur[2 * pp + 1]) * (dpT[1] - delta);
-            const bf16x8 dsb = pack8(ds0, ds1);
-#pragma unroll
-            for (int dt = 0; dt < NB; ++dt) qacc[dt] = mfma16x16x32_bf16(transposed_operand(Kcur, dt, pp), dsb, qacc[dt]);
-            __builtin_amdgcn_sched_barrier(0);                    // keep the two halves apart: bounds the live registers
-        }
-        if (kt + 1 < ntiles) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) p_cur[t] = p_nxt[t];
-        }
+        if (kt + 2 < ntiles) p_issue(ps[PAR], kt + 2);                 // consumed two iterations from now
         lds_barrier();
+    };
+
+    fetch(0, std::integral_constant<int, 0>{});
+    if (ntiles > 1) fetch(1, std::integral_constant<int, 1>{});
+    p_issue(ps[0], 0);
+    if (ntiles > 1) p_issue(ps[1], 1);
+    stage(0, std::integral_constant<int, 0>{});
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; kt += 2) {
+        body(kt, std::integral_constant<int, 0>{});
+        if (kt + 1 < ntiles) body(kt + 1, std::integral_constant<int, 1>{});
     }
     if (!q_ok) return;
     // dQ^T accumulators: lane (q = column i), rows d = 16 dt + 4 g + r: 4 consecutive d of one query row
-    const int64_t off = b * a.dqs.sb + h * a.dqs.sh + static_cast<int64_t>(q) * a.dqs.sn;
 #pragma unroll
-    for (int dt = 0; dt < NB; ++dt) {
-        const f32x4 v = qacc[dt] * a.scale;
-        *reinterpret_cast<u32x2v*>(reinterpret_cast<bf16_t*>(a.dq) + off + 16 * dt + 4 * g) = u32x2v{pk2(v[0], v[1]), pk2(v[2], v[3])};
+    for (int s = 0; s < NS; ++s) {
+        if (b0 + s >= a.B) break;
+        const int64_t off = (b0 + s) * a.dqs.sb + h * a.dqs.sh + static_cast<int64_t>(q) * a.dqs.sn;
+#pragma unroll
+        for (int dt = 0; dt < NB; ++dt) {
+            const f32x4 v = qacc[s][dt] * a.scale;
+            *reinterpret_cast<u32x2v*>(reinterpret_cast<bf16_t*>(a.dq) + off + 16 * dt + 4 * g) = u32x2v{pk2(v[0], v[1]), pk2(v[2], v[3])};
+        }
     }
 }
 
@@ -301,7 +338,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
     const bool stage_do = NW == 4 || tid < 256, stage_q = DKV && (NW == 4 || tid >= 256);
     const int nkt = (a.Nk + R - 1) / R;
     const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
-    const int h = (wg / nkt) % a.H, b = wg / (nkt * a.H);
+    const int b = (wg / nkt) % a.B, h = wg / (nkt * a.B);          // key tile fastest, then the sample, the head slowest (see the query side)
     const int kw = (wg % nkt) * R + wave * 16;                        // first key of this wave
     const int key = kw + i;
     const bool key_ok = key < a.Nk;
@@ -472,10 +509,11 @@ int launch_v3(K kern, const AttnBwdArgs& a, const V3Images& im, dim3 grid, int t
 template <int NW>
 int run_v3(const AttnBwdArgs& a, const V3Images& im, hipStream_t s) {
     constexpr int R = 16 * NW;
-    dim3 gq(((a.Nq + R - 1) / R) * a.H * a.B), gk(((a.Nk + R - 1) / R) * a.H * a.B);
+    constexpr int NS = 2;                                                // samples per query-side workgroup
+    dim3 gq(((a.Nq + R - 1) / R) * a.H * ((a.B + NS - 1) / NS)), gk(((a.Nk + R - 1) / R) * a.H * a.B);
     int rc = MMX_OK;
     if (a.need_dqkv) {
-        rc = launch_v3(attn_bwd_q_v3_kernel<NW>, a, im, gq, 64 * NW, kQLds, s, "attn_bwd_q_v3_kernel");
+        rc = launch_v3(attn_bwd_q_v3_kernel<NW, NS>, a, im, gq, 64 * NW, kQLds, s, "attn_bwd_q_v3_kernel");
         if (rc) return rc;
         rc = launch_v3(attn_bwd_kv_v3_kernel<NW, true>, a, im, gk, 64 * NW, kKvLds, s, "attn_bwd_kv_v3_kernel");
     } else {

@@ -526,9 +526,16 @@ __global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ 
     __shared__ float Bs[kBmmBK][LB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
-    const float* Ab = A + static_cast<int64_t>(blockIdx.z) * sa;
-    const float* Bb = B + static_cast<int64_t>(blockIdx.z) * sb;
+    // 1-D grid, XCD-aware: workgroups are dealt round-robin to the 8 XCDs, so in dispatch order the tiles of ONE batch entry
+    // would land on all eight L2s and every one of them would fetch that entry's A and B (measured at N = 577: FETCH_SIZE
+    // 2.8x the operands, profiles/r02_chain_split_roofline.txt).  xcd_contiguous_id gives each XCD one contiguous range of
+    // (batch, m tile, n tile) triples: an entry's operands live in one L2.
+    const int tiles_n = (N + T - 1) / T, tiles_m = (M + T - 1) / T;
+    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int bx = wg % tiles_n, by = (wg / tiles_n) % tiles_m, bz = wg / (tiles_n * tiles_m);
+    const int m0 = by * T, n0 = bx * T;
+    const float* Ab = A + static_cast<int64_t>(bz) * sa;
+    const float* Bb = B + static_cast<int64_t>(bz) * sb;
     f32x4 acc[W][W];
 #pragma unroll
     for (int i = 0; i < W; ++i)
@@ -580,7 +587,7 @@ __global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ 
         }
         lds_barrier();
     }
-    const int64_t cbase = static_cast<int64_t>(blockIdx.z) * sc;
+    const int64_t cbase = static_cast<int64_t>(bz) * sc;
 #pragma unroll
     for (int i = 0; i < W; ++i)
 #pragma unroll
@@ -608,13 +615,13 @@ static void launch_bmm(const float* A, const float* B, const float* Cin, float* 
     if (wgs128 >= 512 && g_bmm_tile == 128) {
         // 128 x 128 per workgroup (each wave 64 x 64 = 16 accumulator tiles).  Measured SLOWER than 64 x 64 at the
         // long-sequence chain shapes (profiles/r02_bmm_probe.txt: 384 vs 281 us at [32 x 577 x 577]^2), so opt-in only.
-        bmm_f32_kernel<128><<<dim3((N + 127) / 128, (M + 127) / 128, batch), 256, 0, s>>>(A, B, Cin, C, M, N, K, trans_a,
+        bmm_f32_kernel<128><<<dim3(static_cast<unsigned>(wgs128)), 256, 0, s>>>(A, B, Cin, C, M, N, K, trans_a,
                                                                                        sa, sb, sc, nan_to_zero);
     } else if (wgs64 >= 1024) {
-        bmm_f32_kernel<64><<<dim3((N + 63) / 64, (M + 63) / 64, batch), 256, 0, s>>>(A, B, Cin, C, M, N, K, trans_a, sa,
+        bmm_f32_kernel<64><<<dim3(static_cast<unsigned>(wgs64)), 256, 0, s>>>(A, B, Cin, C, M, N, K, trans_a, sa,
                                                                                     sb, sc, nan_to_zero);
     } else {
-        bmm_f32_kernel<32><<<dim3((N + 31) / 32, (M + 31) / 32, batch), 256, 0, s>>>(A, B, Cin, C, M, N, K, trans_a, sa,
+        bmm_f32_kernel<32><<<dim3(static_cast<unsigned>(static_cast<int64_t>((N + 31) / 32) * ((M + 31) / 32) * batch)), 256, 0, s>>>(A, B, Cin, C, M, N, K, trans_a, sa,
                                                                                     sb, sc, nan_to_zero);
     }
 }

@@ -155,25 +155,12 @@ class Generator:
         for a in A:                                                    # bottom-up
             e = ops.chain_matvec(a, e + 1.0, base=e)
         rho = e.reshape(K, 1, n_img)
-        Bq = [ops.avg_heads(*pair(blk.self_attn), batch_size=K, shared_attn=shared) for blk in decoder_blocks]      # [K, Q, Q]
-        n_q = Bq[0].shape[-1]
-        R_qq = torch.eye(n_q, device=dev).repeat(K, 1, 1)
-        R_hat, words = [], []
-        for b in Bq:
-            R_qq = torch.baddbmm(R_qq, b, R_qq)
-            hat, word = ops.handle_residual(R_qq, check_diag="defer")
-            R_hat.append(hat)
-            words.append(word)
-        u = torch.zeros(K, 1, n_q, device=dev)
-        u.scatter_(2, targets.reshape(K, 1, 1), 1.0)                   # e_t, one per sample
-        s = torch.zeros(K, 1, n_img, device=dev)
-        for l in range(len(decoder_blocks) - 1, -1, -1):
-            w = torch.bmm(u, R_hat[l].transpose(1, 2))                                             # u_l N(R_qq^(l))^T
-            cam = ops.avg_heads(*pair(decoder_blocks[l].multihead_attn), batch_size=K, shared_attn=shared)      # [K, Q, Ni]
-            z = torch.bmm(w, cam)
-            clean = ~(torch.isnan(R_hat[l]).flatten(1).any(1) | torch.isnan(cam).flatten(1).any(1))
-            s = s + torch.where(clean.reshape(K, 1, 1), z, torch.zeros_like(z))
-            u = torch.baddbmm(u, u, Bq[l])                                                          # u_(l-1) = u_l (I + B_l)
+        # decoder half: B_l, R_qq^(l), N(R_qq^(l)), w_l = u_l N^T, z_l = w_l C_l and the NaN policy for ALL layers in three
+        # launches (K2-DETR, csrc/detr_rows_kernels.hip) -- no C_l, no R_qq stack, no per-layer torch ops
+        s, dec_word = ops.detr_decoder_rows([pair(blk.self_attn) for blk in decoder_blocks],
+                                            [pair(blk.multihead_attn) for blk in decoder_blocks], targets, shared_attn=shared)
+        s = s.reshape(K, 1, n_img)
+        words = [dec_word]
         v = s / rho
         v2 = v.reshape(K, n_img)
         d = torch.zeros_like(v2)                                       # d = v R_ii - v, top-down: d <- d + (v + d) A
@@ -427,13 +414,17 @@ class MaskGenerator:
         self._graphs = collections.OrderedDict()     # (method, feature shape) -> captured pass, least recently used first
 
     def _per_query(self, img, idx, method):
+        """The reference's per-query dispatch (DETR/mask_generator.py:91-113) for the methods that are not batched here; the
+        LRP ones run the body's ``relprop`` (``detr_model`` has it; a body without one raises ``NotImplementedError``)."""
         if method == "ablation_no_aggregation":
             return self.abl.generate_ours_abl(img, idx, use_lrp=False, normalize_self_attention=False)
+        if method == "ours_with_lrp":
+            return self.gen.generate_ours(img, idx, use_lrp=True)
         fn = {"raw_attn": self.gen.generate_raw_attn, "rollout": self.gen.generate_rollout,
-              "attn_gradcam": self.gen.generate_attn_gradcam}.get(method)
+              "attn_gradcam": self.gen.generate_attn_gradcam, "transformer_att": self.gen.generate_transformer_att,
+              "partial_lrp": self.gen.generate_partial_lrp}.get(method)
         if fn is None:
-            raise ValueError("please provide a valid explainability method (got %r; LRP methods are out of scope)"
-                             % (method,))
+            raise ValueError("please provide a valid explainability method (got %r)" % (method,))
         return fn(img, idx)
 
     def get_masks(self, img, method="ours_no_lrp", outputs=None):

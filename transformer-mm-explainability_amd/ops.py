@@ -699,3 +699,32 @@ def attn_relprop(q, k, v, probs, o, cam_o, scale, scale_mode=_lib.SCALE_Q_FIRST,
                                  _p(probs), _p(cam_probs), _p(cam_q), _p(cam_k), _p(cam_v), *st(cam_q), *st(cam_k), *st(cam_v),
                                  B, H, Nq, Nk, D, float(scale), scale_mode, _stream()), "mmx_attn_relprop")
     return cam_probs, cam_q, cam_k, cam_v
+
+
+def detr_decoder_rows(self_pairs, cross_pairs, targets, shared_attn=False):
+    """K2-DETR (``mmx_detr_decoder_rows``): the decoder half of DETR's rules for ROWS of ``R_q_i`` in three launches.
+    ``self_pairs[l]`` / ``cross_pairs[l]``: ``(attn, grad)`` of decoder layer l's self- / cross-attention, fp32, gradient
+    slabs ``[K*H, Q, *]``, probability slabs the same or ``[H, Q, *]`` when ``shared_attn`` (one forward for the K samples).
+    ``targets``: ``[K]`` long.  Returns ``(s [K, Ni], diag_min [1])`` -- see include/mmx_relevancy.h."""
+    targets = targets.reshape(-1).to(torch.long).contiguous()
+    K = targets.numel()
+    tens = [t for pair in list(self_pairs) + list(cross_pairs) for t in pair]
+    _dev(targets, *tens)
+    if any(t.dtype != torch.float32 or not t.is_contiguous() for t in tens):
+        raise MMXError("detr_decoder_rows: fp32 contiguous slabs only")
+    g0, c0 = self_pairs[0][1], cross_pairs[0][1]
+    Q, Ni = g0.shape[-1], c0.shape[-1]
+    H = g0.numel() // (K * Q * Q)
+    if H * K * Q * Q != g0.numel() or c0.numel() != K * H * Q * Ni:
+        raise MMXError("detr_decoder_rows: slab shapes %s / %s do not fit K = %d" % (tuple(g0.shape), tuple(c0.shape), K))
+    L = len(self_pairs)
+    s_out = torch.empty(K, Ni, dtype=torch.float32, device=g0.device)
+    dmin = torch.empty(1, dtype=torch.float32, device=g0.device)
+    need = lib().mmx_detr_decoder_rows_workspace_bytes(L, K, Q, Ni)
+    ws = _workspace(need, g0.device, "detr_rows")
+    tables = [_lib.ptr_table([pair[w].data_ptr() for pair in grp]) for grp in (self_pairs, cross_pairs) for w in (0, 1)]
+    (sa, _k0), (sg, _k1), (ca, _k2), (cg, _k3) = tables
+    check(lib().mmx_detr_decoder_rows(sa, sg, ca, cg, L, K, H, Q, Ni, 0 if shared_attn else H * Q * Q,
+                                      0 if shared_attn else H * Q * Ni, _p(targets), _p(s_out), _p(dmin), _p(ws), need,
+                                      _stream()), "mmx_detr_decoder_rows")
+    return s_out, dmin
