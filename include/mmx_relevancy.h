@@ -39,8 +39,8 @@ enum mmx_dtype { MMX_F32 = 0, MMX_F16 = 1, MMX_BF16 = 2 };
 #define MMX_ATTN_MMA_BF16 0x100
 /* Backward only, together with MMX_ATTN_MMA_BF16: `do_dev` holds bf16 and dq / dk / dv are written as bf16 (the gradient
  * stream between the bf16 GEMMs of a bf16 body needs no conversion passes); strides stay in elements, 16-byte aligned.
- * With MMX_ATTN_MMA_BF16 a 16-bit `probs` slab is read with 12-byte vector loads that may touch up to 4 bytes past its last
- * element (never used): leave that much slack if the slab ends exactly on a mapping boundary (torch allocations always do). */
+ * No entry point reads or writes outside the buffers it is handed (16-bit slabs: the vector loads of the streaming kernels
+ * fall back to element loads for the last few elements of a slab). */
 #define MMX_ATTN_IO_BF16 0x200
 
 enum mmx_status {

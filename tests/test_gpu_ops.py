@@ -445,7 +445,7 @@ def test_relevancy_chain_row_equals_the_matrix_chain(N, B, shared):
 
 
 @pytest.mark.parametrize("K,H,Q,Ni,L,shared", [(3, 4, 7, 15, 3, True), (2, 2, 33, 70, 2, False), (5, 8, 100, 950, 6, True)])
-def test_detr_decoder_rows_kernels_vs_per_layer_ops(K, H, Q, Ni, L, shared):
+def test_detr_decoder_rows_kernels_vs_per_layer_ops(ops, K, H, Q, Ni, L, shared):
     """K2-DETR (``mmx_detr_decoder_rows``: three launches for all decoder layers) vs the per-layer formulation it replaces,
     written with torch ops in fp64 on the same slabs: rule 5 maps, R_qq^(l), eq. 8-9, w_l = u_l N(R_qq^(l))^T, z_l = w_l C_l,
     u_(l-1) = u_l (I + B_l), the NaN policy (a layer whose cross map holds a NaN contributes nothing to THAT sample) and

@@ -366,7 +366,8 @@ def test_bf16_backward_third_generation_equals_second(N, B, need):
             # same products in the same order; what may differ is how the compiler contracts the fp32 arithmetic around
             # them (delta = rowsum(dO * O), dS) in the two kernels, i.e. a last-place flip of a bf16 result here and there
             diff = (got_out.float() - want_out.float()).abs()
-            assert bool((diff <= 2.0 ** -6 * want_out.float().abs() + 1e-12).all()), (mode, float(diff.max()))   # one bf16 ulp, also across a binade
+            top = float(want_out.float().abs().max())
+            assert float(diff.max()) <= 2.0 ** -7 * top, (mode, float(diff.max()), top)        # <= one bf16 ulp of the largest entries
             assert float((diff > 0).float().mean()) < 0.01, (mode, float((diff > 0).float().mean()))
         # (the relevancy sum is fp32 VALU work: same terms, but the compiler may contract / order the fmas differently)
         assert float((got_rel - want_rel).abs().max()) <= 1e-6 * float(want_rel.abs().max()), mode

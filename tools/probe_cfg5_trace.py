@@ -1,22 +1,17 @@
-"""Kernel-trace target: CLIP ViT-L/14@336 interpret, batch 32, the bf16 body of clip_model.CLIP.set_body_dtype (3 steps)."""
+"""Probe (GPU box, under rocprofv3 --kernel-trace --stats): a few cfg-5 steps (CLIP ViT-L/14@336, bf16 body, batch 128) for the
+per-kernel split of the step."""
+import os
 import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools import bench_legs  # noqa: E402
 from transformer_mm_explainability_amd import clip_explainability as ce  # noqa: E402
-from transformer_mm_explainability_amd import clip_model  # noqa: E402
 
-dev = torch.device("cuda")
-model = clip_model.random_init("ViT-L/14@336", seed=0).to(dev)
-model.set_body_dtype(torch.bfloat16)
-image = torch.randn(1, 3, 336, 336, device=dev)
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-texts = torch.zeros(B, 77, dtype=torch.long)
-texts[:, 0] = 49406
-texts[:, 1:6] = 1000
-texts[:, 6] = 49407
-texts = texts.to(dev)
-for _ in range(3):
-    ce.interpret(image, texts, model, dev, start_layer=0, start_layer_text=0)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+model, image, texts, _, _ = bench_legs.cfg5_setup(B, torch.device("cuda"))
+for _ in range(steps):
+    ce.interpret(image, texts, model, "cuda", start_layer=0, start_layer_text=0)
 torch.cuda.synchronize()

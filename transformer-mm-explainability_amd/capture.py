@@ -29,14 +29,8 @@ class CaptureBuffers:
         self.shape = (n_layers, batch, heads, n_q, n_k)
         self.shared_probs = shared_probs
         self.dtype = dtype
-        # 16-bit slabs: 8 elements of slack behind the last one -- the bf16-MFMA backward reads the probabilities with
-        # 12-byte vector loads that may touch up to 4 bytes past the tensor (attention_bf16.hip; never used)
         p_shape = (n_layers, 1 if shared_probs else batch, heads, n_q, n_k)
-        p_numel = 1
-        for d in p_shape:
-            p_numel *= d
-        self._probs_storage = torch.empty(p_numel + (0 if dtype == torch.float32 else 8), dtype=dtype, device=device)
-        self.probs = self._probs_storage[:p_numel].view(p_shape)
+        self.probs = torch.empty(p_shape, dtype=dtype, device=device)      # (no slack: no kernel reads outside a slab)
         # grads=False: probabilities only (row-relevancy mode of the backward never stores dP)
         self.grads = torch.empty(self.shape, dtype=dtype, device=device) if grads else None
 

@@ -280,17 +280,36 @@ __global__ __launch_bounds__(kTh, 2) void attn_bwd_q_bf16_kernel(const AttnBwdAr
     // prefetch; converted here): a load consumed inside the iteration that issues it waits behind the prefetch it was queued
     // with -- vmcnt retires in order -- and that exposed a full memory round trip per tile (3 us of a 3.2 us tile step).
     // The last tile may run past Nk: clamped element loads, issued and consumed in place (one tile of ~10).
-    // NOTE (16-bit slabs): load4_stream_raw covers up to 5 elements past the 4 it needs.  For the LAST row of the slab and
-    // Nk % 64 == 1 (577) the second-to-last tile's load therefore touches one element (2 bytes) past the tensor -- inside the
-    // allocator's 512-byte granule for every slab torch hands out, never used; capture.CaptureBuffers allocates 16-bit slabs
-    // with 8 elements of slack anyway, and a caller with a hand-carved slab that ends on a mapping boundary should leave 4
-    // bytes (include/mmx_relevancy.h says so).  TODO next round: element-wise path for
-    // that one workgroup's tile (needs a GPU run to validate).
+    // 16-bit slabs: load4_stream_raw fetches the three ALIGNED dwords from element (idx & ~1), i.e. up to 2 elements past
+    // the 4 it needs.  For the last row of the slab and Nk % 64 == 1 (577) that window would end past the tensor: a chunk
+    // whose window does not fit (idx + 6 > slab elements; a handful of lanes of ONE workgroup) is assembled from clamped
+    // element loads instead, into the same raw layout -- nothing is ever read outside the caller's slab.
     const bool want_p = need_ds;
     stream_raw<DT> p_cur[4], p_nxt[4];
+    const int64_t slab_elems = (a.probs_sb == 0 ? 1 : static_cast<int64_t>(a.B)) * a.H * a.Nq * a.Nk;
     auto p_issue = [&](stream_raw<DT> (&raw)[4], int kt) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) raw[t] = load4_stream_raw<DT>(a.probs, prow_idx + kt * kT + 16 * t + 4 * g);
+        for (int t = 0; t < 4; ++t) {
+            const int64_t idx = prow_idx + kt * kT + 16 * t + 4 * g;
+            if constexpr (DT == MMX_F32) {
+                raw[t] = load4_stream_raw<DT>(a.probs, idx);
+            } else {
+                if (idx + 6 <= slab_elems) {
+                    raw[t] = load4_stream_raw<DT>(a.probs, idx);
+                } else {                                                   // the slab's last few elements: element loads
+                    const unsigned short* pe = reinterpret_cast<const unsigned short*>(a.probs);
+                    const int64_t e0 = idx & ~static_cast<int64_t>(1);
+                    unsigned w[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int64_t lo = e0 + 2 * j, hi = lo + 1;
+                        const unsigned a0 = lo < slab_elems ? pe[lo] : 0u, a1 = hi < slab_elems ? pe[hi] : 0u;
+                        w[j] = a0 | (a1 << 16);
+                    }
+                    raw[t].v = u32x3{w[0], w[1], w[2]};
+                }
+            }
+        }
     };
     auto tile_compute = [&](int kt, auto edge) {
         constexpr bool EDGE = decltype(edge)::value;
