@@ -157,7 +157,7 @@ def main_cfg5(args):
                                    "accumulation / LayerNorm / softmax / relevancy); random-init weights, synthetic inputs; eager",
                        "global_batch": world * CFG5_BATCH, "parallelism": "dp%d (independent batches, all-gather of maps)" % world,
                        "resident_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
-            "roofline": {"bound": "mfma", "kernel": "attn_bwd_q_bf16_kernel + attn_bwd_kv_bf16_kernel (one image-tower layer, "
+            "roofline": {"bound": "mfma", "kernel": "attn_bwd_q_v3_kernel + attn_bwd_kv_v3_kernel (one image-tower layer, "
                                                     "row-relevancy mode)", "achieved": round(attn_flops / us / 1e6, 1),
                          "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(attn_flops / us / 1e6 / BF16_MFMA_PEAK_TFLOPS, 4),
                          "traffic": None, "us_per_launch": round(us, 1),

@@ -366,3 +366,62 @@ def test_graphed_generate_ours_batch_replays_any_lengths():
         torch.testing.assert_close(img[b], pert.perturbation_image(one, cam_image[b]), rtol=1e-4, atol=1e-5)
     with pytest.raises(ValueError, match="captured"):
         run(_ragged_batch(g, [5, 5, 5]))
+
+
+def test_lxmert_tape_path_equals_autograd_path():
+    """``LxmertForQuestionAnswering.forward_tape`` / ``backward_tape`` (hand-written vector-Jacobian chain, packed q/k/v GEMMs,
+    fused add + LayerNorm, ``bert_tape.py``) vs the autograd route through the same body: answer scores, every attention
+    block's captured probabilities and gradient slabs, and the relevancies, on a ragged batch."""
+    import types
+    from transformer_mm_explainability_amd import lxmert_explainability as le
+    model, _, g = _model_and_inputs()
+    batch = _ragged_batch(g, [5, 12, 8, 9])
+    want_scores = model(**batch).question_answering_score
+    got_scores, _ = model.forward_tape(**batch)
+    torch.testing.assert_close(got_scores, want_scores, rtol=1e-5, atol=1e-5)
+    gen_a, gen_t = le.GeneratorOurs(types.SimpleNamespace(model=model)), le.GeneratorOurs(types.SimpleNamespace(model=model))
+    gen_a.use_tape = False
+    want = [t.clone() for t in gen_a.generate_ours_batch(batch)]
+    enc = model.lxmert.encoder
+    mods = [b.attention.self for b in list(enc.layer) + list(enc.r_layers)]
+    for x in enc.x_layers:
+        mods += [x.visual_attention.att, x.lang_self_att.self]
+    for x in list(enc.x_layers)[:-1]:
+        mods += [x.visual_attention_copy.att, x.visn_self_att.self]
+    slabs = [(m.get_attn().clone(), m.get_attn_gradients().clone()) for m in mods]
+    got = gen_t.generate_ours_batch(batch)
+    for m, (p, dp) in zip(mods, slabs):
+        torch.testing.assert_close(m.get_attn(), p, rtol=1e-5, atol=2e-6)
+        scale = float(dp.abs().max())
+        assert float((m.get_attn_gradients() - dp).abs().max()) <= 1e-5 * scale + 1e-9
+    for a, b in zip(got, want):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_visualbert_graphed_generate_ours_batch():
+    """hipGraph replay of the batched VisualBERT explain pass (tape path) == the eager call, also after new inputs were
+    copied in; a batch of another text length is refused."""
+    from transformer_mm_explainability_amd import visualbert_explainability as vb
+    model, sample, n_text, V, g = _visualbert_and_sample()
+    B, T = 3, 16
+
+    def make():
+        ids = torch.randint(1, 300, (B, T), generator=g)
+        ids[:, n_text:] = 0
+        mask = torch.zeros(B, T, dtype=torch.long)
+        mask[:, :n_text] = 1
+        return {"input_ids": ids.cuda(), "input_mask": mask.cuda(), "segment_ids": torch.zeros(B, T, dtype=torch.long).cuda(),
+                "image_feature_0": torch.randn(B, V, 40, generator=g).cuda()}
+    first, second = make(), make()
+    run = vb.GraphedGenerateOursBatch(model, first)
+    gen = vb.SelfAttentionGenerator(model)
+    for batch in (first, second):
+        want = gen.generate_ours_batch({k: v.clone() for k, v in batch.items()}).clone()
+        got = run(batch)
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-7)
+    gen.use_tape = False                                                   # the autograd route of the same body
+    torch.testing.assert_close(run(second), gen.generate_ours_batch({k: v.clone() for k, v in second.items()}), rtol=1e-4, atol=1e-6)
+    short = make()
+    short["input_mask"][:, n_text - 1] = 0
+    with pytest.raises(ValueError, match="text tokens"):
+        run(short)

@@ -199,8 +199,10 @@ def leg_cfg5(kernel_time_us, reps=3, batch=128):
                         "bf16 body (fp32 accumulation / LayerNorm / softmax / relevancy), row-relevancy image tower, eager",
             "rate": round(batch / ms * 1e3, 1), "unit": "maps/s", "ms": round(ms, 3),
             "resident_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-            "kernel": _mfma("attn_bwd_q_bf16_kernel + attn_bwd_kv_bf16_kernel (one image-tower layer, B = 128, row-relevancy mode)",
-                            attn_flops, us, BF16_MFMA_PEAK_TFLOPS),
+            "kernel": _mfma("attn_bwd_q_v3_kernel + attn_bwd_kv_v3_kernel (+ the two prep kernels; one image-tower layer, B = 128, "
+                            "row-relevancy mode, attention_bf16_v3.hip)", attn_flops, us, BF16_MFMA_PEAK_TFLOPS,
+                            "bound by L2 -> CU movement of the shared operands and of dO (3.3 GB per launch pair), not by the "
+                            "matrix cores: profiles/r03_cfg5_probe.txt"),
             "source": "profiles/r03_cfg_legs.txt"}
 
 

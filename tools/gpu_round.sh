@@ -1,15 +1,17 @@
 #!/bin/bash
 # One GPU-box round: gpu tests, smoke, bench (JSON line), rocprofv3 kernel trace + PMC passes. Outputs under gpurun_out/$TAG.
 #   $2 = "notest" skips the pytest / smoke legs (profiles only)
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
+nproc > $OUT/nproc.txt
 if [ "$2" != "notest" ]; then
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee $OUT/pytest_gpu.txt
+timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -6 | tee $OUT/pytest_gpu.txt
+cp gpurun_out/parity_errors.json $OUT/parity.json 2>/dev/null
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.txt
 fi
-timeout 600 python bench.py --steps 100 --warmup 5 > $OUT/bench.json 2> $OUT/bench.log; tail -2 $OUT/bench.log; cut -c1-400 $OUT/bench.json
+timeout 900 python bench.py --steps 100 --warmup 5 > $OUT/bench.json 2> $OUT/bench.log; tail -2 $OUT/bench.log; cut -c1-400 $OUT/bench.json
 # kernel trace of headline steps only (2 capture warm-ups + 3 warm-up replays + 20 timed replays = 25 steps in the trace)
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --headline-only > $OUT/bench_traced.json 2> $OUT/trace.log
 python tools/prof_summary.py $OUT/trace/bench_results.db "" --by-grid > $OUT/kernel_stats.txt 2>&1; grep mmx $OUT/kernel_stats.txt | cut -c1-200
@@ -18,8 +20,15 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OU
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --headline-only > /dev/null 2> $OUT/pmc_write.log
 python tools/pmc_summary.py $OUT/pmc_fetch/bench_counter_collection.csv mmx:: > $OUT/pmc_fetch.txt; python tools/pmc_summary.py $OUT/pmc_write/bench_counter_collection.csv mmx:: > $OUT/pmc_write.txt
 cat $OUT/pmc_fetch.txt $OUT/pmc_write.txt
-# trace of the DEFAULT command's legs (headline + variants + the stand-alone chain launches the roofline is measured on): the chain
-# kernels' min / avg there include the 2 x 21 stand-alone launches, which do not overlap with the other tower's kernels
-timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/trace_full -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/trace_full.log
+# trace of the DEFAULT command's legs (headline + variants + the stand-alone chain launches the roofline is measured on + the
+# cfg 1 / 3 / 4 / 5 legs): the chain kernels' min / avg there include the 2 x 21 stand-alone launches
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_full -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/trace_full.log
 python tools/prof_summary.py $OUT/trace_full/bench_results.db "self_chain" --by-grid > $OUT/chain_kernel_trace.txt 2>&1; cat $OUT/chain_kernel_trace.txt | cut -c1-200
-rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/trace $OUT/trace_full
+python tools/prof_summary.py $OUT/trace_full/bench_results.db "" --by-grid 2>&1 | grep -E "kernel  |mmx" | head -70 | cut -c1-200 > $OUT/cfg_legs.txt
+# cfg 5: the step's kernel split, the attention backward pair alone (v2 vs v3), SQ counters of the v3 kernels
+timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/trace_cfg5 -o cfg5 -- python tools/probe_cfg5_trace.py 128 3 > /dev/null 2> $OUT/trace_cfg5.log
+python tools/prof_summary.py $OUT/trace_cfg5/cfg5_results.db "" 2>&1 | head -30 | cut -c1-190 > $OUT/cfg5_step_kernels.txt
+timeout 300 python tools/probe_attn_v3.py 128 2>&1 | grep -v amdgpu.ids > $OUT/attn_v3_probe.txt; cat $OUT/attn_v3_probe.txt
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/pmc_v3 -o v3 -- python tools/probe_attn_v3.py 16 2 > /dev/null 2> $OUT/pmc_v3.log
+python tools/pmc_sq.py $OUT/pmc_v3/v3_counter_collection.csv _v3_ > $OUT/attn_v3_sq.txt 2>&1; cat $OUT/attn_v3_sq.txt
+rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/trace $OUT/trace_full $OUT/trace_cfg5 $OUT/pmc_v3

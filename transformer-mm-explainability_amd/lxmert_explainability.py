@@ -64,6 +64,7 @@ class GeneratorOurs:
         self.model_usage = model_usage
         self.save_visualization = save_visualization
         self.fused = True   # one-launch schedule kernel when T, I <= 48; False forces the per-rule kernels
+        self.use_tape = True   # generate_ours_batch: hand-written forward / backward of the body when it offers one
 
     def _generate_ours_fused(self, model):
         """All 38 rule applications in ONE kernel launch (``mmx_lxmert_schedule``); same results as the per-rule path."""
@@ -103,11 +104,19 @@ class GeneratorOurs:
         self.normalize_self_attention = normalize_self_attention
         self.apply_self_in_rule_10 = apply_self_in_rule_10
         model = self.model_usage.model
-        output = rules.forward_for_backward(model, lambda: model(**model_inputs).question_answering_score)   # [B, A]
-        idx = output.argmax(dim=-1) if index is None else torch.as_tensor(index, device=output.device).reshape(-1)
-        one_hot = torch.zeros_like(output).scatter_(1, idx.reshape(-1, 1), 1.0)
-        model.zero_grad()
-        torch.sum(one_hot * output).backward(retain_graph=True)
+        if self.use_tape and hasattr(model, "forward_tape"):
+            # tape path (lxmert_model.forward_tape / backward_tape, bert_tape.py): no autograd graph through the encoder, packed
+            # q/k/v GEMMs, fused add + LayerNorm, residual adds folded into GEMMs -- about half the launches of the route below
+            output, state = model.forward_tape(**model_inputs)                                           # [B, A]
+            idx = output.argmax(dim=-1) if index is None else torch.as_tensor(index, device=output.device).reshape(-1)
+            one_hot = torch.zeros_like(output).scatter_(1, idx.reshape(-1, 1), 1.0)
+            model.backward_tape(state, one_hot)
+        else:
+            output = rules.forward_for_backward(model, lambda: model(**model_inputs).question_answering_score)   # [B, A]
+            idx = output.argmax(dim=-1) if index is None else torch.as_tensor(index, device=output.device).reshape(-1)
+            one_hot = torch.zeros_like(output).scatter_(1, idx.reshape(-1, 1), 1.0)
+            model.zero_grad()
+            torch.sum(one_hot * output).backward(retain_graph=True)
         T, I = model_inputs["input_ids"].shape[1], model_inputs["visual_feats"].shape[1]
         if max(T, I) > ops.LXMERT_FUSED_MAX_TOKENS:
             raise NotImplementedError("generate_ours_batch runs the one-launch schedule (T, I <= %d)"

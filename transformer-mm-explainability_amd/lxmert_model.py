@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import bert_tape as bt
 from .attention_modules import BertStyleAttention
 
 
@@ -152,6 +153,41 @@ class LxmertXLayer(nn.Module):                                         # lxmert_
         visn = self.visn_output(self.visn_inter(visn), visn)
         return (lang, visn) + lang_att[1:]
 
+    def forward_tape(self, lang, lang_mask, visn, visn_mask):
+        """Same computation as ``forward`` on the tape (``bert_tape``) -> ``(lang, visn, tape)``."""
+        va, vc = self.visual_attention, self.visual_attention_copy
+        ctx_l, t_al = bt.attention_fwd(va.att, lang, visn, visn_mask)            # text -> image
+        lang1, t_ol = bt.dense_add_norm_fwd(va.output, ctx_l, lang)
+        ctx_v, t_av = bt.attention_fwd(vc.att, visn, lang, lang_mask)            # image -> text (the same weights)
+        visn1, t_ov = bt.dense_add_norm_fwd(vc.output, ctx_v, visn)
+        lang2, t_sl = bt.self_block_fwd(self.lang_self_att, lang1, lang_mask)
+        visn2, t_sv = bt.self_block_fwd(self.visn_self_att, visn1, visn_mask)
+        lang3, t_fl = bt.ffn_fwd(self.lang_inter, self.lang_output, lang2)
+        visn3, t_fv = bt.ffn_fwd(self.visn_inter, self.visn_output, visn2)
+        return lang3, visn3, (t_al, t_ol, t_av, t_ov, t_sl, t_sv, t_fl, t_fv)
+
+    def backward_tape(self, tape, d_lang3, d_visn3):
+        """Gradients w.r.t. the block outputs -> gradients w.r.t. its inputs ``(d_lang, d_visn)``; ``d_visn3`` may be ``None``
+        (the top x-layer: the answer reads the language stream only)."""
+        t_al, t_ol, t_av, t_ov, t_sl, t_sv, t_fl, t_fv = tape
+        va, vc = self.visual_attention, self.visual_attention_copy
+        d_lang1 = bt.self_block_bwd(self.lang_self_att, t_sl, bt.ffn_bwd(self.lang_inter, self.lang_output, t_fl, d_lang3))
+        d_ctx_l, d_lang_res = bt.dense_add_norm_bwd(va.output, t_ol, d_lang1)
+        if d_visn3 is None:
+            # the image stream's self-attention / feed-forward of this block feed nothing: their dL/dP is zero (the reference's
+            # hooks never fire for them either -- the generators do not read those two modules of the last x-layer)
+            self.visn_self_att.self.get_attn_gradients().zero_()
+            vc.att.get_attn_gradients().zero_()
+            d_lang, d_visn = bt.attention_bwd(va.att, t_al, d_ctx_l, True, d_hidden_res=d_lang_res)
+            return d_lang, d_visn
+        d_visn1 = bt.self_block_bwd(self.visn_self_att, t_sv, bt.ffn_bwd(self.visn_inter, self.visn_output, t_fv, d_visn3))
+        d_ctx_v, d_visn_res = bt.dense_add_norm_bwd(vc.output, t_ov, d_visn1)
+        # lang1 = LN(dense(att(lang, visn)) + lang):  d_lang = residual + query side, d_visn <- key / value side
+        d_lang, d_visn_kv = bt.attention_bwd(va.att, t_al, d_ctx_l, True, d_hidden_res=d_lang_res)
+        # visn1 = LN(dense(att(visn, lang)) + visn):  d_visn = residual + query side (+ the kv side above), d_lang += kv side
+        d_visn, d_lang = bt.attention_bwd(vc.att, t_av, d_ctx_v, True, d_hidden_res=d_visn_res + d_visn_kv, d_ctx_res=d_lang)
+        return d_lang, d_visn
+
 
 class LxmertVisualFeatureEncoder(nn.Module):                           # lxmert_lrp.py:742-767
     def __init__(self, c):
@@ -184,6 +220,31 @@ class LxmertEncoder(nn.Module):                                        # lxmert_
         for blk in self.x_layers:
             lang_feats, visual_feats = blk(lang_feats, lang_attention_mask, visual_feats, visual_attention_mask)[:2]
         return lang_feats, visual_feats
+
+    # ---- tape path of the explainability pass (bert_tape.py): no autograd graph, no weight gradients
+    def forward_tape(self, lang, lang_mask, visual_feats, visual_pos, visn_mask=None):
+        visn = self.visn_fc(visual_feats, visual_pos)
+        tapes = {"l": [], "r": [], "x": []}
+        for blk in self.layer:
+            lang, t = bt.layer_fwd(blk, lang, lang_mask)
+            tapes["l"].append(t)
+        for blk in self.r_layers:
+            visn, t = bt.layer_fwd(blk, visn, visn_mask)
+            tapes["r"].append(t)
+        for blk in self.x_layers:
+            lang, visn, t = blk.forward_tape(lang, lang_mask, visn, visn_mask)
+            tapes["x"].append(t)
+        return lang, visn, tapes
+
+    def backward_tape(self, tapes, d_lang, d_visn=None):
+        """``d_lang [B, T, E]`` (and optionally ``d_visn``): gradients w.r.t. the encoder outputs; fills the gradient slab of
+        every attention block (the lowest block of each stream skips its input gradients: nothing below reads them)."""
+        for blk, t in zip(reversed(self.x_layers), reversed(tapes["x"])):
+            d_lang, d_visn = blk.backward_tape(t, d_lang, d_visn)
+        for i in range(len(self.r_layers) - 1, -1, -1):
+            d_visn = bt.layer_bwd(self.r_layers[i], tapes["r"][i], d_visn, need_input=i > 0)
+        for i in range(len(self.layer) - 1, -1, -1):
+            d_lang = bt.layer_bwd(self.layer[i], tapes["l"][i], d_lang, need_input=i > 0)
 
 
 class LxmertPooler(nn.Module):                                         # lxmert_lrp.py:868-884
@@ -251,3 +312,30 @@ class LxmertForQuestionAnswering(nn.Module):                           # lxmert_
                           inputs_embeds)
         out.question_answering_score = self.answer_head(out.pooled_output)
         return out
+
+    # ---- tape path of the explainability pass: same scores, every attention block's P in its slab; ``backward_tape`` fills
+    # the gradient slabs from d(scores) without an autograd graph through the encoder (bert_tape.py)
+    def forward_tape(self, input_ids=None, visual_feats=None, visual_pos=None, attention_mask=None,
+                     visual_attention_mask=None, token_type_ids=None, inputs_embeds=None, **unused):
+        m = self.lxmert
+        with torch.no_grad():
+            emb = m.embeddings(input_ids, token_type_ids, inputs_embeds)
+            if attention_mask is None:
+                attention_mask = torch.ones(emb.shape[:2], device=emb.device)
+            lang, visn, tapes = m.encoder.forward_tape(emb, _extended_mask(attention_mask, emb.dtype), visual_feats, visual_pos,
+                                                       _extended_mask(visual_attention_mask, emb.dtype))
+        # the head (pooler + answer head on the [CLS] row, B x 768) goes through autograd: a handful of tiny ops
+        cls = lang[:, 0].detach().requires_grad_(True)
+        with torch.enable_grad():
+            scores = self.answer_head(torch.tanh(m.pooler.dense(cls)))
+        return scores, (tapes, cls, scores, lang.shape)
+
+    @torch.no_grad()
+    def backward_tape(self, state, d_scores):
+        """``d_scores [B, answers]`` (one-hot seeds): d(sum seeds * scores)/dP into every attention module's gradient slab."""
+        tapes, cls, scores, lang_shape = state
+        with torch.enable_grad():
+            (d_cls,) = torch.autograd.grad(scores, cls, d_scores, retain_graph=True)
+        d_lang = torch.zeros(lang_shape, dtype=torch.float32, device=d_cls.device)
+        d_lang[:, 0] = d_cls                                           # only the [CLS] row feeds the pooler
+        self.lxmert.encoder.backward_tape(tapes, d_lang, None)

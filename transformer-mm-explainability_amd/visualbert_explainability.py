@@ -40,6 +40,7 @@ class SelfAttentionGenerator:
     def __init__(self, model):
         self.model = model
         self.model.eval()
+        self.use_tape = True       # generate_ours_batch: hand-written forward / backward of the body when it offers one
 
     def _blocks(self):
         return self.model.model.bert.encoder.layer
@@ -55,7 +56,7 @@ class SelfAttentionGenerator:
         cls_per_token_score[:, cls_index] = 0
         return cls_per_token_score
 
-    def generate_ours_batch(self, input, index=None):
+    def generate_ours_batch(self, input, index=None, _n_text=None):
         """B items with the same number of real text tokens in ONE forward + ONE backward + ONE chain launch.
 
         ``input``: the ``sample_list`` dict with batch-first tensors of B items whose ``input_mask`` rows have equal sums
@@ -64,22 +65,31 @@ class SelfAttentionGenerator:
         (sample, layer group) per workgroup.  Returns ``[B, N]``: row ``b`` equals ``generate_ours`` of item ``b``.
         """
         mask = input["input_mask"]
-        lengths = mask.sum(1)
-        if int((lengths != lengths[0]).sum()) != 0:
-            raise ValueError("generate_ours_batch needs items of equal text length (bucket them: sharding.length_buckets)")
-        n_text = int(lengths[0])
+        if _n_text is None:
+            lengths = mask.sum(1)
+            if int((lengths != lengths[0]).sum()) != 0:
+                raise ValueError("generate_ours_batch needs items of equal text length (bucket them: sharding.length_buckets)")
+            n_text = int(lengths[0])
+        else:
+            n_text = _n_text                       # (a captured replay: the length was fixed, and checked, at capture time)
         B = mask.shape[0]
         model = self.model.model                                     # VisualBERTForClassification
         ids, seg = input["input_ids"][:, :n_text], input["segment_ids"][:, :n_text]
         feats = input["image_feature_0"]
         text_mask = torch.ones(B, n_text, dtype=torch.long, device=ids.device)
         visual_mask = torch.ones(B, feats.shape[1], dtype=torch.long, device=ids.device)
-        output = rules.forward_for_backward(self.model, lambda: model(
-            ids, text_mask, torch.cat((text_mask, visual_mask), dim=-1), seg, feats, torch.zeros_like(visual_mask))["scores"])
-        idx = output.argmax(dim=-1) if index is None else torch.as_tensor(index, device=output.device).reshape(-1)
-        one_hot = torch.zeros_like(output).scatter_(1, idx.reshape(-1, 1), 1.0)
-        self.model.zero_grad()
-        torch.sum(one_hot * output).backward(retain_graph=True)
+        args = (ids, text_mask, torch.cat((text_mask, visual_mask), dim=-1), seg, feats, torch.zeros_like(visual_mask))
+        if self.use_tape and hasattr(model, "forward_tape"):
+            # hand-written forward / backward of the BERT stack (visualbert_model.forward_tape, bert_tape.py)
+            output, state = model.forward_tape(*args)
+            idx = output.argmax(dim=-1) if index is None else torch.as_tensor(index, device=output.device).reshape(-1)
+            model.backward_tape(state, torch.zeros_like(output).scatter_(1, idx.reshape(-1, 1), 1.0))
+        else:
+            output = rules.forward_for_backward(self.model, lambda: model(*args)["scores"])
+            idx = output.argmax(dim=-1) if index is None else torch.as_tensor(index, device=output.device).reshape(-1)
+            one_hot = torch.zeros_like(output).scatter_(1, idx.reshape(-1, 1), 1.0)
+            self.model.zero_grad()
+            torch.sum(one_hot * output).backward(retain_graph=True)
         blocks = self._blocks()
         cls_index = n_text - 2
         scores = ops.relevancy_chain_row([blk.attention.self.get_attn() for blk in blocks],
@@ -143,3 +153,51 @@ class SelfAttentionGenerator:
         cls_per_token_score = cam[0, cls_index]
         cls_per_token_score[:, cls_index] = 0
         return cls_per_token_score
+
+
+class GraphedGenerateOursBatch:
+    """``SelfAttentionGenerator.generate_ours_batch`` captured once into a hipGraph and replayed (the batched explain pass is
+    a few hundred launches of a few microseconds each, i.e. bound by the host when run eagerly).  Batch size, number of
+    regions and the number of real text tokens are fixed at construction; new ``input_ids`` / ``segment_ids`` /
+    ``image_feature_0`` values are copied into the captured buffers.
+
+        run = GraphedGenerateOursBatch(model, example_sample_list)      # B items of equal text length
+        scores = run(sample_list)                                        # [B, N], == generate_ours_batch(sample_list)
+    """
+
+    KEYS = ("input_ids", "input_mask", "segment_ids", "image_feature_0")
+
+    def __init__(self, model, example, index=None, warmup=2):
+        lengths = example["input_mask"].sum(1)
+        if int((lengths != lengths[0]).sum()) != 0:
+            raise ValueError("GraphedGenerateOursBatch needs items of equal text length")
+        self.n_text = int(lengths[0])
+        self.static = {k: example[k].clone() for k in self.KEYS}
+        self.static_index = None if index is None else torch.as_tensor(index, device=example["input_ids"].device).clone()
+        self.gen = SelfAttentionGenerator(model)
+        self._call = lambda: self.gen.generate_ours_batch(self.static, self.static_index, _n_text=self.n_text)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._call()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.output = self._call()
+        self._pinned = ops.pinned_state(model)
+
+    def __call__(self, input=None, index=None):
+        if input is not None:
+            if int(input["input_mask"].sum(1)[0]) != self.n_text:
+                raise ValueError("this graph was captured for %d text tokens" % self.n_text)
+            for k in self.KEYS:
+                if input[k].shape != self.static[k].shape:
+                    raise ValueError("%s: %s, captured for %s" % (k, tuple(input[k].shape), tuple(self.static[k].shape)))
+                self.static[k].copy_(input[k])
+        if index is not None:
+            if self.static_index is None:
+                raise ValueError("the graph was captured with index=None (arg-max answers)")
+            self.static_index.copy_(torch.as_tensor(index))
+        self.graph.replay()
+        return self.output

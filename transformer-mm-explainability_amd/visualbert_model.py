@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import bert_tape as bt
 from .attention_modules import BertStyleAttention
 
 
@@ -190,6 +191,40 @@ class VisualBERTForClassification(nn.Module):                          # visual_
             index = input_mask.sum(1) - 2                              # second-to-last text token
             pooled_output = sequence_output[torch.arange(sequence_output.shape[0], device=index.device), index]
         return {"scores": self.classifier(pooled_output).reshape(-1, self.num_labels)}
+
+    # ---- tape path of the explainability pass (bert_tape.py): same scores, P of every block in its slab; ``backward_tape``
+    # fills the gradient slabs from d(scores) with a hand-written vector-Jacobian chain (no autograd graph through the stack)
+    def forward_tape(self, input_ids, input_mask, attention_mask=None, token_type_ids=None, visual_embeddings=None,
+                     visual_embeddings_type=None, image_text_alignment=None):
+        bert = self.bert
+        with torch.no_grad():
+            x = bert.embeddings(input_ids, token_type_ids, visual_embeddings, visual_embeddings_type, image_text_alignment)
+            if attention_mask is None:
+                attention_mask = torch.ones(x.shape[:2], device=x.device)
+            extended = (1.0 - attention_mask[:, None, None, :].to(x.dtype)) * -10000.0
+            tapes = []
+            for blk in bert.encoder.layer:
+                x, t = bt.layer_fwd(blk, x, extended)
+                tapes.append(t)
+            rows = torch.arange(x.shape[0], device=x.device)
+            index = input_mask.sum(1) - 2 if self.pooler_strategy == "vqa" else torch.zeros_like(rows)
+            picked = x[rows, index]
+        leaf = picked.detach().requires_grad_(True)
+        with torch.enable_grad():                                      # the head on B rows: a handful of tiny autograd ops
+            pooled = leaf if self.pooler_strategy == "vqa" else torch.tanh(bert.pooler.dense(leaf))
+            scores = self.classifier(pooled).reshape(-1, self.num_labels)
+        return scores, (tapes, leaf, scores, x.shape, rows, index)
+
+    @torch.no_grad()
+    def backward_tape(self, state, d_scores):
+        tapes, leaf, scores, shape, rows, index = state
+        with torch.enable_grad():
+            (d_leaf,) = torch.autograd.grad(scores, leaf, d_scores, retain_graph=True)
+        dx = torch.zeros(shape, dtype=torch.float32, device=d_leaf.device)
+        dx[rows, index] = d_leaf                                       # only the pooled token feeds the classifier
+        layers = self.bert.encoder.layer
+        for i in range(len(layers) - 1, -1, -1):
+            dx = bt.layer_bwd(layers[i], tapes[i], dx, need_input=i > 0)
 
 
 class VisualBERT(nn.Module):
