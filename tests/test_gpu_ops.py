@@ -490,3 +490,40 @@ def test_detr_decoder_rows_kernels_vs_per_layer_ops(ops, K, H, Q, Ni, L, shared)
     assert abs(float(dmin) - float(torch.stack(dm).min())) <= 1e-6
     # the poisoned layer really was dropped for that sample only: recompute without the drop and compare
     assert float((s[poisoned[0]].double() - want[poisoned[0]]).abs().max()) <= 2e-6 * scale
+
+
+def test_graph_capture_holds_the_garbage_collector_off(ops):
+    """Every ``Graphed*`` wrapper captures through ``ops.graph_capture``: Python's cyclic collector must not run inside a
+    capture (it may destroy an earlier wrapper's CUDAGraph, whose pool release is illegal while a stream is capturing and
+    aborts the process -- seen once in this suite), and its state is restored afterwards, also on an exception."""
+    import gc
+
+    class Cyclic:                                  # cyclic garbage holding a captured graph, like a dropped Graphed* wrapper
+        def __init__(self):
+            self.graph = torch.cuda.CUDAGraph()
+            self.x = torch.zeros(1024, device="cuda")
+            with ops.graph_capture(self.graph):
+                self.y = self.x * 2 + 1
+            self.me = self
+
+    for _ in range(3):
+        Cyclic()                                   # unreachable at once, only the cyclic collector frees it
+    g = torch.cuda.CUDAGraph()
+    x = torch.zeros(4, device="cuda")
+    assert gc.isenabled()
+    with ops.graph_capture(g):
+        assert not gc.isenabled()
+        junk = [[i] for i in range(5000)]          # enough allocations to trigger generation-0 collections if they were on
+        y = x + len(junk)
+    assert gc.isenabled()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(y[0]) == 5000.0
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")            # (torch warns about the empty capture it ends on the way out)
+        with pytest.raises(RuntimeError):
+            with ops.graph_capture(torch.cuda.CUDAGraph()):
+                raise RuntimeError("inside")
+    assert gc.isenabled()
+    gc.collect()

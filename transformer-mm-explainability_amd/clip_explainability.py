@@ -152,7 +152,7 @@ class GraphedInterpret:
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: a collective backend's watchdog thread (RCCL, one rank per GPU) may poll events while this
         # thread captures; only calls made by the capturing thread must be capture-safe
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with ops.graph_capture(self.graph):
             self.outputs = self._call()
         # The graph bakes in the raw addresses of the towers' capture slabs and of the cached chain plans' scratch.  Pin
         # them: a later interpret() / GraphedInterpret on the same model with another batch, sharing mode or text length

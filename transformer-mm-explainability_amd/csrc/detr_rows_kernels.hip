@@ -8,7 +8,7 @@
 // this step (K x H x Q x Ni x 4 per layer and operand: 30 MB at K = 10, Ni = 950).  Three launches for ALL decoder layers
 // replace, per layer, avg_heads (self) + baddbmm + row_normalise + bmm + avg_heads (cross) + bmm + isnan / any / where / add +
 // baddbmm (torch launches in the round-2 rows-only route):
-//   1. detr_decoder_vectors_kernel   one workgroup per sample, R_qq and B_l in LDS: bottom-up B_l, R_qq^(l), N(R_qq^(l)) (+ the
+//   1. detr_decoder_vectors_kernel   one workgroup per sample, R_qq and B_l in LDS (products on the exact-fp32 MFMA): bottom-up B_l, R_qq^(l), N(R_qq^(l)) (+ the
 //                                    diag >= 0 word of handle_residual and the NaN flag of the DETR policy), then top-down
 //                                    w_l = u_l . N(R_qq^(l))^T and u_(l-1) = u_l (I + B_l)
 //   2. detr_cross_rows_kernel        z_l = w_l . C_l WITHOUT materialising C_l: every (sample, layer, 64-column tile)
@@ -41,16 +41,21 @@ struct DetrRowsArgs {
     float* diag_min;                     // [1] or null
 };
 
+// LDS: R and B as [QP][LD] (QP = 16 ceil(Q / 16) rows, zero padded: the MFMA tiles read whole 16 x 4 blocks), LD = QP + 1.
 __global__ __launch_bounds__(kVecThreads) void detr_decoder_vectors_kernel(const DetrRowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int Q = a.Q, LD = Q + 1, QQ = Q * Q;
-    float* R = smem;                     // [Q][LD]
-    float* Bm = R + Q * LD;              // [Q][LD]
-    float* u = Bm + Q * LD;              // [2][Q]
+    const int Q = a.Q, NTQ = (Q + 15) / 16, QP = NTQ * 16, LD = QP + 1, QQ = Q * Q;
+    float* R = smem;                     // [QP][LD]
+    float* Bm = R + QP * LD;             // [QP][LD]
+    float* u = Bm + QP * LD;             // [2][kMaxQ]
     float* red = u + 2 * kMaxQ;          // [kMaxQ]
-    const int tid = threadIdx.x, k = blockIdx.x;
-    const float inv_h = 1.0f / static_cast<float>(a.H);
-    for (int e = tid; e < QQ; e += kVecThreads) R[(e / Q) * LD + e % Q] = (e / Q == e % Q) ? 1.f : 0.f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = blockIdx.x;
+    const int i_a = lane & 15, kk = lane >> 4;
+    for (int e = tid; e < QP * LD; e += kVecThreads) {
+        const int i = e / LD, j = e - i * LD;
+        R[e] = (i == j && i < Q) ? 1.f : 0.f;
+        Bm[e] = 0.f;
+    }
     if (tid < 2 * a.L) a.flags[(tid / a.L) * a.K * a.L + k * a.L + tid % a.L] = 0;
     float dmin = __builtin_inff();
     __syncthreads();
@@ -62,29 +67,46 @@ __global__ __launch_bounds__(kVecThreads) void detr_decoder_vectors_kernel(const
         for (int e = tid; e < QQ; e += kVecThreads) {
             float sum = 0.f;
             for (int h = 0; h < a.H; ++h) sum += relu_nan(G[static_cast<int64_t>(h) * QQ + e] * A[static_cast<int64_t>(h) * QQ + e]);
-            sum *= inv_h;
+            sum = sum / static_cast<float>(a.H);
             Bm[(e / Q) * LD + e % Q] = sum;
             Bg[e] = sum;
         }
         __syncthreads();
-        float acc[(kMaxQ * kMaxQ + kVecThreads - 1) / kVecThreads];
-        int n = 0;
-        for (int e = tid; e < QQ; e += kVecThreads, ++n) {
-            const int i = e / Q, j = e % Q;
-            float s = 0.f;
-            for (int c = 0; c < Q; ++c) s += Bm[i * LD + c] * R[c * LD + j];
-            acc[n] = R[i * LD + j] + s;
+        // R_new = R + B R on the exact-fp32 MFMA: 16 x 16 output tiles dealt round-robin to the 16 waves, both operands in LDS
+        // (A = B_l [i][c], B = R [c][j], zero padded); the new tiles stay in registers until every wave has read the old R
+        constexpr int kMaxTiles = (kMaxQ / 16) * (kMaxQ / 16) / (kVecThreads / 64);       // 4 tiles per wave at Q = 128
+        f32x4 acc[kMaxTiles];
+        int nt = 0;
+        for (int tile = wave; tile < NTQ * NTQ; tile += kVecThreads / 64, ++nt) {
+            const int ti = tile / NTQ, tj = tile - ti * NTQ;
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < QP / 4; ++ks)
+                c = mfma16x16x4(Bm[(ti * 16 + i_a) * LD + 4 * ks + kk], R[(4 * ks + kk) * LD + tj * 16 + i_a], c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] += R[(ti * 16 + kk * 4 + r) * LD + tj * 16 + i_a];
+            if (nt < kMaxTiles) acc[nt] = c;
         }
         __syncthreads();
-        n = 0;
-        for (int e = tid; e < QQ; e += kVecThreads, ++n) R[(e / Q) * LD + e % Q] = acc[n];
+        nt = 0;
+        for (int tile = wave; tile < NTQ * NTQ; tile += kVecThreads / 64, ++nt) {
+            const int ti = tile / NTQ, tj = tile - ti * NTQ;
+            if (nt < kMaxTiles) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) R[(ti * 16 + kk * 4 + r) * LD + tj * 16 + i_a] = acc[nt][r];
+            }
+        }
         __syncthreads();
         float* Hg = a.Rhat + (static_cast<int64_t>(k) * a.L + l) * QQ;
-        if (tid < Q) {                                              // row sums of R - I (a thread per row: Q <= 128)
+        {   // row sums of R - I: 8 lanes per row, 16 columns at a time each
+            const int row = tid >> 3, part = tid & 7;
             float s = 0.f;
-            for (int j = 0; j < Q; ++j) s += R[tid * LD + j] - (j == tid ? 1.f : 0.f);
-            red[tid] = s;
-            dmin = fminf(dmin, R[tid * LD + tid] - 1.f);
+            if (row < Q)
+                for (int j = part; j < Q; j += 8) s += R[row * LD + j] - (j == row ? 1.f : 0.f);
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            if (row < Q && part == 0) {
+                red[row] = s;
+                dmin = fminf(dmin, R[row * LD + row] - 1.f);
+            }
         }
         __syncthreads();
         bool nan_seen = false;
@@ -98,15 +120,15 @@ __global__ __launch_bounds__(kVecThreads) void detr_decoder_vectors_kernel(const
         if (nan_seen) atomicOr(&a.flags[k * a.L + l], 1);
         __syncthreads();
     }
-    // diag(R - I) >= 0 contract of handle_residual: the smallest value any layer saw
-    if (tid < Q) red[tid] = dmin;
+    // diag(R - I) >= 0 contract of handle_residual: the smallest value any layer saw (threads 8 row own row's running minimum)
+    if ((tid & 7) == 0 && (tid >> 3) < Q) red[tid >> 3] = dmin;
     __syncthreads();
     if (tid == 0) {
         float m = red[0];
         for (int i = 1; i < Q; ++i) m = fminf(m, red[i]);
         a.diag_k[k] = m;
     }
-    // ---- top-down: w_l = u_l N(R_qq^(l))^T, u_(l-1) = u_l (I + B_l)
+    // ---- top-down: w_l = u_l N(R_qq^(l))^T, u_(l-1) = u_l (I + B_l); 8 lanes per output element
     const int t = static_cast<int>(a.targets[k]);
     if (tid < Q) u[tid] = (tid == t) ? 1.f : 0.f;
     int cur = 0;
@@ -119,13 +141,19 @@ __global__ __launch_bounds__(kVecThreads) void detr_decoder_vectors_kernel(const
             Bm[(e / Q) * LD + e % Q] = Bg[e];
         }
         __syncthreads();
-        if (tid < Q) {
-            float s = 0.f;
-            for (int j = 0; j < Q; ++j) s += u[cur * kMaxQ + j] * R[tid * LD + j];       // w[q] = sum_j u[j] N[q][j]
-            a.w[(static_cast<int64_t>(k) * a.L + l) * Q + tid] = s;
-            float v = u[cur * kMaxQ + tid];
-            for (int c = 0; c < Q; ++c) v += u[cur * kMaxQ + c] * Bm[c * LD + tid];       // u <- u + u B
-            u[(cur ^ 1) * kMaxQ + tid] = v;
+        const int row = tid >> 3, part = tid & 7;
+        float s = 0.f, v = 0.f;
+        if (row < Q)
+            for (int j = part; j < Q; j += 8) {
+                const float uj = u[cur * kMaxQ + j];
+                s += uj * R[row * LD + j];                           // w[q] = sum_j u[j] N[q][j]
+                v += uj * Bm[j * LD + row];                          // (u B)[q] = sum_c u[c] B[c][q]
+            }
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+        if (row < Q && part == 0) {
+            a.w[(static_cast<int64_t>(k) * a.L + l) * Q + row] = s;
+            u[(cur ^ 1) * kMaxQ + row] = u[cur * kMaxQ + row] + v;
         }
         cur ^= 1;
     }
@@ -142,7 +170,7 @@ __global__ __launch_bounds__(256) void detr_cross_rows_kernel(const DetrRowsArgs
     const float* A = a.cross_a[l] + static_cast<int64_t>(k) * a.cross_a_bs;
     const float* G = a.cross_g[l] + static_cast<int64_t>(k) * a.H * hs;
     const float* w = a.w + (static_cast<int64_t>(k) * a.L + l) * Q;
-    const float inv_h = 1.0f / static_cast<float>(a.H);
+    const float fH = static_cast<float>(a.H);
     const bool full = n0 + 3 < Ni, any = n0 < Ni;
     f32x4 zacc = {0.f, 0.f, 0.f, 0.f};
     bool nan_seen = false;
@@ -162,7 +190,7 @@ __global__ __launch_bounds__(256) void detr_cross_rows_kernel(const DetrRowsArgs
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float c = cam[r] * inv_h;
+            const float c = cam[r] / fH;                            // (as avg_heads_kernel: sum / H)
             nan_seen |= (c != c);
             zacc[r] += wq * c;
         }
@@ -247,7 +275,8 @@ extern "C" int mmx_detr_decoder_rows(const void* const* self_attn, const void* c
     a.s_out = static_cast<float*>(s_out_dev);
     a.diag_min = static_cast<float*>(diag_min_dev);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t lds = sizeof(float) * (2 * static_cast<size_t>(Q) * (Q + 1) + 3 * kMaxQ);
+    const size_t QP = (static_cast<size_t>(Q) + 15) / 16 * 16;
+    const size_t lds = sizeof(float) * (2 * QP * (QP + 1) + 3 * kMaxQ);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(detr_decoder_vectors_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));

@@ -499,7 +499,7 @@ class GraphedGenerateOursMulti:
                 self._call()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with ops.graph_capture(self.graph):
             self.out = self._call()
             self.diag_min = self.gen.diag_min
         # the graph holds raw addresses of the attention modules' slabs and of scratch buffers that were allocated by the

@@ -376,7 +376,7 @@ class GraphedGenerateOursBatch:
                 self._call()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with ops.graph_capture(self.graph):
             self.outputs = self._call()
             self.diag_min = self.gen.diag_min
             self.R_i_i, self.R_i_t = self.gen.R_i_i, self.gen.R_i_t

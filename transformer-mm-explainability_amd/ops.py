@@ -5,8 +5,9 @@ path and no PyTorch-op fallback: a CPU tensor or a missing ``libmmx_hip.so`` rai
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
-
+import gc
 import weakref
 
 import torch
@@ -62,6 +63,27 @@ def _workspace(nbytes, device, tag="default"):
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+@contextlib.contextmanager
+def graph_capture(graph):
+    """``torch.cuda.graph(graph, capture_error_mode="thread_local")`` with Python's cyclic garbage collector held off for
+    the duration of the capture.  A collection that happens to run INSIDE a capture may destroy objects whose destructors
+    issue HIP calls that are illegal while a stream is capturing -- a ``torch.cuda.CUDAGraph`` of an earlier, already dropped
+    ``Graphed*`` wrapper releases its private memory pool (``hipFree``) -- and an exception in a C++ destructor aborts the
+    process (seen as "Fatal Python error: Aborted ... Garbage-collecting" in the GPU test suite).  ``torch.cuda.graph``
+    collects once BEFORE the capture begins; this keeps the collector from firing again until it has ended.
+    thread_local: a collective backend's watchdog thread (RCCL, one rank per GPU) may poll events while this thread captures;
+    only calls made by the capturing thread must be capture-safe."""
+    was_enabled = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def pinned_state(model=None):

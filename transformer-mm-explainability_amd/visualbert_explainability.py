@@ -183,7 +183,7 @@ class GraphedGenerateOursBatch:
                 self._call()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with ops.graph_capture(self.graph):
             self.output = self._call()
         self._pinned = ops.pinned_state(model)
 

@@ -264,7 +264,7 @@ class GraphedRelevance:
                 call()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with ops.graph_capture(self.graph):
             self.output = call()
 
     def __call__(self, input=None, indices=None):
