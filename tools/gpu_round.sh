@@ -31,4 +31,7 @@ python tools/prof_summary.py $OUT/trace_cfg5/cfg5_results.db "" 2>&1 | head -30 
 timeout 300 python tools/probe_attn_v3.py 128 2>&1 | grep -v amdgpu.ids > $OUT/attn_v3_probe.txt; cat $OUT/attn_v3_probe.txt
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/pmc_v3 -o v3 -- python tools/probe_attn_v3.py 16 2 > /dev/null 2> $OUT/pmc_v3.log
 python tools/pmc_sq.py $OUT/pmc_v3/v3_counter_collection.csv _v3_ > $OUT/attn_v3_sq.txt 2>&1; cat $OUT/attn_v3_sq.txt
-rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/trace $OUT/trace_full $OUT/trace_cfg5 $OUT/pmc_v3
+# cfg 3: DETR K = 10 pass with the three-launch decoder rules (rows of R_q_i only)
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_detr -o detr -- python tools/probe_detr_trace.py 5 10 rows > /dev/null 2> $OUT/trace_detr.log
+python tools/prof_summary.py $OUT/trace_detr/detr_results.db "" 2>&1 | head -40 | cut -c1-190 > $OUT/detr_rows_kernels.txt
+rm -rf $OUT/trace_detr $OUT/pmc_fetch $OUT/pmc_write $OUT/trace $OUT/trace_full $OUT/trace_cfg5 $OUT/pmc_v3
