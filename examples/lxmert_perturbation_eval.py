@@ -35,13 +35,37 @@ def synthetic_item(k, regions, feat_dim, vocab, answers):
                 visual_pos=torch.rand(regions, 4, generator=g), label=label)
 
 
-# methods of the reference's --method flag this batched evaluator runs (rule flags of GeneratorOurs.generate_ours_batch);
-# the others exist per item on the generator classes (lxmert_explainability.GeneratorBaselines / ...AblationNoAggregation,
-# LRP ones need a body with relprop) and are not batched here
+# methods of the reference's --method flag (lxmert/lxmert/perturbation.py:216-245).  The first group is explained a whole
+# batch at a time (rule flags of GeneratorOurs.generate_ours_batch); the others run the reference's per-item generator call
+# (lxmert_explainability.GeneratorOurs / GeneratorBaselines / GeneratorOursAblationNoAggregation; the LRP ones on the body's
+# own relprop pass) followed by the same batched perturbation of that one item.
 BATCHED_METHODS = {"ours_no_lrp": {}, "ours_no_lrp_no_norm": {"normalize_self_attention": False},
                    "ablation_no_self_in_10": {"apply_self_in_rule_10": False}}
 OTHER_METHODS = {"ours_with_lrp", "rollout", "partial_lrp", "transformer_att", "raw_attn", "attn_gradcam",
                  "ours_with_lrp_no_normalization", "ablation_no_aggregation"}
+
+
+class ItemUsage:
+    """``ModelUsage`` of the reference for one item (lxmert/lxmert/perturbation.py:45-83): ``forward`` runs the body and leaves
+    the item's text / region counts where the generators read them."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def forward(self, inputs):
+        self.text_len, self.image_boxes_len = inputs["input_ids"].shape[1], inputs["visual_feats"].shape[1]
+        return self.model(**inputs)
+
+
+def per_item_method(name, le, usage):
+    """The reference's dispatch (perturbation.py:218-243) -> ``item -> (R_t_t, R_t_i)``."""
+    ours, base, abl = le.GeneratorOurs(usage), le.GeneratorBaselines(usage), le.GeneratorOursAblationNoAggregation(usage)
+    return {"transformer_att": base.generate_transformer_attr, "attn_gradcam": base.generate_attn_gradcam,
+            "partial_lrp": base.generate_partial_lrp, "raw_attn": base.generate_raw_attn, "rollout": base.generate_rollout,
+            "ours_with_lrp_no_normalization": lambda it: ours.generate_ours(it, normalize_self_attention=False),
+            "ours_with_lrp": lambda it: ours.generate_ours(it, use_lrp=True),
+            "ablation_no_aggregation": lambda it: abl.generate_ours_no_agg(it, use_lrp=False, normalize_self_attention=False),
+            }[name]
 
 
 def ref_bool(text):
@@ -65,11 +89,11 @@ def main():
     ap.add_argument("--bucket-by-length", action="store_true",
                     help="round-1 behaviour: group items by question length, eager explain pass per group")
     args = ap.parse_args()
-    if args.method not in BATCHED_METHODS:
-        raise SystemExit("--method %s is a per-item method of the generator classes; this batched evaluator runs %s"
-                         % (args.method, sorted(BATCHED_METHODS)))
     args.text, args.positive = args.is_text_pert, args.is_positive_pert
-    rule_flags = BATCHED_METHODS[args.method]
+    per_item = args.method not in BATCHED_METHODS
+    if per_item:
+        args.max_batch, args.bucket_by_length = 1, True                # one item per explain call, its own length
+    rule_flags = BATCHED_METHODS.get(args.method, {})
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
     torch.cuda.set_device(dev)
@@ -115,7 +139,12 @@ def main():
                      token_type_ids=torch.zeros(B, T, dtype=torch.long, device=dev),
                      visual_feats=torch.stack([it["visual_feats"] for it in items]).to(dev),
                      visual_pos=torch.stack([it["visual_pos"] for it in items]).to(dev))
-        if args.bucket_by_length:
+        if per_item:
+            if "explain" not in graphed:
+                graphed["explain"] = per_item_method(args.method, le, ItemUsage(model))
+            usage_item = dict(batch)
+            R_t_t, R_t_i = (r.unsqueeze(0) for r in graphed["explain"](usage_item))
+        elif args.bucket_by_length:
             R_t_t, R_t_i = gen.generate_ours_batch(batch, **rule_flags)
         else:
             if "run" not in graphed:           # captured once; serves every later batch whatever its question lengths

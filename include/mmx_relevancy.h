@@ -360,6 +360,25 @@ int mmx_attn_relprop(const void* q_dev, const void* k_dev, const void* v_dev, co
                      int64_t cv_sb, int64_t cv_sh, int64_t cv_sn,
                      int B, int H, int Nq, int Nk, int D, float scale, int scale_mode, void* stream);
 
+/* The same core in halves (BertSelfAttention.relprop, VisualBERT/mmf/models/transformers/backends/BERT_ours.py:345-395, applies
+ * Add.relprop of [scores / sqrt(d), attention_mask] -- a rule with whole-tensor sums -- between the two matmul relprops):
+ *   MMX_LRP_VALUES: cam_P (-> cam_probs_dev) and cam_V from cam_O;  q / k are still read (tiling), cam_q / cam_k may be NULL.
+ *   MMX_LRP_SCORES: cam_Q and cam_K from S1 = safe_divide(cam_scores, Z);  cam_scores_dev [B, H, Nq, Nk] fp32 = the relevance of
+ *                   the pre-softmax scores the caller derived from cam_P;  v / o / cam_o / probs / cam_probs / cam_v may be NULL.
+ * MMX_LRP_VALUES | MMX_LRP_SCORES with cam_scores_dev == NULL is mmx_attn_relprop (LxmertAttention.relprop,
+ * lxmert/lxmert/src/lxmert_lrp.py:422-461: its attention_mask slot is never assigned, the Add rule is skipped). */
+#define MMX_LRP_VALUES 1
+#define MMX_LRP_SCORES 2
+int mmx_attn_relprop_phase(const void* q_dev, const void* k_dev, const void* v_dev, const void* o_dev, const void* cam_o_dev,
+                           int64_t q_sb, int64_t q_sh, int64_t q_sn, int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                           int64_t v_sb, int64_t v_sh, int64_t v_sn, int64_t o_sb, int64_t o_sh, int64_t o_sn,
+                           int64_t co_sb, int64_t co_sh, int64_t co_sn,
+                           const void* probs_dev, void* cam_probs_dev, void* cam_q_dev, void* cam_k_dev, void* cam_v_dev,
+                           int64_t cq_sb, int64_t cq_sh, int64_t cq_sn, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn,
+                           int64_t cv_sb, int64_t cv_sh, int64_t cv_sn,
+                           int B, int H, int Nq, int Nk, int D, float scale, int scale_mode,
+                           const void* cam_scores_dev, int phase, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused QuickGELU of the CLIP body's MLP, y = x * sigmoid(1.702 x) (CLIP/clip/model.py:162-164): one HBM pass forward,
  * one backward (dx from x and dy; nothing saved but x) instead of PyTorch's 3 + 5 elementwise kernels.

@@ -950,6 +950,107 @@ def gen_visualbert_perturbation():
     save("visualbert_perturbation", **arrays)
 
 
+def gen_lxmert_model_lrp():
+    """The reference's REAL LRP pass of LXMERT: every ``relprop`` of ``lxmert_lrp.py`` (answer head :955-958, pooler :886-892,
+    encoder :855-866, x-layer :735-740, layers :601-606, attention :422-461) over the layer library
+    ``lxmert/lxmert/src/layers.py``, on the body and inputs of ``lxmert_model.npz`` (same weights).  ``LxmertModel.relprop`` /
+    ``LxmertForQuestionAnswering.relprop`` (:1253-1257, :1689-1692) are restated on the wrapper (flagged glue, like its forward).
+    Recorded: ``generate_ours`` with its DEFAULT arguments (``use_lrp=True``), the two LRP baselines, every attention module's
+    ``attn_cam`` and the relevances the pass returns."""
+    model, weights, inputs, cfg, T, I = _build_lxmert_ref()
+
+    def model_relprop(self, cam, **kw):                                 # lxmert_lrp.py:1253-1257
+        cam_lang, cam_vis = cam
+        cam_lang = self.pooler.relprop(cam_lang, **kw)
+        return self.encoder.relprop((cam_lang, cam_vis), **kw)
+
+    def qa_relprop(self, cam, **kw):                                    # lxmert_lrp.py:1689-1692 (vis_shape: :1677)
+        cam_lang = self.answer_head.relprop(cam, **kw)
+        cam_vis = torch.zeros(1, I, cfg.hidden_size)
+        return self.lxmert.relprop((cam_lang, cam_vis), **kw)
+
+    type(model.lxmert).relprop = model_relprop
+    type(model).relprop = qa_relprop
+    usage = types.SimpleNamespace(model=model, text_len=T, image_boxes_len=I, forward=lambda item: model(**inputs))
+    gen = lx_eg.GeneratorOurs(usage)
+    R_t_t, R_t_i = gen.generate_ours(None)                              # DEFAULT arguments: use_lrp=True
+    enc = model.lxmert.encoder
+    cams = {}
+    for i, b in enumerate(enc.layer):
+        cams["l%d" % i] = b.attention.self.get_attn_cam()
+    for i, b in enumerate(enc.r_layers):
+        cams["r%d" % i] = b.attention.self.get_attn_cam()
+    for i, b in enumerate(enc.x_layers):
+        cams["x%d_lang_self" % i] = b.lang_self_att.self.get_attn_cam()
+        cams["x%d_visn_self" % i] = b.visn_self_att.self.get_attn_cam()
+        cams["x%d_cross" % i] = b.visual_attention.att.get_attn_cam()
+        cams["x%d_cross_copy" % i] = b.visual_attention_copy.att.get_attn_cam()
+    arrays = {"cam__" + k: v.detach().clone() for k, v in cams.items()}
+    arrays.update(R_t_t=R_t_t, R_t_i=R_t_i, R_i_i=gen.R_i_i, R_i_t=gen.R_i_t)
+    # the relevance the pass hands back for the encoder inputs
+    out = model(**inputs).question_answering_score
+    index = int(out.argmax())
+    one_hot = torch.zeros_like(out)
+    one_hot[0, index] = 1
+    model.zero_grad()
+    torch.sum(one_hot * out).backward(retain_graph=True)
+    cam_lang, cam_vis = model.relprop(one_hot.clone(), alpha=1)
+    arrays.update(cam_lang=cam_lang, cam_vis=cam_vis, index=np.int64(index))
+    base = lx_eg.GeneratorBaselines(usage)
+    arrays["transformer_attr_R_t_t"], arrays["transformer_attr_R_t_i"] = base.generate_transformer_attr(None)
+    arrays["partial_lrp_R_t_t"], arrays["partial_lrp_R_t_i"] = base.generate_partial_lrp(None)
+    save("lxmert_model_lrp", **arrays)
+
+
+def gen_visualbert_model_lrp():
+    """The reference's REAL LRP pass of VisualBERT's BERT stack: ``BERT_ours.py`` (``BertEncoder.relprop`` :152-156,
+    ``BertLayer`` :506-515, ``BertAttention`` :227-232, ``BertSelfAttention`` :345-395 incl. the Add rule of the attention
+    mask, ``BertPredictionHeadTransform`` :533-537) over ``layers_ours.py``, on the body and sample of
+    ``visualbert_model.npz`` (same weights).  The wrapper's pooling is switched to the reference's ``IndexSelect`` module
+    (``vqa_pooler``, visual_bert.py:390) and ``relprop`` of the classification model / base model / wrapper
+    (visual_bert.py:398-403, :150-153, :615-616) is restated on it (flagged glue).  Recorded: the two LRP methods of
+    ``SelfAttentionGenerator``, every layer's ``attn_cam``, the relevance the pass returns."""
+    import importlib
+    model, sample, cfg, ids, mask, feats, vdim, labels = _build_visualbert_ref()
+    lo = importlib.import_module("vb_backends.layers_ours")
+    cls = model.model
+    head_linear = lo.Linear(cfg.hidden_size, labels)                   # visual_bert.py:312-315: an LRP ``Linear``
+    head_linear.load_state_dict(cls.classifier[1].state_dict())
+    cls.classifier[1] = head_linear.eval()
+    cls.vqa_pooler = lo.IndexSelect()
+
+    def cls_forward(self, ids_, input_mask, attention_mask, types_, vis, vis_types):
+        ext = (1.0 - attention_mask[:, None, None, :].float()) * -10000.0
+        seq = self.bert.encoder(self.bert.embeddings(ids_, types_, vis, vis_types), ext)[0]
+        index = input_mask.sum(1) - 2                                   # visual_bert.py:376-390
+        pooled = self.vqa_pooler(seq, 1, index)
+        return {"scores": self.classifier(pooled).contiguous().view(-1, labels)}
+
+    def cls_relprop(self, cam, **kw):                                   # visual_bert.py:398-403
+        for m in reversed(self.classifier._modules.values()):
+            cam = m.relprop(cam, **kw)
+        cam = self.vqa_pooler.relprop(cam, **kw)
+        return self.bert.encoder.relprop(cam, **kw)                     # VisualBERTBase.relprop, :150-153
+
+    type(cls).forward = cls_forward
+    type(cls).relprop = cls_relprop
+    type(model).relprop = lambda self, cam, **kw: self.model.relprop(cam, **kw)          # visual_bert.py:615-616
+    arrays = dict(scores=model(sample())["scores"])
+    gen = vb_eg.SelfAttentionGenerator(model)
+    arrays["transformer_att_out"] = gen.generate_transformer_att(sample())
+    blocks = cls.bert.encoder.layer
+    arrays["attn_cam"] = torch.stack([b.attention.self.get_attn_cam() for b in blocks])
+    arrays["attn_grad"] = torch.stack([b.attention.self.get_attn_gradients() for b in blocks])
+    arrays["partial_lrp_out"] = vb_eg.SelfAttentionGenerator(model).generate_partial_lrp(sample())
+    out = model(sample())["scores"]
+    index = int(out.argmax())
+    one_hot = torch.zeros_like(out)
+    one_hot[0, index] = 1
+    arrays["cam_input"] = model.relprop(one_hot.clone(), alpha=1)
+    arrays["index"] = np.int64(index)
+    save("visualbert_model_lrp", **arrays)
+
+
 ROUND1 = ("rules", "detr_chain", "lxmert_chain", "vit_chain", "visualbert_chain", "clip_tiny", "detr_mha",
           "detr_transformer", "lxmert_model", "visualbert_model")
 
@@ -978,6 +1079,7 @@ def main(which):
         "lxmert_perturbation": gen_lxmert_perturbation, "visualbert_perturbation": gen_visualbert_perturbation,
         # round 3
         "detr_transformer_lrp": gen_detr_transformer_lrp, "lrp_layers": gen_lrp_layers,
+        "lxmert_model_lrp": gen_lxmert_model_lrp, "visualbert_model_lrp": gen_visualbert_model_lrp,
     }
     for name in (which or list(todo)):
         todo[name]()

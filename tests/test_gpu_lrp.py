@@ -114,3 +114,106 @@ def test_detr_r50_shape_default_arguments_run():
         assert torch.isfinite(blk.multihead_attn.get_attn_cam()).all() and blk.multihead_attn.get_attn_cam().shape == (8, 100, 950)
     for blk in model.transformer.encoder.layers:
         assert torch.isfinite(blk.self_attn.get_attn_cam()).all()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# LXMERT / VisualBERT: the bodies' own LRP pass (bert_lrp.py) on the HIP attention-core kernels, against the reference's
+# REAL pass (lxmert_lrp.py / BERT_ours.py over their LRP layer library; fixtures lxmert_model_lrp.npz, visualbert_model_lrp.npz).
+# Relevances go through safe_divide by layer outputs: compared at 1e-4 of the tensor's largest entry (the CPU suite's bound,
+# tests/test_bert_lrp_host.py); the relevancy maps the generators return from them at the usual 1e-5.
+def rel_close(got, want, rel=1e-4, what=""):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    top = float(np.abs(want).max())
+    close(got, want, atol=rel * max(top, 1e-30), what=what)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D", [(2, 3, 20, 36, 64), (1, 12, 70, 70, 64), (2, 2, 9, 5, 16)])
+def test_attn_relprop_phases(B, H, Nq, Nk, D):
+    """``mmx_attn_relprop_phase``: VALUES then SCORES fed with cam_P reproduces the fused call bit for bit; SCORES with another
+    relevance of the scores equals the plain-torch referee (``bert_lrp.core_torch``) within its own fp32 noise."""
+    from transformer_mm_explainability_amd import _lib, bert_lrp, ops
+    g = torch.Generator().manual_seed(B + Nq * 7 + Nk)
+    q, k, v = (torch.randn(B, n, H, D, generator=g).cuda() for n in (Nq, Nk, Nk))
+    probs = torch.softmax(torch.einsum("bthd,bshd->bhts", q, k) / D ** 0.5, dim=-1).contiguous()
+    o = torch.einsum("bhts,bshd->bthd", probs, v).contiguous()
+    cam_o = (torch.randn(B, Nq, H, D, generator=g) * 0.1).cuda()
+    fused = ops.attn_relprop(q, k, v, probs, o, cam_o, 1.0, _lib.SCALE_SCORES)
+    cam_p, none_q, none_k, cam_v = ops.attn_relprop(q, k, v, probs, o, cam_o, 1.0, _lib.SCALE_SCORES, phase=_lib.LRP_VALUES)
+    assert none_q is None and none_k is None
+    none_p, cam_q, cam_k, none_v = ops.attn_relprop(q, k, None, None, None, None, 1.0, _lib.SCALE_SCORES, phase=_lib.LRP_SCORES,
+                                                    cam_scores=cam_p)
+    assert none_p is None and none_v is None
+    for a, b in zip(fused, (cam_p, cam_q, cam_k, cam_v)):
+        assert torch.equal(a, b)
+    other = (torch.rand(B, H, Nq, Nk, generator=g) * 0.01).cuda()
+    _, cam_q, cam_k, _ = ops.attn_relprop(q, k, None, None, None, None, 1.0, _lib.SCALE_SCORES, phase=_lib.LRP_SCORES,
+                                          cam_scores=other)
+    tape = dict(q=q, k=k, v=v, o=o, probs=probs)
+    t64 = {n: x.double() for n, x in tape.items()}
+    _, q32, k32, _ = bert_lrp.core_torch(tape, None, other, _lib.LRP_SCORES)
+    _, q64, k64, _ = bert_lrp.core_torch(t64, None, other.double(), _lib.LRP_SCORES)
+    for name, a, r32, r64 in (("cam_q", cam_q, q32, q64), ("cam_k", cam_k, k32, k64)):
+        err, noise, top = (float(x.abs().max()) for x in (a.double() - r64, r32.double() - r64, r64))
+        assert err <= 8 * noise + 1e-6 * top, (name, err, noise, top)
+    with pytest.raises(Exception, match="cam_scores"):
+        ops.attn_relprop(q, k, None, None, None, None, 1.0, _lib.SCALE_SCORES, phase=_lib.LRP_SCORES)
+
+
+def test_lxmert_default_generate_ours_runs_the_lrp_pass(golden):
+    """``GeneratorOurs(usage).generate_ours(input)`` with its DEFAULT arguments (``use_lrp=True``,
+    lxmert/lxmert/src/ExplanationGenerator.py:131) on ``lxmert_model``: the body's own ``relprop`` (HIP attention cores), every
+    attention module's ``attn_cam``, the four relevancy maps and the two LRP baselines against the reference's real pass."""
+    from test_gpu_generators import _lxmert_from_golden
+    from test_bert_lrp_host import lxmert_cams
+    from transformer_mm_explainability_amd import lxmert_explainability as le
+    gm, g = golden("lxmert_model"), golden("lxmert_model_lrp")
+    model, usage = _lxmert_from_golden(gm)
+    gen = le.GeneratorOurs(usage)
+    R_t_t, R_t_i = gen.generate_ours(None)
+    for name, module in lxmert_cams(model).items():
+        rel_close(module.get_attn_cam(), g["cam__" + name], what="lxmert attn_cam " + name)
+    close(R_t_t, g["R_t_t"], what="lxmert lrp R_t_t")
+    close(R_t_i, g["R_t_i"], what="lxmert lrp R_t_i")
+    close(gen.R_i_i, g["R_i_i"], what="lxmert lrp R_i_i")
+    close(gen.R_i_t, g["R_i_t"], what="lxmert lrp R_i_t")
+    base = le.GeneratorBaselines(usage)
+    a, b = base.generate_transformer_attr(None)
+    close(a, g["transformer_attr_R_t_t"], what="lxmert transformer_attr R_t_t")
+    close(b, g["transformer_attr_R_t_i"], what="lxmert transformer_attr R_t_i")
+    a, b = base.generate_partial_lrp(None)
+    close(a, g["partial_lrp_R_t_t"], what="lxmert partial_lrp R_t_t")
+    close(b, g["partial_lrp_R_t_i"], what="lxmert partial_lrp R_t_i")
+    # the relevance handed back for the encoder inputs, through the model's own entry point
+    out = usage.forward(None).question_answering_score
+    one_hot = torch.zeros_like(out)
+    one_hot[0, int(g["index"])] = 1
+    torch.sum(one_hot * out).backward()
+    cam_lang, cam_vis = model.relprop(one_hot.clone(), alpha=1)
+    rel_close(cam_lang, g["cam_lang"], what="lxmert cam_lang")
+    rel_close(cam_vis, g["cam_vis"], what="lxmert cam_vis")
+
+
+def test_visualbert_lrp_methods_run_on_the_bodys_own_pass(golden):
+    """``SelfAttentionGenerator(visualbert_model).generate_transformer_att`` / ``generate_partial_lrp``
+    (VisualBERT/.../ExplanationGenerator.py:23-60, 100-126) on the body's own ``relprop`` -- incl. the Add rule of the attention
+    mask between the two halves of the attention core -- against the reference's real pass on padded text."""
+    from test_gpu_perturbation import _visualbert_from_golden
+    from transformer_mm_explainability_amd import visualbert_explainability as vb
+    gm, g = golden("visualbert_model"), golden("visualbert_model_lrp")
+    model = _visualbert_from_golden(gm)
+
+    def sample():
+        return {"input_ids": cu(gm["input_ids"]), "input_mask": cu(gm["input_mask"]),
+                "segment_ids": torch.zeros_like(cu(gm["input_ids"])), "image_feature_0": cu(gm["image_feature_0"])}
+
+    close(vb.SelfAttentionGenerator(model).generate_transformer_att(sample()), g["transformer_att_out"],
+          what="visualbert transformer_att")
+    for i, b in enumerate(model.model.bert.encoder.layer):
+        rel_close(b.attention.self.get_attn_cam(), g["attn_cam"][i], what="visualbert attn_cam %d" % i)
+    close(vb.SelfAttentionGenerator(model).generate_partial_lrp(sample()), g["partial_lrp_out"], what="visualbert partial_lrp")
+    out = model(sample())["scores"]
+    one_hot = torch.zeros_like(out)
+    one_hot[0, int(g["index"])] = 1
+    rel_close(model.relprop(one_hot, alpha=1), g["cam_input"], what="visualbert cam_input")

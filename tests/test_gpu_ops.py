@@ -319,6 +319,46 @@ def test_layernorm_bwd_add(ops, B, N, E, shared):
     close(got2, xr.grad.float().numpy(), atol=2e-5)
 
 
+@pytest.mark.parametrize("B,N,E4", [(12, 9, 64), (3, 5, 16), (1, 7, 24), (37, 3, 8)])
+def test_quick_gelu_bwd_bf16_gradient_stream(ops, B, N, E4):
+    """bf16 dy / dx, fp32 pre-activation shared by the batch (sweep kernel for B >= 4, element kernel below): the fp32
+    product rounded ONCE to bf16."""
+    g = torch.Generator().manual_seed(B * 131 + N)
+    m = (torch.randn(1, N, E4, generator=g) * 3).cuda()
+    dy = torch.randn(B, N, E4, generator=g).cuda().to(torch.bfloat16)
+    got = ops.quick_gelu_bwd(m, dy)
+    assert got.dtype == torch.bfloat16 and got.shape == dy.shape
+    md = m.double()
+    sg = torch.sigmoid(1.702 * md)
+    want = dy.double() * (sg + 1.702 * md * sg * (1 - sg))
+    err = (got.double() - want).abs()
+    assert float((err / want.abs().clamp_min(1e-30)).max()) <= 2 ** -8 + 1e-6       # half a bf16 ulp + the fp32 rounding of the factor
+    assert torch.equal(ops.quick_gelu_bwd(m.expand(B, N, E4).contiguous(), dy), got)   # un-shared form: the same bits
+
+
+@pytest.mark.parametrize("B,N,E,shared,res", [(8, 11, 1024, True, True), (3, 5, 768, False, True), (2, 4, 512, True, False),
+                                              (2, 3, 1280, False, True), (3, 7, 96, True, True)])
+def test_layernorm_bwd_add_bf16_gradient_stream(ops, B, N, E, shared, res):
+    """bf16 upstream gradient, fp32 + bf16 results in one pass (row-resident kernel for E = 256 k, generic otherwise)."""
+    g = torch.Generator().manual_seed(B + N + E)
+    xb = 1 if shared else B
+    x = torch.randn(xb, N, E, generator=g).double()
+    gamma, beta = torch.randn(E, generator=g).double(), torch.randn(E, generator=g).double()
+    dy = torch.randn(B, N, E, generator=g).to(torch.bfloat16)
+    d_res = torch.randn(B, N, E, generator=g) if res else None
+    xr = x.expand(B, N, E).clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (E,), gamma, beta, 1e-5).backward(dy.double())
+    want = xr.grad + (d_res.double() if res else 0)
+    _, mean, rstd = torch.native_layer_norm(x.float().cuda(), (E,), gamma.float().cuda(), beta.float().cuda(), 1e-5)
+    dx, dx_h = ops.layernorm_bwd_add_bf16(dy.cuda(), x.float().cuda(), mean, rstd, gamma.float().cuda(),
+                                          d_res.cuda() if res else None)
+    close(dx, want.float().numpy(), atol=3e-5)
+    assert torch.equal(dx_h, dx.to(torch.bfloat16))
+    _, only_h = ops.layernorm_bwd_add_bf16(dy.cuda(), x.float().cuda(), mean, rstd, gamma.float().cuda(),
+                                           d_res.cuda() if res else None, want_f32=False)
+    assert torch.equal(only_h, dx_h)
+
+
 def test_unsupported_shapes_fail_loudly(ops):
     """The C-ABI refuses what it does not implement (negative return code -> MMXError with the library's message);
     nothing falls back to another implementation."""

@@ -17,6 +17,7 @@ MMX_ATTN_IO_BF16 = 0x200        # backward: bf16 dO in, bf16 dq / dk / dv out (w
 MMX_ATTN_MMA_BF16 = 0x100       # OR-ed into slab_dtype of the attention *_ex entry points (bf16 matrix cores)
 MM_NORMALIZE, MM_SELF_IN_RULE10, MM_NAN_TO_ZERO = 1, 2, 4
 SCALE_Q_FIRST, SCALE_SCORES = 0, 1
+LRP_VALUES, LRP_SCORES = 1, 2        # phases of mmx_attn_relprop_phase
 MAX_LAYERS = 48
 
 _vp, _i, _i64, _sz, _f, _u = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float, C.c_uint
@@ -58,6 +59,7 @@ _PROTOTYPES = {
     "mmx_attn_capture_bwd": (_i, [_vp, _vp, _vp] + [_i64] * 9 + [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]
                              + [_i64] * 9 + [_i, _i, _i, _i, _i, _f, _i, _i, _vp, _sz, _vp]),
     "mmx_attn_relprop": (_i, [_vp] * 5 + [_i64] * 15 + [_vp] * 5 + [_i64] * 9 + [_i, _i, _i, _i, _i, _f, _i, _vp]),
+    "mmx_attn_relprop_phase": (_i, [_vp] * 5 + [_i64] * 15 + [_vp] * 5 + [_i64] * 9 + [_i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp]),
     "mmx_detr_decoder_rows_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mmx_detr_decoder_rows": (_i, [_vpp] * 4 + [_i] * 5 + [_i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mmx_chain_matvec": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),

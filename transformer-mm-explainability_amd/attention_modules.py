@@ -15,8 +15,9 @@ forward hook and a tensor backward hook.  These classes keep that surface but th
 ``save_attn_cam`` / ``get_attn_cam`` are the plain slot of the reference (DETR/modules/layers.py:699-703): an LRP pass
 (``model.relprop``) stores its per-head relevance there and the rule kernels read it like any other cam.
 ``MultiheadAttention.relprop`` (layers.py:770-801) produces it: closed-form Linear rules (``lrp.py``) around the HIP
-attention-core kernels (``csrc/attention_lrp.hip``).  The BERT-style module has no ``relprop`` yet (a caller-supplied LRP
-pass may still fill the slot); reading an empty slot raises.
+attention-core kernels (``csrc/attention_lrp.hip``).  The BERT-style module keeps a tape for ``bert_lrp.attention_relprop``
+(the ``relprop`` of the LXMERT / VisualBERT bodies); a caller-supplied LRP pass may still fill the slot; reading an empty slot
+raises.
 """
 from __future__ import annotations
 
@@ -217,5 +218,8 @@ class BertStyleAttention(_SlabOwner):
         o = attention_capture(q, k, v, probs, grads, math.sqrt(D), mask=mask, scale_mode=_lib.SCALE_SCORES)
         self.save_attn(probs)
         self.save_attn_gradients(grads)
+        if torch.is_grad_enabled():      # what the body's LRP pass reads (bert_lrp.attention_relprop); references, no copies
+            self._lrp_tape = dict(hidden=hidden_states.detach(), context=context.detach(), q=q.detach(), k=k.detach(),
+                                  v=v.detach(), o=o.detach().view(B, Nq, H, D), probs=probs, mask=attention_mask)
         context_layer = o.reshape(B, Nq, H * D)
         return (context_layer, probs) if output_attentions else (context_layer,)

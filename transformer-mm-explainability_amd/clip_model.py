@@ -176,11 +176,16 @@ class Transformer(nn.Module):
         return mask
 
     @torch.no_grad()
-    def forward_tape(self, x, batch=None, first_grad_layer=0, grads=True):
+    def forward_tape(self, x, batch=None, first_grad_layer=0, grads=True, out_rows=None):
         """``x``: ``[Bx, N, E]`` block input (embedded, through ``ln_pre`` for the image tower).  ``batch``: how many
         upstream gradients ``backward_tape`` will carry (default ``Bx``; ``Bx == 1 < batch`` = shared-forward mode).
         Returns ``(y [Bx, N, E], tape)``; the probabilities of every block are in the capture slabs afterwards.
-        ``grads=False``: no gradient slab is allocated (``backward_tape(..., rel_row=...)`` does not store dP)."""
+        ``grads=False``: no gradient slab is allocated (``backward_tape(..., rel_row=...)`` does not store dP).
+
+        ``out_rows`` (``[Bx]`` long): the caller reads ONE token per sample from the tower output (class token / EOT token:
+        CLIP/clip/model.py:235, 360).  Everything after the attention of the top block is row-wise, so ``out_proj``, ``ln_2``
+        and the MLP of that block run on those Bx rows only (3 of its 4 GEMMs); ``y`` is then ``[Bx, E]`` -- those rows -- and
+        ``backward_tape`` must be given the same rows as ``dy_rows``."""
         if not x.is_cuda:
             raise _lib.MMXError("the CLIP body runs its attention on the HIP capture op: move the model and "
                                 "inputs to the MI355X (there is no CPU attention path)")
@@ -204,6 +209,17 @@ class Transformer(nn.Module):
             qkv = self._linear(h1, at.in_proj_weight, at.in_proj_bias).view(Bx, N, 3, at.num_heads, at.head_dim)
             o = ops.attn_capture_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], buffers.probs[l], at.head_dim ** -0.5,
                                      _lib.SCALE_Q_FIRST, mask, layout="bnhd", mma_bf16=mma)
+            if out_rows is not None and l + 1 == len(blocks):
+                ar = torch.arange(Bx, device=x.device)
+                x1, h2, mean2, rstd2 = ops.add_layernorm(
+                    x[ar, out_rows], self._linear(o.view(Bx, N, E)[ar, out_rows], at.out_proj.weight, at.out_proj.bias),
+                    blk.ln_2.weight, blk.ln_2.bias, blk.ln_2.eps)
+                m = self._linear(h2, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
+                mlp_out = self._linear(ops.quick_gelu_fwd(m), blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
+                # (x1, mean2, rstd2, m hold the Bx selected rows only: what _top_block_rows reads)
+                tape.append((x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o, out_rows) if l >= first_grad_layer else None)
+                blk.attn_probs, blk.attn_grad = buffers.layer_probs(l), buffers.layer_grads(l)
+                return x1 + mlp_out, tape
             x1, h2, mean2, rstd2 = ops.add_layernorm(x, self._linear(o.view(Bx, N, E), at.out_proj.weight, at.out_proj.bias),
                                                      blk.ln_2.weight, blk.ln_2.bias, blk.ln_2.eps)
             m = self._linear(h2, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
@@ -251,8 +267,11 @@ class Transformer(nn.Module):
         for l in range(top, first_grad_layer - 1, -1):
             blk = self.resblocks[l]
             at = blk.attn
-            x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o_fwd = tape[l]
+            x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o_fwd = tape[l][:9]
             shared = x.shape[0] != B
+            if len(tape[l]) > 9 and (l != top or dy_rows is None):
+                raise ValueError("backward_tape: the forward kept only the output rows of the top block (out_rows): "
+                                 "pass the same rows as dy_rows")
             if l == top and dy_rows is not None:
                 d_x1, d_o = self._top_block_rows(blk, tape[l], dy, dy_rows, shared)
                 if stream16:
@@ -296,18 +315,20 @@ class Transformer(nn.Module):
     def _top_block_rows(self, blk, entry, dy, rows, shared):
         """MLP / ``out_proj`` backward of the top block on the one row per sample that carries a gradient.
         Returns dense ``(d_x1 [B, N, E], d_o [B, N, E])`` that are zero elsewhere."""
-        x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o_fwd = entry
+        x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o_fwd = entry[:9]
         B, N, E = dy.shape
         ar = torch.arange(B, device=dy.device)
         src = torch.zeros_like(rows) if shared else ar                     # sample index into the (shared) tape
         g = dy[ar, rows]                                                     # [B, E]
-        m_r = m[src, rows]                                                   # [B, 4E]
+        if len(entry) > 9:                                                   # forward_tape(out_rows=...): rows only on the tape
+            m_r, x1_r, mean2_r, rstd2_r = m[src], x1[src], mean2.reshape(-1)[src], rstd2.reshape(-1)[src]
+        else:
+            flat = src * N + rows                                            # row of the [Bx*N] statistics
+            m_r, x1_r, mean2_r, rstd2_r = m[src, rows], x1[src, rows], mean2.reshape(-1)[flat], rstd2.reshape(-1)[flat]
         d_a = self._gemm(g, blk.mlp.c_proj.weight)
         sg = torch.sigmoid(1.702 * m_r)
         d_h2 = self._gemm(d_a * (sg + 1.702 * m_r * sg * (1 - sg)), blk.mlp.c_fc.weight)
-        flat = src * N + rows                                                # row of the [Bx*N] statistics
-        d_x1_r = ops.layernorm_bwd_add(d_h2, x1[src, rows], mean2.reshape(-1)[flat], rstd2.reshape(-1)[flat],
-                                       blk.ln_2.weight, g)
+        d_x1_r = ops.layernorm_bwd_add(d_h2, x1_r, mean2_r, rstd2_r, blk.ln_2.weight, g)
         d_x1 = torch.zeros_like(dy)
         d_x1[ar, rows] = d_x1_r
         d_o = torch.zeros_like(dy)
@@ -383,11 +404,13 @@ class VisualTransformer(nn.Module):
     def forward_tape(self, image, batch=None, first_grad_layer=0, grads=True):
         """``image [Bx, 3, R, R]`` -> ``(features [Bx, output_dim], state)``; ``Bx == 1 < batch``: shared-forward mode
         (see ``Transformer.forward_tape``)."""
-        y, tape = self.transformer.forward_tape(self._embed(image), batch, first_grad_layer, grads=grads)
-        cls = y[:, 0, :]
+        x = self._embed(image)
+        y, tape = self.transformer.forward_tape(x, batch, first_grad_layer, grads=grads,
+                                                out_rows=torch.zeros(x.shape[0], dtype=torch.long, device=x.device))
+        cls = y                                                              # [Bx, width]: the class-token rows
         f, mean, rstd = torch.native_layer_norm(cls, (cls.shape[-1],), self.ln_post.weight, self.ln_post.bias,
                                                 self.ln_post.eps)
-        return f @ self.proj, (tape, y.shape, cls, mean, rstd)
+        return f @ self.proj, (tape, x.shape, cls, mean, rstd)
 
     def forward_shared(self, image, batch):
         return self.forward_tape(image, batch)
@@ -490,12 +513,11 @@ class CLIP(nn.Module):
             text = text[:, :n_tokens]
         n = text.shape[1]
         x = self.token_embedding(text).type(self.dtype) + self.positional_embedding[:n].type(self.dtype)
-        y, tape = self.transformer.forward_tape(x, first_grad_layer=first_grad_layer)
         eot = text.argmax(dim=-1)                                            # model.py:360
-        rows = y[torch.arange(y.shape[0], device=y.device), eot]
+        rows, tape = self.transformer.forward_tape(x, first_grad_layer=first_grad_layer, out_rows=eot)
         f, mean, rstd = torch.native_layer_norm(rows, (rows.shape[-1],), self.ln_final.weight, self.ln_final.bias,
                                                 self.ln_final.eps)
-        return f @ self.text_projection, (tape, y.shape, rows, mean, rstd, eot)
+        return f @ self.text_projection, (tape, x.shape, rows, mean, rstd, eot)
 
     @torch.no_grad()
     def backward_text_tape(self, state, d_features, first_grad_layer=0):

@@ -15,6 +15,12 @@
 // walks the keys in 64-key tiles (cam_P, cam_Q); the key side owns 16 keys and walks the queries in 64-row tiles (cam_K,
 // cam_V; it re-reads cam_P from the slab the query side wrote, so it must be launched after it on the same stream).  All
 // products are exact-fp32 MFMAs (v_mfma_f32_16x16x4_f32); Z is recomputed from q and k, never stored.
+//
+// Phases (mmx_attn_relprop_phase): BertSelfAttention.relprop (VisualBERT/.../BERT_ours.py:345-395) puts one more rule
+// between the two matmul relprops -- Add.relprop of [scores / sqrt(d), attention_mask], whose rescale needs sums over the
+// whole tensor -- so the core can be run in halves: MMX_LRP_VALUES (cam_P, cam_V from cam_O) and MMX_LRP_SCORES
+// (cam_Q, cam_K from a caller-supplied relevance of the scores, `cam_scores`).  Both bits without `cam_scores` = the
+// fused form above (LxmertAttention.relprop, lxmert_lrp.py:422-461, never sees its mask: its attention_mask slot stays None).
 #include "mmx_common.h"
 #include "attention_args.h"
 
@@ -40,6 +46,8 @@ struct LrpArgs {
     Strides cqs, cks, cvs;
     int B, H, Nq, Nk, D;
     float scale; int scale_mode;
+    const float* cam_scores; // [B, H, Nq, Nk] relevance of the pre-softmax scores, or null: cam_P itself
+    int phase;               // MMX_LRP_VALUES | MMX_LRP_SCORES
 };
 
 // rows x D tile (row r at base + (row0 + r) * sn) -> LDS [rows_cap][DP + 2], zero padded, times mul
@@ -85,6 +93,7 @@ __global__ __launch_bounds__(256) void attn_lrp_q_kernel(const LrpArgs a) {
     const float* kb = a.k + b * a.ks.sb + h * a.ks.sh;
     const float* vb = a.v + b * a.vs.sb + h * a.vs.sh;
     const int64_t slab = (static_cast<int64_t>(b) * a.H + h) * a.Nq * a.Nk;
+    const bool values = a.phase & MMX_LRP_VALUES, scores = a.phase & MMX_LRP_SCORES;
     f32x4 acc_q = {0.f, 0.f, 0.f, 0.f};
     for (int kt = 0; kt < a.Nk; kt += kT64) {
         __syncthreads();                                                  // previous tile's readers are done
@@ -106,22 +115,25 @@ __global__ __launch_bounds__(256) void attn_lrp_q_kernel(const LrpArgs a) {
             float s1 = 0.f;
             if (row < qv && key < a.Nk) {
                 const int64_t idx = slab + static_cast<int64_t>(q0 + row) * a.Nk + key;
-                const float camp = a.probs[idx] * dp[r] * 0.5f;
-                a.cam_probs[idx] = camp;
-                s1 = safe_divide(camp, z[r]);
+                float camp = 0.f;
+                if (values) {
+                    camp = a.probs[idx] * dp[r] * 0.5f;
+                    a.cam_probs[idx] = camp;
+                }
+                if (scores) s1 = safe_divide(a.cam_scores ? a.cam_scores[idx] : camp, z[r]);
             }
             S1s[row * TS + wave * 16 + i_a] = s1;
         }
         __syncthreads();
         // C_q[row][d] += sum_key S1[row][key] k[key][d]; wave w owns d = 16w .. 16w+15
-        if (wave * 16 < DP) {
+        if (scores && wave * 16 < DP) {
 #pragma unroll
             for (int ks = 0; ks < kT64 / 4; ++ks)
                 acc_q = mfma16x16x4(S1s[i_a * TS + 4 * ks + kk], Ks[(4 * ks + kk) * LS + wave * 16 + i_a], acc_q);
         }
     }
     const int d = wave * 16 + i_a;
-    if (d < a.D) {
+    if (scores && d < a.D) {
         float* out = a.cam_q + b * a.cqs.sb + h * a.cqs.sh;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -147,6 +159,8 @@ __global__ __launch_bounds__(256) void attn_lrp_kv_kernel(const LrpArgs a) {
     const float* ob = a.o + b * a.os.sb + h * a.os.sh;
     const float* cb = a.cam_o + b * a.cos.sb + h * a.cos.sh;
     const int64_t slab = (static_cast<int64_t>(b) * a.H + h) * a.Nq * a.Nk;
+    const bool values = a.phase & MMX_LRP_VALUES, scores = a.phase & MMX_LRP_SCORES;
+    const float* cam_s = a.cam_scores ? a.cam_scores : a.cam_probs;        // fused form: what the query side just wrote
     f32x4 acc_k = {0.f, 0.f, 0.f, 0.f}, acc_v = {0.f, 0.f, 0.f, 0.f};
     for (int qt = 0; qt < a.Nq; qt += kT64) {
         __syncthreads();
@@ -166,8 +180,8 @@ __global__ __launch_bounds__(256) void attn_lrp_kv_kernel(const LrpArgs a) {
             float s1 = 0.f, p = 0.f;
             if (key < kv && query < a.Nq) {
                 const int64_t idx = slab + static_cast<int64_t>(query) * a.Nk + k0 + key;
-                p = a.probs[idx];
-                s1 = safe_divide(a.cam_probs[idx], z[r]);
+                if (values) p = a.probs[idx];
+                if (scores) s1 = safe_divide(cam_s[idx], z[r]);
             }
             S1t[key * TS + wave * 16 + i_a] = s1;
             Pt[key * TS + wave * 16 + i_a] = p;
@@ -190,8 +204,8 @@ __global__ __launch_bounds__(256) void attn_lrp_kv_kernel(const LrpArgs a) {
         for (int r = 0; r < 4; ++r) {
             const int key = kk * 4 + r;
             if (key < kv) {
-                outk[static_cast<int64_t>(k0 + key) * a.cks.sn + d] = Ks[key * LS + d] * acc_k[r] * 0.5f;
-                outv[static_cast<int64_t>(k0 + key) * a.cvs.sn + d] = Vs[key * LS + d] * acc_v[r] * 0.5f;
+                if (scores) outk[static_cast<int64_t>(k0 + key) * a.cks.sn + d] = Ks[key * LS + d] * acc_k[r] * 0.5f;
+                if (values) outv[static_cast<int64_t>(k0 + key) * a.cvs.sn + d] = Vs[key * LS + d] * acc_v[r] * 0.5f;
             }
         }
     }
@@ -212,16 +226,23 @@ int launch(const LrpArgs& a, hipStream_t s) {
 
 using namespace mmx;
 
-extern "C" int mmx_attn_relprop(const void* q_dev, const void* k_dev, const void* v_dev, const void* o_dev, const void* cam_o_dev,
-                                int64_t q_sb, int64_t q_sh, int64_t q_sn, int64_t k_sb, int64_t k_sh, int64_t k_sn,
-                                int64_t v_sb, int64_t v_sh, int64_t v_sn, int64_t o_sb, int64_t o_sh, int64_t o_sn,
-                                int64_t co_sb, int64_t co_sh, int64_t co_sn,
-                                const void* probs_dev, void* cam_probs_dev, void* cam_q_dev, void* cam_k_dev, void* cam_v_dev,
-                                int64_t cq_sb, int64_t cq_sh, int64_t cq_sn, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn,
-                                int64_t cv_sb, int64_t cv_sh, int64_t cv_sn,
-                                int B, int H, int Nq, int Nk, int D, float scale, int scale_mode, void* stream) {
-    MMX_CHECK_ARG(q_dev && k_dev && v_dev && o_dev && cam_o_dev && probs_dev && cam_probs_dev && cam_q_dev && cam_k_dev &&
-                  cam_v_dev, "mmx_attn_relprop: null pointer");
+extern "C" int mmx_attn_relprop_phase(const void* q_dev, const void* k_dev, const void* v_dev, const void* o_dev,
+                                      const void* cam_o_dev,
+                                      int64_t q_sb, int64_t q_sh, int64_t q_sn, int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                                      int64_t v_sb, int64_t v_sh, int64_t v_sn, int64_t o_sb, int64_t o_sh, int64_t o_sn,
+                                      int64_t co_sb, int64_t co_sh, int64_t co_sn,
+                                      const void* probs_dev, void* cam_probs_dev, void* cam_q_dev, void* cam_k_dev, void* cam_v_dev,
+                                      int64_t cq_sb, int64_t cq_sh, int64_t cq_sn, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn,
+                                      int64_t cv_sb, int64_t cv_sh, int64_t cv_sn,
+                                      int B, int H, int Nq, int Nk, int D, float scale, int scale_mode,
+                                      const void* cam_scores_dev, int phase, void* stream) {
+    const bool values = phase & MMX_LRP_VALUES, scores = phase & MMX_LRP_SCORES;
+    MMX_CHECK_ARG((values || scores) && !(phase & ~(MMX_LRP_VALUES | MMX_LRP_SCORES)), "mmx_attn_relprop: bad phase %d", phase);
+    MMX_CHECK_ARG(q_dev && k_dev, "mmx_attn_relprop: null q / k");
+    MMX_CHECK_ARG(!values || (v_dev && o_dev && cam_o_dev && probs_dev && cam_probs_dev && cam_v_dev),
+                  "mmx_attn_relprop: the values phase needs v, o, cam_o, probs, cam_probs, cam_v");
+    MMX_CHECK_ARG(!scores || (cam_q_dev && cam_k_dev && (values || cam_scores_dev)),
+                  "mmx_attn_relprop: the scores phase needs cam_q, cam_k and (without the values phase) cam_scores");
     MMX_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0 && D > 0, "mmx_attn_relprop: bad sizes B=%d H=%d Nq=%d Nk=%d D=%d", B, H,
                   Nq, Nk, D);
     MMX_CHECK_ARG(scale_mode == MMX_SCALE_Q_FIRST || scale_mode == MMX_SCALE_SCORES, "mmx_attn_relprop: bad scale_mode %d",
@@ -232,14 +253,33 @@ extern "C" int mmx_attn_relprop(const void* q_dev, const void* k_dev, const void
         return MMX_ENOTSUP;
     }
     LrpArgs a;
-    a.q = static_cast<const float*>(q_dev); a.k = static_cast<const float*>(k_dev); a.v = static_cast<const float*>(v_dev);
-    a.o = static_cast<const float*>(o_dev); a.cam_o = static_cast<const float*>(cam_o_dev);
-    a.qs = {q_sb, q_sh, q_sn}; a.ks = {k_sb, k_sh, k_sn}; a.vs = {v_sb, v_sh, v_sn}; a.os = {o_sb, o_sh, o_sn};
-    a.cos = {co_sb, co_sh, co_sn};
+    // (a phase that does not run never dereferences its operands; q stands in so that the staging loops stay uniform)
+    a.q = static_cast<const float*>(q_dev); a.k = static_cast<const float*>(k_dev);
+    a.v = static_cast<const float*>(values ? v_dev : k_dev);
+    a.o = static_cast<const float*>(values ? o_dev : q_dev); a.cam_o = static_cast<const float*>(values ? cam_o_dev : q_dev);
+    a.qs = {q_sb, q_sh, q_sn}; a.ks = {k_sb, k_sh, k_sn};
+    a.vs = values ? Strides{v_sb, v_sh, v_sn} : a.ks;
+    a.os = values ? Strides{o_sb, o_sh, o_sn} : a.qs;
+    a.cos = values ? Strides{co_sb, co_sh, co_sn} : a.qs;
     a.probs = static_cast<const float*>(probs_dev); a.cam_probs = static_cast<float*>(cam_probs_dev);
     a.cam_q = static_cast<float*>(cam_q_dev); a.cam_k = static_cast<float*>(cam_k_dev); a.cam_v = static_cast<float*>(cam_v_dev);
     a.cqs = {cq_sb, cq_sh, cq_sn}; a.cks = {ck_sb, ck_sh, ck_sn}; a.cvs = {cv_sb, cv_sh, cv_sn};
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D; a.scale = scale; a.scale_mode = scale_mode;
+    a.cam_scores = static_cast<const float*>(cam_scores_dev); a.phase = phase;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return D <= 32 ? launch<32>(a, s) : launch<64>(a, s);
+}
+
+extern "C" int mmx_attn_relprop(const void* q_dev, const void* k_dev, const void* v_dev, const void* o_dev, const void* cam_o_dev,
+                                int64_t q_sb, int64_t q_sh, int64_t q_sn, int64_t k_sb, int64_t k_sh, int64_t k_sn,
+                                int64_t v_sb, int64_t v_sh, int64_t v_sn, int64_t o_sb, int64_t o_sh, int64_t o_sn,
+                                int64_t co_sb, int64_t co_sh, int64_t co_sn,
+                                const void* probs_dev, void* cam_probs_dev, void* cam_q_dev, void* cam_k_dev, void* cam_v_dev,
+                                int64_t cq_sb, int64_t cq_sh, int64_t cq_sn, int64_t ck_sb, int64_t ck_sh, int64_t ck_sn,
+                                int64_t cv_sb, int64_t cv_sh, int64_t cv_sn,
+                                int B, int H, int Nq, int Nk, int D, float scale, int scale_mode, void* stream) {
+    return mmx_attn_relprop_phase(q_dev, k_dev, v_dev, o_dev, cam_o_dev, q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn,
+                                  o_sb, o_sh, o_sn, co_sb, co_sh, co_sn, probs_dev, cam_probs_dev, cam_q_dev, cam_k_dev, cam_v_dev,
+                                  cq_sb, cq_sh, cq_sn, ck_sb, ck_sh, ck_sn, cv_sb, cv_sh, cv_sn, B, H, Nq, Nk, D, scale,
+                                  scale_mode, nullptr, MMX_LRP_VALUES | MMX_LRP_SCORES, stream);
 }

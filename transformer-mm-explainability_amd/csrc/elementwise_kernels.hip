@@ -283,6 +283,101 @@ __global__ __launch_bounds__(256) void quick_gelu_bwd_bf16_kernel(const f32x4* _
     }
 }
 
+// Shared-forward mode (x is ONE sample's pre-activation, dy carries `batch` upstream gradients): a thread keeps its 8 columns,
+// forms QuickGELU'(x) for them once and sweeps `per` samples with it -- no transcendental and no index arithmetic per element,
+// the pass is the bf16 read + write of dy / dx.
+__global__ __launch_bounds__(256) void quick_gelu_bwd_bf16_sweep_kernel(const f32x4* __restrict__ x, const u32x4* __restrict__ dy,
+                                                                        u32x4* __restrict__ dx, int64_t x_n8, int batch, int per) {
+    const int64_t p = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (p >= x_n8) return;
+    const f32x4 v0 = x[2 * p], v1 = x[2 * p + 1];
+    const float xv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    float d[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float sg = sigmoid_f(1.702f * xv[e]);
+        d[e] = sg + 1.702f * xv[e] * sg * (1.f - sg);
+    }
+    const int b0 = blockIdx.y * per, b1 = min(batch, b0 + per);
+    const u32x4* src = dy + static_cast<int64_t>(b0) * x_n8 + p;
+    u32x4* dst = dx + static_cast<int64_t>(b0) * x_n8 + p;
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        u32x4 g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = __builtin_nontemporal_load(src + u * x_n8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = bf_pack(bf_lo(g[u][e]) * d[2 * e], bf_hi(g[u][e]) * d[2 * e + 1]);
+            __builtin_nontemporal_store(o, dst + u * x_n8);
+        }
+        src += 4 * x_n8;
+        dst += 4 * x_n8;
+    }
+    for (; b < b1; ++b) {
+        const u32x4 g = *src;
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = bf_pack(bf_lo(g[e]) * d[2 * e], bf_hi(g[e]) * d[2 * e + 1]);
+        *dst = o;
+        src += x_n8;
+        dst += x_n8;
+    }
+}
+
+// E = 256 * ITER: the row lives in registers between the two passes (one round of independent loads per wave instead of two
+// dependent sweeps); same summation order as the generic kernel below.
+template <int ITER>
+__global__ __launch_bounds__(256) void layernorm_bwd_add_bf16_row_kernel(const unsigned short* __restrict__ dy,
+                                                                         const float* __restrict__ x, const float* __restrict__ mean,
+                                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                         const float* d_res, float* __restrict__ dx,
+                                                                         unsigned short* __restrict__ dx_h, int64_t rows, int x_rows) {
+    constexpr int E = 256 * ITER;
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int m = static_cast<int>(r % x_rows);
+    const u32x2* dyr = reinterpret_cast<const u32x2*>(dy + r * E);
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + static_cast<int64_t>(m) * E);
+    const f32x4* gm = reinterpret_cast<const f32x4*>(gamma);
+    const f32x4* dr = d_res ? reinterpret_cast<const f32x4*>(d_res + r * E) : nullptr;
+    u32x2 raw[ITER];
+    f32x4 xh[ITER], res[ITER], g[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) raw[k] = __builtin_nontemporal_load(dyr + lane + 64 * k);
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) xh[k] = xr[lane + 64 * k];
+    if (dr) {
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) res[k] = __builtin_nontemporal_load(dr + lane + 64 * k);
+    }
+    const float mu = mean[m], rs = rstd[m];
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        g[k] = f32x4{bf_lo(raw[k][0]), bf_hi(raw[k][0]), bf_lo(raw[k][1]), bf_hi(raw[k][1])} * gm[lane + 64 * k];
+        xh[k] = (xh[k] - mu) * rs;
+        a += g[k][0] + g[k][1] + g[k][2] + g[k][3];
+        b += g[k][0] * xh[k][0] + g[k][1] * xh[k][1] + g[k][2] * xh[k][2] + g[k][3] * xh[k][3];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    a /= static_cast<float>(E);
+    b /= static_cast<float>(E);
+    f32x4* out = dx ? reinterpret_cast<f32x4*>(dx + r * E) : nullptr;
+    u32x2* out_h = dx_h ? reinterpret_cast<u32x2*>(dx_h + r * E) : nullptr;
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        f32x4 o = (g[k] - a - xh[k] * b) * rs;
+        if (dr) o = o + res[k];
+        if (out) out[lane + 64 * k] = o;
+        if (out_h) out_h[lane + 64 * k] = u32x2{bf_pack(o[0], o[1]), bf_pack(o[2], o[3])};
+    }
+}
+
 __global__ __launch_bounds__(256) void layernorm_bwd_add_bf16_kernel(const unsigned short* __restrict__ dy,
                                                                      const float* __restrict__ x, const float* __restrict__ mean,
                                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -334,6 +429,14 @@ extern "C" int mmx_quick_gelu_bwd_bcast_bf16(const void* x_dev, const void* dy_d
     MMX_CHECK_ARG(((reinterpret_cast<uintptr_t>(x_dev) | reinterpret_cast<uintptr_t>(dy_dev) |
                     reinterpret_cast<uintptr_t>(dx_dev)) & 15u) == 0, "mmx_quick_gelu_bwd_bcast_bf16: pointers must be 16-byte aligned");
     const int64_t n8 = n / 8;
+    if (n / x_n >= 4 && n / x_n <= 65535 * 8) {       // shared-forward mode: derivative once per column, swept over the samples
+        const int batch = static_cast<int>(n / x_n), per = 8;
+        const dim3 grid(static_cast<unsigned>((x_n / 8 + 255) / 256), static_cast<unsigned>((batch + per - 1) / per));
+        quick_gelu_bwd_bf16_sweep_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(
+            static_cast<const f32x4*>(x_dev), static_cast<const u32x4*>(dy_dev), static_cast<u32x4*>(dx_dev), x_n / 8, batch, per);
+        MMX_LAUNCH_CHECK("quick_gelu_bwd_bf16_sweep_kernel");
+        return MMX_OK;
+    }
     quick_gelu_bwd_bf16_kernel<<<gelu_grid(n8), 256, 0, static_cast<hipStream_t>(stream)>>>(
         static_cast<const f32x4*>(x_dev), static_cast<const u32x4*>(dy_dev), static_cast<u32x4*>(dx_dev), n8, x_n / 8);
     MMX_LAUNCH_CHECK("quick_gelu_bwd_bf16_kernel");
@@ -347,6 +450,21 @@ extern "C" int mmx_layernorm_bwd_add_bf16(const void* dy_dev, const void* x_dev,
                   "mmx_layernorm_bwd_add_bf16: null pointer");
     MMX_CHECK_ARG(rows > 0 && x_rows > 0 && E > 0 && E % 4 == 0, "mmx_layernorm_bwd_add_bf16: rows=%ld x_rows=%d E=%d (E %% 4 must be 0)",
                   static_cast<long>(rows), x_rows, E);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(dy_dev) | reinterpret_cast<uintptr_t>(x_dev) | reinterpret_cast<uintptr_t>(gamma_dev) |
+                           reinterpret_cast<uintptr_t>(d_res_dev) | reinterpret_cast<uintptr_t>(dx_dev) |
+                           reinterpret_cast<uintptr_t>(dx_bf16_dev)) & 15u) == 0;
+#define MMX_LN_ROW(ITER)                                                                                                          \
+    if (aligned && E == 256 * ITER) {                                                                                            \
+        mmx::layernorm_bwd_add_bf16_row_kernel<ITER><<<static_cast<unsigned>((rows + 3) / 4), 256, 0,                             \
+                                                       static_cast<hipStream_t>(stream)>>>(                                      \
+            static_cast<const unsigned short*>(dy_dev), static_cast<const float*>(x_dev), static_cast<const float*>(mean_dev),   \
+            static_cast<const float*>(rstd_dev), static_cast<const float*>(gamma_dev), static_cast<const float*>(d_res_dev),     \
+            static_cast<float*>(dx_dev), static_cast<unsigned short*>(dx_bf16_dev), rows, x_rows);                               \
+        MMX_LAUNCH_CHECK("layernorm_bwd_add_bf16_row_kernel");                                                                   \
+        return MMX_OK;                                                                                                           \
+    }
+    MMX_LN_ROW(2) MMX_LN_ROW(3) MMX_LN_ROW(4) MMX_LN_ROW(5)
+#undef MMX_LN_ROW
     mmx::layernorm_bwd_add_bf16_kernel<<<static_cast<unsigned>((rows + 3) / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(
         static_cast<const unsigned short*>(dy_dev), static_cast<const float*>(x_dev), static_cast<const float*>(mean_dev),
         static_cast<const float*>(rstd_dev), static_cast<const float*>(gamma_dev), static_cast<const float*>(d_res_dev),

@@ -29,8 +29,16 @@ def safe_divide(a, b):
     return a / den * b.ne(0).to(b.dtype)
 
 
-def linear_relprop(R, X, weight, alpha=1):
-    """``Linear.relprop`` (layers.py:409-437).  ``X [..., in]``, ``weight [out, in]``, ``R [..., out]`` -> ``[..., in]``."""
+def sample_sum(t):
+    """Sum over everything but the batch dimension, kept broadcastable: what a whole-tensor ``.sum()`` of the reference's
+    one-sample pass is for each sample of a batch."""
+    return t.sum(dim=tuple(range(1, t.dim())), keepdim=True) if t.dim() > 1 else t
+
+
+def linear_relprop(R, X, weight, alpha=1, normalize=True):
+    """``Linear.relprop`` (layers.py:409-437).  ``X [..., in]``, ``weight [out, in]``, ``R [..., out]`` -> ``[..., in]``.
+    ``normalize=False``: the LXMERT / VisualBERT flavour of the library (lxmert/lxmert/src/layers.py:230-252), the same rule
+    without DETR's closing ``R_out * safe_divide(R.sum(), R_out.sum())`` (layers.py:432)."""
     if alpha != 1:
         raise NotImplementedError("the generators call relprop with alpha = 1 (DETR/modules/ExplanationGenerator.py:148)")
     pw, nw = weight.clamp(min=0), weight.clamp(max=0)
@@ -38,14 +46,15 @@ def linear_relprop(R, X, weight, alpha=1):
     Z = torch.matmul(px, pw.t()) + torch.matmul(nx, nw.t())
     S = safe_divide(R, Z)
     out = px * torch.matmul(S, pw) + nx * torch.matmul(S, nw)                  # activator relevances; beta = alpha - 1 = 0
-    return out * safe_divide(R.sum(), out.sum())
+    return out * safe_divide(R.sum(), out.sum()) if normalize else out
 
 
-def add_relprop(R, a, b):
-    """``Add.relprop`` (layers.py:197-222) -> ``(R_a, R_b)``."""
+def add_relprop(R, a, b, per_sample=False):
+    """``Add.relprop`` (layers.py:197-222) -> ``(R_a, R_b)``.  ``per_sample``: the three whole-tensor sums per batch item."""
     S = safe_divide(R, a + b)
     ra, rb = a * S, b * S
-    sa, sb, total = ra.sum(), rb.sum(), R.sum()
+    total_of = sample_sum if per_sample else torch.sum
+    sa, sb, total = total_of(ra), total_of(rb), total_of(R)
     fa = safe_divide(sa.abs(), sa.abs() + sb.abs()) * total
     fb = safe_divide(sb.abs(), sa.abs() + sb.abs()) * total
     return ra * safe_divide(fa, sa), rb * safe_divide(fb, sb)

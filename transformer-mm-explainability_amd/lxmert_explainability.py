@@ -10,10 +10,11 @@ lxmert/lxmert/perturbation.py:45-83).  Attention modules are reached through the
 Underneath: the 9 language and 5 vision self-attention layers are one chain launch each (rules 6+7 carry the
 cross matrices as second right-hand side), the cross layers use the rule-10/11 kernels; both cross directions are
 computed from the pre-update state and added afterwards, exactly like the reference (:176-196).
-LRP methods (``use_lrp=True``, ``generate_transformer_attr``, ``generate_partial_lrp``) run the reference's schedule on
-``get_attn_cam()`` when the body brings its own LRP pass (``model.relprop(one_hot, alpha=1)`` filling ``save_attn_cam``,
-lxmert/lxmert/src/lxmert_lrp.py:422-461); ``lxmert_model`` has none and these then raise
-``NotImplementedError`` naming the missing method.
+LRP methods (``use_lrp=True`` -- the default argument --, ``generate_transformer_attr``, ``generate_partial_lrp``) run the
+reference's schedule on ``get_attn_cam()``, filled by the body's LRP pass ``model.relprop(one_hot, alpha=1)``
+(lxmert/lxmert/src/lxmert_lrp.py:422-461, 1689-1692).  ``lxmert_model.LxmertForQuestionAnswering.relprop`` is that pass
+(``bert_lrp.py``: closed-form rules around the HIP attention-core kernels); a body without ``relprop`` raises
+``NotImplementedError`` naming the missing method before any work is done.
 """
 from __future__ import annotations
 

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import bert_tape as bt
+from . import bert_lrp, bert_tape as bt, lrp
 from .attention_modules import BertStyleAttention
 
 
@@ -75,7 +75,10 @@ class LxmertAttentionOutput(nn.Module):                                # lxmert_
         self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=1e-12)
 
     def forward(self, hidden_states, input_tensor):
-        return self.LayerNorm(self.dense(hidden_states) + input_tensor)
+        d = self.dense(hidden_states)
+        if torch.is_grad_enabled():                                    # Add / Linear inputs of the LRP pass (bert_lrp.py)
+            self._lrp_tape = (hidden_states.detach(), d.detach(), input_tensor.detach())
+        return self.LayerNorm(d + input_tensor)
 
 
 class LxmertCrossAttentionLayer(nn.Module):                            # lxmert_lrp.py:489-503
@@ -88,7 +91,14 @@ class LxmertCrossAttentionLayer(nn.Module):                            # lxmert_
 
     def forward(self, input_tensor, ctx_tensor, ctx_att_mask=None, output_attentions=False):
         out = self.att(input_tensor, ctx_tensor, ctx_att_mask, output_attentions=output_attentions)
-        return (self.output(out[0], input_tensor),) + out[1:]
+        y = self.output(out[0], input_tensor)
+        # ``output`` is ONE module for both directions of an x-layer (the reference deep-copies the layer, lxmert_lrp.py:640-641):
+        # each direction keeps its own record of that call
+        self._lrp_out = getattr(self.output, "_lrp_tape", None)
+        return (y,) + out[1:]
+
+    def relprop(self, cam, **kwargs):
+        return bert_lrp.cross_layer_relprop(self, cam, kwargs.get("core"))
 
 
 class LxmertSelfAttentionLayer(nn.Module):                             # lxmert_lrp.py:513-531
@@ -99,7 +109,12 @@ class LxmertSelfAttentionLayer(nn.Module):                             # lxmert_
 
     def forward(self, input_tensor, attention_mask, output_attentions=False):
         out = self.self(input_tensor, input_tensor, attention_mask, output_attentions=output_attentions)
-        return (self.output(out[0], input_tensor),) + out[1:]
+        y = self.output(out[0], input_tensor)
+        self._lrp_out = getattr(self.output, "_lrp_tape", None)
+        return (y,) + out[1:]
+
+    def relprop(self, cam, **kwargs):
+        return bert_lrp.self_layer_relprop(self, cam, kwargs.get("core"))
 
 
 class LxmertIntermediate(nn.Module):                                   # lxmert_lrp.py:543-552
@@ -109,6 +124,8 @@ class LxmertIntermediate(nn.Module):                                   # lxmert_
         self.intermediate_act_fn = _act(c.hidden_act)
 
     def forward(self, hidden_states):
+        if torch.is_grad_enabled():
+            self._lrp_tape = hidden_states.detach()
         return self.intermediate_act_fn(self.dense(hidden_states))
 
 
@@ -127,6 +144,9 @@ class LxmertLayer(nn.Module):                                          # lxmert_
     def forward(self, hidden_states, attention_mask=None, output_attentions=False):
         out = self.attention(hidden_states, attention_mask, output_attentions=output_attentions)
         return (self.output(self.intermediate(out[0]), out[0]),) + out[1:]
+
+    def relprop(self, cam, **kwargs):
+        return bert_lrp.lxmert_layer_relprop(self, cam, kwargs.get("core"))
 
 
 class LxmertXLayer(nn.Module):                                         # lxmert_lrp.py:609-740
@@ -152,6 +172,22 @@ class LxmertXLayer(nn.Module):                                         # lxmert_
         lang = self.lang_output(self.lang_inter(lang), lang)
         visn = self.visn_output(self.visn_inter(visn), visn)
         return (lang, visn) + lang_att[1:]
+
+    def relprop(self, cam, **kwargs):
+        """lxmert_lrp.py:735-740: ``relprop_output`` (:691-700), ``relprop_self`` (:672-676), ``relprop_cross`` (:657-664)."""
+        core = kwargs.get("core")
+        cam_lang, cam_vis = cam
+        cam_vis = bert_lrp.ffn_relprop(self.visn_inter, self.visn_output, self.visn_inter._lrp_tape, self.visn_output._lrp_tape,
+                                       cam_vis)
+        cam_lang = bert_lrp.ffn_relprop(self.lang_inter, self.lang_output, self.lang_inter._lrp_tape,
+                                        self.lang_output._lrp_tape, cam_lang)
+        cam_vis = bert_lrp.self_layer_relprop(self.visn_self_att, cam_vis, core)
+        cam_lang = bert_lrp.self_layer_relprop(self.lang_self_att, cam_lang, core)
+        cam_vis2, cam_lang2 = bert_lrp.cross_layer_relprop(self.visual_attention_copy, cam_vis, core)
+        cam_lang1, cam_vis1 = bert_lrp.cross_layer_relprop(self.visual_attention, cam_lang, core)
+        lang_in = self.visual_attention.att._lrp_tape["hidden"]           # the x-layer's inputs (clone1 / clone2)
+        vis_in = self.visual_attention_copy.att._lrp_tape["hidden"]
+        return lrp.clone_relprop((cam_lang1, cam_lang2), lang_in), lrp.clone_relprop((cam_vis1, cam_vis2), vis_in)
 
     def forward_tape(self, lang, lang_mask, visn, visn_mask):
         """Same computation as ``forward`` on the tape (``bert_tape``) -> ``(lang, visn, tape)``."""
@@ -221,6 +257,18 @@ class LxmertEncoder(nn.Module):                                        # lxmert_
             lang_feats, visual_feats = blk(lang_feats, lang_attention_mask, visual_feats, visual_attention_mask)[:2]
         return lang_feats, visual_feats
 
+    def relprop(self, cam, **kwargs):
+        """lxmert_lrp.py:855-866: x-layers, then the image stream's r-layers, then the language layers (the relevance stops at
+        the encoder inputs: the embeddings' rules are not part of the reference's pass)."""
+        cam_lang, cam_vis = cam
+        for blk in reversed(self.x_layers):
+            cam_lang, cam_vis = blk.relprop((cam_lang, cam_vis), **kwargs)
+        for blk in reversed(self.r_layers):
+            cam_vis = blk.relprop(cam_vis, **kwargs)
+        for blk in reversed(self.layer):
+            cam_lang = blk.relprop(cam_lang, **kwargs)
+        return cam_lang, cam_vis
+
     # ---- tape path of the explainability pass (bert_tape.py): no autograd graph, no weight gradients
     def forward_tape(self, lang, lang_mask, visual_feats, visual_pos, visn_mask=None):
         visn = self.visn_fc(visual_feats, visual_pos)
@@ -253,7 +301,12 @@ class LxmertPooler(nn.Module):                                         # lxmert_
         self.dense = nn.Linear(c.hidden_size, c.hidden_size)
 
     def forward(self, hidden_states):
+        if torch.is_grad_enabled():
+            self._lrp_tape = hidden_states.detach()
         return torch.tanh(self.dense(hidden_states[:, 0]))
+
+    def relprop(self, cam, **kwargs):
+        return bert_lrp.pooler_relprop(self, cam)
 
 
 class LxmertVisualAnswerHead(nn.Module):                               # lxmert_lrp.py:941-953
@@ -264,7 +317,17 @@ class LxmertVisualAnswerHead(nn.Module):                               # lxmert_
                                       nn.Linear(h * 2, num_labels))
 
     def forward(self, hidden_states):
-        return self.logit_fc(hidden_states)
+        fc = self.logit_fc
+        normed = fc[2](fc[1](fc[0](hidden_states)))
+        if torch.is_grad_enabled():
+            self._lrp_tape = (hidden_states.detach(), normed.detach())
+        return fc[3](normed)
+
+    def relprop(self, cam, **kwargs):
+        """lxmert_lrp.py:955-958: the two Linear rules (GELU and LayerNorm pass relevance through)."""
+        x, normed = self._lrp_tape
+        cam = lrp.linear_relprop(cam, normed, self.logit_fc[3].weight, normalize=False)
+        return lrp.linear_relprop(cam, x, self.logit_fc[0].weight, normalize=False)
 
 
 def _extended_mask(mask, dtype):
@@ -293,6 +356,11 @@ class LxmertModel(nn.Module):                                          # lxmert_
                                   _extended_mask(visual_attention_mask, emb.dtype))
         return types.SimpleNamespace(language_output=lang, vision_output=visn, pooled_output=self.pooler(lang))
 
+    def relprop(self, cam, **kwargs):
+        """lxmert_lrp.py:1253-1257."""
+        cam_lang, cam_vis = cam
+        return self.encoder.relprop((self.pooler.relprop(cam_lang, **kwargs), cam_vis), **kwargs)
+
 
 class LxmertForQuestionAnswering(nn.Module):                           # lxmert_lrp.py:1532-1692
     def __init__(self, c):
@@ -311,7 +379,19 @@ class LxmertForQuestionAnswering(nn.Module):                           # lxmert_
         out = self.lxmert(input_ids, visual_feats, visual_pos, attention_mask, visual_attention_mask, token_type_ids,
                           inputs_embeds)
         out.question_answering_score = self.answer_head(out.pooled_output)
+        self.vis_shape = out.vision_output.shape                       # lxmert_lrp.py:1677
         return out
+
+    def relprop(self, cam, **kwargs):
+        """``model.relprop(one_hot, alpha=1)`` (lxmert_lrp.py:1689-1692): the LRP pass of the forward that just ran with grad
+        mode on; fills ``get_attn_cam()`` of every attention module and returns ``(cam_lang [B, T, E], cam_vis [B, I, E])``.
+        Closed-form rules (``lrp.py`` / ``bert_lrp.py``), the attention cores on the HIP kernels of ``csrc/attention_lrp.hip``."""
+        if kwargs.get("alpha", 1) != 1:
+            raise NotImplementedError("the generators call relprop with alpha = 1 (lxmert/.../ExplanationGenerator.py:137)")
+        with torch.no_grad():
+            cam_lang = self.answer_head.relprop(cam.to(torch.float32), **kwargs)
+            cam_vis = torch.zeros(self.vis_shape, dtype=torch.float32, device=cam_lang.device)
+            return self.lxmert.relprop((cam_lang, cam_vis), **kwargs)
 
     # ---- tape path of the explainability pass: same scores, every attention block's P in its slab; ``backward_tape`` fills
     # the gradient slabs from d(scores) without an autograd graph through the encoder (bert_tape.py)

@@ -696,13 +696,19 @@ def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCA
     return dq, dk, dv
 
 
-def attn_relprop(q, k, v, probs, o, cam_o, scale, scale_mode=_lib.SCALE_Q_FIRST, layout="bnhd"):
-    """LRP relevance through the attention core (``mmx_attn_relprop``; the two halved ``einsum`` relprops of
-    DETR/modules/layers.py:770-781).  ``q [B, Nq, H, D]``, ``k`` / ``v [B, Nk, H, D]``, ``o`` / ``cam_o [B, Nq, H, D]``
-    (strided views ok), ``probs [B, H, Nq, Nk]`` fp32 contiguous.  Returns ``(cam_probs [B, H, Nq, Nk], cam_q, cam_k, cam_v)``
-    with the cams of q / k / v contiguous in ``layout``."""
-    _dev(q, k, v, probs, o, cam_o)
-    if any(t.dtype != torch.float32 for t in (q, k, v, probs, o, cam_o)):
+def attn_relprop(q, k, v, probs, o, cam_o, scale, scale_mode=_lib.SCALE_Q_FIRST, layout="bnhd", phase=3, cam_scores=None):
+    """LRP relevance through the attention core (``mmx_attn_relprop[_phase]``; the two halved matmul / ``einsum`` relprops of
+    DETR/modules/layers.py:770-781, lxmert_lrp.py:422-461, BERT_ours.py:345-395).  ``q [B, Nq, H, D]``, ``k`` / ``v [B, Nk,
+    H, D]``, ``o`` / ``cam_o [B, Nq, H, D]`` (strided views ok), ``probs [B, H, Nq, Nk]`` fp32 contiguous.  Returns ``(cam_probs
+    [B, H, Nq, Nk], cam_q, cam_k, cam_v)`` with the cams of q / k / v contiguous in ``layout``.
+
+    ``phase``: ``_lib.LRP_VALUES`` -> ``(cam_probs, None, None, cam_v)`` from ``cam_o``; ``_lib.LRP_SCORES`` -> ``(None, cam_q,
+    cam_k, None)`` from ``cam_scores [B, H, Nq, Nk]`` (the relevance of the pre-softmax scores; ``v / probs / o / cam_o`` may be
+    ``None``); both (default) with ``cam_scores=None``: the fused core."""
+    values, scores = bool(phase & _lib.LRP_VALUES), bool(phase & _lib.LRP_SCORES)
+    given = [t for t in (q, k, v, probs, o, cam_o, cam_scores) if t is not None]
+    _dev(*given)
+    if any(t.dtype != torch.float32 for t in given):
         raise MMXError("attn_relprop: fp32 operands only")
     if layout == "bnhd":
         B, Nq, H, D = q.shape
@@ -710,16 +716,23 @@ def attn_relprop(q, k, v, probs, o, cam_o, scale, scale_mode=_lib.SCALE_Q_FIRST,
     else:
         B, H, Nq, D = q.shape
         Nk = k.shape[2]
-    if not probs.is_contiguous() or probs.numel() != B * H * Nq * Nk:
-        raise MMXError("attn_relprop: probs must be a contiguous [B,H,Nq,Nk] slab")
-    if cam_o.stride(-1) != 1:
+    for name, t in (("probs", probs if values else None), ("cam_scores", cam_scores)):
+        if t is not None and (not t.is_contiguous() or t.numel() != B * H * Nq * Nk):
+            raise MMXError("attn_relprop: %s must be a contiguous [B,H,Nq,Nk] slab" % name)
+    if scores and not values and cam_scores is None:
+        raise MMXError("attn_relprop: the scores phase alone needs cam_scores")
+    if values and cam_o.stride(-1) != 1:
         cam_o = cam_o.contiguous()
-    cam_probs = torch.empty(B, H, Nq, Nk, dtype=torch.float32, device=q.device)
-    cam_q, cam_k, cam_v = (torch.empty(tuple(t.shape), dtype=torch.float32, device=q.device) for t in (q, k, v))
-    st = lambda t: _bhnd_strides(t, layout)                                   # noqa: E731
-    check(lib().mmx_attn_relprop(_p(q), _p(k), _p(v), _p(o), _p(cam_o), *st(q), *st(k), *st(v), *st(o), *st(cam_o),
-                                 _p(probs), _p(cam_probs), _p(cam_q), _p(cam_k), _p(cam_v), *st(cam_q), *st(cam_k), *st(cam_v),
-                                 B, H, Nq, Nk, D, float(scale), scale_mode, _stream()), "mmx_attn_relprop")
+    new = lambda t: torch.empty(tuple(t.shape), dtype=torch.float32, device=q.device)          # noqa: E731
+    cam_probs = torch.empty(B, H, Nq, Nk, dtype=torch.float32, device=q.device) if values else None
+    cam_q, cam_k = (new(q), new(k)) if scores else (None, None)
+    cam_v = new(v) if values else None
+    zero3 = (0, 0, 0)
+    st = lambda t: zero3 if t is None else _bhnd_strides(t, layout)           # noqa: E731
+    check(lib().mmx_attn_relprop_phase(_p(q), _p(k), _p(v), _p(o), _p(cam_o), *st(q), *st(k), *st(v), *st(o), *st(cam_o),
+                                       _p(probs), _p(cam_probs), _p(cam_q), _p(cam_k), _p(cam_v), *st(cam_q), *st(cam_k),
+                                       *st(cam_v), B, H, Nq, Nk, D, float(scale), scale_mode, _p(cam_scores), int(phase),
+                                       _stream()), "mmx_attn_relprop_phase")
     return cam_probs, cam_q, cam_k, cam_v
 
 

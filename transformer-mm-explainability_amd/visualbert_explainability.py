@@ -4,9 +4,10 @@ surface (``SelfAttentionGenerator``) on the HIP kernels.
 ``model`` is duck-typed as in the reference: ``model(input)['scores']``, ``model.model.bert.encoder.layer[i].attention.self``
 with ``get_attn()`` / ``get_attn_gradients()`` -> ``[1, H, N, N]``; ``input['input_mask']`` gives the ``[CLS]``-row index
 ``input_mask.sum(1) - 2`` (reference :94-95).  Visualisation flags are accepted and ignored (cv2 drawing is not part of
-the path).  LRP methods (``generate_transformer_att``, ``generate_partial_lrp``) run on ``get_attn_cam()`` when the body
-brings its own LRP pass (``model.relprop(one_hot, alpha=1)`` filling ``save_attn_cam``, BERT_ours.py:345-395);
-``visualbert_model`` has none and they then raise ``NotImplementedError``.
+the path).  LRP methods (``generate_transformer_att``, ``generate_partial_lrp``) run on ``get_attn_cam()``, filled by the
+body's LRP pass ``model.relprop(one_hot, alpha=1)`` (BERT_ours.py:345-395, visual_bert.py:398-403);
+``visualbert_model.VisualBERT.relprop`` is that pass (``bert_lrp.py``: closed-form rules around the HIP attention-core
+kernels, 'vqa' pooling like the reference); a body without ``relprop`` raises ``NotImplementedError``.
 """
 from __future__ import annotations
 

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import bert_tape as bt
+from . import bert_lrp, bert_tape as bt, lrp
 from .attention_modules import BertStyleAttention
 
 
@@ -89,7 +89,10 @@ class _DenseAddNorm(nn.Module):                                        # BertSel
         self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
 
     def forward(self, hidden_states, input_tensor):
-        return self.LayerNorm(self.dense(hidden_states) + input_tensor)
+        d = self.dense(hidden_states)
+        if torch.is_grad_enabled():                                    # Add / Linear inputs of the LRP pass (bert_lrp.py)
+            self._lrp_tape = (hidden_states.detach(), d.detach(), input_tensor.detach())
+        return self.LayerNorm(d + input_tensor)
 
 
 class BertAttention(nn.Module):                                        # BERT_ours.py:189-232
@@ -109,6 +112,8 @@ class BertIntermediate(nn.Module):                                     # BERT_ou
         self.intermediate_act_fn = {"gelu": F.gelu, "relu": F.relu}[c.hidden_act]
 
     def forward(self, hidden_states):
+        if torch.is_grad_enabled():
+            self._lrp_tape = hidden_states.detach()
         return self.intermediate_act_fn(self.dense(hidden_states))
 
 
@@ -123,6 +128,9 @@ class BertLayer(nn.Module):                                            # BERT_ou
         attended = self.attention(hidden_states, attention_mask)
         return self.output(self.intermediate(attended), attended)
 
+    def relprop(self, cam, **kwargs):
+        return bert_lrp.bert_layer_relprop(self, cam, kwargs.get("core"))
+
 
 class BertEncoder(nn.Module):                                          # BERT_ours.py:93-157
     def __init__(self, c):
@@ -133,6 +141,11 @@ class BertEncoder(nn.Module):                                          # BERT_ou
         for blk in self.layer:
             hidden_states = blk(hidden_states, attention_mask)
         return hidden_states
+
+    def relprop(self, cam, **kwargs):                                  # BERT_ours.py:152-156
+        for blk in reversed(self.layer):
+            cam = blk.relprop(cam, **kwargs)
+        return cam
 
 
 class BertPooler(nn.Module):                                           # BERT_ours.py:159-187
@@ -152,7 +165,12 @@ class BertPredictionHeadTransform(nn.Module):                          # BERT_ou
         self.transform_act_fn = {"gelu": F.gelu, "relu": F.relu}[c.hidden_act]
 
     def forward(self, hidden_states):
+        if torch.is_grad_enabled():
+            self._lrp_tape = hidden_states.detach()
         return self.LayerNorm(self.transform_act_fn(self.dense(hidden_states)))
+
+    def relprop(self, cam, **kwargs):                                  # BERT_ours.py:533-537: LayerNorm / activation pass through
+        return lrp.linear_relprop(cam, self._lrp_tape, self.dense.weight, normalize=False)
 
 
 class VisualBERTBase(nn.Module):                                       # visual_bert.py:34-153 (no bypass_transformer)
@@ -190,7 +208,29 @@ class VisualBERTForClassification(nn.Module):                          # visual_
         if self.pooler_strategy == "vqa":
             index = input_mask.sum(1) - 2                              # second-to-last text token
             pooled_output = sequence_output[torch.arange(sequence_output.shape[0], device=index.device), index]
-        return {"scores": self.classifier(pooled_output).reshape(-1, self.num_labels)}
+        transformed = self.classifier[0](pooled_output)
+        if torch.is_grad_enabled():
+            self._lrp_tape = (sequence_output.detach(), index if self.pooler_strategy == "vqa" else None, transformed.detach())
+        return {"scores": self.classifier[1](transformed).reshape(-1, self.num_labels)}
+
+    def relprop(self, cam, **kwargs):
+        """``model.relprop(one_hot, alpha=1)`` (visual_bert.py:398-403, :150-153): the classifier's two Linear rules, the
+        ``IndexSelect`` of the pooled token (``vqa_pooler``), the encoder top-down (BERT_ours.py:152-156).  Fills
+        ``get_attn_cam()`` of every ``BertSelfAttention``; returns the relevance of the encoder input ``[B, N, E]``.  The
+        reference's pass is defined for ``pooler_strategy == "vqa"`` only (it always goes through ``vqa_pooler``)."""
+        if kwargs.get("alpha", 1) != 1:
+            raise NotImplementedError("the generators call relprop with alpha = 1 (ExplanationGenerator.py:27)")
+        sequence_output, index, transformed = self._lrp_tape
+        if index is None:
+            raise NotImplementedError("relprop: the reference's LRP pass exists for pooler_strategy == 'vqa' only")
+        with torch.no_grad():
+            cam = lrp.linear_relprop(cam.to(torch.float32), transformed, self.classifier[1].weight, normalize=False)
+            cam = self.classifier[0].relprop(cam, **kwargs)                                     # [B, E]
+            rows = torch.arange(sequence_output.shape[0], device=index.device)
+            picked = sequence_output[rows, index]
+            full = torch.zeros_like(sequence_output)
+            full[rows, index] = picked * lrp.safe_divide(cam, picked)      # IndexSelect.relprop, one token per sample
+            return self.bert.encoder.relprop(full, **kwargs)
 
     # ---- tape path of the explainability pass (bert_tape.py): same scores, P of every block in its slab; ``backward_tape``
     # fills the gradient slabs from d(scores) with a hand-written vector-Jacobian chain (no autograd graph through the stack)
@@ -258,3 +298,6 @@ class VisualBERT(nn.Module):
         return self.model(sample_list["input_ids"], sample_list["input_mask"], sample_list["attention_mask"],
                           sample_list["token_type_ids"], feats, sample_list["visual_embeddings_type"],
                           sample_list.get("image_text_alignment"))
+
+    def relprop(self, cam, **kwargs):                                  # visual_bert.py:615-616
+        return self.model.relprop(cam, **kwargs)
