@@ -971,34 +971,47 @@ def gen_lxmert_model_lrp():
 
     type(model.lxmert).relprop = model_relprop
     type(model).relprop = qa_relprop
-    usage = types.SimpleNamespace(model=model, text_len=T, image_boxes_len=I, forward=lambda item: model(**inputs))
-    gen = lx_eg.GeneratorOurs(usage)
-    R_t_t, R_t_i = gen.generate_ours(None)                              # DEFAULT arguments: use_lrp=True
-    enc = model.lxmert.encoder
-    cams = {}
-    for i, b in enumerate(enc.layer):
-        cams["l%d" % i] = b.attention.self.get_attn_cam()
-    for i, b in enumerate(enc.r_layers):
-        cams["r%d" % i] = b.attention.self.get_attn_cam()
-    for i, b in enumerate(enc.x_layers):
-        cams["x%d_lang_self" % i] = b.lang_self_att.self.get_attn_cam()
-        cams["x%d_visn_self" % i] = b.visn_self_att.self.get_attn_cam()
-        cams["x%d_cross" % i] = b.visual_attention.att.get_attn_cam()
-        cams["x%d_cross_copy" % i] = b.visual_attention_copy.att.get_attn_cam()
-    arrays = {"cam__" + k: v.detach().clone() for k, v in cams.items()}
-    arrays.update(R_t_t=R_t_t, R_t_i=R_t_i, R_i_i=gen.R_i_i, R_i_t=gen.R_i_t)
-    # the relevance the pass hands back for the encoder inputs
-    out = model(**inputs).question_answering_score
-    index = int(out.argmax())
-    one_hot = torch.zeros_like(out)
-    one_hot[0, index] = 1
-    model.zero_grad()
-    torch.sum(one_hot * out).backward(retain_graph=True)
-    cam_lang, cam_vis = model.relprop(one_hot.clone(), alpha=1)
-    arrays.update(cam_lang=cam_lang, cam_vis=cam_vis, index=np.int64(index))
-    base = lx_eg.GeneratorBaselines(usage)
-    arrays["transformer_attr_R_t_t"], arrays["transformer_attr_R_t_i"] = base.generate_transformer_attr(None)
-    arrays["partial_lrp_R_t_t"], arrays["partial_lrp_R_t_i"] = base.generate_partial_lrp(None)
+    def record(prefix):
+        usage = types.SimpleNamespace(model=model, text_len=T, image_boxes_len=I, forward=lambda item: model(**inputs))
+        gen = lx_eg.GeneratorOurs(usage)
+        R_t_t, R_t_i = gen.generate_ours(None)                          # DEFAULT arguments: use_lrp=True
+        enc = model.lxmert.encoder
+        cams = {}
+        for i, b in enumerate(enc.layer):
+            cams["l%d" % i] = b.attention.self.get_attn_cam()
+        for i, b in enumerate(enc.r_layers):
+            cams["r%d" % i] = b.attention.self.get_attn_cam()
+        for i, b in enumerate(enc.x_layers):
+            cams["x%d_lang_self" % i] = b.lang_self_att.self.get_attn_cam()
+            cams["x%d_visn_self" % i] = b.visn_self_att.self.get_attn_cam()
+            cams["x%d_cross" % i] = b.visual_attention.att.get_attn_cam()
+            cams["x%d_cross_copy" % i] = b.visual_attention_copy.att.get_attn_cam()
+        arrays = {"cam__" + k: v.detach().clone() for k, v in cams.items()}
+        arrays.update(R_t_t=R_t_t, R_t_i=R_t_i, R_i_i=gen.R_i_i, R_i_t=gen.R_i_t)
+        # the relevance the pass hands back for the encoder inputs
+        out = model(**inputs).question_answering_score
+        index = int(out.argmax())
+        one_hot = torch.zeros_like(out)
+        one_hot[0, index] = 1
+        model.zero_grad()
+        torch.sum(one_hot * out).backward(retain_graph=True)
+        cam_lang, cam_vis = model.relprop(one_hot.clone(), alpha=1)
+        arrays.update(cam_lang=cam_lang, cam_vis=cam_vis, index=np.int64(index))
+        base = lx_eg.GeneratorBaselines(usage)
+        arrays["transformer_attr_R_t_t"], arrays["transformer_attr_R_t_i"] = base.generate_transformer_attr(None)
+        arrays["partial_lrp_R_t_t"], arrays["partial_lrp_R_t_i"] = base.generate_partial_lrp(None)
+        return {prefix + k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in arrays.items()}
+
+    arrays = record("")
+    # The same reference pass in float64 ("f64__" entries): safe_divide by layer outputs makes the fp32 pass itself uncertain at
+    # ~1e-3 of a cam's largest entry; the distance fp32 <-> fp64 OF THE REFERENCE is the yardstick the GPU tests use.
+    torch.set_default_dtype(torch.float64)
+    try:
+        model.double()
+        inputs = {k: (v.double() if v.is_floating_point() else v) for k, v in inputs.items()}
+        arrays.update(record("f64__"))
+    finally:
+        torch.set_default_dtype(torch.float32)
     save("lxmert_model_lrp", **arrays)
 
 
@@ -1035,19 +1048,34 @@ def gen_visualbert_model_lrp():
     type(cls).forward = cls_forward
     type(cls).relprop = cls_relprop
     type(model).relprop = lambda self, cam, **kw: self.model.relprop(cam, **kw)          # visual_bert.py:615-616
-    arrays = dict(scores=model(sample())["scores"])
-    gen = vb_eg.SelfAttentionGenerator(model)
-    arrays["transformer_att_out"] = gen.generate_transformer_att(sample())
-    blocks = cls.bert.encoder.layer
-    arrays["attn_cam"] = torch.stack([b.attention.self.get_attn_cam() for b in blocks])
-    arrays["attn_grad"] = torch.stack([b.attention.self.get_attn_gradients() for b in blocks])
-    arrays["partial_lrp_out"] = vb_eg.SelfAttentionGenerator(model).generate_partial_lrp(sample())
-    out = model(sample())["scores"]
-    index = int(out.argmax())
-    one_hot = torch.zeros_like(out)
-    one_hot[0, index] = 1
-    arrays["cam_input"] = model.relprop(one_hot.clone(), alpha=1)
-    arrays["index"] = np.int64(index)
+    def record(prefix, sample):
+        arrays = dict(scores=model(sample())["scores"])
+        gen = vb_eg.SelfAttentionGenerator(model)
+        arrays["transformer_att_out"] = gen.generate_transformer_att(sample())
+        blocks = cls.bert.encoder.layer
+        arrays["attn_cam"] = torch.stack([b.attention.self.get_attn_cam() for b in blocks])
+        arrays["attn_grad"] = torch.stack([b.attention.self.get_attn_gradients() for b in blocks])
+        arrays["partial_lrp_out"] = vb_eg.SelfAttentionGenerator(model).generate_partial_lrp(sample())
+        out = model(sample())["scores"]
+        index = int(out.argmax())
+        one_hot = torch.zeros_like(out)
+        one_hot[0, index] = 1
+        arrays["cam_input"] = model.relprop(one_hot.clone(), alpha=1)
+        arrays["index"] = np.int64(index)
+        return {prefix + k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in arrays.items()}
+
+    arrays = record("", sample)
+    torch.set_default_dtype(torch.float64)                             # the reference's own fp32 uncertainty: see gen_lxmert_model_lrp
+    try:
+        model.double()
+
+        def sample64():
+            b = sample()
+            b["image_feature_0"] = b["image_feature_0"].double()
+            return b
+        arrays.update(record("f64__", sample64))
+    finally:
+        torch.set_default_dtype(torch.float32)
     save("visualbert_model_lrp", **arrays)
 
 

@@ -6,8 +6,11 @@ No GPU here: the capture op of the attention modules is replaced by a plain-torc
 attention core of the pass runs on the referee ``bert_lrp.core_torch``; what is pinned is the host logic -- tapes, rule order,
 Clone / Add / Linear closed forms, per-sample sums.  The HIP kernels are pinned on the same fixtures in ``tests/test_gpu_lrp.py``.
 
-Tolerances: the pass divides by layer outputs (``safe_divide``) -- a near-zero denominator amplifies fp32 rounding of the two
-implementations (closed form vs autograd-in-autograd) differently, so relevances are compared at 1e-4 of the tensor's max."""
+Tolerances: the pass divides by layer outputs (``safe_divide``), which makes the reference's OWN fp32 pass uncertain at up to
+~2e-3 of a cam's largest entry -- measured: the fixtures also hold the same reference pass run in float64 (``f64__`` entries).
+The yardstick is that distance: a result must be as close to the reference's float64 values as the reference's float32 values
+are, within a factor (``within_reference_noise``).  (On the CPU these closed forms reproduce the reference's fp32 values bit
+for bit in this image; the bound does not rely on it.)"""
 import math
 import types
 
@@ -18,12 +21,17 @@ import torch
 from transformer_mm_explainability_amd import attention_modules, bert_lrp
 
 
-def rel_close(got, want, rel=1e-4, what=""):
-    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
-    assert got.shape == want.shape, (what, got.shape, want.shape)
-    bound = rel * max(float(np.abs(want).max()), 1e-30)
-    err = float(np.abs(got - want).max())
-    assert err <= bound, "%s: max |diff| %.3e > %.3e" % (what, err, bound)
+def within_reference_noise(got, g, key, factor=4.0, floor=1e-5, what=None):
+    """``|got - ref64| <= factor * |ref32 - ref64| + floor * max|ref64|`` (max norms), refs = the reference's pass in fp32 / fp64."""
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    got, r32, r64 = (np.asarray(x, dtype=np.float64) for x in (got, g[key], g["f64__" + key]))
+    assert got.shape == r64.shape, (what or key, got.shape, r64.shape)
+    top = float(np.abs(r64).max())
+    err, noise = float(np.abs(got - r64).max()), float(np.abs(r32 - r64).max())
+    assert err <= factor * noise + floor * max(top, 1e-30), \
+        "%s: |got - ref64| %.3e > %.1f x the reference's own fp32 noise %.3e (+ %.1e of max %.3e)" % (what or key, err, factor,
+                                                                                                      noise, floor, top)
+    return err, noise, top
 
 
 def capture_stand_in(q, k, v, probs, grads, scale, mask=None, scale_mode=None, **_):
@@ -85,9 +93,9 @@ def test_lxmert_relprop_matches_reference_pass(golden, cpu_body):
     torch.sum(one_hot * out).backward()
     cam_lang, cam_vis = model.relprop(one_hot.clone(), alpha=1, core=bert_lrp.core_torch)
     for name, module in lxmert_cams(model).items():
-        rel_close(module.get_attn_cam(), g["cam__" + name], what=name)
-    rel_close(cam_lang, g["cam_lang"], what="cam_lang")
-    rel_close(cam_vis, g["cam_vis"], what="cam_vis")
+        within_reference_noise(module.get_attn_cam(), g, "cam__" + name)
+    within_reference_noise(cam_lang, g, "cam_lang")
+    within_reference_noise(cam_vis, g, "cam_vis")
     # the top x-layer's image stream carries no relevance (the answer reads the language stream): zeros, as in the reference
     assert float(np.abs(g["cam__x2_cross_copy"]).max()) == 0.0
     assert float(model.lxmert.encoder.x_layers[-1].visual_attention_copy.att.get_attn_cam().abs().max()) == 0.0
@@ -106,8 +114,8 @@ def test_lxmert_relprop_is_per_sample(golden, cpu_body):
     one_hot[1, 3] = 1
     torch.sum(one_hot * out).backward()
     cam_lang, _ = model.relprop(one_hot.clone(), alpha=1, core=bert_lrp.core_torch)
-    rel_close(cam_lang[:1], g["cam_lang"], what="cam_lang of item 0 in a batch of 2")
-    rel_close(model.lxmert.encoder.layer[0].attention.self.get_attn_cam()[:1], g["cam__l0"], what="l0 of item 0")
+    within_reference_noise(cam_lang[:1], g, "cam_lang", what="cam_lang of item 0 in a batch of 2")
+    within_reference_noise(model.lxmert.encoder.layer[0].attention.self.get_attn_cam()[:1], g, "cam__l0", what="l0 of item 0")
 
 
 def visualbert_from_golden(g):
@@ -132,9 +140,8 @@ def test_visualbert_relprop_matches_reference_pass(golden, cpu_body):
     torch.sum(one_hot * out).backward()
     cam_in = model.relprop(one_hot.clone(), alpha=1, core=bert_lrp.core_torch)
     blocks = model.model.bert.encoder.layer
-    for i, b in enumerate(blocks):
-        rel_close(b.attention.self.get_attn_cam(), g["attn_cam"][i], what="layer %d" % i)
-    rel_close(cam_in, g["cam_input"], what="cam_input")
+    within_reference_noise(torch.stack([b.attention.self.get_attn_cam() for b in blocks]), g, "attn_cam")
+    within_reference_noise(cam_in, g, "cam_input")
 
 
 def test_mask_add_rule_keeps_the_relevance_on_the_scores():

@@ -119,14 +119,15 @@ def test_detr_r50_shape_default_arguments_run():
 # ----------------------------------------------------------------------------------------------------------------------
 # LXMERT / VisualBERT: the bodies' own LRP pass (bert_lrp.py) on the HIP attention-core kernels, against the reference's
 # REAL pass (lxmert_lrp.py / BERT_ours.py over their LRP layer library; fixtures lxmert_model_lrp.npz, visualbert_model_lrp.npz).
-# Relevances go through safe_divide by layer outputs: compared at 1e-4 of the tensor's largest entry (the CPU suite's bound,
-# tests/test_bert_lrp_host.py); the relevancy maps the generators return from them at the usual 1e-5.
-def rel_close(got, want, rel=1e-4, what=""):
-    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
-    want = np.asarray(want)
-    assert got.shape == want.shape, (what, got.shape, want.shape)
-    top = float(np.abs(want).max())
-    close(got, want, atol=rel * max(top, 1e-30), what=what)
+# Relevances go through safe_divide by layer outputs, which makes the reference's OWN fp32 pass uncertain (up to 2e-3 of a cam's
+# largest entry, 2e-2 for the small LRP R_t_i map -- measured: the fixtures also hold the reference's pass run in float64, "f64__").
+# The yardstick is that distance (tests/test_bert_lrp_host.py::within_reference_noise): a result must be as close to the
+# reference's float64 values as the reference's float32 values are, within a factor of 4; measured errors go to the parity record.
+def in_noise(got, g, key, what):
+    from parity import note
+    from test_bert_lrp_host import within_reference_noise
+    err, noise, top = within_reference_noise(got, g, key, what=what)
+    note(what + " (vs reference fp64; bound = 4 x the reference's fp32-vs-fp64 distance)", err, 4 * noise + 1e-5 * top, top)
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,D", [(2, 3, 20, 36, 64), (1, 12, 70, 70, 64), (2, 2, 9, 5, 16)])
@@ -173,26 +174,26 @@ def test_lxmert_default_generate_ours_runs_the_lrp_pass(golden):
     gen = le.GeneratorOurs(usage)
     R_t_t, R_t_i = gen.generate_ours(None)
     for name, module in lxmert_cams(model).items():
-        rel_close(module.get_attn_cam(), g["cam__" + name], what="lxmert attn_cam " + name)
-    close(R_t_t, g["R_t_t"], what="lxmert lrp R_t_t")
-    close(R_t_i, g["R_t_i"], what="lxmert lrp R_t_i")
-    close(gen.R_i_i, g["R_i_i"], what="lxmert lrp R_i_i")
-    close(gen.R_i_t, g["R_i_t"], what="lxmert lrp R_i_t")
+        in_noise(module.get_attn_cam(), g, "cam__" + name, "lxmert attn_cam " + name)
+    in_noise(R_t_t, g, "R_t_t", "lxmert lrp R_t_t")
+    in_noise(R_t_i, g, "R_t_i", "lxmert lrp R_t_i")
+    in_noise(gen.R_i_i, g, "R_i_i", "lxmert lrp R_i_i")
+    in_noise(gen.R_i_t, g, "R_i_t", "lxmert lrp R_i_t")
     base = le.GeneratorBaselines(usage)
     a, b = base.generate_transformer_attr(None)
-    close(a, g["transformer_attr_R_t_t"], what="lxmert transformer_attr R_t_t")
-    close(b, g["transformer_attr_R_t_i"], what="lxmert transformer_attr R_t_i")
+    in_noise(a, g, "transformer_attr_R_t_t", "lxmert transformer_attr R_t_t")
+    in_noise(b, g, "transformer_attr_R_t_i", "lxmert transformer_attr R_t_i")
     a, b = base.generate_partial_lrp(None)
-    close(a, g["partial_lrp_R_t_t"], what="lxmert partial_lrp R_t_t")
-    close(b, g["partial_lrp_R_t_i"], what="lxmert partial_lrp R_t_i")
+    in_noise(a, g, "partial_lrp_R_t_t", "lxmert partial_lrp R_t_t")
+    in_noise(b, g, "partial_lrp_R_t_i", "lxmert partial_lrp R_t_i")
     # the relevance handed back for the encoder inputs, through the model's own entry point
     out = usage.forward(None).question_answering_score
     one_hot = torch.zeros_like(out)
     one_hot[0, int(g["index"])] = 1
     torch.sum(one_hot * out).backward()
     cam_lang, cam_vis = model.relprop(one_hot.clone(), alpha=1)
-    rel_close(cam_lang, g["cam_lang"], what="lxmert cam_lang")
-    rel_close(cam_vis, g["cam_vis"], what="lxmert cam_vis")
+    in_noise(cam_lang, g, "cam_lang", "lxmert cam_lang")
+    in_noise(cam_vis, g, "cam_vis", "lxmert cam_vis")
 
 
 def test_visualbert_lrp_methods_run_on_the_bodys_own_pass(golden):
@@ -208,12 +209,12 @@ def test_visualbert_lrp_methods_run_on_the_bodys_own_pass(golden):
         return {"input_ids": cu(gm["input_ids"]), "input_mask": cu(gm["input_mask"]),
                 "segment_ids": torch.zeros_like(cu(gm["input_ids"])), "image_feature_0": cu(gm["image_feature_0"])}
 
-    close(vb.SelfAttentionGenerator(model).generate_transformer_att(sample()), g["transformer_att_out"],
-          what="visualbert transformer_att")
-    for i, b in enumerate(model.model.bert.encoder.layer):
-        rel_close(b.attention.self.get_attn_cam(), g["attn_cam"][i], what="visualbert attn_cam %d" % i)
-    close(vb.SelfAttentionGenerator(model).generate_partial_lrp(sample()), g["partial_lrp_out"], what="visualbert partial_lrp")
+    in_noise(vb.SelfAttentionGenerator(model).generate_transformer_att(sample()), g, "transformer_att_out",
+             "visualbert transformer_att")
+    in_noise(torch.stack([b.attention.self.get_attn_cam() for b in model.model.bert.encoder.layer]), g, "attn_cam",
+             "visualbert attn_cam")
+    in_noise(vb.SelfAttentionGenerator(model).generate_partial_lrp(sample()), g, "partial_lrp_out", "visualbert partial_lrp")
     out = model(sample())["scores"]
     one_hot = torch.zeros_like(out)
     one_hot[0, int(g["index"])] = 1
-    rel_close(model.relprop(one_hot, alpha=1), g["cam_input"], what="visualbert cam_input")
+    in_noise(model.relprop(one_hot, alpha=1), g, "cam_input", "visualbert cam_input")
