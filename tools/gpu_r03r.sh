@@ -1,0 +1,15 @@
+#!/bin/bash
+# r03r: LXMERT two-stream tape path + fast perturbation forward; DETR rows-route kernel trace
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/r03r; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_gpu_perturbation.py tests/test_gpu_generators.py tests/test_gpu_lrp.py tests/test_gpu_lrp_route.py -q -x 2>&1 | tail -8 | tee $OUT/pytest.txt
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --legs cfg4,cfg3 > $OUT/bench.json 2> $OUT/bench.log; tail -3 $OUT/bench.log
+python - <<'P'
+import json
+d=json.loads(open("gpurun_out/r03r/bench.json").read().strip().splitlines()[-1])
+for k,v in d["configs"].items(): print(k, {kk:vv for kk,vv in v.items() if kk in ("rate","ms","explain_ms","perturb_ms","K10","K20")})
+P
+timeout 300 python tools/probe_lxmert_pert.py 2>&1 | tail -6 | tee $OUT/lxmert_probe.txt
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_detr -o detr -- python tools/probe_detr_trace.py 5 10 rows > /dev/null 2> $OUT/trace_detr.log
+python tools/prof_summary.py $OUT/trace_detr/detr_results.db "" 2>&1 | head -45 | cut -c1-190 > $OUT/detr_rows_kernels.txt; cat $OUT/detr_rows_kernels.txt
+rm -rf $OUT/trace_detr

@@ -16,6 +16,7 @@ Things a caller can observe:
 """
 from __future__ import annotations
 
+import contextlib
 import types
 from dataclasses import dataclass
 
@@ -23,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import bert_lrp, bert_tape as bt, lrp
+from . import bert_lrp, bert_tape as bt, lrp, ops
 from .attention_modules import BertStyleAttention
 
 
@@ -189,22 +190,32 @@ class LxmertXLayer(nn.Module):                                         # lxmert_
         vis_in = self.visual_attention_copy.att._lrp_tape["hidden"]
         return lrp.clone_relprop((cam_lang1, cam_lang2), lang_in), lrp.clone_relprop((cam_vis1, cam_vis2), vis_in)
 
-    def forward_tape(self, lang, lang_mask, visn, visn_mask):
-        """Same computation as ``forward`` on the tape (``bert_tape``) -> ``(lang, visn, tape)``."""
+    def forward_tape(self, lang, lang_mask, visn, visn_mask, side=None):
+        """Same computation as ``forward`` on the tape (``bert_tape``) -> ``(lang, visn, tape)``.
+
+        After the two cross-attentions read both inputs, the layer is two independent chains (text: cross -> self -> FFN;
+        image: the same).  ``side``: a stream for the image chain -- the caller has made both streams wait for each other,
+        ``lang`` / everything returned for the text chain lives on the current stream, ``visn`` and the image chain on ``side``."""
         va, vc = self.visual_attention, self.visual_attention_copy
+        side_ctx = contextlib.nullcontext() if side is None else torch.cuda.stream(side)
+        if side is not None:          # each input is read on the other chain's stream too: its block must outlive those reads
+            lang.record_stream(side)
+            visn.record_stream(torch.cuda.current_stream())
         ctx_l, t_al = bt.attention_fwd(va.att, lang, visn, visn_mask)            # text -> image
         lang1, t_ol = bt.dense_add_norm_fwd(va.output, ctx_l, lang)
-        ctx_v, t_av = bt.attention_fwd(vc.att, visn, lang, lang_mask)            # image -> text (the same weights)
-        visn1, t_ov = bt.dense_add_norm_fwd(vc.output, ctx_v, visn)
         lang2, t_sl = bt.self_block_fwd(self.lang_self_att, lang1, lang_mask)
-        visn2, t_sv = bt.self_block_fwd(self.visn_self_att, visn1, visn_mask)
         lang3, t_fl = bt.ffn_fwd(self.lang_inter, self.lang_output, lang2)
-        visn3, t_fv = bt.ffn_fwd(self.visn_inter, self.visn_output, visn2)
+        with side_ctx:
+            ctx_v, t_av = bt.attention_fwd(vc.att, visn, lang, lang_mask)        # image -> text (the same weights)
+            visn1, t_ov = bt.dense_add_norm_fwd(vc.output, ctx_v, visn)
+            visn2, t_sv = bt.self_block_fwd(self.visn_self_att, visn1, visn_mask)
+            visn3, t_fv = bt.ffn_fwd(self.visn_inter, self.visn_output, visn2)
         return lang3, visn3, (t_al, t_ol, t_av, t_ov, t_sl, t_sv, t_fl, t_fv)
 
-    def backward_tape(self, tape, d_lang3, d_visn3):
+    def backward_tape(self, tape, d_lang3, d_visn3, side=None):
         """Gradients w.r.t. the block outputs -> gradients w.r.t. its inputs ``(d_lang, d_visn)``; ``d_visn3`` may be ``None``
-        (the top x-layer: the answer reads the language stream only)."""
+        (the top x-layer: the answer reads the language stream only).  ``side``: as in ``forward_tape`` (``d_visn3`` and the
+        returned ``d_visn`` live on it; the two chains meet once, for the cross terms)."""
         t_al, t_ol, t_av, t_ov, t_sl, t_sv, t_fl, t_fv = tape
         va, vc = self.visual_attention, self.visual_attention_copy
         d_lang1 = bt.self_block_bwd(self.lang_self_att, t_sl, bt.ffn_bwd(self.lang_inter, self.lang_output, t_fl, d_lang3))
@@ -215,13 +226,31 @@ class LxmertXLayer(nn.Module):                                         # lxmert_
             self.visn_self_att.self.get_attn_gradients().zero_()
             vc.att.get_attn_gradients().zero_()
             d_lang, d_visn = bt.attention_bwd(va.att, t_al, d_ctx_l, True, d_hidden_res=d_lang_res)
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())                 # d_visn moves to the image chain's stream
+                d_visn.record_stream(side)
             return d_lang, d_visn
-        d_visn1 = bt.self_block_bwd(self.visn_self_att, t_sv, bt.ffn_bwd(self.visn_inter, self.visn_output, t_fv, d_visn3))
-        d_ctx_v, d_visn_res = bt.dense_add_norm_bwd(vc.output, t_ov, d_visn1)
-        # lang1 = LN(dense(att(lang, visn)) + lang):  d_lang = residual + query side, d_visn <- key / value side
-        d_lang, d_visn_kv = bt.attention_bwd(va.att, t_al, d_ctx_l, True, d_hidden_res=d_lang_res)
-        # visn1 = LN(dense(att(visn, lang)) + visn):  d_visn = residual + query side (+ the kv side above), d_lang += kv side
-        d_visn, d_lang = bt.attention_bwd(vc.att, t_av, d_ctx_v, True, d_hidden_res=d_visn_res + d_visn_kv, d_ctx_res=d_lang)
+        if side is None:
+            d_visn1 = bt.self_block_bwd(self.visn_self_att, t_sv, bt.ffn_bwd(self.visn_inter, self.visn_output, t_fv, d_visn3))
+            d_ctx_v, d_visn_res = bt.dense_add_norm_bwd(vc.output, t_ov, d_visn1)
+            # lang1 = LN(dense(att(lang, visn)) + lang):  d_lang = residual + query side, d_visn <- key / value side
+            d_lang, d_visn_kv = bt.attention_bwd(va.att, t_al, d_ctx_l, True, d_hidden_res=d_lang_res)
+            # visn1 = LN(dense(att(visn, lang)) + visn):  d_visn = residual + query side (+ the kv side above), d_lang += kv side
+            d_visn, d_lang = bt.attention_bwd(vc.att, t_av, d_ctx_v, True, d_hidden_res=d_visn_res + d_visn_kv, d_ctx_res=d_lang)
+            return d_lang, d_visn
+        main = torch.cuda.current_stream()
+        d_lang_q, d_visn_kv = bt.attention_bwd(va.att, t_al, d_ctx_l, True, d_hidden_res=d_lang_res)
+        with torch.cuda.stream(side):
+            d_visn1 = bt.self_block_bwd(self.visn_self_att, t_sv, bt.ffn_bwd(self.visn_inter, self.visn_output, t_fv, d_visn3))
+            d_ctx_v, d_visn_res = bt.dense_add_norm_bwd(vc.output, t_ov, d_visn1)
+            d_visn_q, d_lang_kv = bt.attention_bwd(vc.att, t_av, d_ctx_v, True, d_hidden_res=d_visn_res)
+        main.wait_stream(side)
+        side.wait_stream(main)
+        d_lang_kv.record_stream(main)                                        # made on one stream, consumed on the other
+        d_visn_kv.record_stream(side)
+        d_lang = d_lang_q.add_(d_lang_kv)
+        with torch.cuda.stream(side):
+            d_visn = d_visn_q.add_(d_visn_kv)
         return d_lang, d_visn
 
 
@@ -270,29 +299,52 @@ class LxmertEncoder(nn.Module):                                        # lxmert_
         return cam_lang, cam_vis
 
     # ---- tape path of the explainability pass (bert_tape.py): no autograd graph, no weight gradients
+    overlap_modalities = True     # tape path: the image chain of every layer group on a side stream beside the text chain
+
     def forward_tape(self, lang, lang_mask, visual_feats, visual_pos, visn_mask=None):
-        visn = self.visn_fc(visual_feats, visual_pos)
-        tapes = {"l": [], "r": [], "x": []}
+        """The 9 language layers and the 5 object-relationship layers are independent of each other, and so are the two chains
+        of every cross-modality layer after its cross-attentions (``LxmertXLayer.forward_tape``): at the batch sizes of an
+        explainability pass these are 448- / 1152-row GEMMs that each fill a fraction of the chip, so the image chain runs on a
+        side stream beside the text chain (fork / join inside one hipGraph when captured)."""
+        main = torch.cuda.current_stream()
+        side = ops.side_stream(lang.device, "lxmert") if self.overlap_modalities else None
+        tapes = {"l": [], "r": [], "x": [], "side": side}
+        if side is not None:
+            side.wait_stream(main)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            visn = self.visn_fc(visual_feats, visual_pos)
+            for blk in self.r_layers:
+                visn, t = bt.layer_fwd(blk, visn, visn_mask)
+                tapes["r"].append(t)
         for blk in self.layer:
             lang, t = bt.layer_fwd(blk, lang, lang_mask)
             tapes["l"].append(t)
-        for blk in self.r_layers:
-            visn, t = bt.layer_fwd(blk, visn, visn_mask)
-            tapes["r"].append(t)
         for blk in self.x_layers:
-            lang, visn, t = blk.forward_tape(lang, lang_mask, visn, visn_mask)
+            if side is not None:                                      # each chain reads the other's output of the layer below
+                main.wait_stream(side)
+                side.wait_stream(main)
+            lang, visn, t = blk.forward_tape(lang, lang_mask, visn, visn_mask, side)
             tapes["x"].append(t)
+        if side is not None:
+            main.wait_stream(side)
         return lang, visn, tapes
 
     def backward_tape(self, tapes, d_lang, d_visn=None):
         """``d_lang [B, T, E]`` (and optionally ``d_visn``): gradients w.r.t. the encoder outputs; fills the gradient slab of
         every attention block (the lowest block of each stream skips its input gradients: nothing below reads them)."""
+        side = tapes.get("side")
+        main = torch.cuda.current_stream()
+        if side is not None:
+            side.wait_stream(main)
         for blk, t in zip(reversed(self.x_layers), reversed(tapes["x"])):
-            d_lang, d_visn = blk.backward_tape(t, d_lang, d_visn)
-        for i in range(len(self.r_layers) - 1, -1, -1):
-            d_visn = bt.layer_bwd(self.r_layers[i], tapes["r"][i], d_visn, need_input=i > 0)
+            d_lang, d_visn = blk.backward_tape(t, d_lang, d_visn, side)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            for i in range(len(self.r_layers) - 1, -1, -1):
+                d_visn = bt.layer_bwd(self.r_layers[i], tapes["r"][i], d_visn, need_input=i > 0)
         for i in range(len(self.layer) - 1, -1, -1):
             d_lang = bt.layer_bwd(self.layer[i], tapes["l"][i], d_lang, need_input=i > 0)
+        if side is not None:
+            main.wait_stream(side)
 
 
 class LxmertPooler(nn.Module):                                         # lxmert_lrp.py:868-884
@@ -409,6 +461,23 @@ class LxmertForQuestionAnswering(nn.Module):                           # lxmert_
         with torch.enable_grad():
             scores = self.answer_head(torch.tanh(m.pooler.dense(cls)))
         return scores, (tapes, cls, scores, lang.shape)
+
+    @torch.no_grad()
+    def scores_no_grad(self, input_ids=None, visual_feats=None, visual_pos=None, attention_mask=None,
+                       visual_attention_mask=None, token_type_ids=None, inputs_embeds=None, **unused):
+        """``forward(...).question_answering_score`` through the tape forward (packed q / k / v GEMMs, fused bias / add /
+        LayerNorm, the two modalities side by side) without keeping anything for a backward -- what the perturbation evaluator's
+        re-runs need (lxmert/lxmert/perturbation.py:119-131).  An empty region set takes the module forward."""
+        if visual_feats.shape[1] == 0 or input_ids is None:
+            return self.forward(input_ids, visual_feats, visual_pos, attention_mask, visual_attention_mask, token_type_ids,
+                                inputs_embeds).question_answering_score
+        m = self.lxmert
+        emb = m.embeddings(input_ids, token_type_ids, inputs_embeds)
+        if attention_mask is None:
+            attention_mask = torch.ones(emb.shape[:2], device=emb.device)
+        lang, _, _ = m.encoder.forward_tape(emb, _extended_mask(attention_mask, emb.dtype), visual_feats, visual_pos,
+                                            _extended_mask(visual_attention_mask, emb.dtype))
+        return self.answer_head(m.pooler(lang))
 
     @torch.no_grad()
     def backward_tape(self, state, d_scores):

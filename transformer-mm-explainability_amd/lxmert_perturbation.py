@@ -109,6 +109,11 @@ class LxmertPerturbation:
         self.model = model
         self.steps = tuple(steps)
 
+    def _scores(self, **kw):
+        """Answer scores of one batched re-run: the body's grad-free fast forward when it has one."""
+        fast = getattr(self.model, "scores_no_grad", None)
+        return fast(**kw) if fast is not None else self.model(**kw).question_answering_score
+
     @staticmethod
     def _rep(x, S):
         return x.repeat_interleave(S, dim=0)
@@ -126,18 +131,18 @@ class LxmertPerturbation:
         if live:
             rows = torch.tensor(live, device=keep.device)
             n = len(live)
-            out = self.model(input_ids=self._rep(inputs["input_ids"], n),
+            out = self._scores(input_ids=self._rep(inputs["input_ids"], n),
                              attention_mask=self._rep(inputs["attention_mask"], n),
                              token_type_ids=self._rep(inputs["token_type_ids"], n),
                              visual_feats=self._rep(inputs["visual_feats"], n),
                              visual_pos=self._rep(inputs["visual_pos"], n),
-                             visual_attention_mask=keep[:, rows].reshape(B * n, I)).question_answering_score
+                               visual_attention_mask=keep[:, rows].reshape(B * n, I))
             scores = out.new_empty(B, S, out.shape[-1])
             scores[:, rows] = out.reshape(B, n, -1)
         if len(live) < S:                                    # steps that keep no region at all: region-free forward
-            out = self.model(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
-                             token_type_ids=inputs["token_type_ids"], visual_feats=inputs["visual_feats"][:, :0],
-                             visual_pos=inputs["visual_pos"][:, :0]).question_answering_score
+            out = self._scores(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
+                               token_type_ids=inputs["token_type_ids"], visual_feats=inputs["visual_feats"][:, :0],
+                               visual_pos=inputs["visual_pos"][:, :0])
             if scores is None:
                 scores = out.new_empty(B, S, out.shape[-1])
             dead = torch.tensor([s for s in range(S) if s not in live], device=keep.device)
@@ -155,9 +160,8 @@ class LxmertPerturbation:
         parts = [text_keep_batch(inputs["input_ids"][b:b + 1], inputs["token_type_ids"][b:b + 1], cams[b], self.steps,
                                  is_positive_pert, n_tokens=lens[b]) for b in range(B)]
         ids, types, mask = (torch.cat([p[k] for p in parts]) for k in range(3))                     # [B*S, T]
-        out = self.model(input_ids=ids, attention_mask=mask, token_type_ids=types,
-                         visual_feats=self._rep(inputs["visual_feats"], S),
-                         visual_pos=self._rep(inputs["visual_pos"], S)).question_answering_score
+        out = self._scores(input_ids=ids, attention_mask=mask, token_type_ids=types,
+                           visual_feats=self._rep(inputs["visual_feats"], S), visual_pos=self._rep(inputs["visual_pos"], S))
         out = out.reshape(B, S, -1)
         return out[0] if single else out
 

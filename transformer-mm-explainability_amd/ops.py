@@ -65,6 +65,19 @@ def _workspace(nbytes, device, tag="default"):
     return buf
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(device, slot=0):
+    """A side stream per (device, slot), created once (a hipGraph capture must not create streams): independent chains of an
+    explainability pass -- CLIP's two towers, LXMERT's two modalities -- run on it beside the current stream."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), slot)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key[0])
+    return _SIDE_STREAMS[key]
+
+
 @contextlib.contextmanager
 def graph_capture(graph):
     """``torch.cuda.graph(graph, capture_error_mode="thread_local")`` with Python's cyclic garbage collector held off for
