@@ -288,6 +288,37 @@ def test_attn_capture_fwd_bwd(ops, B, H, Nq, Nk, D, mode, masked, path):
     assert torch.equal(dprobs, dprobs2)
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,D,mode,masked", [(1, 8, 950, 950, 32, 0, False), (1, 8, 100, 950, 32, 0, False),
+                                                     (1, 3, 37, 130, 20, 1, True), (2, 2, 16, 65, 32, 0, True),
+                                                     (1, 1, 5, 300, 8, 0, False)])
+def test_attn_fwd_small_grid_split_kernel(ops, B, H, Nq, Nk, D, mode, masked):
+    """``attn_fwd_split_kernel`` (16-row workgroups whose four waves split the keys: the shared forward of DETR's K-query pass)
+    against the fp64 softmax and against the 64-row streaming kernel it replaces on small grids (option ``attn_fwd_split``)."""
+    ops.set_option("attn_head", 0)
+    ops.set_option("attn_small", 0)
+    g = torch.Generator().manual_seed(Nq * 5 + Nk)
+    q, k, v = (torch.randn(B, n, H, D, generator=g) for n in (Nq, Nk, Nk))
+    scale = D ** -0.5 if mode == 0 else D ** 0.5
+    mask = (torch.randn(B, 1, Nk, generator=g) > 1.0).float() * -10000.0 if masked else None
+    p_ref, o_ref = torch_attention(*(t.permute(0, 2, 1, 3) for t in (q, k, v)), scale, mode,
+                                   None if mask is None else mask[:, None])
+    outs = []
+    try:
+        for split in (1, 0):
+            ops.set_option("attn_fwd_split", split)
+            probs = torch.full((B, H, Nq, Nk), float("nan"), device="cuda")
+            o = ops.attn_capture_fwd(q.cuda(), k.cuda(), v.cuda(), probs, scale, mode, mask.cuda() if masked else None)
+            close(probs, p_ref.float().numpy(), atol=2e-6)
+            close(o.permute(0, 2, 1, 3), o_ref.float().numpy(), atol=1e-5)
+            outs.append((probs, o))
+    finally:
+        ops.set_option("attn_fwd_split", 1)
+        ops.set_option("attn_head", 1)
+        ops.set_option("attn_small", 1)
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=0, atol=1e-6)       # the same softmax, other summation order
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=0, atol=2e-6)
+
+
 @pytest.mark.parametrize("shape", [(4928, 2048), (7, 13), (1, 3), (3, 4)])
 def test_quick_gelu_fused(ops, shape):
     g = torch.Generator().manual_seed(sum(shape))
@@ -390,9 +421,11 @@ def test_attn_capture_half_precision_slabs(ops, dtype, rel, B, H, Nq, Nk, D, mas
     p32 = torch.empty(B, H, Nq, Nk, device="cuda")
     dp32 = torch.empty_like(p32)
     ops.set_option("attn_small", 0)                                      # fp32 reference on the same (streaming) kernels
+    ops.set_option("attn_fwd_split", 0)                                  # (half-precision slabs always take the 64-row forward)
     o32 = ops.attn_capture_fwd(q, k, v, p32, scale, 0, mask)
     ops.attn_capture_bwd(q, k, v, p32, d_o, dp32, scale, 0)
     ops.set_option("attn_small", 1)
+    ops.set_option("attn_fwd_split", 1)
     p16 = torch.empty(B, H, Nq, Nk, device="cuda", dtype=dtype)
     dp16 = torch.empty_like(p16)
     o16 = ops.attn_capture_fwd(q, k, v, p16, scale, 0, mask)

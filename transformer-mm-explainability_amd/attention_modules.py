@@ -138,13 +138,33 @@ class MultiheadAttention(_SlabOwner):
 
 
     # ---- shared-forward mode (one forward at batch 1, K upstream gradients): batch-first tensors
-    def forward_shared(self, query, key, value, batch):
+    def forward_shared(self, query, key, value, batch, kv=None):
         """``query [1, T, E]``, ``key`` / ``value [1, S, E]``.  Returns ``(out [1, T, E], tape)``; ``get_attn()`` then is
-        the ONE ``[H, T, S]`` slab and ``get_attn_gradients()`` the ``[batch*H, T, S]`` slab ``backward_shared`` fills."""
-        T, S, H, D = query.shape[1], key.shape[1], self.num_heads, self.head_dim
-        q = self.q_proj(query).view(1, T, H, D)
-        k = self.k_proj(key).view(1, S, H, D)
-        v = self.v_proj(value).view(1, S, H, D)
+        the ONE ``[H, T, S]`` slab and ``get_attn_gradients()`` the ``[batch*H, T, S]`` slab ``backward_shared`` fills.
+        ``key is query`` (DETR's self-attentions: q = k = x + pos): q and k come out of ONE GEMM against the packed
+        ``[Wq; Wk]``.  ``kv = (k, v)`` ``[1, S, H, D]`` views: projections the caller already has (the decoder's
+        cross-attentions read the same memory in every layer: all layers' keys / values are two GEMMs)."""
+        T, H, D = query.shape[1], self.num_heads, self.head_dim
+        if kv is not None:
+            q = self.q_proj(query).view(1, T, H, D)
+            k, v = kv
+        elif key is query:
+            from .bert_tape import packed_linear
+            W, b = packed_linear((self.q_proj, self.k_proj))
+            # the value projection beside the q / k one: at one sample these are launch-latency-sized GEMMs
+            main, side = torch.cuda.current_stream(), ops.side_stream(query.device, "mha_value")
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                v = self.v_proj(value).view(1, -1, H, D)
+            qk = torch.addmm(b, query.reshape(T, -1), W.t()).view(1, T, 2, H, D)
+            q, k = qk[:, :, 0], qk[:, :, 1]
+            main.wait_stream(side)
+            v.record_stream(main)
+        else:
+            q = self.q_proj(query).view(1, T, H, D)
+            k = self.k_proj(key).view(1, -1, H, D)
+            v = self.v_proj(value).view(1, -1, H, D)
+        S = k.shape[1]
         dev = query.device
         if self._probs is None or tuple(self._probs.shape) != (1, H, T, S) or self._probs.device != dev:
             self._probs = torch.empty(1, H, T, S, dtype=torch.float32, device=dev)
@@ -171,6 +191,39 @@ class MultiheadAttention(_SlabOwner):
         return (ops.backward_gemm(dq.reshape(K, T, E), self.q_proj.weight, gemm_dtype),
                 ops.backward_gemm(dk.reshape(K, -1, E), self.k_proj.weight, gemm_dtype),
                 ops.backward_gemm(dv.reshape(K, -1, E), self.v_proj.weight, gemm_dtype))
+
+    @torch.no_grad()
+    def backward_shared_into(self, tape, d_out, acc_q, acc_kv=None, same_source=True, kv_weights=None):
+        """``backward_shared`` with the input-gradient GEMMs ACCUMULATING (beta = 1) into buffers the caller owns, fp32.
+
+        ``same_source=True`` (self-attention whose q, k and v inputs are the same tensor up to the constant positional term):
+        the attention backward writes one packed ``[K, T, 3, H, D]`` gradient and ``acc_q [K, T, E] += [dq | dk | dv] .
+        [Wq; Wk; Wv]`` is ONE GEMM (instead of three GEMMs and three adds).  Returns ``acc_q``.
+        ``same_source=False`` (cross-attention): ``acc_q += dq . Wq``; ``acc_kv [K, S, E] += [dk | dv] . [Wk; Wv]`` (``acc_kv=None``:
+        a fresh product).  ``kv_weights``: the packed ``[2E, E]`` weight when the caller holds it.  Returns ``(acc_q, acc_kv)``."""
+        from .bert_tape import packed_linear
+        q, k, v, o_fwd = tape
+        K, T, E = d_out.shape[0], d_out.shape[1], self.embed_dim
+        H, D = self.num_heads, self.head_dim
+        d_o = torch.matmul(d_out, self.out_proj.weight).view(K, T, H, D)
+        scale = float(D) ** -0.5
+        if same_source:
+            dqkv = torch.empty(K, T, 3, H, D, dtype=torch.float32, device=d_out.device)
+            ops.attn_capture_bwd(q, k, v, self._probs, d_o, self._grads, scale, _lib.SCALE_Q_FIRST, need_dqkv=True,
+                                 layout="bnhd", batch=K, o=o_fwd, out=(dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]))
+            W, _ = packed_linear((self.q_proj, self.k_proj, self.v_proj))
+            acc_q.view(K * T, E).addmm_(dqkv.view(K * T, 3 * E), W)
+            return acc_q
+        S = k.shape[1]
+        dq = torch.empty(K, T, H, D, dtype=torch.float32, device=d_out.device)
+        dkv = torch.empty(K, S, 2, H, D, dtype=torch.float32, device=d_out.device)
+        ops.attn_capture_bwd(q, k, v, self._probs, d_o, self._grads, scale, _lib.SCALE_Q_FIRST, need_dqkv=True,
+                             layout="bnhd", batch=K, o=o_fwd, out=(dq, dkv[:, :, 0], dkv[:, :, 1]))
+        acc_q.view(K * T, E).addmm_(dq.view(K * T, E), self.q_proj.weight)
+        W = kv_weights if kv_weights is not None else packed_linear((self.k_proj, self.v_proj))[0]
+        flat = dkv.view(K * S, 2 * E)
+        acc_kv = torch.mm(flat, W).view(K, S, E) if acc_kv is None else acc_kv.view(K * S, E).addmm_(flat, W).view(K, S, E)
+        return acc_q, acc_kv
 
 
 class BertStyleAttention(_SlabOwner):

@@ -32,6 +32,7 @@ constexpr int kThreads = 256;
 constexpr int kPS = kTile + 4; // row stride of a wave's private [16][64] P / dS tile (16-byte rows, conflict-free b128)
 
 int g_attn_stream = 1;
+int g_attn_fwd_split = 1;   // option "attn_fwd_split": the small-grid forward (attn_fwd_split_kernel)
 
 // exp(x) = 2^(x log2 e) on the hardware v_exp_f32 (1 ulp).  The rounding of x * log2(e) adds |x| * 6e-8 of relative
 // error; the ABSOLUTE error of a probability p = exp(x) is then at most max_x |x| e^x * 6e-8 = 2.2e-8, and its relative
@@ -377,6 +378,187 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_ke
         for (int r = 0; r < 4; ++r)
             if (rows[r] < a.Nq && 16 * dt + i < a.D)
                 ob[static_cast<int64_t>(rows[r]) * a.os.sn + 16 * dt + i] = oacc[0][dt][r] + oacc[1][dt][r];
+}
+
+// =============================================================================================== forward, small grids
+// One shared forward (DETR's K kept queries of ONE image: B = 1, 8 heads, 950 tokens) gives the kernel above 15 x 8 = 120
+// workgroups, each walking all 15 key tiles twice behind workgroup barriers: 67 us for 0.9 GFLOP.  Here a workgroup owns 16
+// query rows and its four waves SPLIT THE KEYS (wave w takes tiles w, w + 4, ...), each staging its own tiles in a private
+// LDS region (no workgroup barrier inside the sweeps; a wave's LDS traffic is in order).  The per-wave softmax statistics
+// and partial O = P.V are merged through LDS: 4x the workgroups, a quarter of the serial tile chain each.  Exact fp32, fp32
+// slabs, head_dim <= 32 (the per-wave K + V tiles of a 64-wide head would not fit).
+template <int DP>
+struct WaveTileRegs {
+    f32x4 raw[DP / 4];
+    int row0;
+};
+template <int DP>
+__device__ __forceinline__ void wave_tile_fetch(WaveTileRegs<DP>& reg, const float* base, int64_t sn, int row0, int rows_total,
+                                                int D, int lane) {
+    constexpr int C4 = DP / 4;
+    reg.row0 = row0;
+#pragma unroll
+    for (int e = 0; e < DP / 4; ++e) {
+        const int f = lane + 64 * e;
+        const int row = row0 + f / C4, c = (f % C4) * 4;
+        const bool ok = row < rows_total && c < D;
+        reg.raw[e] = *reinterpret_cast<const f32x4*>(base + (ok ? static_cast<int64_t>(row) * sn + c : 0));
+    }
+}
+template <int DP>
+__device__ __forceinline__ void wave_tile_store(float* lds, const WaveTileRegs<DP>& reg, int rows_total, int D, int lane) {
+    constexpr int C4 = DP / 4, LS = DP + 4;
+#pragma unroll
+    for (int e = 0; e < DP / 4; ++e) {
+        const int f = lane + 64 * e;
+        const bool ok = reg.row0 + f / C4 < rows_total && (f % C4) * 4 < D;
+        *reinterpret_cast<f32x4*>(lds + (f / C4) * LS + (f % C4) * 4) = ok ? reg.raw[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_wave_barrier();          // keep the compiler from moving this wave's tile reads above the stores
+}
+
+template <int DP>
+constexpr size_t split_lds_bytes() {
+    return sizeof(float) * (4 * (2 * kTile * (DP + 4) + 16 * kPS) + 4 * 16 * 2 + 4 * 16 * DP);
+}
+
+template <int DP>
+__global__ __launch_bounds__(kThreads, 1) void attn_fwd_split_kernel(const AttnFwdArgs a) {
+    constexpr int LS = DP + 4, NB = DP / 16, kWave = 2 * kTile * LS + 16 * kPS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    float* Ks = smem + wave * kWave;
+    float* Vs = Ks + kTile * LS;
+    float* Pw = Vs + kTile * LS;
+    float* stat = smem + 4 * kWave;                       // [4 waves][16 rows][max, sum]
+    float* opart = stat + 4 * 16 * 2;                     // [4 waves][16 rows][DP]
+    const int nrt = (a.Nq + 15) / 16;
+    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int h = (wg / nrt) % a.H, b = wg / (nrt * a.H);
+    const int rw = (wg % nrt) * 16;                       // the 16 query rows of this workgroup (all four waves)
+    const float* qb = a.q + b * a.qs.sb + h * a.qs.sh;
+    const float* kb = a.k + b * a.ks.sb + h * a.ks.sh;
+    const float* vb = a.v + b * a.vs.sb + h * a.vs.sh;
+    const bool q_first = (a.scale_mode == MMX_SCALE_Q_FIRST);
+    const float ninf = -__builtin_inff();
+
+    f32x4 qa[NB];
+    load_a_rows<DP>(qa, qb, a.qs.sn, min(rw + i, a.Nq - 1), a.D, g, q_first ? a.scale : 1.f);
+    int rows[4];
+    const float* mrow[4];
+    float* pout[4];
+    const int64_t pbase = (static_cast<int64_t>(b) * a.H + h) * a.Nq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        rows[r] = rw + 4 * g + r;
+        mrow[r] = a.mask ? a.mask + b * a.mask_sb + static_cast<int64_t>(min(rows[r], a.Nq - 1)) * a.mask_sq : nullptr;
+        pout[r] = rows[r] < a.Nq ? a.probs + (pbase + rows[r]) * a.Nk + i : nullptr;
+    }
+    auto score = [&](float sc, int r, int k0) {           // every tile takes the key-range test here (few tiles per wave)
+        if (!q_first) sc = sc / a.scale;
+        if (a.mask) sc += mrow[r][min(k0 + i, a.Nk - 1)];
+        return k0 + i < a.Nk ? sc : ninf;
+    };
+    const int ntiles = (a.Nk + kTile - 1) / kTile;
+    WaveTileRegs<DP> kreg, vreg;
+
+    // ---- sweep 1 over this wave's tiles: lane-local running max / sum
+    float m[4] = {ninf, ninf, ninf, ninf}, l[4] = {0.f, 0.f, 0.f, 0.f};
+    if (wave < ntiles) wave_tile_fetch<DP>(kreg, kb, a.ks.sn, wave * kTile, a.Nk, a.D, lane);
+    for (int kt = wave; kt < ntiles; kt += 4) {
+        wave_tile_store<DP>(Ks, kreg, a.Nk, a.D, lane);
+        if (kt + 4 < ntiles) wave_tile_fetch<DP>(kreg, kb, a.ks.sn, (kt + 4) * kTile, a.Nk, a.D, lane);
+        f32x4 sacc[4];
+        tile_abt4<DP>(sacc, qa, Ks, i, g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float sv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sv[t] = score(sacc[t][r], r, kt * kTile + 16 * t);
+            const float mn = fmaxf(fmaxf(m[r], fmaxf(sv[0], sv[1])), fmaxf(sv[2], sv[3]));
+            const float base = (mn == ninf) ? 0.f : mn;
+            l[r] = l[r] * exp_fast(m[r] - base) + exp_fast(sv[0] - base) + exp_fast(sv[1] - base) +
+                   exp_fast(sv[2] - base) + exp_fast(sv[3] - base);
+            m[r] = mn;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // this wave's statistics per row, then the four waves' (a fully masked row ends as 0 * inf = NaN like torch.softmax)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float mall = group16_max(m[r]);
+        const float base = (mall == ninf) ? 0.f : mall;
+        const float lw = group16_sum(l[r] * exp_fast(m[r] - base));
+        if (i == 0) {
+            stat[(wave * 16 + 4 * g + r) * 2] = mall;
+            stat[(wave * 16 + 4 * g + r) * 2 + 1] = lw;
+        }
+    }
+    __syncthreads();
+    float linv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float mw[4], mall = ninf;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            mw[w] = stat[(w * 16 + 4 * g + r) * 2];
+            mall = fmaxf(mall, mw[w]);
+        }
+        const float base = (mall == ninf) ? 0.f : mall;
+        float lsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float bw = (mw[w] == ninf) ? 0.f : mw[w];
+            lsum += stat[(w * 16 + 4 * g + r) * 2 + 1] * exp_fast(bw - base);
+        }
+        linv[r] = 1.f / lsum;
+        m[r] = base;
+    }
+
+    // ---- sweep 2 over the same tiles: P -> capture slab, partial O += P.V
+    f32x4 oacc[2][NB];
+#pragma unroll
+    for (int dt = 0; dt < NB; ++dt) oacc[0][dt] = oacc[1][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (wave < ntiles) {
+        wave_tile_fetch<DP>(kreg, kb, a.ks.sn, wave * kTile, a.Nk, a.D, lane);
+        wave_tile_fetch<DP>(vreg, vb, a.vs.sn, wave * kTile, a.Nk, a.D, lane);
+    }
+    for (int kt = wave; kt < ntiles; kt += 4) {
+        wave_tile_store<DP>(Ks, kreg, a.Nk, a.D, lane);
+        wave_tile_store<DP>(Vs, vreg, a.Nk, a.D, lane);
+        if (kt + 4 < ntiles) {
+            wave_tile_fetch<DP>(kreg, kb, a.ks.sn, (kt + 4) * kTile, a.Nk, a.D, lane);
+            wave_tile_fetch<DP>(vreg, vb, a.vs.sn, (kt + 4) * kTile, a.Nk, a.D, lane);
+        }
+        f32x4 sacc[4];
+        tile_abt4<DP>(sacc, qa, Ks, i, g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k0 = kt * kTile + 16 * t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = exp_fast(score(sacc[t][r], r, k0) - m[r]) * linv[r];
+                if (k0 + i >= a.Nk) p = 0.f;                                // (also keeps NaN rows out of the padding)
+                if (pout[r] && k0 + i < a.Nk) pout[r][k0] = p;
+                Pw[(4 * g + r) * kPS + 16 * t + i] = p;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        tile_wt<DP>(oacc, Pw, Vs, i, g);
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int dt = 0; dt < NB; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) opart[(wave * 16 + 4 * g + r) * DP + 16 * dt + i] = oacc[0][dt][r] + oacc[1][dt][r];
+    __syncthreads();
+    float* ob = a.o + b * a.os.sb + h * a.os.sh;
+    for (int idx = tid; idx < 16 * DP; idx += kThreads) {
+        const int row = idx / DP, d = idx % DP;
+        if (rw + row < a.Nq && d < a.D)
+            ob[static_cast<int64_t>(rw + row) * a.os.sn + d] = (opart[row * DP + d] + opart[(16 + row) * DP + d]) +
+                                                              (opart[(32 + row) * DP + d] + opart[(48 + row) * DP + d]);
+    }
 }
 
 // =============================================================================================== backward, query side
@@ -810,6 +992,7 @@ int launch_bwd_dt(const AttnBwdArgs& a, dim3 gq, dim3 gk, hipStream_t s) {
 }  // namespace
 
 void attn_stream_enable(int on) { g_attn_stream = on & 1; }
+void attn_fwd_split_enable(int on) { g_attn_fwd_split = on & 1; }
 
 // returns 1 if the streaming kernel was launched (rc in *rc_out), 0 if the shape / layout is not eligible.
 // Slabs in fp16 / bf16 (slab_dt) exist on this path only: they ignore the "attn_stream" switch.
@@ -817,6 +1000,12 @@ int attn_fwd_stream_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out) {
     if ((!g_attn_stream && a.slab_dt == MMX_F32 && !a.mma_bf16) || a.D % 4 || a.D > 64) return 0;
     if (!aligned16(a.q, a.qs) || !aligned16(a.k, a.ks) || !aligned16(a.v, a.vs)) return 0;
     dim3 grid(((a.Nq + kRows - 1) / kRows) * a.H * a.B);
+    // a grid that leaves most of the chip idle (one shared forward): 16-row workgroups whose waves split the keys
+    if (g_attn_fwd_split && grid.x < 160 && a.slab_dt == MMX_F32 && !a.mma_bf16 && a.D <= 32 && a.Nk > kTile) {
+        *rc_out = launch_stream(attn_fwd_split_kernel<32>, a, dim3(((a.Nq + 15) / 16) * a.H * a.B), split_lds_bytes<32>(), s,
+                                "attn_fwd_split_kernel<32>");
+        return 1;
+    }
     switch (a.slab_dt) {
         case MMX_F32: *rc_out = launch_fwd_dt<MMX_F32>(a, grid, s); break;
         case MMX_F16: *rc_out = launch_fwd_dt<MMX_F16>(a, grid, s); break;

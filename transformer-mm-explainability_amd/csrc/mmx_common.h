@@ -200,6 +200,7 @@ int self_chain_big_try(const void* const* attn_layers, const void* const* grad_l
                        int dtype, int64_t attn_bstride, const void* R_init, void* R_out, void* workspace,
                        size_t workspace_bytes, hipStream_t s, int* rc_out);
 void attn_stream_enable(int on);
+void attn_fwd_split_enable(int on);
 void attn_bf16_v2_enable(int on);
 void attn_bf16_v3_enable(int mode);
 int hip_fail(hipError_t e, const char* what);

@@ -983,6 +983,10 @@ extern "C" int mmx_set_option(const char* key, int value) {
         attn_stream_enable(value);
         return MMX_OK;
     }
+    if (key && strcmp(key, "attn_fwd_split") == 0) {
+        attn_fwd_split_enable(value);
+        return MMX_OK;
+    }
     if (key && strcmp(key, "debug_flags") == 0) {
         g_debug_flags = value;
         return MMX_OK;

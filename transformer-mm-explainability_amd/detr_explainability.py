@@ -127,7 +127,42 @@ class Generator:
         aggregated = self.R_q_i.unsqueeze_(0)
         return aggregated[:, target_index, :].unsqueeze_(0).detach()
 
-    def _rows_only_rules(self, encoder_blocks, decoder_blocks, targets, K, shared, pair, check_diag):
+    overlap_rules = True    # rows_only + shared forward: rule kernels start on a side stream as soon as their slabs are complete
+
+    def _rows_early_hooks(self, targets, K):
+        """Hooks for ``Transformer.backward_shared`` (shared forward, ``rows_only``): the decoder half of the rules
+        (``ops.detr_decoder_rows``: 10 workgroups, latency-bound) and every encoder layer's head average (HBM-bound) need only
+        slabs that are complete long before the backward ends, so they run on a side stream beside the rest of it.
+        Returns ``(hooks, collect)``; ``collect()`` joins the side stream and returns ``(A, s, dec_word)``."""
+        tr = self.model.transformer
+        main = torch.cuda.current_stream()
+        side = ops.side_stream(targets.device, "detr_rules")
+        got = {"A": [None] * len(tr.encoder.layers)}
+
+        def pair(mod):
+            return mod.get_attn().detach(), mod.get_attn_gradients().detach()
+
+        def decoder_done():
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                got["s"], got["word"] = ops.detr_decoder_rows([pair(b.self_attn) for b in tr.decoder.layers],
+                                                              [pair(b.multihead_attn) for b in tr.decoder.layers], targets,
+                                                              shared_attn=True)
+
+        def encoder_layer_done(i):
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                got["A"][i] = ops.avg_heads(*pair(tr.encoder.layers[i].self_attn), batch_size=K, shared_attn=True)
+
+        def collect():
+            main.wait_stream(side)
+            for t in got["A"] + [got["s"], got["word"]]:
+                t.record_stream(main)                  # made on the side stream, read (and released) on this one
+            return got["A"], got["s"], got["word"]
+
+        return {"decoder_done": decoder_done, "encoder_layer_done": encoder_layer_done}, collect
+
+    def _rows_only_rules(self, encoder_blocks, decoder_blocks, targets, K, shared, pair, check_diag, early=None):
         """Rules 6 / 7 / 10 of ``generate_ours`` (DETR/modules/ExplanationGenerator.py:110-140) for ONE row per sample.
 
         With ``A_l`` the head-averaged encoder maps, ``B_l`` the decoder self-attention ones, ``C_l`` the cross-attention
@@ -147,7 +182,10 @@ class Generator:
         if not (self.apply_self_in_rule_10 and self.normalize_self_attention):
             raise NotImplementedError("rows_only covers the default rule set (normalize_self_attention, apply_self_in_rule_10)")
         dev = targets.device
-        A = [ops.avg_heads(*pair(blk.self_attn), batch_size=K, shared_attn=shared) for blk in encoder_blocks]      # [K, Ni, Ni]
+        if early is not None:                                          # produced beside the backward (``_rows_early_hooks``)
+            A, s_early, dec_word_early = early
+        else:
+            A = [ops.avg_heads(*pair(blk.self_attn), batch_size=K, shared_attn=shared) for blk in encoder_blocks]  # [K, Ni, Ni]
         n_img = A[0].shape[-1]
         # rho = R_ii 1 - 1 carried as the deviation e from 1 (e <- e + A (1 + e)): forming R_ii 1 and subtracting 1 at the
         # end would cancel 2-3 digits of rho (the matrix route has that noise in diag(R_ii) - 1 as well)
@@ -157,8 +195,11 @@ class Generator:
         rho = e.reshape(K, 1, n_img)
         # decoder half: B_l, R_qq^(l), N(R_qq^(l)), w_l = u_l N^T, z_l = w_l C_l and the NaN policy for ALL layers in three
         # launches (K2-DETR, csrc/detr_rows_kernels.hip) -- no C_l, no R_qq stack, no per-layer torch ops
-        s, dec_word = ops.detr_decoder_rows([pair(blk.self_attn) for blk in decoder_blocks],
-                                            [pair(blk.multihead_attn) for blk in decoder_blocks], targets, shared_attn=shared)
+        if early is not None:
+            s, dec_word = s_early, dec_word_early
+        else:
+            s, dec_word = ops.detr_decoder_rows([pair(blk.self_attn) for blk in decoder_blocks],
+                                                [pair(blk.multihead_attn) for blk in decoder_blocks], targets, shared_attn=shared)
         s = s.reshape(K, 1, n_img)
         words = [dec_word]
         v = s / rho
@@ -211,6 +252,7 @@ class Generator:
             raise ValueError("generate_ours_multi explains the queries of ONE image (got batch %d)" % img.shape[0])
         rows = torch.arange(K, device=img.device)
         shared = bool(share_forward and K > 1 and hasattr(self.model, "forward_shared"))
+        early = None
         if shared:
             with torch.no_grad():
                 logits, state = self.model.forward_shared(img, K)                                     # [1, Q, C+1]
@@ -225,7 +267,11 @@ class Generator:
                 one_hot = torch.zeros(K, logits.shape[1] * n_cls, dtype=logits.dtype, device=img.device)
                 one_hot.scatter_(1, (targets * n_cls + index).reshape(K, 1), 1.0)
                 one_hot = one_hot.view(K, logits.shape[1], n_cls)
-                self.model.backward_shared(state, one_hot)
+                early = self._rows_early_hooks(targets, K) if rows_only and self.overlap_rules else None
+                if early is None:
+                    self.model.backward_shared(state, one_hot)
+                else:
+                    self.model.backward_shared(state, one_hot, early[0])
         else:
             batch = img.expand(K, *img.shape[1:])
             outputs = rules.forward_for_backward(self.model, lambda: self.model(batch)["pred_logits"])   # [K, Q, C+1]
@@ -243,7 +289,8 @@ class Generator:
             return mod.get_attn().detach(), mod.get_attn_gradients().detach()
 
         if rows_only:
-            return self._rows_only_rules(encoder_blocks, decoder_blocks, targets, K, shared, pair, check_diag)
+            return self._rows_only_rules(encoder_blocks, decoder_blocks, targets, K, shared, pair, check_diag,
+                                         early[1]() if early is not None else None)
         enc = [pair(blk.self_attn) for blk in encoder_blocks]
         self.R_i_i = ops.relevancy_self_chain([a for a, _ in enc], [g for _, g in enc], K, shared_attn=shared)   # [K, Ni, Ni]
         n_img = self.R_i_i.shape[-1]

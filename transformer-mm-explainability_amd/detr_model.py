@@ -58,6 +58,12 @@ def _ln_fwd(ln, x):
     return y, (x, mean, rstd)
 
 
+def _add_ln_fwd(ln, x, y):
+    """``LayerNorm(x + y)`` in one fused pass, keeping what the hand-written backward needs: ``(out, (x + y, mean, rstd))``."""
+    s, out, mean, rstd = ops.add_layernorm(x, y, ln.weight, ln.bias, ln.eps)
+    return out, (s, mean, rstd)
+
+
 def _ln_bwd(ln, saved, dy, d_res=None):
     """``LN'(dy) [+ d_res]`` for K upstream gradients against ONE forward's statistics (``ops.layernorm_bwd_add``)."""
     x, mean, rstd = saved
@@ -80,6 +86,14 @@ class _FeedForward:
         """``d_out [K, T, E]`` -> gradient w.r.t. the feed-forward input; ``h [1, T, F]`` is the shared pre-activation."""
         d_h = ops.backward_gemm(d_out, self.linear2.weight, gemm_dtype) * (h > 0)
         return ops.backward_gemm(d_h, self.linear1.weight, gemm_dtype)
+
+    def _ffn_bwd_shared_into(self, live, d_out):
+        """fp32: ``d_out [K, T, E]`` becomes ``d_out + FFN'(d_out)`` IN PLACE (the residual add is the second GEMM's beta = 1);
+        ``live [1, T, F]``: the ReLU's 0 / 1 mask of the shared forward."""
+        K, T, E = d_out.shape
+        d_h = F.linear(d_out, ops.transposed_weight(self.linear2.weight)).mul_(live)      # (NT layout: ops.transposed_weight)
+        d_out.view(K * T, E).addmm_(d_h.view(K * T, -1), self.linear1.weight)
+        return d_out
 
 
 class TransformerEncoderLayer(nn.Module, _FeedForward):
@@ -125,18 +139,25 @@ class TransformerEncoderLayer(nn.Module, _FeedForward):
         if self.normalize_before:
             raise NotImplementedError("shared-forward mode covers the post-norm layers DETR ships")
         qk = _with_pos(src, pos)
-        a, att = self.self_attn.forward_shared(qk, qk, src, batch)
-        src1, ln1 = _ln_fwd(self.norm1, src + a)
+        a, att = self.self_attn.forward_shared(qk, qk, src, batch)               # q and k: one packed GEMM
+        src1, ln1 = _add_ln_fwd(self.norm1, src, a)
         ff, h = self._ffn_fwd_shared(src1)
-        out, ln2 = _ln_fwd(self.norm2, src1 + ff)
-        return out, (att, ln1, h, ln2)
+        out, ln2 = _add_ln_fwd(self.norm2, src1, ff)
+        return out, (att, ln1, h, ln2, (h > 0).to(h.dtype))
 
     def backward_shared(self, tape, d_out, need_input_grad=True, gemm_dtype=torch.float32):
-        att, ln1, h, ln2 = tape
+        att, ln1, h, ln2, live = tape
         d_z2 = _ln_bwd(self.norm2, ln2, d_out)                           # w.r.t. src1 + ff
-        d_z1 = _ln_bwd(self.norm1, ln1, d_z2 + self._ffn_bwd_shared(h, d_z2, gemm_dtype))   # w.r.t. src + attention output
-        dq, dk, dv = self.self_attn.backward_shared(att, d_z1, need_input_grad, gemm_dtype)
-        return d_z1 + dq + dk + dv if need_input_grad else None          # pos is a constant: q, k and v all lead to src
+        if gemm_dtype != torch.float32:                                  # opt-in bf16 input-gradient GEMMs: the unfused chain
+            d_z1 = _ln_bwd(self.norm1, ln1, d_z2 + self._ffn_bwd_shared(h, d_z2, gemm_dtype))
+            dq, dk, dv = self.self_attn.backward_shared(att, d_z1, need_input_grad, gemm_dtype)
+            return d_z1 + dq + dk + dv if need_input_grad else None
+        d_z1 = _ln_bwd(self.norm1, ln1, self._ffn_bwd_shared_into(live, d_z2))   # w.r.t. src + attention output
+        if not need_input_grad:
+            self.self_attn.backward_shared(att, d_z1, False)
+            return None
+        # pos is a constant: q, k and v all lead to src -- d_src = d_z1 + [dq | dk | dv] . [Wq; Wk; Wv], one GEMM, in place
+        return self.self_attn.backward_shared_into(att, d_z1, d_z1)
 
 
 class TransformerDecoderLayer(nn.Module, _FeedForward):
@@ -191,27 +212,43 @@ class TransformerDecoderLayer(nn.Module, _FeedForward):
 
 
     # ---- shared-forward mode (post-norm), batch-first tensors
-    def forward_shared(self, tgt, memory, pos, query_pos, batch):
+    def forward_shared(self, tgt, memory, pos, query_pos, batch, memory_kv=None):
+        """``memory_kv``: this layer's ``(k, v)`` projections of ``memory + pos`` / ``memory`` when the caller made them for all
+        layers at once (``Transformer.forward_shared``)."""
         if self.normalize_before:
             raise NotImplementedError("shared-forward mode covers the post-norm layers DETR ships")
         qk = _with_pos(tgt, query_pos)
         a, t_self = self.self_attn.forward_shared(qk, qk, tgt, batch)
-        tgt1, ln1 = _ln_fwd(self.norm1, tgt + a)
-        c, t_cross = self.multihead_attn.forward_shared(_with_pos(tgt1, query_pos), _with_pos(memory, pos), memory, batch)
-        tgt2, ln2 = _ln_fwd(self.norm2, tgt1 + c)
+        tgt1, ln1 = _add_ln_fwd(self.norm1, tgt, a)
+        if memory_kv is None:
+            c, t_cross = self.multihead_attn.forward_shared(_with_pos(tgt1, query_pos), _with_pos(memory, pos), memory, batch)
+        else:
+            c, t_cross = self.multihead_attn.forward_shared(_with_pos(tgt1, query_pos), None, None, batch, kv=memory_kv)
+        tgt2, ln2 = _add_ln_fwd(self.norm2, tgt1, c)
         ff, h = self._ffn_fwd_shared(tgt2)
-        out, ln3 = _ln_fwd(self.norm3, tgt2 + ff)
-        return out, (t_self, ln1, t_cross, ln2, h, ln3)
+        out, ln3 = _add_ln_fwd(self.norm3, tgt2, ff)
+        return out, (t_self, ln1, t_cross, ln2, h, ln3, (h > 0).to(h.dtype))
 
-    def backward_shared(self, tape, d_out, need_tgt_grad=True, gemm_dtype=torch.float32):
-        """``d_out [K, Q, E]`` -> ``(d_tgt [K, Q, E] | None, d_memory [K, N, E])``."""
-        t_self, ln1, t_cross, ln2, h, ln3 = tape
+    def backward_shared(self, tape, d_out, need_tgt_grad=True, gemm_dtype=torch.float32, d_memory=None):
+        """``d_out [K, Q, E]`` -> ``(d_tgt [K, Q, E] | None, d_memory [K, N, E])``.  fp32: the memory gradient ACCUMULATES into
+        ``d_memory`` (in place) when one is handed in; the opt-in bf16 route returns this layer's share."""
+        t_self, ln1, t_cross, ln2, h, ln3, live = tape
         d_z3 = _ln_bwd(self.norm3, ln3, d_out)                             # w.r.t. tgt2 + ff
-        d_z2 = _ln_bwd(self.norm2, ln2, d_z3 + self._ffn_bwd_shared(h, d_z3, gemm_dtype))   # w.r.t. tgt1 + cross-attn output
-        dq, dk, dv = self.multihead_attn.backward_shared(t_cross, d_z2, True, gemm_dtype)
-        d_z1 = _ln_bwd(self.norm1, ln1, d_z2 + dq)                         # w.r.t. tgt + self-attention output
-        sq, sk, sv = self.self_attn.backward_shared(t_self, d_z1, need_tgt_grad, gemm_dtype)
-        return (d_z1 + sq + sk + sv if need_tgt_grad else None), dk + dv
+        if gemm_dtype != torch.float32:
+            d_z2 = _ln_bwd(self.norm2, ln2, d_z3 + self._ffn_bwd_shared(h, d_z3, gemm_dtype))
+            dq, dk, dv = self.multihead_attn.backward_shared(t_cross, d_z2, True, gemm_dtype)
+            d_z1 = _ln_bwd(self.norm1, ln1, d_z2 + dq)
+            sq, sk, sv = self.self_attn.backward_shared(t_self, d_z1, need_tgt_grad, gemm_dtype)
+            share = dk + dv
+            return (d_z1 + sq + sk + sv if need_tgt_grad else None), share if d_memory is None else d_memory + share
+        d_z2 = _ln_bwd(self.norm2, ln2, self._ffn_bwd_shared_into(live, d_z3))          # w.r.t. tgt1 + cross-attn output
+        # d_z2 <- d_z2 + dq . Wq (in place: it is dead afterwards); d_memory (+)= [dk | dv] . [Wk; Wv]
+        d_sum, d_memory = self.multihead_attn.backward_shared_into(t_cross, d_z2, d_z2, d_memory, same_source=False)
+        d_z1 = _ln_bwd(self.norm1, ln1, d_sum)                             # w.r.t. tgt + self-attention output
+        if not need_tgt_grad:
+            self.self_attn.backward_shared(t_self, d_z1, False)
+            return None, d_memory
+        return self.self_attn.backward_shared_into(t_self, d_z1, d_z1), d_memory
 
 
 class TransformerEncoder(nn.Module):
@@ -318,7 +355,10 @@ class Transformer(nn.Module):
     # ---- shared-forward mode: ONE forward at batch 1, the backward at batch K (K upstream gradients)
     def forward_shared(self, src, query_embed, pos_embed, batch):
         """``src [1, C, h, w]`` -> ``(hs_last [1, Q, C], tape)``: the last decoder level through the shared decoder norm
-        (what ``pred_logits`` reads).  Every attention block keeps ONE probability slab and a ``batch``-sized gradient slab."""
+        (what ``pred_logits`` reads).  Every attention block keeps ONE probability slab and a ``batch``-sized gradient slab.
+        The decoder's cross-attentions all read the same memory: their key / value projections are TWO GEMMs for all layers
+        (``memory + pos`` against the stacked ``Wk``, ``memory`` against the stacked ``Wv``)."""
+        from .bert_tape import packed_linear
         tokens = src.flatten(2).transpose(1, 2)                         # [1, hw, C], batch-first
         pos = pos_embed.flatten(2).transpose(1, 2)
         query_pos = query_embed.unsqueeze(0)
@@ -329,25 +369,39 @@ class Transformer(nn.Module):
             enc_tapes.append(t)
         if self.encoder.norm is not None:
             raise NotImplementedError("shared-forward mode covers the post-norm encoder (no final encoder norm)")
+        L = len(self.decoder.layers)
+        S, E = memory.shape[1], memory.shape[2]
+        H = self.decoder.layers[0].multihead_attn.num_heads
+        Wk, bk = packed_linear(tuple(layer.multihead_attn.k_proj for layer in self.decoder.layers))
+        Wv, bv = packed_linear(tuple(layer.multihead_attn.v_proj for layer in self.decoder.layers))
+        k_all = torch.addmm(bk, (memory + pos).view(S, E), Wk.t()).view(1, S, L, H, E // H)
+        v_all = torch.addmm(bv, memory.view(S, E), Wv.t()).view(1, S, L, H, E // H)
         out = torch.zeros_like(query_pos)
-        for layer in self.decoder.layers:
-            out, t = layer.forward_shared(out, memory, pos, query_pos, batch)
+        for i, layer in enumerate(self.decoder.layers):
+            out, t = layer.forward_shared(out, memory, pos, query_pos, batch, memory_kv=(k_all[:, :, i], v_all[:, :, i]))
             dec_tapes.append(t)
         hs, ln = _ln_fwd(self.decoder.norm, out)
         return hs, (enc_tapes, dec_tapes, ln)
 
     @torch.no_grad()
-    def backward_shared(self, tape, d_hs):
-        """``d_hs [K, Q, C]``: per-sample upstream gradients of ``hs_last``; fills every block's gradient slab."""
+    def backward_shared(self, tape, d_hs, hooks=None):
+        """``d_hs [K, Q, C]``: per-sample upstream gradients of ``hs_last``; fills every block's gradient slab.
+        ``hooks``: ``{"decoder_done": f(), "encoder_layer_done": f(i)}`` called right after the named gradient slabs are
+        complete on the current stream (the rule kernels that only need those can start beside the rest of the backward)."""
         enc_tapes, dec_tapes, ln = tape
+        hooks = hooks or {}
         gd = getattr(self, "backward_gemm_dtype", torch.float32)      # torch.bfloat16: opt-in bf16 MFMA for the dX GEMMs
         d_out = _ln_bwd(self.decoder.norm, ln, d_hs)
         d_memory = None
         for i in range(len(self.decoder.layers) - 1, -1, -1):
-            d_out, d_mem = self.decoder.layers[i].backward_shared(dec_tapes[i], d_out, need_tgt_grad=i > 0, gemm_dtype=gd)
-            d_memory = d_mem if d_memory is None else d_memory + d_mem
+            d_out, d_memory = self.decoder.layers[i].backward_shared(dec_tapes[i], d_out, need_tgt_grad=i > 0, gemm_dtype=gd,
+                                                                     d_memory=d_memory)
+        if "decoder_done" in hooks:
+            hooks["decoder_done"]()
         for i in range(len(self.encoder.layers) - 1, -1, -1):         # the first layer's input is a constant of the pass
             d_memory = self.encoder.layers[i].backward_shared(enc_tapes[i], d_memory, need_input_grad=i > 0, gemm_dtype=gd)
+            if "encoder_layer_done" in hooks:
+                hooks["encoder_layer_done"](i)
 
 
 class PositionEmbeddingSine(nn.Module):
@@ -470,9 +524,10 @@ class DETRFromFeatures(nn.Module):
         return self.class_embed(hs), tape
 
     @torch.no_grad()
-    def backward_shared(self, state, d_logits):
-        """``d_logits [K, Q, classes+1]``: one upstream gradient of ``pred_logits`` per explained target."""
-        self.transformer.backward_shared(state, torch.matmul(d_logits, self.class_embed.weight))
+    def backward_shared(self, state, d_logits, hooks=None):
+        """``d_logits [K, Q, classes+1]``: one upstream gradient of ``pred_logits`` per explained target.  ``hooks``: see
+        ``Transformer.backward_shared``."""
+        self.transformer.backward_shared(state, torch.matmul(d_logits, self.class_embed.weight), hooks)
 
 
 def detr_resnet50_head(num_classes=91, num_queries=100):

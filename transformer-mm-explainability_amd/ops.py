@@ -338,6 +338,21 @@ def _converted(weight, dtype):
     return hit[1]
 
 
+def transposed_weight(weight):
+    """Cached contiguous ``weight.t()`` (until the parameter is modified in place).  The input-gradient product ``dY . W`` of
+    a Linear with few outputs and many inputs (DETR's ``linear2``: 256 -> 2048 on the way back) gets a poor library kernel in its
+    natural NN layout (64x64x16 tiles: 140 us at 9500 rows); as ``F.linear(dY, W^T)`` the heuristic picks a 256-wide one
+    (104 us) -- profiles/r03_detr_probe.txt."""
+    per_weight = _GEMM_WEIGHTS.get(id(weight))
+    if per_weight is None:
+        per_weight = _GEMM_WEIGHTS[id(weight)] = {}
+        weakref.finalize(weight, _GEMM_WEIGHTS.pop, id(weight), None)
+    hit = per_weight.get("t")
+    if hit is None or hit[0] != weight._version or hit[1].device != weight.device:
+        hit = per_weight["t"] = (weight._version, weight.detach().t().contiguous())
+    return hit[1]
+
+
 _MM_OUT_DTYPE = [None]      # does torch.mm(a, b, out_dtype=torch.float32) work on this build / device?  probed once
 
 
