@@ -133,6 +133,12 @@ int mmx_bmm_f32(const void* A_dev, const void* B_dev, const void* Cin_dev, void*
                 int64_t stride_a, int64_t stride_b, int64_t stride_c,
                 int nan_to_zero, void* stream);
 
+/* y = x . Wt + bias on the same kernel (32 x 32 tiles at these sizes):  x [M, K], Wt [K, N] (the TRANSPOSED nn.Linear weight,
+ * row-major), bias [N] or NULL, y [M, N], fp32 contiguous.  For the handful of one-sample projections of a shared forward where
+ * the library's heuristic picks a 256-row tile for ~100 rows (DETR decoder, 100 queries, 256 -> 256: 30 us in the library, 9 us
+ * here -- profiles/r03_detr_probe.txt); everything else stays on the library GEMMs, which are faster from 256 x 512 outputs up. */
+int mmx_linear_f32(const void* x_dev, const void* wt_dev, const void* bias_dev, void* out_dev, int M, int N, int K, void* stream);
+
 /* The chain on VECTORS (rows-only DETR rules): when a caller returns single rows of R_q_i (`aggregated[:, target_index, :]`,
  * DETR/modules/ExplanationGenerator.py:180-182) the encoder product R_ii = (I + A_6) ... (I + A_1) (`:110-118`) is needed only
  * as  R_ii . 1  (the row sums `handle_residual` divides by, `:26-31`) and as  v . R_ii : mat-vecs with the head-averaged maps.

@@ -319,6 +319,24 @@ def test_attn_fwd_small_grid_split_kernel(ops, B, H, Nq, Nk, D, mode, masked):
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("rows,E,bias", [(100, 256, True), (1, 256, True), (37, 48, False), (128, 64, True), (129, 256, True),
+                                         (100, 512, True)])
+def test_small_linear_routes_the_few_row_square_projections(ops, rows, E, bias):
+    """``ops.small_linear`` (``mmx_linear_f32``: exact-fp32 MFMA, bias in the epilogue) against ``nn.Linear`` in float64; shapes
+    outside its family (more than 128 rows, wider than 256) fall through to the module itself."""
+    torch.manual_seed(rows + E)
+    lin = torch.nn.Linear(E, E, bias=bias).cuda()
+    x = torch.randn(1, rows, E, device="cuda")
+    got = ops.small_linear(x, lin)
+    want = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double() if bias else None)
+    assert got.shape == want.shape
+    close(got, want.detach().float().cpu().numpy(), atol=5e-6)
+    with torch.no_grad():
+        lin.weight.mul_(2.0)                                             # in-place update: the cached transposed copy is refreshed
+    want2 = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double() if bias else None)
+    close(ops.small_linear(x, lin), want2.detach().float().cpu().numpy(), atol=1e-5)
+
+
 @pytest.mark.parametrize("shape", [(4928, 2048), (7, 13), (1, 3), (3, 4)])
 def test_quick_gelu_fused(ops, shape):
     g = torch.Generator().manual_seed(sum(shape))

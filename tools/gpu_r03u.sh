@@ -2,7 +2,7 @@
 # r03u: small-grid split forward attention kernel, NT layout of the FFN backward GEMM, value projection beside q/k
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r03u; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_generators.py tests/test_gpu_lrp.py tests/test_gpu_parity_fullsize.py -q -x -k "attn or detr or DETR" 2>&1 | tail -8 | tee $OUT/pytest.txt
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_generators.py tests/test_gpu_lrp.py tests/test_gpu_parity_fullsize.py -q -x -k "attn or detr or DETR or small_linear" 2>&1 | tail -8 | tee $OUT/pytest.txt
 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --legs cfg3 > $OUT/bench.json 2> $OUT/bench.log; tail -2 $OUT/bench.log
 python - <<'P'
 import json

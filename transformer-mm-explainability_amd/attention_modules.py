@@ -146,7 +146,7 @@ class MultiheadAttention(_SlabOwner):
         cross-attentions read the same memory in every layer: all layers' keys / values are two GEMMs)."""
         T, H, D = query.shape[1], self.num_heads, self.head_dim
         if kv is not None:
-            q = self.q_proj(query).view(1, T, H, D)
+            q = ops.small_linear(query, self.q_proj).view(1, T, H, D)
             k, v = kv
         elif key is query:
             from .bert_tape import packed_linear
@@ -155,7 +155,7 @@ class MultiheadAttention(_SlabOwner):
             main, side = torch.cuda.current_stream(), ops.side_stream(query.device, "mha_value")
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                v = self.v_proj(value).view(1, -1, H, D)
+                v = ops.small_linear(value, self.v_proj).view(1, -1, H, D)
             qk = torch.addmm(b, query.reshape(T, -1), W.t()).view(1, T, 2, H, D)
             q, k = qk[:, :, 0], qk[:, :, 1]
             main.wait_stream(side)
@@ -173,7 +173,7 @@ class MultiheadAttention(_SlabOwner):
         o = ops.attn_capture_fwd(q, k, v, self._probs, float(D) ** -0.5, _lib.SCALE_Q_FIRST, None, layout="bnhd")
         self.save_attn(self._probs.view(H, T, S))
         self.save_attn_gradients(self._grads.view(batch * H, T, S))
-        return self.out_proj(o.reshape(1, T, self.embed_dim)), (q, k, v, o)
+        return ops.small_linear(o.reshape(1, T, self.embed_dim), self.out_proj), (q, k, v, o)
 
     @torch.no_grad()
     def backward_shared(self, tape, d_out, need_input_grads=True, gemm_dtype=torch.float32):

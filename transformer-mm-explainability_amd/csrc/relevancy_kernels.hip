@@ -518,7 +518,7 @@ template <int T>
 __global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                       const float* Cin, float* C, int M, int N, int K,
                                                       int trans_a, int64_t sa, int64_t sb, int64_t sc,
-                                                      int nan_to_zero) {
+                                                      int nan_to_zero, int cin_is_row) {
     constexpr int W = T / 32;              // MFMA tiles per wave and dimension
     constexpr int E = kBmmBK * T / 256;    // elements of each operand per thread and slab
     constexpr int LA = T + 17, LB = T + 16;   // odd A stride: the k-fastest stores of a row-major A spread over the banks
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ 
                 if (gm < M && gn < N) {
                     const int64_t off = cbase + static_cast<int64_t>(gm) * N + gn;
                     float v = acc[i][j][r];
-                    if (Cin) v = Cin[off] + v;
+                    if (Cin) v = (cin_is_row ? Cin[gn] : Cin[off]) + v;      // cin_is_row: a bias row shared by every row
                     if (nan_to_zero && v != v) v = 0.f;
                     C[off] = v;
                 }
@@ -609,20 +609,20 @@ __global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ 
 static int g_bmm_tile = 64;   // 128: try the 128 x 128 tiling where the grid is large enough (A/B profiling)
 
 static void launch_bmm(const float* A, const float* B, const float* Cin, float* C, int batch, int M, int N, int K,
-                       int trans_a, int64_t sa, int64_t sb, int64_t sc, int nan_to_zero, hipStream_t s) {
+                       int trans_a, int64_t sa, int64_t sb, int64_t sc, int nan_to_zero, hipStream_t s, int cin_is_row = 0) {
     const int64_t wgs64 = static_cast<int64_t>((N + 63) / 64) * ((M + 63) / 64) * batch;
     const int64_t wgs128 = static_cast<int64_t>((N + 127) / 128) * ((M + 127) / 128) * batch;
     if (wgs128 >= 512 && g_bmm_tile == 128) {
         // 128 x 128 per workgroup (each wave 64 x 64 = 16 accumulator tiles).  Measured SLOWER than 64 x 64 at the
         // long-sequence chain shapes (profiles/r02_bmm_probe.txt: 384 vs 281 us at [32 x 577 x 577]^2), so opt-in only.
         bmm_f32_kernel<128><<<dim3(static_cast<unsigned>(wgs128)), 256, 0, s>>>(A, B, Cin, C, M, N, K, trans_a,
-                                                                                       sa, sb, sc, nan_to_zero);
+                                                                                       sa, sb, sc, nan_to_zero, cin_is_row);
     } else if (wgs64 >= 1024) {
         bmm_f32_kernel<64><<<dim3(static_cast<unsigned>(wgs64)), 256, 0, s>>>(A, B, Cin, C, M, N, K, trans_a, sa,
-                                                                                    sb, sc, nan_to_zero);
+                                                                                    sb, sc, nan_to_zero, cin_is_row);
     } else {
         bmm_f32_kernel<32><<<dim3(static_cast<unsigned>(static_cast<int64_t>((N + 31) / 32) * ((M + 31) / 32) * batch)), 256, 0, s>>>(A, B, Cin, C, M, N, K, trans_a, sa,
-                                                                                    sb, sc, nan_to_zero);
+                                                                                    sb, sc, nan_to_zero, cin_is_row);
     }
 }
 
@@ -710,6 +710,16 @@ extern "C" int mmx_bmm_f32(const void* A_dev, const void* B_dev, const void* Cin
                static_cast<float*>(C_dev), batch, M, N, K, trans_a, stride_a, stride_b, stride_c, nan_to_zero,
                static_cast<hipStream_t>(stream));
     MMX_LAUNCH_CHECK("bmm_f32_kernel");
+    return MMX_OK;
+}
+
+extern "C" int mmx_linear_f32(const void* x_dev, const void* wt_dev, const void* bias_dev, void* out_dev, int M, int N, int K,
+                              void* stream) {
+    MMX_CHECK_ARG(x_dev && wt_dev && out_dev, "mmx_linear_f32: null pointer");
+    MMX_CHECK_ARG(M > 0 && N > 0 && K > 0, "mmx_linear_f32: non-positive size");
+    launch_bmm(static_cast<const float*>(x_dev), static_cast<const float*>(wt_dev), static_cast<const float*>(bias_dev),
+               static_cast<float*>(out_dev), 1, M, N, K, 0, 0, 0, 0, 0, static_cast<hipStream_t>(stream), 1);
+    MMX_LAUNCH_CHECK("bmm_f32_kernel (linear)");
     return MMX_OK;
 }
 

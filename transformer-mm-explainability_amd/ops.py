@@ -460,6 +460,20 @@ def matmul(a, b, add_to=None, trans_a=False, nan_to_zero=False):
     return out[0] if squeeze else out
 
 
+def small_linear(x, lin):
+    """``lin(x)`` for an ``nn.Linear`` applied to a FEW rows (a shared forward's 100 decoder queries) with a SQUARE weight of at
+    most 256: the one shape family where the library's heuristic leaves the chip idle (a 256-row tile for 100 rows: 3
+    workgroups, 30 us; ``mmx_linear_f32``: 9 us).  Anything else goes to ``lin`` itself."""
+    rows = x.numel() // x.shape[-1]
+    if not (x.is_cuda and x.dtype == torch.float32 and rows <= 128 and lin.in_features == lin.out_features <= 256):
+        return lin(x)
+    x2 = _f32c(x).view(rows, lin.in_features)
+    out = torch.empty(rows, lin.out_features, dtype=torch.float32, device=x.device)
+    check(lib().mmx_linear_f32(_p(x2), _p(transposed_weight(lin.weight)), _p(lin.bias.detach() if lin.bias is not None else None),
+                               _p(out), rows, lin.out_features, lin.in_features, _stream()), "mmx_linear_f32")
+    return out.view(*x.shape[:-1], lin.out_features)
+
+
 def chain_matvec(A, y, base=None):
     """``base + A @ y`` for ``A [B, N, N]``, ``y`` / ``base [B, N]`` (fp32; ``base`` defaults to ``y``): one column of
     the chain ``R <- R + A R``."""
