@@ -1,5 +1,6 @@
 #!/bin/bash
-# r03y: chain kernel with wide (all-heads) raw-buffer load batches: tests, probe wide vs narrow, bench headline + roofline
+# r03y (experiment, NOT kept: the "self_chain_wide" option it toggles existed only in that build -- profiles/r03_chain_wide_probe.txt):
+# chain kernel with wide (all-heads) raw-buffer load batches: tests, probe wide vs narrow, bench headline + roofline
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r03y; mkdir -p $OUT
 timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_clip.py tests/test_gpu_generators.py -q -x -k "chain or clip or small_linear or lxmert or visualbert" 2>&1 | tail -5 | tee $OUT/pytest.txt
