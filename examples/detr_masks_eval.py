@@ -35,12 +35,13 @@ def synthetic_features(k, channels=2048, h=25, w=38, device="cpu"):
 
 
 def image_stats(masks, keep, image_id):
-    """``masks [1, Q, h, w]`` (0 / 255 on kept queries, -1 elsewhere), ``keep [Q]`` -> one fixed-shape row."""
-    kept = masks[0, keep]
-    n = float(keep.sum())
-    area = float((kept == 255).float().mean()) if n else 0.0
-    checksum = float((kept == 255).float().sum() % 65521) if n else 0.0
-    return torch.tensor([n, area, checksum, float(image_id)], dtype=torch.float32)
+    """``masks [1, Q, h, w]`` (0 / 255 on kept queries, -1 elsewhere), ``keep [Q]`` -> one fixed-shape row, computed where the
+    masks live (no device -> host read: the rows of a rank are gathered once, at the end)."""
+    on = (masks[0] == 255).to(torch.float32) * keep.view(-1, 1, 1)          # [Q, h, w], zero on the queries not kept
+    n = keep.sum().to(torch.float32)
+    total = on.sum()
+    area = total / (n * on.shape[1] * on.shape[2]).clamp_min(1.0)
+    return torch.stack((n, area, total % 65521, torch.as_tensor(float(image_id), device=masks.device)))
 
 
 def evaluate(image_ids, masks_of, store=None, device="cpu"):
@@ -86,10 +87,11 @@ def main():
         with torch.no_grad():       # the 0.5 confidence cut of mask_generator.py:50 keeps nothing on random weights
             outputs = model(feats)
             conf = outputs["pred_logits"].softmax(-1)[0, :, :-1].max(-1).values
-        mg.threshold = float(conf.sort().values[-args.keep_top - 1])
-        masks, keep = mg.get_masks(feats, args.method, outputs=outputs)          # (one forward per image, not two)
-        queries[0] += int(keep.sum())
-        return masks.cpu(), keep.cpu()
+        mg.threshold = conf.sort().values[-args.keep_top - 1]                   # a device scalar: no host read for it
+        # one forward per image (not two), ONE device -> host read per image (the keep mask, inside get_masks)
+        masks, keep = mg.get_masks(feats, args.method, outputs=outputs)
+        queries[0] += mg.last_kept
+        return masks, keep
 
     cfg = {"evaluator": "detr_masks", "method": args.method, "keep_top": args.keep_top}
     store = sharding.PartialScores(args.resume_dir, rank, config=cfg) if args.resume_dir else None
@@ -97,6 +99,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     table = evaluate(ids, masks_of, store=store, device=dev)
+    mg.check_diag()                              # the handle_residual word of the last image's passes
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:

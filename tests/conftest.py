@@ -17,6 +17,21 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (HIP kernels are executed)")
+    # debugging aid: MMX_TEST_TOGGLES="norules,novalue,norecord,nosplit,nolxmert" switches schedule features off for a whole run
+    toggles = [t for t in os.environ.get("MMX_TEST_TOGGLES", "").split(",") if t]
+    if toggles:
+        import torch
+        from transformer_mm_explainability_amd import attention_modules, detr_explainability, lxmert_model, ops
+        if "norules" in toggles:
+            detr_explainability.Generator.overlap_rules = False
+        if "novalue" in toggles:
+            attention_modules.MultiheadAttention.overlap_value_proj = False
+        if "nolxmert" in toggles:
+            lxmert_model.LxmertEncoder.overlap_modalities = False
+        if "norecord" in toggles:
+            torch.Tensor.record_stream = lambda self, stream: None
+        if "nosplit" in toggles:
+            ops.set_option("attn_fwd_split", 0)
 
 
 @pytest.fixture(scope="session")

@@ -432,6 +432,45 @@ def test_detr_mask_generator_r50_shape():
     assert set(rollout_masks[0, kept].unique().tolist()) <= {0.0, 255.0}
 
 
+def test_detr_rule_kernels_beside_the_backward_equal_the_serial_schedule(golden):
+    """``Generator.overlap_rules`` (rows_only, shared forward: the decoder rule kernels and the encoder head averages start on
+    a side stream from hooks inside ``backward_shared``) is a schedule, not arithmetic: bit-identical rows."""
+    from transformer_mm_explainability_amd.detr_explainability import Generator
+    g = golden("detr_transformer")
+    model = _detr_from_golden(g)
+    feats = cu(g["features"])
+    targets = torch.tensor([4, 0, 6, 2], device="cuda")
+    gen = Generator(model)
+    outs = []
+    for overlap in (True, False, True):
+        gen.overlap_rules = overlap
+        outs.append(gen.generate_ours_multi(feats, targets, rows_only=True).clone())
+        torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    close(outs[0], Generator(model).generate_ours_multi(feats, targets).cpu().numpy(), atol=1e-6)   # == the matrix route
+
+
+def test_detr_mask_generator_reads_the_device_once_per_image(golden):
+    """``MaskGenerator.get_masks``: the keep mask and the previous images' ``handle_residual`` word travel in ONE device -> host
+    copy; the word of the last image is asserted by ``check_diag()``; a poisoned word trips the NEXT call."""
+    from transformer_mm_explainability_amd.detr_explainability import MaskGenerator
+    g = golden("detr_transformer")
+    model = _detr_from_golden(g)
+    feats = cu(g["features"])
+    mg = MaskGenerator(model, threshold=0.0, graph_slots=4)
+    masks, keep = mg.get_masks(feats, "ours_no_lrp")
+    assert mg.last_kept == int(keep.sum()) > 4                        # more kept queries than slots: several replays
+    assert mg._diag_running is not None and float(mg._diag_running) >= 0
+    eager = MaskGenerator(model, threshold=0.0)
+    masks2, _ = eager.get_masks(feats, "ours_no_lrp")
+    assert (masks != masks2).float().mean() < 0.01                    # graph / eager GEMM selection: threshold-edge pixels only
+    mg.check_diag()
+    assert mg._diag_running is None
+    mg._diag_running = torch.full((1,), float("nan"), device="cuda")
+    with pytest.raises(AssertionError, match="handle_residual"):
+        mg.get_masks(feats, "ours_no_lrp")
+
+
 def test_detr_bf16_backward_gemms_stay_close(golden):
     """Opt-in bf16 input-gradient GEMMs in the shared-forward DETR backward: relevancies within bf16 precision."""
     from transformer_mm_explainability_amd.detr_explainability import Generator

@@ -398,6 +398,42 @@ def test_lxmert_tape_path_equals_autograd_path():
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
 
 
+def test_lxmert_two_stream_tape_path_equals_one_stream():
+    """``LxmertEncoder.overlap_modalities`` (the image chain of every layer group on a side stream beside the text chain) is a
+    schedule: the forward gives the same bits, slabs and relevancies equal the one-stream tape path to fp32 rounding; the
+    perturbation re-runs through ``scores_no_grad`` equal the module forward (to fp32 rounding: other GEMM shapes)."""
+    import types
+    from transformer_mm_explainability_amd import lxmert_explainability as le
+    from transformer_mm_explainability_amd import lxmert_perturbation as lp
+    model, _, g = _model_and_inputs()
+    batch = _ragged_batch(g, [5, 12, 8, 9])
+    enc = model.lxmert.encoder
+    outs = []
+    try:
+        for overlap in (True, False):
+            enc.overlap_modalities = overlap
+            gen = le.GeneratorOurs(types.SimpleNamespace(model=model))
+            R = [t.clone() for t in gen.generate_ours_batch(batch)]
+            slabs = [b.attention.self.get_attn_gradients().clone() for b in list(enc.layer) + list(enc.r_layers)]
+            slabs += [x.visual_attention_copy.att.get_attn_gradients().clone() for x in list(enc.x_layers)[:-1]]
+            outs.append((R, slabs, model.scores_no_grad(**batch).clone()))
+            torch.cuda.synchronize()
+    finally:
+        enc.overlap_modalities = True
+    assert torch.equal(outs[0][2], outs[1][2])                        # the forward: the same kernels in another order
+    for a, b in zip(outs[0][0], outs[1][0]):                          # (the backward joins the two chains with an add where the
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)        # one-stream path accumulates inside a GEMM: rounding)
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
+    torch.testing.assert_close(outs[0][2], model(**batch).question_answering_score, rtol=1e-5, atol=1e-5)
+    cams = torch.rand(4, batch["visual_feats"].shape[1], generator=g).cuda()
+    fast = lp.LxmertPerturbation(model).perturbation_image(batch, cams)
+    class Plain:                                                     # a body without the fast forward: the module route
+        def __call__(self, **kw):
+            return model(**kw)
+    torch.testing.assert_close(fast, lp.LxmertPerturbation(Plain()).perturbation_image(batch, cams), rtol=1e-4, atol=1e-5)
+
+
 def test_visualbert_graphed_generate_ours_batch():
     """hipGraph replay of the batched VisualBERT explain pass (tape path) == the eager call, also after new inputs were
     copied in; a batch of another text length is refused."""

@@ -137,6 +137,8 @@ class MultiheadAttention(_SlabOwner):
         return cam_q.permute(1, 0, 2), cam_k.permute(1, 0, 2), cam_v.permute(1, 0, 2)
 
 
+    overlap_value_proj = True     # shared-forward mode: the value projection on a side stream beside the packed q / k GEMM
+
     # ---- shared-forward mode (one forward at batch 1, K upstream gradients): batch-first tensors
     def forward_shared(self, query, key, value, batch, kv=None):
         """``query [1, T, E]``, ``key`` / ``value [1, S, E]``.  Returns ``(out [1, T, E], tape)``; ``get_attn()`` then is
@@ -151,15 +153,19 @@ class MultiheadAttention(_SlabOwner):
         elif key is query:
             from .bert_tape import packed_linear
             W, b = packed_linear((self.q_proj, self.k_proj))
-            # the value projection beside the q / k one: at one sample these are launch-latency-sized GEMMs
-            main, side = torch.cuda.current_stream(), ops.side_stream(query.device, "mha_value")
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
+            if self.overlap_value_proj:
+                # the value projection beside the q / k one: at one sample these are launch-latency-sized GEMMs
+                main, side = torch.cuda.current_stream(), ops.side_stream(query.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    v = ops.small_linear(value, self.v_proj).view(1, -1, H, D)
+                qk = torch.addmm(b, query.reshape(T, -1), W.t()).view(1, T, 2, H, D)
+                main.wait_stream(side)
+                v.record_stream(main)
+            else:
                 v = ops.small_linear(value, self.v_proj).view(1, -1, H, D)
-            qk = torch.addmm(b, query.reshape(T, -1), W.t()).view(1, T, 2, H, D)
+                qk = torch.addmm(b, query.reshape(T, -1), W.t()).view(1, T, 2, H, D)
             q, k = qk[:, :, 0], qk[:, :, 1]
-            main.wait_stream(side)
-            v.record_stream(main)
         else:
             q = self.q_proj(query).view(1, T, H, D)
             k = self.k_proj(key).view(1, -1, H, D)

@@ -136,7 +136,7 @@ class Generator:
         Returns ``(hooks, collect)``; ``collect()`` joins the side stream and returns ``(A, s, dec_word)``."""
         tr = self.model.transformer
         main = torch.cuda.current_stream()
-        side = ops.side_stream(targets.device, "detr_rules")
+        side = ops.side_stream(targets.device)          # (the same side stream as the value projections of the forward)
         got = {"A": [None] * len(tr.encoder.layers)}
 
         def pair(mod):
@@ -459,6 +459,20 @@ class MaskGenerator:
         self.graph_slots = graph_slots
         self.max_graphs = max_graphs
         self._graphs = collections.OrderedDict()     # (method, feature shape) -> captured pass, least recently used first
+        self._diag_running = None                    # smallest handle_residual word of the batched passes not checked yet
+        self.last_kept = 0
+
+    def _fold_diag(self, word):
+        """Keep the smallest ``handle_residual`` word of the batched passes on the device (NaN propagates: ``minimum``)."""
+        if word is not None:
+            w = word.detach().reshape(1).to(torch.float32)
+            self._diag_running = w.clone() if self._diag_running is None else torch.minimum(self._diag_running, w)
+
+    def check_diag(self):
+        """The reference's ``assert diag.min() >= 0`` for the passes not checked yet (call after the last image)."""
+        if self._diag_running is not None:
+            word, self._diag_running = float(self._diag_running), None
+            assert word >= 0, "handle_residual: diag(R - I) < 0 (or NaN) in a relevancy pass"
 
     def _per_query(self, img, idx, method):
         """The reference's per-query dispatch (DETR/mask_generator.py:91-113) for the methods that are not batched here; the
@@ -483,8 +497,15 @@ class MaskGenerator:
                 outputs = self.model(img)
         h, w = self.model.spatial_dim
         probas = outputs["pred_logits"].softmax(-1)[0, :, :-1]
-        keep = probas.max(-1).values > self.threshold
-        kept = keep.nonzero().reshape(-1)
+        keep = probas.max(-1).values > self.threshold               # (``threshold`` may be a 0-dim device tensor)
+        # ONE device -> host read per image: the keep mask (its size decides how many passes follow) together with the
+        # ``handle_residual`` word left by the passes of the PREVIOUS images (the reference asserts it inside every call; here
+        # the batched passes leave it on the device and it is checked one image late, the last one by ``check_diag()``)
+        word = self._diag_running if self._diag_running is not None else torch.zeros(1, device=img.device)
+        host = torch.cat((keep.to(torch.float32), word.reshape(1).to(torch.float32))).cpu()
+        assert float(host[-1]) >= 0, "handle_residual: diag(R - I) < 0 (or NaN) in a relevancy pass of an earlier image"
+        kept = torch.nonzero(host[:-1]).reshape(-1).to(img.device, non_blocking=True)
+        self.last_kept = int(kept.numel())
         masks = torch.full((1, probas.shape[0], h, w), -1.0, device=img.device)
         if kept.numel() == 0:
             return masks, keep
@@ -498,9 +519,11 @@ class MaskGenerator:
                     self._graphs.popitem(last=False)
                 self._graphs[key] = GraphedGenerateOursMulti(self.model, img, self.graph_slots, **self._BATCHED[method])
             self._graphs.move_to_end(key)
-            cams = self._graphs[key](img, kept, index=classes)[0, 0]
+            cams = self._graphs[key](img, kept, index=classes, check=self._fold_diag)[0, 0]
         elif method in self._BATCHED:
-            cams = self.gen.generate_ours_multi(img, kept, index=classes, **self._BATCHED[method])[0, 0]   # [K, Ni]
+            cams = self.gen.generate_ours_multi(img, kept, index=classes, check_diag="defer",
+                                                **self._BATCHED[method])[0, 0]                             # [K, Ni]
+            self._fold_diag(self.gen.diag_min)
         else:
             cams = torch.cat([self._per_query(img, idx.reshape(1), method).reshape(1, -1) for idx in kept])
         masks[0, kept] = postprocess.otsu_masks(cams).reshape(-1, h, w)
@@ -569,7 +592,9 @@ class GraphedGenerateOursMulti:
                 self.targets[part.numel():] = part[-1]
                 self.index[part.numel():] = self.index[part.numel() - 1]
             self.graph.replay()
-            if check and self.diag_min is not None:
+            if callable(check):                       # the caller folds the device word into its own check (no sync here)
+                check(self.diag_min)
+            elif check and self.diag_min is not None:
                 assert self.diag_min.item() >= 0
             chunks.append(self.out[:, :, :part.numel()].clone())
         return torch.cat(chunks, dim=2) if len(chunks) != 1 else chunks[0]

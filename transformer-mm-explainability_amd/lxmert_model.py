@@ -307,7 +307,7 @@ class LxmertEncoder(nn.Module):                                        # lxmert_
         explainability pass these are 448- / 1152-row GEMMs that each fill a fraction of the chip, so the image chain runs on a
         side stream beside the text chain (fork / join inside one hipGraph when captured)."""
         main = torch.cuda.current_stream()
-        side = ops.side_stream(lang.device, "lxmert") if self.overlap_modalities else None
+        side = ops.side_stream(lang.device) if self.overlap_modalities else None
         tapes = {"l": [], "r": [], "x": [], "side": side}
         if side is not None:
             side.wait_stream(main)

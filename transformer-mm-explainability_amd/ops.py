@@ -70,7 +70,11 @@ _SIDE_STREAMS = {}
 
 def side_stream(device, slot=0):
     """A side stream per (device, slot), created once (a hipGraph capture must not create streams): independent chains of an
-    explainability pass -- CLIP's two towers, LXMERT's two modalities -- run on it beside the current stream."""
+    explainability pass -- LXMERT's two modalities, DETR's value projections and rule kernels -- run on it beside the current
+    stream.  Use ONE side stream per captured pass (the default slot): a DETR pass captured across two side streams (value
+    projections on one, rule kernels on another) replayed fine on its own but segfaulted inside hipGraphLaunch when CLIP graphs
+    had been captured and destroyed earlier in the process (round 3, tests/test_gpu_generators.py); with both on the same side
+    stream the same sequence is clean."""
     dev = torch.device(device)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), slot)
     if key not in _SIDE_STREAMS:
