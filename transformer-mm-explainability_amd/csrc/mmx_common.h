@@ -19,6 +19,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(4))) f32x4_u { f32x4 v; };
 __device__ __forceinline__ f32x4 ldg4_u(const float* p) { return reinterpret_cast<const f32x4_u*>(p)->v; }
 
+// A pointer the caller knows to be wave-uniform, pinned to SGPRs (a buffer resource must live in SGPRs: a base the compiler
+// cannot prove uniform would be wrapped in a waterfall loop).
+__device__ __forceinline__ const char* sgpr_ptr(const void* p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(u));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(u >> 32));
+    return reinterpret_cast<const char*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kRawBufferFlags = 0x00020000;   // word 3 of a raw (untyped, stride 0) buffer resource on gfx9 / CDNA: DATA_FORMAT = 32
+
 struct __attribute__((packed, aligned(2))) u16x4_u { unsigned short v[4]; };
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
