@@ -65,9 +65,10 @@ const char* mmx_last_error(void);
 /* tuning knobs (process-wide; results stay within the parity tolerance for every setting):
  *   "self_chain_algo"    0 auto | 1 one workgroup per (sample, layer group), no scratch beyond the partial products |
  *                        2 one workgroup per (sample, layer) + last-arriver chain (bit-identical to 1 at groups = 1)
- *   "self_chain_pipe"    1 (default) fused chain, fp32 slabs: the stream waves run a software pipeline of raw buffer loads (the next
- *                        batch of 8 16-byte loads in flight across the head reduction, the LDS write and the per-layer barrier) |
- *                        0 the plain chunk loop of rounds 1-2; same arithmetic, bit-identical results
+ *   "self_chain_pipe"    4 (default) fused chain, fp32 slabs, N >= 40: the stream waves run a software pipeline of raw buffer loads (the
+ *                        next batch of 8 16-byte loads in flight across the head reduction, the LDS write and the per-layer barrier)
+ *                        with up to 4 KB contiguous per (head, array) and wave | 2 / 1: at most 2 / 1 KB contiguous |
+ *                        0 the plain chunk loop of rounds 1-2.  Same arithmetic, bit-identical results
  *   "self_chain_groups"  0 auto | 1..8 layer groups per sample of the fused chain kernel (1 = strict sequential order)
  *   "self_chain_big"     2: N > 128 (<= 1152, no second right-hand side) runs the ONE-launch persistent team kernel |
  *                        0 / 1 (default): the per-layer split path, which measures 1.7-2x faster on MI355X

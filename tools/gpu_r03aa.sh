@@ -19,11 +19,11 @@ for name, L, B, H, N in (("txt", 12, 64, 8, 77), ("img", 12, 64, 12, 50), ("lxme
     attn = [torch.softmax(torch.randn(B * H, N, N, device="cuda"), -1) for _ in range(L)]
     grad = [torch.randn(B * H, N, N, device="cuda") * 0.05 for _ in range(L)]
     mb = 2 * L * B * H * N * N * 4 / 1e6
-    for pipe in (0, 1):
+    for pipe in (0, 1, 2, 4):
         ops.set_option("self_chain_pipe", pipe)
         t = us(lambda: ops.relevancy_self_chain(attn, grad, B))
         print("%-12s L=%d B=%d H=%d N=%d  pipe=%d: %.1f us  %.3f TB/s (%.1f MB)" % (name, L, B, H, N, pipe, t, mb / t, mb))
-ops.set_option("self_chain_pipe", 1)
+ops.set_option("self_chain_pipe", 4)
 P
 timeout 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-config-legs > $OUT/bench.json 2> $OUT/bench.log; tail -2 $OUT/bench.log
 python - <<'P'

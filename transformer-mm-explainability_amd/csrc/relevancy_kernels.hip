@@ -5,6 +5,8 @@
 // layouts, the algorithmic-byte model and the roofline each kernel is bound by.
 #include "mmx_common.h"
 
+#include <type_traits>
+
 namespace mmx {
 
 // =====================================================================================================
@@ -227,67 +229,91 @@ __global__ __launch_bounds__(THREADS) void self_chain_fused_kernel(const ChainAr
             // plain loop below drains its loads at every chunk and restarts cold after every barrier).  Raw buffer loads: one
             // wave-uniform resource per (layer, array), a scalar head offset, ONE lane offset register for all 16 loads of two
             // batches, which is what lets two batches fit the 128-VGPR budget of the 1024-thread workgroup.
-            const int nk = (stream_end + SSTRIDE - 1) / SSTRIDE;       // chunks per lane (lanes past the end redo the last one)
-            const int HB = (H + 3) >> 2;
-            const int total = L * nk * HB;
-            const int hstride = static_cast<int>(NN) * 4;
-            auto issue = [&](int it, u32x4 (&av)[4], u32x4 (&gv)[4]) {
-                const int hb = it % HB, k = (it / HB) % nk, l = it / (HB * nk);
-                const int c = min(lt + k * SSTRIDE, stream_end - 1);
-                const unsigned voff = static_cast<unsigned>(c) * 16u;
-                const auto rA = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(a.attn[l0 + l]) + sampleA * 4)), 0, 0x7fffffff,
-                    kRawBufferFlags);
-                const auto rG = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(a.grad[l0 + l]) + sample * 4)), 0, 0x7fffffff,
-                    kRawBufferFlags);
+            // Chunk-to-lane mapping: a stream wave owns blocks of 64 * CPL consecutive chunks and a batch is 4 / CPL heads x CPL
+            // chunks x 2 arrays, so that one batch reads CPL KB CONTIGUOUS per (head, array) instead of 1 KB from each of 8
+            // streams (CPL = 1).  CPL is as large as still leaves every stream wave a block (text tower, 77 tokens: 1408 chunks
+            // = 11 waves x 128 -> CPL = 2).  Heads are summed in ascending order whatever CPL: bit-identical results.
+            auto run = [&](auto cpl_tag) {
+                constexpr int CPL = decltype(cpl_tag)::value, HPB = 4 / CPL;
+                constexpr int NW = LT / 64;
+                const int ws = wave - NT;                                   // this stream wave
+                const int nk = (stream_end + LT * CPL - 1) / (LT * CPL);   // rounds (lanes past the end redo the last chunk)
+                const int HB = (H + HPB - 1) / HPB;
+                const int total = L * nk * HB;
+                const int hstride = static_cast<int>(NN) * 4;
+                auto issue = [&](int it, u32x4 (&av)[4], u32x4 (&gv)[4]) {
+                    const int hb = it % HB, k = (it / HB) % nk, l = it / (HB * nk);
+                    const int base = (ws + k * NW) * (64 * CPL) + lane;
+                    const auto rA = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(a.attn[l0 + l]) + sampleA * 4)), 0, 0x7fffffff,
+                        kRawBufferFlags);
+                    const auto rG = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(a.grad[l0 + l]) + sample * 4)), 0, 0x7fffffff,
+                        kRawBufferFlags);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int hoff = min(hb * 4 + u, H - 1) * hstride;          // clamped: no conditional load
-                    av[u] = __builtin_amdgcn_raw_buffer_load_b128(rA, voff, hoff, 0);
-                    gv[u] = __builtin_amdgcn_raw_buffer_load_b128(rG, voff, hoff, 0);
-                }
-            };
-            f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            auto consume = [&](int it, bool valid, const u32x4 (&av)[4], const u32x4 (&gv)[4]) {
-                const int hb = it % HB, k = (it / HB) % nk, l = it / (HB * nk);
+                    for (int u = 0; u < HPB; ++u) {
+                        const int hoff = min(hb * HPB + u, H - 1) * hstride;        // clamped: no conditional load
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    // heads in order: the same sum as the plain loop.  Every loaded register is USED unconditionally (a head
-                    // beyond H is a clamped duplicate, weighted 0): behind a branch the compiler would have to assume the
-                    // skipped loads still pending and drain vmcnt before the next batch may overwrite their registers.
-                    const float w = (valid && hb * 4 + u < H) ? 1.f : 0.f;
-                    const f32x4 x = __builtin_bit_cast(f32x4, gv[u]) * __builtin_bit_cast(f32x4, av[u]);
-                    s[0] += relu_nan(x[0]) * w; s[1] += relu_nan(x[1]) * w;
-                    s[2] += relu_nan(x[2]) * w; s[3] += relu_nan(x[3]) * w;
-                }
-                if (valid && hb == HB - 1) {
-                    const int c = lt + k * SSTRIDE;
-                    if (c < stream_end) {
-                        float* Ab = smem + (l & 1) * NP * S;
-                        const int p = c * 4;
-                        int row = p / N, cc = p - row * N;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            Ab[row * S + cc] = s[e] / fH;
-                            if (++cc == N) { cc = 0; ++row; }
+                        for (int jj = 0; jj < CPL; ++jj) {
+                            const unsigned voff = static_cast<unsigned>(min(base + jj * 64, stream_end - 1)) * 16u;
+                            av[u * CPL + jj] = __builtin_amdgcn_raw_buffer_load_b128(rA, voff, hoff, 0);
+                            gv[u * CPL + jj] = __builtin_amdgcn_raw_buffer_load_b128(rG, voff, hoff, 0);
                         }
                     }
-                    s = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (k == nk - 1) __syncthreads();  // publish A_bar_l (pairs with the matrix waves' barrier of layer l)
+                };
+                f32x4 s[CPL];
+#pragma unroll
+                for (int jj = 0; jj < CPL; ++jj) s[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                auto consume = [&](int it, bool valid, const u32x4 (&av)[4], const u32x4 (&gv)[4]) {
+                    const int hb = it % HB, k = (it / HB) % nk, l = it / (HB * nk);
+#pragma unroll
+                    for (int u = 0; u < HPB; ++u) {
+                        // heads in order: the same sum as the plain loop.  Every loaded register is USED unconditionally (a
+                        // head beyond H is a clamped duplicate, weighted 0): behind a branch the compiler would have to assume
+                        // the skipped loads still pending and drain vmcnt before the next batch may overwrite their registers.
+                        const float w = (valid && hb * HPB + u < H) ? 1.f : 0.f;
+#pragma unroll
+                        for (int jj = 0; jj < CPL; ++jj) {
+                            const f32x4 x = __builtin_bit_cast(f32x4, gv[u * CPL + jj]) * __builtin_bit_cast(f32x4, av[u * CPL + jj]);
+                            s[jj][0] += relu_nan(x[0]) * w; s[jj][1] += relu_nan(x[1]) * w;
+                            s[jj][2] += relu_nan(x[2]) * w; s[jj][3] += relu_nan(x[3]) * w;
+                        }
+                    }
+                    if (valid && hb == HB - 1) {
+                        float* Ab = smem + (l & 1) * NP * S;
+#pragma unroll
+                        for (int jj = 0; jj < CPL; ++jj) {
+                            const int c = (ws + k * NW) * (64 * CPL) + jj * 64 + lane;
+                            if (c < stream_end) {
+                                const int p = c * 4;
+                                int row = p / N, cc = p - row * N;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    Ab[row * S + cc] = s[jj][e] / fH;
+                                    if (++cc == N) { cc = 0; ++row; }
+                                }
+                            }
+                            s[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                        if (k == nk - 1) __syncthreads();  // publish A_bar_l (pairs with the matrix waves' barrier of layer l)
+                    }
+                };
+                // Two register sets; every issue is UNCONDITIONAL (past the end: the last batch again, consumed with weight 0)
+                // so that the number of loads in flight is the same on every path -- with a conditional issue the compiler
+                // merges the two paths' wait counts and drains everything before each reduction.
+                u32x4 a0[4], g0[4], a1[4], g1[4];
+                if (total > 0) issue(0, a0, g0);
+                for (int it = 0; it < total; it += 2) {
+                    issue(min(it + 1, total - 1), a1, g1);
+                    consume(it, true, a0, g0);
+                    issue(min(it + 2, total - 1), a0, g0);
+                    consume(min(it + 1, total - 1), it + 1 < total, a1, g1);
                 }
             };
-            // Two register sets; every issue is UNCONDITIONAL (past the end: the last batch again, consumed with weight 0) so
-            // that the number of loads in flight is the same on every path -- with a conditional issue the compiler merges the
-            // two paths' wait counts and drains everything before each reduction.
-            u32x4 a0[4], g0[4], a1[4], g1[4];
-            if (total > 0) issue(0, a0, g0);
-            for (int it = 0; it < total; it += 2) {
-                issue(min(it + 1, total - 1), a1, g1);
-                consume(it, true, a0, g0);
-                issue(min(it + 2, total - 1), a0, g0);
-                consume(min(it + 1, total - 1), it + 1 < total, a1, g1);
-            }
+            constexpr int NWs = LT / 64;
+            if (a.pipe >= 4 && stream_end >= NWs * 256) run(std::integral_constant<int, 4>{});
+            else if (a.pipe >= 2 && stream_end >= NWs * 128) run(std::integral_constant<int, 2>{});
+            else run(std::integral_constant<int, 1>{});
         } else
         for (int l = 0; l < L; ++l) {
             float* Ab = smem + (l & 1) * NP * S;
@@ -1024,7 +1050,7 @@ extern "C" int mmx_rollout_chain(const void* const* layers, int n_layers, int B,
 // ----------------------------------------------------------------------------------------- self chain
 static int nt_for(int N) { return (N + 15) / 16; }
 static int g_debug_flags = 0;
-static int g_chain_pipe = 1;     // option "self_chain_pipe": software-pipelined stream waves of the fused chain (fp32 slabs)
+static int g_chain_pipe = 4;     // option "self_chain_pipe": software-pipelined stream waves of the fused chain (fp32 slabs)
 static int g_chain_groups = 0;  // layer groups per sample of the per-sample kernel: 0 auto, 1 = strict sequential order
 static int g_chain_algo = 0;  // 0 auto, 1 per-sample wave-specialised, 2 reduce + last-arriver chain
 
@@ -1033,8 +1059,8 @@ extern "C" int mmx_set_option(const char* key, int value) {
         g_chain_algo = value;
         return MMX_OK;
     }
-    if (key && strcmp(key, "self_chain_pipe") == 0) {
-        g_chain_pipe = value & 1;
+    if (key && strcmp(key, "self_chain_pipe") == 0 && value >= 0 && value <= 4) {
+        g_chain_pipe = value;            // 0 off | 1 one chunk per lane and head | 2 / 4: up to that many contiguous chunks
         return MMX_OK;
     }
     if (key && strcmp(key, "self_chain_groups") == 0 && value >= 0 && value <= 8) {
@@ -1234,7 +1260,7 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
         args.G = fused_groups(n_layers, B, H, N);
         args.debug = g_debug_flags;
         args.attn_bstride = attn_batch_stride;
-        args.pipe = g_chain_pipe && N * N >= 1600;      // (below ~40 tokens the pipeline's bookkeeping costs more than it hides)
+        args.pipe = N * N >= 1600 ? g_chain_pipe : 0;   // (below ~40 tokens the pipeline's bookkeeping costs more than it hides)
         if (args.G > 1) {
             const size_t need = mmx_self_chain_workspace_bytes(n_layers, B, H, N, M, dtype);
             if (workspace_bytes < need || !workspace_dev) {
