@@ -64,6 +64,28 @@ def test_generate_relevance_and_batched_targets(img, patch, dim, depth, heads):
     close(top()[0], want[None])
 
 
+def test_vit_b16_full_size_graph_replay_after_other_graphs():
+    """ViT-B/16 at full size (197 tokens: the row chain interleaved with the backward) captured and replayed in a process that
+    already holds a captured two-tower CLIP pass (``bench.py``'s leg order; round 3: a side-stream form of this pass
+    segfaulted in exactly that situation) == the eager call."""
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    from transformer_mm_explainability_amd import clip_model, vit_model
+    torch.manual_seed(0)
+    clip = clip_model.CLIP(64, 64, 2, 64, 16, 12, 100, 64, 2, 2).cuda().eval()
+    image = torch.randn(1, 3, 64, 64, device="cuda")
+    texts = torch.randint(1, 99, (4, 12), device="cuda")
+    clip_graph = ce.GraphedInterpret(clip, image, texts)
+    clip_graph(image, texts)
+    model = build(224, 16, 768, 12, 12, classes=1000).cuda()
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(3)).cuda()
+    want = vit_model.generate_relevance_multi(model, x, [5, 980]).clone()
+    run = vit_model.GraphedRelevance(model, x, indices=[5, 980])
+    for _ in range(3):
+        got = run(x)
+    close(got, want.cpu().numpy(), atol=1e-6)
+    clip_graph(image, texts)
+
+
 def test_vit_b16_full_size_properties():
     """BASELINE.json config 1's architecture (ViT-B/16: 12 layers x 12 heads x 197 tokens) at full size: the K-target
     pass (shared forward, streaming attention kernels, split chain path with a shared probability slab) equals K

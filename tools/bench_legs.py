@@ -96,6 +96,30 @@ def leg_cfg3(kernel_time_us, reps=10):
         ms = _timed_ms(lambda: run(feats, t), reps)
         out[K] = ms
         del run
+    # the --masks evaluator's inner loop (DETR/engine.py:153-215 around MaskGenerator.get_masks): per image one forward, the keep
+    # set, ONE K-slot pass for all kept queries, Otsu masks -- one device -> host read per image (examples/detr_masks_eval.py)
+    from transformer_mm_explainability_amd.detr_explainability import MaskGenerator
+    mg = MaskGenerator(model, threshold=0.5, graph_slots=8)
+    keep_top, n_img = 8, 40
+
+    def one_image(k):
+        f = torch.randn(1, 2048, 25, 38, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5000 + k)) * 0.5
+        with torch.no_grad():
+            outputs = model(f)
+            conf = outputs["pred_logits"].softmax(-1)[0, :, :-1].max(-1).values
+        mg.threshold = conf.sort().values[-keep_top - 1]            # random weights: flat logits, keep the 8 most confident
+        return mg.get_masks(f, "ours_no_lrp", outputs=outputs)[0]
+
+    for k in range(2):
+        one_image(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(2, 2 + n_img):
+        one_image(k)
+    mg.check_diag()
+    torch.cuda.synchronize()
+    ev_ms = (time.perf_counter() - t0) / n_img * 1e3
+    del mg
     # dominant kernels of OUR part: the encoder self-attention backward pair (d = 32 streaming kernels) at K = 10
     K, H, N, D = 10, 8, 950, 32
     q, k, v = (torch.randn(1, N, H, D, device="cuda") for _ in range(3))
@@ -115,6 +139,10 @@ def leg_cfg3(kernel_time_us, reps=10):
             "rate": round(20 / out[20] * 1e3, 1), "unit": "queries/s", "ms": round(out[20], 3),
             "K10": {"ms": round(out[10], 3), "ms_per_query": round(out[10] / 10, 3)},
             "K20": {"ms": round(out[20], 3), "ms_per_query": round(out[20] / 20, 3)},
+            "evaluator": {"ms_per_image": round(ev_ms, 3), "images_per_s": round(1e3 / ev_ms, 1), "kept_queries_per_image": keep_top,
+                          "queries_per_s": round(keep_top * 1e3 / ev_ms, 1),
+                          "what": "forward + keep set + one K-slot pass (hipGraph, 8 slots) + Otsu masks per image, one device->host "
+                                  "read per image, %d images after 2 warm-up images" % n_img},
             "kernel": kern, "source": "profiles/r03_cfg_legs.txt"}
 
 

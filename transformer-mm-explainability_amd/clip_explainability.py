@@ -31,15 +31,9 @@ def _plan(buffers, first, last, batch_size, shared):
     return cache[key]
 
 
-_SIDE_STREAMS = {}
-
-
 def _side_stream(device):
-    """One side stream per device for the image tower (created once: a hipGraph capture must not create streams)."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
-    return _SIDE_STREAMS[key]
+    """The side stream of the image tower (``ops.side_stream``: shared by eager calls, private to a capture inside one)."""
+    return ops.side_stream(device)
 
 
 def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, share_image_forward=True,

@@ -6,8 +6,10 @@ path and no PyTorch-op fallback: a CPU tensor or a missing ``libmmx_hip.so`` rai
 from __future__ import annotations
 
 import contextlib
+import threading
 import ctypes as C
 import gc
+import os
 import weakref
 
 import torch
@@ -66,15 +68,22 @@ def _workspace(nbytes, device, tag="default"):
 
 
 _SIDE_STREAMS = {}
+_CAPTURE = threading.local()     # .side: the private side stream of the capture in progress on this thread (graph_capture)
 
 
 def side_stream(device, slot=0):
-    """A side stream per (device, slot), created once (a hipGraph capture must not create streams): independent chains of an
-    explainability pass -- LXMERT's two modalities, DETR's value projections and rule kernels -- run on it beside the current
-    stream.  Use ONE side stream per captured pass (the default slot): a DETR pass captured across two side streams (value
-    projections on one, rule kernels on another) replayed fine on its own but segfaulted inside hipGraphLaunch when CLIP graphs
-    had been captured and destroyed earlier in the process (round 3, tests/test_gpu_generators.py); with both on the same side
-    stream the same sequence is clean."""
+    """The side stream independent chains of an explainability pass run on beside the current stream (LXMERT's two modalities,
+    DETR's / ViT's rule kernels beside the backward, CLIP's second tower).  Eager calls share one stream per (device, slot),
+    created once; INSIDE ``graph_capture`` every capture gets a PRIVATE side stream (and a private capture stream) that lives
+    and dies with its graph.  Why: graphs captured across streams that earlier, since destroyed, graphs had also been captured
+    across segfaulted inside ``hipGraphLaunch`` (round 3: the DETR pass after CLIP / ViT graphs in one process, ``bench.py``'s
+    config legs and the GPU test suite) -- with no stream shared between two captures the same sequences are clean.
+    Use ONE side stream per pass."""
+    if os.environ.get("MMX_DEBUG_NO_SIDE"):          # debugging aid (MMX_DEBUG_NO_SIDE=1): every chain on the current stream
+        return torch.cuda.current_stream(device)
+    private = getattr(_CAPTURE, "side", None)
+    if private is not None:
+        return private
     dev = torch.device(device)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), slot)
     if key not in _SIDE_STREAMS:
@@ -84,21 +93,30 @@ def side_stream(device, slot=0):
 
 @contextlib.contextmanager
 def graph_capture(graph):
-    """``torch.cuda.graph(graph, capture_error_mode="thread_local")`` with Python's cyclic garbage collector held off for
-    the duration of the capture.  A collection that happens to run INSIDE a capture may destroy objects whose destructors
-    issue HIP calls that are illegal while a stream is capturing -- a ``torch.cuda.CUDAGraph`` of an earlier, already dropped
-    ``Graphed*`` wrapper releases its private memory pool (``hipFree``) -- and an exception in a C++ destructor aborts the
-    process (seen as "Fatal Python error: Aborted ... Garbage-collecting" in the GPU test suite).  ``torch.cuda.graph``
-    collects once BEFORE the capture begins; this keeps the collector from firing again until it has ended.
-    thread_local: a collective backend's watchdog thread (RCCL, one rank per GPU) may poll events while this thread captures;
-    only calls made by the capturing thread must be capture-safe."""
+    """``torch.cuda.graph(graph, ...)`` the way every ``Graphed*`` wrapper of this package captures:
+
+    * Python's cyclic garbage collector is held off for the duration of the capture.  A collection that happens to run INSIDE a
+      capture may destroy objects whose destructors issue HIP calls that are illegal while a stream is capturing -- a
+      ``torch.cuda.CUDAGraph`` of an earlier, already dropped wrapper releases its private memory pool (``hipFree``) -- and an
+      exception in a C++ destructor aborts the process (seen as "Fatal Python error: Aborted ... Garbage-collecting" in the GPU
+      test suite).  ``torch.cuda.graph`` collects once BEFORE the capture begins; this keeps the collector from firing again.
+    * the capture runs on its OWN capture stream and ``side_stream()`` hands out a side stream private to this capture (see
+      there); both, and the scratch buffers first allocated on them, are kept on the graph object and released with it.
+    * ``capture_error_mode="thread_local"``: a collective backend's watchdog thread (RCCL, one rank per GPU) may poll events
+      while this thread captures; only calls made by the capturing thread must be capture-safe."""
     was_enabled = gc.isenabled()
     gc.collect()
     gc.disable()
+    capture_stream, private_side = torch.cuda.Stream(), torch.cuda.Stream()
+    known = set(_ws_cache)
+    _CAPTURE.side = private_side
     try:
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        with torch.cuda.graph(graph, stream=capture_stream, capture_error_mode="thread_local"):
             yield
     finally:
+        _CAPTURE.side = None
+        # scratch first allocated on the private streams belongs to this graph alone: off the shared cache, onto the graph
+        graph._mmx_private = ([_ws_cache.pop(k) for k in list(_ws_cache) if k not in known], capture_stream, private_side)
         if was_enabled:
             gc.enable()
 

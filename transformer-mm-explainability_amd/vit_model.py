@@ -19,7 +19,6 @@ backward passes run as one batch-K backward over the shared activations (same sc
 """
 from __future__ import annotations
 
-import math
 
 import torch
 import torch.nn as nn
@@ -159,46 +158,44 @@ class VisionTransformer(nn.Module):
         N, E = x.shape[1], x.shape[2]
         buf = self._slabs(n_targets, N, x.device, shared=True)
         tape = []
+        # every LayerNorm but the first is fused with the residual add that produces its input (ops.add_layernorm: one pass
+        # writes the sum, the normalised rows and their statistics)
+        first = self.blocks[0].norm1
+        _, h1, mean1, rstd1 = ops.add_layernorm(x, None, first.weight, first.bias, first.eps)
         for l, blk in enumerate(self.blocks):
             at = blk.attn
-            h1, mean1, rstd1 = torch.native_layer_norm(x, (E,), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
             qkv = at.qkv(h1).view(1, N, 3, at.num_heads, at.head_dim)
             o = ops.attn_capture_fwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], buf.probs[l], 1.0 / at.scale,
                                      _lib.SCALE_SCORES, None, layout="bnhd")
-            x1 = x + at.proj(o.view(1, N, E))
-            h2, mean2, rstd2 = torch.native_layer_norm(x1, (E,), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            x1, h2, mean2, rstd2 = ops.add_layernorm(x, at.proj(o.view(1, N, E)), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
             m = blk.mlp.fc1(h2)
-            x2 = x1 + blk.mlp.fc2(F.gelu(m))
+            mlp_out = blk.mlp.fc2(F.gelu(m))
             tape.append((x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o))
             at.attention_map, at.attn_gradients = buf.probs[l], buf.grads[l]
-            x = x2
-        f, mean, rstd = torch.native_layer_norm(x, (E,), self.norm.weight, self.norm.bias, self.norm.eps)
-        return self.head(f[:, 0]), (tape, x, mean, rstd)
-
-    @staticmethod
-    def _ln_backward(dy, x, mean, rstd, ln):
-        B = dy.shape[0]
-        return torch.ops.aten.native_layer_norm_backward(
-            dy.contiguous(), x.expand(B, -1, -1).contiguous(), (x.shape[-1],), mean.expand(B, -1, -1).contiguous(),
-            rstd.expand(B, -1, -1).contiguous(), ln.weight, ln.bias, [True, False, False])[0]
+            nxt = self.blocks[l + 1].norm1 if l + 1 < self.depth else self.norm
+            x, h1, mean1, rstd1 = ops.add_layernorm(x1, mlp_out, nxt.weight, nxt.bias, nxt.eps)
+        return self.head(h1[:, 0]), (tape, x, mean1, rstd1)
 
     @torch.no_grad()
-    def backward_shared(self, state, d_logits):
-        """``d_logits [K, C]``: K upstream gradients over the ONE forward; fills ``grads`` of every block (batch K)."""
+    def backward_shared(self, state, d_logits, on_layer_done=None):
+        """``d_logits [K, C]``: K upstream gradients over the ONE forward; fills ``grads`` of every block (batch K).
+        ``on_layer_done(l)``: called right after block l's gradient slab is complete on the current stream (the backward runs
+        top-down -- the order a relevancy ROW is carried in -- so a caller can apply layer l's rule beside the rest of it)."""
         tape, x_last, mean, rstd = state
         K = d_logits.shape[0]
         N, E = x_last.shape[1], x_last.shape[2]
         d_f = torch.zeros(K, N, E, dtype=torch.float32, device=d_logits.device)
         d_f[:, 0, :] = torch.matmul(d_logits, self.head.weight)
-        dx = self._ln_backward(d_f, x_last, mean, rstd, self.norm)
+        dx = ops.layernorm_bwd_add(d_f, x_last, mean, rstd, self.norm.weight)
         buf = self.buffers_
         for l in range(self.depth - 1, -1, -1):
             blk = self.blocks[l]
             at = blk.attn
             x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o_fwd = tape[l]
             d_a = self._gemm(dx, blk.mlp.fc2.weight)
-            gelu_prime = 0.5 * (1 + torch.erf(m / math.sqrt(2.0))) + m * torch.exp(-0.5 * m * m) / math.sqrt(2 * math.pi)
-            d_h2 = self._gemm(d_a * gelu_prime, blk.mlp.fc1.weight)
+            # d_a * GELU'(m), exact (erf) form, in ONE library kernel (m [1, N, 4E] is the shared pre-activation: broadcast)
+            d_m = torch.ops.aten.gelu_backward(d_a, m.expand_as(d_a))
+            d_h2 = self._gemm(d_m, blk.mlp.fc1.weight)
             d_x1 = ops.layernorm_bwd_add(d_h2, x1, mean2, rstd2, blk.norm2.weight, dx)
             d_o = self._gemm(d_x1, at.proj.weight).view(K, N, at.num_heads, at.head_dim)
             need = l > 0
@@ -206,6 +203,8 @@ class VisionTransformer(nn.Module):
             out = (dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]) if need else None
             ops.attn_capture_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], buf.probs[l], d_o, buf.grads[l], 1.0 / at.scale,
                                  _lib.SCALE_SCORES, need_dqkv=need, layout="bnhd", out=out, batch=K, o=o_fwd)
+            if on_layer_done is not None:
+                on_layer_done(l)
             if not need:
                 break
             d_h1 = self._gemm(dqkv.view(K, N, 3 * E), at.qkv.weight)
@@ -235,11 +234,38 @@ def generate_relevance_multi(model, input, indices=None, top_k=None):
         idx = logits[0].topk(K).indices
     d_logits = torch.zeros(K, logits.shape[-1], dtype=torch.float32, device=input.device)
     d_logits.scatter_(1, idx.reshape(K, 1), 1.0)                     # one one-hot per target (capturable: no host sync)
-    model.backward_shared(state, d_logits)
     buf = model.buffers_
-    row = ops.relevancy_chain_row([buf.probs[l] for l in range(model.depth)], [buf.grads[l] for l in range(model.depth)],
-                                  K, 0, shared_attn=K > 1)           # R[:, 0, :] carried as row vectors: no 197^3 products
-    return row[:, 1:]
+    N = buf.probs[0].shape[-1]
+    if N <= 128:        # the one-launch fused chain (all layers, R in registers) is faster there; the row is picked afterwards
+        model.backward_shared(state, d_logits)
+        row = ops.relevancy_chain_row([buf.probs[l] for l in range(model.depth)], [buf.grads[l] for l in range(model.depth)],
+                                      K, 0, shared_attn=K > 1)
+        return row[:, 1:]
+    # R[:, 0, :] carried as a ROW vector from the top layer down, x <- x + x . A_bar_l (no 197^3 products): the backward visits the
+    # layers in that same order, so layer l's head average + mat-vec start as soon as its gradient slab is complete, on a side
+    # stream beside the rest of the backward
+    main = torch.cuda.current_stream()
+    # (eager calls only: THIS fork pattern captured into a hipGraph -- 12 re-waits of the side stream on the main one, three
+    # kernels each -- replayed fine in a fresh process and segfaulted inside hipGraphLaunch once CLIP graphs existed in the
+    # process (bench.py's leg order; bisected with MMX_DEBUG_NO_SIDE).  Under capture the rule kernels stay on the main stream.)
+    side = main if torch.cuda.is_current_stream_capturing() else ops.side_stream(input.device)
+    x = torch.zeros(K, N, dtype=torch.float32, device=input.device)
+    x[:, 0] = 1.0
+    row = [x]
+
+    def layer_rule(l):
+        if side is main:
+            row[0] = ops.chain_vecmat(row[0], ops.avg_heads(buf.probs[l], buf.grads[l], batch_size=K, shared_attn=K > 1))
+            return
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            row[0] = ops.chain_vecmat(row[0], ops.avg_heads(buf.probs[l], buf.grads[l], batch_size=K, shared_attn=K > 1))
+
+    model.backward_shared(state, d_logits, layer_rule)
+    if side is not main:
+        main.wait_stream(side)
+        row[0].record_stream(main)
+    return row[0][:, 1:]
 
 
 class GraphedRelevance:
