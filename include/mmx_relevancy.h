@@ -75,7 +75,7 @@ const char* mmx_last_error(void);
  *   "attn_head"          1 (default) register-resident whole-head attention kernels (Nk <= 128, Nq <= 256) | 0 never
  *   "attn_small"         1 (default) whole-head-in-LDS attention kernels where the head fits | 0 never
  *   "attn_stream"        1 (default) long-sequence streaming attention kernels | 0 first-generation tiled kernels
- *   "attn_fwd_split"     1 (default) streaming forward on a small grid (< 160 workgroups of 64 rows, head_dim <= 32, fp32 slabs):
+ *   "attn_fwd_split"     1 (default) streaming forward on a small grid (< 160 workgroups of 64 rows, fp32 slabs):
  *                        16-row workgroups whose waves split the keys | 0 always the 64-row kernel
  *   "debug_flags"        profiling only (phase skipping); 0 in production
  * Unknown keys / out-of-range values return MMX_EINVAL. */

@@ -310,7 +310,8 @@ def test_attn_capture_fwd_bwd(ops, B, H, Nq, Nk, D, mode, masked, path):
 
 @pytest.mark.parametrize("B,H,Nq,Nk,D,mode,masked", [(1, 8, 950, 950, 32, 0, False), (1, 8, 100, 950, 32, 0, False),
                                                      (1, 3, 37, 130, 20, 1, True), (2, 2, 16, 65, 32, 0, True),
-                                                     (1, 1, 5, 300, 8, 0, False)])
+                                                     (1, 1, 5, 300, 8, 0, False), (1, 12, 197, 197, 64, 1, False),
+                                                     (1, 2, 70, 300, 48, 0, True), (2, 3, 130, 577, 64, 0, False)])
 def test_attn_fwd_small_grid_split_kernel(ops, B, H, Nq, Nk, D, mode, masked):
     """``attn_fwd_split_kernel`` (16-row workgroups whose four waves split the keys: the shared forward of DETR's K-query pass)
     against the fp64 softmax and against the 64-row streaming kernel it replaces on small grids (option ``attn_fwd_split``)."""

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kThreads, DP == 32 ? 3 : 2) void attn_fwd_stream_ke
 // query rows and its four waves SPLIT THE KEYS (wave w takes tiles w, w + 4, ...), each staging its own tiles in a private
 // LDS region (no workgroup barrier inside the sweeps; a wave's LDS traffic is in order).  The per-wave softmax statistics
 // and partial O = P.V are merged through LDS: 4x the workgroups, a quarter of the serial tile chain each.  Exact fp32, fp32
-// slabs, head_dim <= 32 (the per-wave K + V tiles of a 64-wide head would not fit).
+// slabs; head_dim <= 64 (ViT-B/16 at one image: 12 heads x 197 tokens = 48 workgroups of the kernel above).
 template <int DP>
 struct WaveTileRegs {
     f32x4 raw[DP / 4];
@@ -417,9 +417,10 @@ __device__ __forceinline__ void wave_tile_store(float* lds, const WaveTileRegs<D
     __builtin_amdgcn_wave_barrier();          // keep the compiler from moving this wave's tile reads above the stores
 }
 
+// (the partial-O exchange at the end reuses the tile regions: a 64-wide head's four K + V regions alone are 153 KB of the 160)
 template <int DP>
 constexpr size_t split_lds_bytes() {
-    return sizeof(float) * (4 * (2 * kTile * (DP + 4) + 16 * kPS) + 4 * 16 * 2 + 4 * 16 * DP);
+    return sizeof(float) * (4 * (2 * kTile * (DP + 4) + 16 * kPS) + 4 * 16 * 2);
 }
 
 template <int DP>
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_split_kernel(const AttnF
     float* Vs = Ks + kTile * LS;
     float* Pw = Vs + kTile * LS;
     float* stat = smem + 4 * kWave;                       // [4 waves][16 rows][max, sum]
-    float* opart = stat + 4 * 16 * 2;                     // [4 waves][16 rows][DP]
+    float* opart = smem;                                  // [4 waves][16 rows][DP], over the tile regions once the sweeps are done
     const int nrt = (a.Nq + 15) / 16;
     const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
     const int h = (wg / nrt) % a.H, b = wg / (nrt * a.H);
@@ -547,6 +548,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_split_kernel(const AttnF
         tile_wt<DP>(oacc, Pw, Vs, i, g);
         __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();                                      // every wave is done with its tiles: their LDS becomes the exchange
 #pragma unroll
     for (int dt = 0; dt < NB; ++dt)
 #pragma unroll
@@ -1001,9 +1003,10 @@ int attn_fwd_stream_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out) {
     if (!aligned16(a.q, a.qs) || !aligned16(a.k, a.ks) || !aligned16(a.v, a.vs)) return 0;
     dim3 grid(((a.Nq + kRows - 1) / kRows) * a.H * a.B);
     // a grid that leaves most of the chip idle (one shared forward): 16-row workgroups whose waves split the keys
-    if (g_attn_fwd_split && grid.x < 160 && a.slab_dt == MMX_F32 && !a.mma_bf16 && a.D <= 32 && a.Nk > kTile) {
-        *rc_out = launch_stream(attn_fwd_split_kernel<32>, a, dim3(((a.Nq + 15) / 16) * a.H * a.B), split_lds_bytes<32>(), s,
-                                "attn_fwd_split_kernel<32>");
+    if (g_attn_fwd_split && grid.x < 160 && a.slab_dt == MMX_F32 && !a.mma_bf16 && a.Nk > kTile) {
+        const dim3 g16(((a.Nq + 15) / 16) * a.H * a.B);
+        *rc_out = a.D <= 32 ? launch_stream(attn_fwd_split_kernel<32>, a, g16, split_lds_bytes<32>(), s, "attn_fwd_split_kernel<32>")
+                            : launch_stream(attn_fwd_split_kernel<64>, a, g16, split_lds_bytes<64>(), s, "attn_fwd_split_kernel<64>");
         return 1;
     }
     switch (a.slab_dt) {
