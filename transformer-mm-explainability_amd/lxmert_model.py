@@ -301,8 +301,13 @@ class LxmertEncoder(nn.Module):                                        # lxmert_
     # ---- tape path of the explainability pass (bert_tape.py): no autograd graph, no weight gradients
     overlap_modalities = True     # tape path: the image chain of every layer group on a side stream beside the text chain
 
-    def forward_tape(self, lang, lang_mask, visual_feats, visual_pos, visn_mask=None):
-        """The 9 language layers and the 5 object-relationship layers are independent of each other, and so are the two chains
+    def forward_tape(self, lang, lang_mask, visual_feats, visual_pos, visn_mask=None, lang_repeat=1, visn_repeat=1):
+        """``lang_repeat`` / ``visn_repeat`` (forward-only callers): the single-modality layers run on the batch as given and
+        their output (and mask) is repeated that many times, sample-major, before the cross-modality layers -- the perturbation
+        evaluator re-runs a sample 9 times with only ONE modality changed, so the other modality's own layers (9 language / 5
+        object-relationship layers: 20 % / 28 % of a forward) are the same for all 9 and run once.
+
+        The 9 language layers and the 5 object-relationship layers are independent of each other, and so are the two chains
         of every cross-modality layer after its cross-attentions (``LxmertXLayer.forward_tape``): at the batch sizes of an
         explainability pass these are 448- / 1152-row GEMMs that each fill a fraction of the chip, so the image chain runs on a
         side stream beside the text chain (fork / join inside one hipGraph when captured)."""
@@ -319,6 +324,13 @@ class LxmertEncoder(nn.Module):                                        # lxmert_
         for blk in self.layer:
             lang, t = bt.layer_fwd(blk, lang, lang_mask)
             tapes["l"].append(t)
+        if lang_repeat > 1:
+            lang = lang.repeat_interleave(lang_repeat, dim=0)
+            lang_mask = None if lang_mask is None else lang_mask.repeat_interleave(lang_repeat, dim=0)
+        if visn_repeat > 1:
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                visn = visn.repeat_interleave(visn_repeat, dim=0)
+                visn_mask = None if visn_mask is None else visn_mask.repeat_interleave(visn_repeat, dim=0)
         for blk in self.x_layers:
             if side is not None:                                      # each chain reads the other's output of the layer below
                 main.wait_stream(side)
@@ -464,11 +476,16 @@ class LxmertForQuestionAnswering(nn.Module):                           # lxmert_
 
     @torch.no_grad()
     def scores_no_grad(self, input_ids=None, visual_feats=None, visual_pos=None, attention_mask=None,
-                       visual_attention_mask=None, token_type_ids=None, inputs_embeds=None, **unused):
+                       visual_attention_mask=None, token_type_ids=None, inputs_embeds=None, lang_repeat=1, visn_repeat=1,
+                       **unused):
         """``forward(...).question_answering_score`` through the tape forward (packed q / k / v GEMMs, fused bias / add /
         LayerNorm, the two modalities side by side) without keeping anything for a backward -- what the perturbation evaluator's
-        re-runs need (lxmert/lxmert/perturbation.py:119-131).  An empty region set takes the module forward."""
+        re-runs need (lxmert/lxmert/perturbation.py:119-131).  An empty region set takes the module forward.
+        ``lang_repeat`` / ``visn_repeat``: the text (visual) inputs are given ONCE per sample and their own layers' output is
+        repeated for the cross-modality layers (``LxmertEncoder.forward_tape``); the other modality comes already repeated."""
         if visual_feats.shape[1] == 0 or input_ids is None:
+            if lang_repeat != 1 or visn_repeat != 1:
+                raise ValueError("scores_no_grad: the repeat hints need a non-empty region set and token ids")
             return self.forward(input_ids, visual_feats, visual_pos, attention_mask, visual_attention_mask, token_type_ids,
                                 inputs_embeds).question_answering_score
         m = self.lxmert
@@ -476,7 +493,7 @@ class LxmertForQuestionAnswering(nn.Module):                           # lxmert_
         if attention_mask is None:
             attention_mask = torch.ones(emb.shape[:2], device=emb.device)
         lang, _, _ = m.encoder.forward_tape(emb, _extended_mask(attention_mask, emb.dtype), visual_feats, visual_pos,
-                                            _extended_mask(visual_attention_mask, emb.dtype))
+                                            _extended_mask(visual_attention_mask, emb.dtype), lang_repeat, visn_repeat)
         return self.answer_head(m.pooler(lang))
 
     @torch.no_grad()

@@ -131,12 +131,16 @@ class LxmertPerturbation:
         if live:
             rows = torch.tensor(live, device=keep.device)
             n = len(live)
-            out = self._scores(input_ids=self._rep(inputs["input_ids"], n),
-                             attention_mask=self._rep(inputs["attention_mask"], n),
-                             token_type_ids=self._rep(inputs["token_type_ids"], n),
-                             visual_feats=self._rep(inputs["visual_feats"], n),
-                             visual_pos=self._rep(inputs["visual_pos"], n),
-                               visual_attention_mask=keep[:, rows].reshape(B * n, I))
+            vis = dict(visual_feats=self._rep(inputs["visual_feats"], n), visual_pos=self._rep(inputs["visual_pos"], n),
+                       visual_attention_mask=keep[:, rows].reshape(B * n, I))
+            if hasattr(self.model, "scores_no_grad"):
+                # the text is the same in all n re-runs of a sample: its own 9 layers run once per sample (lang_repeat)
+                out = self.model.scores_no_grad(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
+                                                token_type_ids=inputs["token_type_ids"], lang_repeat=n, **vis)
+            else:
+                out = self._scores(input_ids=self._rep(inputs["input_ids"], n),
+                                   attention_mask=self._rep(inputs["attention_mask"], n),
+                                   token_type_ids=self._rep(inputs["token_type_ids"], n), **vis)
             scores = out.new_empty(B, S, out.shape[-1])
             scores[:, rows] = out.reshape(B, n, -1)
         if len(live) < S:                                    # steps that keep no region at all: region-free forward
@@ -160,8 +164,13 @@ class LxmertPerturbation:
         parts = [text_keep_batch(inputs["input_ids"][b:b + 1], inputs["token_type_ids"][b:b + 1], cams[b], self.steps,
                                  is_positive_pert, n_tokens=lens[b]) for b in range(B)]
         ids, types, mask = (torch.cat([p[k] for p in parts]) for k in range(3))                     # [B*S, T]
-        out = self._scores(input_ids=ids, attention_mask=mask, token_type_ids=types,
-                           visual_feats=self._rep(inputs["visual_feats"], S), visual_pos=self._rep(inputs["visual_pos"], S))
+        if hasattr(self.model, "scores_no_grad") and inputs["visual_feats"].shape[1] > 0:
+            # the regions are the same in all S re-runs of a sample: their own 5 layers run once per sample (visn_repeat)
+            out = self.model.scores_no_grad(input_ids=ids, attention_mask=mask, token_type_ids=types,
+                                            visual_feats=inputs["visual_feats"], visual_pos=inputs["visual_pos"], visn_repeat=S)
+        else:
+            out = self._scores(input_ids=ids, attention_mask=mask, token_type_ids=types,
+                               visual_feats=self._rep(inputs["visual_feats"], S), visual_pos=self._rep(inputs["visual_pos"], S))
         out = out.reshape(B, S, -1)
         return out[0] if single else out
 
