@@ -143,6 +143,12 @@ int mmx_bmm_f32(const void* A_dev, const void* B_dev, const void* Cin_dev, void*
  * here -- profiles/r03_detr_probe.txt); everything else stays on the library GEMMs, which are faster from 256 x 512 outputs up. */
 int mmx_linear_f32(const void* x_dev, const void* wt_dev, const void* bias_dev, void* out_dev, int M, int N, int K, void* stream);
 
+/* One row per sample <-> a dense [B, N, E] fp32 tensor (the top block of a CLIP tower carries a gradient on ONE token per sample,
+ * the class / EOT token: CLIP/clip/model.py:235, 360):  mmx_rows_to_dense: out[b, n, :] = (n == rows[b]) ? vals[b, :] : 0;
+ * mmx_rows_add: dense[b, rows[b], :] += vals[b, :].  rows: int64 [B] (0 <= rows[b] < N), vals [B, E], E % 4 == 0, 16-byte aligned. */
+int mmx_rows_to_dense(const void* vals_dev, const void* rows_dev, void* out_dev, int B, int N, int E, void* stream);
+int mmx_rows_add(void* dense_dev, const void* rows_dev, const void* vals_dev, int B, int N, int E, void* stream);
+
 /* The chain on VECTORS (rows-only DETR rules): when a caller returns single rows of R_q_i (`aggregated[:, target_index, :]`,
  * DETR/modules/ExplanationGenerator.py:180-182) the encoder product R_ii = (I + A_6) ... (I + A_1) (`:110-118`) is needed only
  * as  R_ii . 1  (the row sums `handle_residual` divides by, `:26-31`) and as  v . R_ii : mat-vecs with the head-averaged maps.

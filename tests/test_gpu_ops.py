@@ -340,6 +340,23 @@ def test_attn_fwd_small_grid_split_kernel(ops, B, H, Nq, Nk, D, mode, masked):
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("B,N,E", [(64, 77, 512), (3, 5, 8), (1, 1, 4), (128, 577, 1024)])
+def test_rows_to_dense_and_rows_add(ops, B, N, E):
+    """One row per sample scattered into a zeroed dense tensor / added to an existing one (the class / EOT token's gradient of a
+    CLIP tower's top block): equal to torch's zeros + index_put and gather + add + index_put, bit for bit."""
+    g = torch.Generator().manual_seed(B + N)
+    vals = torch.randn(B, E, generator=g).cuda()
+    rows = torch.randint(0, N, (B,), generator=g).cuda()
+    ar = torch.arange(B, device="cuda")
+    want = torch.zeros(B, N, E, device="cuda")
+    want[ar, rows] = vals
+    assert torch.equal(ops.rows_to_dense(vals, rows, N), want)
+    dense = torch.randn(B, N, E, generator=g).cuda()
+    want2 = dense.clone()
+    want2[ar, rows] += vals
+    assert torch.equal(ops.rows_add_(dense, rows, vals), want2)
+
+
 @pytest.mark.parametrize("rows,E,bias", [(100, 256, True), (1, 256, True), (37, 48, False), (128, 64, True), (129, 256, True),
                                          (100, 512, True)])
 def test_small_linear_routes_the_few_row_square_projections(ops, rows, E, bias):

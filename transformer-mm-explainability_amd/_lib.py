@@ -63,6 +63,8 @@ _PROTOTYPES = {
     "mmx_detr_decoder_rows_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mmx_detr_decoder_rows": (_i, [_vpp] * 4 + [_i] * 5 + [_i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mmx_linear_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mmx_rows_to_dense": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mmx_rows_add": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "mmx_chain_matvec": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mmx_chain_vecmat_workspace_bytes": (_sz, [_i, _i]),
     "mmx_chain_vecmat": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),

@@ -240,7 +240,7 @@ class Transformer(nn.Module):
         return self.forward_tape(x, batch)
 
     @torch.no_grad()
-    def backward_tape(self, tape, dy, first_grad_layer=0, dy_rows=None, rel_row=None):
+    def backward_tape(self, tape, dy, first_grad_layer=0, dy_rows=None, rel_row=None, dy_row_values=None):
         """``dy``: ``[B, N, E]`` upstream gradients w.r.t. the tower output; fills ``buffers.grads`` of every block
         ``>= first_grad_layer``.
 
@@ -253,11 +253,21 @@ class Transformer(nn.Module):
         ``dy_rows`` (``[B]`` long, optional): promise that ``dy`` is zero outside row ``dy_rows[b]`` of sample ``b`` -- both
         CLIP towers read their feature from ONE token (class token / EOT token).  The top block's MLP and ``out_proj``
         vector-Jacobian products are row-wise, so they then run on those B rows instead of B*N (3 of the 4 GEMMs of
-        that block); below the top block's attention the gradient is dense and everything runs in full."""
-        B, N, E = dy.shape
+        that block); below the top block's attention the gradient is dense and everything runs in full.
+        ``dy_row_values`` (``[B, E]``, with ``dy_rows``): those rows themselves -- ``dy`` may then be ``None`` (no dense zero
+        tensor is built just to be gathered from again)."""
+        if dy is None:
+            if dy_rows is None or dy_row_values is None:
+                raise ValueError("backward_tape: dy=None needs dy_rows and dy_row_values")
+            B, N, E = dy_row_values.shape[0], tape[-1][0].shape[1], dy_row_values.shape[1]
+            if self.layers - 1 < first_grad_layer:
+                return rel_row
+        else:
+            B, N, E = dy.shape
         buffers = self.buffers
         top = self.layers - 1
         dx = dy
+        top_rows = None                      # (rows, d_x1 of those rows): the top block's residual gradient, added after LN1'
         mma = bool(getattr(self, "attention_mma_bf16", False)) and N > 128
         # bf16 body on the streaming kernels: the gradients BETWEEN the GEMMs are bf16 (what the bf16 GEMMs produce and
         # consume; the elementwise kernels and the attention backward read / write bf16 directly -- no conversion
@@ -273,7 +283,9 @@ class Transformer(nn.Module):
                 raise ValueError("backward_tape: the forward kept only the output rows of the top block (out_rows): "
                                  "pass the same rows as dy_rows")
             if l == top and dy_rows is not None:
-                d_x1, d_o = self._top_block_rows(blk, tape[l], dy, dy_rows, shared)
+                g = dy_row_values if dy_row_values is not None else dy[torch.arange(B, device=dy_rows.device), dy_rows]
+                d_x1_r, d_o = self._top_block_rows(blk, tape[l], g, dy_rows, shared, N)
+                d_x1, top_rows = None, (dy_rows, d_x1_r)
                 if stream16:
                     d_o = d_o.to(torch.bfloat16)
             elif stream16:
@@ -294,7 +306,7 @@ class Transformer(nn.Module):
                 d_o = self._gemm(d_x1, at.out_proj.weight)
             d_o = d_o.view(B, N, at.num_heads, at.head_dim)
             need = l > first_grad_layer                                       # nothing below needs gradients
-            dqkv = torch.empty(B, N, 3, at.num_heads, at.head_dim, dtype=d_o.dtype, device=dy.device) if need else None
+            dqkv = torch.empty(B, N, 3, at.num_heads, at.head_dim, dtype=d_o.dtype, device=d_o.device) if need else None
             out = (dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]) if need else None
             res = ops.attn_capture_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], buffers.probs[l], d_o,
                                        buffers.grads[l] if buffers.grads is not None else None,
@@ -310,30 +322,31 @@ class Transformer(nn.Module):
             else:
                 d_h1 = self._gemm(dqkv.view(B, N, 3 * E), at.in_proj_weight)
                 dx = ops.layernorm_bwd_add(d_h1, x, mean1, rstd1, blk.ln_1.weight, d_x1)
+            if l == top and top_rows is not None:
+                # the top block's residual gradient lives on one row per sample: added to LN1'(.) there (no dense zero tensor)
+                ops.rows_add_(dx, *top_rows)
+                if stream16:
+                    dx_h = dx.to(torch.bfloat16)
         return rel_row
 
-    def _top_block_rows(self, blk, entry, dy, rows, shared):
-        """MLP / ``out_proj`` backward of the top block on the one row per sample that carries a gradient.
-        Returns dense ``(d_x1 [B, N, E], d_o [B, N, E])`` that are zero elsewhere."""
+    def _top_block_rows(self, blk, entry, g, rows, shared, N):
+        """MLP / ``out_proj`` backward of the top block on the one row per sample that carries a gradient (``g [B, E]``).
+        Returns ``(d_x1 rows [B, E], d_o dense [B, N, E])`` -- the attention backward wants every row of ``d_o``, zero elsewhere."""
         x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o_fwd = entry[:9]
-        B, N, E = dy.shape
-        ar = torch.arange(B, device=dy.device)
+        B = g.shape[0]
+        ar = torch.arange(B, device=g.device)
         src = torch.zeros_like(rows) if shared else ar                     # sample index into the (shared) tape
-        g = dy[ar, rows]                                                     # [B, E]
         if len(entry) > 9:                                                   # forward_tape(out_rows=...): rows only on the tape
             m_r, x1_r, mean2_r, rstd2_r = m[src], x1[src], mean2.reshape(-1)[src], rstd2.reshape(-1)[src]
         else:
             flat = src * N + rows                                            # row of the [Bx*N] statistics
             m_r, x1_r, mean2_r, rstd2_r = m[src, rows], x1[src, rows], mean2.reshape(-1)[flat], rstd2.reshape(-1)[flat]
         d_a = self._gemm(g, blk.mlp.c_proj.weight)
-        sg = torch.sigmoid(1.702 * m_r)
-        d_h2 = self._gemm(d_a * (sg + 1.702 * m_r * sg * (1 - sg)), blk.mlp.c_fc.weight)
+        d_m = ops.quick_gelu_bwd(m_r, d_a) if d_a.dtype == torch.float32 and m_r.numel() % 4 == 0 else \
+            d_a * (torch.sigmoid(1.702 * m_r) * (1 + 1.702 * m_r * (1 - torch.sigmoid(1.702 * m_r))))
+        d_h2 = self._gemm(d_m, blk.mlp.c_fc.weight)
         d_x1_r = ops.layernorm_bwd_add(d_h2, x1_r, mean2_r, rstd2_r, blk.ln_2.weight, g)
-        d_x1 = torch.zeros_like(dy)
-        d_x1[ar, rows] = d_x1_r
-        d_o = torch.zeros_like(dy)
-        d_o[ar, rows] = self._gemm(d_x1_r, blk.attn.out_proj.weight)
-        return d_x1, d_o
+        return d_x1_r, ops.rows_to_dense(self._gemm(d_x1_r, blk.attn.out_proj.weight), rows, N)
 
     def backward_shared(self, tape, dy, first_grad_layer=0):
         """Round-1 name of ``backward_tape``."""
@@ -408,8 +421,7 @@ class VisualTransformer(nn.Module):
         y, tape = self.transformer.forward_tape(x, batch, first_grad_layer, grads=grads,
                                                 out_rows=torch.zeros(x.shape[0], dtype=torch.long, device=x.device))
         cls = y                                                              # [Bx, width]: the class-token rows
-        f, mean, rstd = torch.native_layer_norm(cls, (cls.shape[-1],), self.ln_post.weight, self.ln_post.bias,
-                                                self.ln_post.eps)
+        _, f, mean, rstd = ops.add_layernorm(cls, None, self.ln_post.weight, self.ln_post.bias, self.ln_post.eps)
         return f @ self.proj, (tape, x.shape, cls, mean, rstd)
 
     def forward_shared(self, image, batch):
@@ -423,17 +435,15 @@ class VisualTransformer(nn.Module):
         tape, y_shape, cls, mean, rstd = state
         B = d_features.shape[0]
         d_f = torch.matmul(d_features, self.proj.t())
-        d_cls = torch.ops.aten.native_layer_norm_backward(
-            d_f.contiguous(), cls.expand(B, -1).contiguous(), (cls.shape[-1],), mean.expand(B, -1).contiguous(),
-            rstd.expand(B, -1).contiguous(), self.ln_post.weight, self.ln_post.bias, [True, False, False])[0]
-        dy = torch.zeros(B, y_shape[1], y_shape[2], dtype=torch.float32, device=d_features.device)
-        dy[:, 0, :] = d_cls                                                  # only the class token feeds the features
+        # LayerNorm' against the (shared) class-token rows' statistics; only the class token feeds the features
+        d_cls = ops.layernorm_bwd_add(d_f, cls, mean, rstd, self.ln_post.weight)
         rel_row = None
         if cls_row:
-            rel_row = torch.zeros(B, y_shape[1], dtype=torch.float32, device=dy.device)
+            rel_row = torch.zeros(B, y_shape[1], dtype=torch.float32, device=d_f.device)
             rel_row[:, 0] = 1.0                                              # e_0: row 0 of the identity R starts from
-        return self.transformer.backward_tape(tape, dy, first_grad_layer,
-                                              dy_rows=torch.zeros(B, dtype=torch.long, device=dy.device), rel_row=rel_row)
+        return self.transformer.backward_tape(tape, None, first_grad_layer,
+                                              dy_rows=torch.zeros(B, dtype=torch.long, device=d_f.device), rel_row=rel_row,
+                                              dy_row_values=d_cls)
 
     def backward_shared(self, state, d_features, first_grad_layer=0):
         return self.backward_tape(state, d_features, first_grad_layer)
@@ -515,8 +525,7 @@ class CLIP(nn.Module):
         x = self.token_embedding(text).type(self.dtype) + self.positional_embedding[:n].type(self.dtype)
         eot = text.argmax(dim=-1)                                            # model.py:360
         rows, tape = self.transformer.forward_tape(x, first_grad_layer=first_grad_layer, out_rows=eot)
-        f, mean, rstd = torch.native_layer_norm(rows, (rows.shape[-1],), self.ln_final.weight, self.ln_final.bias,
-                                                self.ln_final.eps)
+        _, f, mean, rstd = ops.add_layernorm(rows, None, self.ln_final.weight, self.ln_final.bias, self.ln_final.eps)
         return f @ self.text_projection, (tape, x.shape, rows, mean, rstd, eot)
 
     @torch.no_grad()
@@ -525,12 +534,8 @@ class CLIP(nn.Module):
         EOT rows carry a gradient into the stack)."""
         tape, y_shape, rows, mean, rstd, eot = state
         d_f = torch.matmul(d_features, self.text_projection.t())
-        d_rows = torch.ops.aten.native_layer_norm_backward(
-            d_f.contiguous(), rows.contiguous(), (rows.shape[-1],), mean, rstd, self.ln_final.weight, self.ln_final.bias,
-            [True, False, False])[0]
-        dy = torch.zeros(y_shape, dtype=torch.float32, device=d_features.device)
-        dy[torch.arange(y_shape[0], device=dy.device), eot] = d_rows
-        self.transformer.backward_tape(tape, dy, first_grad_layer, dy_rows=eot)
+        d_rows = ops.layernorm_bwd_add(d_f, rows, mean, rstd, self.ln_final.weight)
+        self.transformer.backward_tape(tape, None, first_grad_layer, dy_rows=eot, dy_row_values=d_rows)
 
     def forward(self, image, text):
         return self.logits(self.encode_image(image), self.encode_text(text))

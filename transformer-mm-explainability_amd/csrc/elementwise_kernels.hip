@@ -419,7 +419,48 @@ __global__ __launch_bounds__(256) void layernorm_bwd_add_bf16_kernel(const unsig
     }
 }
 
+// One row per sample scattered into a zeroed dense [B, N, E] tensor / added to an existing one: the top block of a CLIP tower
+// carries a gradient on ONE token per sample (class / EOT token); torch's zeros + index_put pair is two launches of 19 + 27 us.
+__global__ __launch_bounds__(256) void rows_to_dense_kernel(const f32x4* __restrict__ vals, const long long* __restrict__ rows,
+                                                            f32x4* __restrict__ out, int N, int E4) {
+    const int b = blockIdx.y;
+    const long long row = rows[b];
+    const int64_t per = static_cast<int64_t>(N) * E4;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < per; i += static_cast<int64_t>(gridDim.x) * 256) {
+        const int n = static_cast<int>(i / E4), e = static_cast<int>(i - static_cast<int64_t>(n) * E4);
+        out[b * per + i] = n == row ? vals[static_cast<int64_t>(b) * E4 + e] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+__global__ __launch_bounds__(256) void rows_add_kernel(f32x4* __restrict__ dense, const long long* __restrict__ rows,
+                                                       const f32x4* __restrict__ vals, int N, int E4) {
+    const int b = blockIdx.y;
+    const long long row = rows[b];
+    f32x4* dst = dense + (static_cast<int64_t>(b) * N + row) * E4;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < E4; e += gridDim.x * 256) dst[e] = dst[e] + vals[static_cast<int64_t>(b) * E4 + e];
+}
+
 }  // namespace mmx
+
+extern "C" int mmx_rows_to_dense(const void* vals_dev, const void* rows_dev, void* out_dev, int B, int N, int E, void* stream) {
+    MMX_CHECK_ARG(vals_dev && rows_dev && out_dev && B > 0 && N > 0 && E > 0 && E % 4 == 0 && B <= 65535,
+                  "mmx_rows_to_dense: bad argument (B=%d N=%d E=%d, E %% 4 must be 0)", B, N, E);
+    const int64_t per = static_cast<int64_t>(N) * (E / 4);
+    const dim3 grid(static_cast<unsigned>(per / 256 + 1 > 64 ? 64 : per / 256 + 1), B);
+    mmx::rows_to_dense_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const f32x4*>(vals_dev), static_cast<const long long*>(rows_dev), static_cast<f32x4*>(out_dev), N, E / 4);
+    MMX_LAUNCH_CHECK("rows_to_dense_kernel");
+    return MMX_OK;
+}
+
+extern "C" int mmx_rows_add(void* dense_dev, const void* rows_dev, const void* vals_dev, int B, int N, int E, void* stream) {
+    MMX_CHECK_ARG(dense_dev && rows_dev && vals_dev && B > 0 && N > 0 && E > 0 && E % 4 == 0 && B <= 65535,
+                  "mmx_rows_add: bad argument (B=%d N=%d E=%d, E %% 4 must be 0)", B, N, E);
+    mmx::rows_add_kernel<<<dim3((E / 4 + 255) / 256, B), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<f32x4*>(dense_dev), static_cast<const long long*>(rows_dev), static_cast<const f32x4*>(vals_dev), N, E / 4);
+    MMX_LAUNCH_CHECK("rows_add_kernel");
+    return MMX_OK;
+}
 
 extern "C" int mmx_quick_gelu_bwd_bcast_bf16(const void* x_dev, const void* dy_dev, void* dx_dev, int64_t n, int64_t x_n,
                                              void* stream) {

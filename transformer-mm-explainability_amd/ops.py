@@ -482,6 +482,26 @@ def matmul(a, b, add_to=None, trans_a=False, nan_to_zero=False):
     return out[0] if squeeze else out
 
 
+def rows_to_dense(vals, rows, n_tokens):
+    """``out [B, n_tokens, E]`` = zeros with ``out[b, rows[b]] = vals[b]`` in ONE launch (``mmx_rows_to_dense``)."""
+    _dev(vals, rows)
+    vals, rows = _f32c(vals), rows.to(torch.long).contiguous()
+    B, E = vals.shape
+    out = torch.empty(B, n_tokens, E, dtype=torch.float32, device=vals.device)
+    check(lib().mmx_rows_to_dense(_p(vals), _p(rows), _p(out), B, n_tokens, E, _stream()), "mmx_rows_to_dense")
+    return out
+
+
+def rows_add_(dense, rows, vals):
+    """``dense[b, rows[b]] += vals[b]`` in place (``mmx_rows_add``); ``dense [B, N, E]`` fp32 contiguous."""
+    _dev(dense, rows, vals)
+    if dense.dtype != torch.float32 or not dense.is_contiguous():
+        raise MMXError("rows_add_: dense must be fp32 contiguous")
+    B, N, E = dense.shape
+    check(lib().mmx_rows_add(_p(dense), _p(rows.to(torch.long).contiguous()), _p(_f32c(vals)), B, N, E, _stream()), "mmx_rows_add")
+    return dense
+
+
 def small_linear(x, lin):
     """``lin(x)`` for an ``nn.Linear`` applied to a FEW rows (a shared forward's 100 decoder queries) with a SQUARE weight of at
     most 256: the one shape family where the library's heuristic leaves the chip idle (a 256-row tile for 100 rows: 3
