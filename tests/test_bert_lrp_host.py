@@ -3,7 +3,7 @@
 fixtures ``lxmert_model_lrp.npz`` / ``visualbert_model_lrp.npz`` from ``tests/golden/make_golden.py``).
 
 No GPU here: the capture op of the attention modules is replaced by a plain-torch stand-in (test infrastructure, below) and the
-attention core of the pass runs on the referee ``bert_lrp.core_torch``; what is pinned is the host logic -- tapes, rule order,
+attention core of the pass runs on the referee ``oracle/lrp_torch.py``; what is pinned is the host logic -- tapes, rule order,
 Clone / Add / Linear closed forms, per-sample sums.  The HIP kernels are pinned on the same fixtures in ``tests/test_gpu_lrp.py``.
 
 Tolerances: the pass divides by layer outputs (``safe_divide``), which makes the reference's OWN fp32 pass uncertain at up to
@@ -18,6 +18,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import lrp_torch as lrp_oracle
 from transformer_mm_explainability_amd import attention_modules, bert_lrp
 
 
@@ -91,7 +92,7 @@ def test_lxmert_relprop_matches_reference_pass(golden, cpu_body):
     one_hot = torch.zeros_like(out)
     one_hot[0, int(g["index"])] = 1
     torch.sum(one_hot * out).backward()
-    cam_lang, cam_vis = model.relprop(one_hot.clone(), alpha=1, core=bert_lrp.core_torch)
+    cam_lang, cam_vis = model.relprop(one_hot.clone(), alpha=1, core=lrp_oracle.core)
     for name, module in lxmert_cams(model).items():
         within_reference_noise(module.get_attn_cam(), g, "cam__" + name)
     within_reference_noise(cam_lang, g, "cam_lang")
@@ -113,7 +114,7 @@ def test_lxmert_relprop_is_per_sample(golden, cpu_body):
     one_hot[0, int(g["index"])] = 1
     one_hot[1, 3] = 1
     torch.sum(one_hot * out).backward()
-    cam_lang, _ = model.relprop(one_hot.clone(), alpha=1, core=bert_lrp.core_torch)
+    cam_lang, _ = model.relprop(one_hot.clone(), alpha=1, core=lrp_oracle.core)
     within_reference_noise(cam_lang[:1], g, "cam_lang", what="cam_lang of item 0 in a batch of 2")
     within_reference_noise(model.lxmert.encoder.layer[0].attention.self.get_attn_cam()[:1], g, "cam__l0", what="l0 of item 0")
 
@@ -138,7 +139,7 @@ def test_visualbert_relprop_matches_reference_pass(golden, cpu_body):
     one_hot = torch.zeros_like(out)
     one_hot[0, int(g["index"])] = 1
     torch.sum(one_hot * out).backward()
-    cam_in = model.relprop(one_hot.clone(), alpha=1, core=bert_lrp.core_torch)
+    cam_in = model.relprop(one_hot.clone(), alpha=1, core=lrp_oracle.core)
     blocks = model.model.bert.encoder.layer
     within_reference_noise(torch.stack([b.attention.self.get_attn_cam() for b in blocks]), g, "attn_cam")
     within_reference_noise(cam_in, g, "cam_input")

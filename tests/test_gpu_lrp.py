@@ -38,7 +38,7 @@ def test_mha_relprop_kernels_vs_reference_layer(golden, tag):
 
 @pytest.mark.parametrize("B,H,Nq,Nk,D", [(2, 3, 37, 37, 32), (1, 2, 70, 130, 64), (1, 8, 100, 950, 32), (2, 1, 5, 9, 20)])
 def test_attn_relprop_kernel_vs_torch_referee(B, H, Nq, Nk, D):
-    """The kernels vs the plain-torch form of the same two einsum relprops (``lrp.attn_core_torch``, itself pinned on the
+    """The kernels vs the plain-torch form of the same two einsum relprops (``oracle/lrp_torch.py``, itself pinned on the
     reference in the CPU suite), ragged tiles and DETR's cross-attention size included.  ``safe_divide(cam_P, Z)`` divides
     by pre-softmax scores Z = q . k that come arbitrarily close to zero, so single elements are ill-conditioned in fp32 FOR
     THE REFERENCE TOO: the yardstick is the referee itself -- evaluated in fp32 and in fp64 on the same inputs -- and the
@@ -55,8 +55,9 @@ def test_attn_relprop_kernel_vs_torch_referee(B, H, Nq, Nk, D):
     dd = lambda t: t.double()                                                # noqa: E731
     tape32 = dict(q=q, k=k, v=v, o=o, probs=probs, scale=scale)
     tape64 = {n: (dd(t) if torch.is_tensor(t) else t) for n, t in tape32.items()}
-    ref32 = lrp.attn_core_torch(tape32)(cam_o)
-    ref64 = lrp.attn_core_torch(tape64)(dd(cam_o))
+    from oracle import lrp_torch as lrp_oracle
+    ref32 = lrp_oracle.detr_core(tape32)(cam_o)
+    ref64 = lrp_oracle.detr_core(tape64)(dd(cam_o))
     report = []
     for name, a, r32, r64 in zip(("cam_probs", "cam_q", "cam_k", "cam_v"), got, ref32, ref64):
         assert a.shape == r64.shape
@@ -133,7 +134,7 @@ def in_noise(got, g, key, what):
 @pytest.mark.parametrize("B,H,Nq,Nk,D", [(2, 3, 20, 36, 64), (1, 12, 70, 70, 64), (2, 2, 9, 5, 16)])
 def test_attn_relprop_phases(B, H, Nq, Nk, D):
     """``mmx_attn_relprop_phase``: VALUES then SCORES fed with cam_P reproduces the fused call bit for bit; SCORES with another
-    relevance of the scores equals the plain-torch referee (``bert_lrp.core_torch``) within its own fp32 noise."""
+    relevance of the scores equals the plain-torch referee (``oracle/lrp_torch.py``) within its own fp32 noise."""
     from transformer_mm_explainability_amd import _lib, bert_lrp, ops
     g = torch.Generator().manual_seed(B + Nq * 7 + Nk)
     q, k, v = (torch.randn(B, n, H, D, generator=g).cuda() for n in (Nq, Nk, Nk))
@@ -153,8 +154,9 @@ def test_attn_relprop_phases(B, H, Nq, Nk, D):
                                           cam_scores=other)
     tape = dict(q=q, k=k, v=v, o=o, probs=probs)
     t64 = {n: x.double() for n, x in tape.items()}
-    _, q32, k32, _ = bert_lrp.core_torch(tape, None, other, _lib.LRP_SCORES)
-    _, q64, k64, _ = bert_lrp.core_torch(t64, None, other.double(), _lib.LRP_SCORES)
+    from oracle import lrp_torch as lrp_oracle
+    _, q32, k32, _ = lrp_oracle.core(tape, None, other, _lib.LRP_SCORES)
+    _, q64, k64, _ = lrp_oracle.core(t64, None, other.double(), _lib.LRP_SCORES)
     for name, a, r32, r64 in (("cam_q", cam_q, q32, q64), ("cam_k", cam_k, k32, k64)):
         err, noise, top = (float(x.abs().max()) for x in (a.double() - r64, r32.double() - r64, r64))
         assert err <= 8 * noise + 1e-6 * top, (name, err, noise, top)

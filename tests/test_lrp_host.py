@@ -1,10 +1,11 @@
 """CPU suite: the closed-form LRP rules of ``lrp.py`` against outputs of the reference's own LRP layer library
 (``DETR/modules/layers.py``, fixture ``lrp_layers.npz`` made by ``tests/golden/make_golden.py::gen_lrp_layers``).
-The attention core runs on the plain-torch referee here (``lrp.attn_core_torch``); the HIP kernels that replace it on the
+The attention core runs on the plain-torch referee here (``oracle/lrp_torch.py``); the HIP kernels that replace it on the
 product path are pinned on the same fixture in ``tests/test_gpu_lrp.py``."""
 import numpy as np
 import torch
 
+from oracle import lrp_torch as lrp_oracle
 from transformer_mm_explainability_amd import lrp
 
 
@@ -51,7 +52,7 @@ def test_mha_relprop_matches_reference(golden):
     for tag in ("mha", "mha0"):                                             # mha0: zero value stream -> the rescale branch
         tape, weights = mha_tape(g, tag)
         cam_q, cam_k, cam_v, cam_p = lrp.mha_relprop(t(g[tag + "_cam_out"]).permute(1, 0, 2), tape, weights,
-                                                     lrp.attn_core_torch(tape))
+                                                     lrp_oracle.detr_core(tape))
         B, H, T, S = cam_p.shape
         close(cam_p.reshape(B * H, T, S), g[tag + "_attn_cam"], atol=2e-6)
         close(cam_q.permute(1, 0, 2), g[tag + "_cam_q"], atol=2e-6)

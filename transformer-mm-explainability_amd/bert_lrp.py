@@ -26,8 +26,8 @@ The rule variants differ from DETR's library in two places: ``Linear.relprop`` h
 ``einsum``).  LayerNorm, GELU / Tanh, Softmax and Dropout pass relevance through (``RelProp.relprop``, layers.py:45-46).
 
 The reference runs one sample per pass; every whole-tensor sum of its rules (``Add.relprop``) is taken PER SAMPLE here, so a
-batch gives what the reference gives item by item.  ``core``: the attention-core implementation -- the HIP op by default;
-``core_torch`` is the referee of the CPU test suite (NOT the product path).
+batch gives what the reference gives item by item.  ``core``: the attention-core implementation -- the HIP op (``core_hip``)
+unless a caller hands in another one (the CPU test suite passes the plain-torch referee of ``oracle/lrp_torch.py``).
 """
 from __future__ import annotations
 
@@ -47,23 +47,6 @@ def _lin(R, X, weight):
 def core_hip(t, cam_o, cam_scores=None, phase=VALUES | SCORES):
     """``(cam_probs, cam_q, cam_k, cam_v)`` of one attention module's tape on the HIP kernels (``None`` for a phase not run)."""
     return ops.attn_relprop(t["q"], t["k"], t["v"], t["probs"], t["o"], cam_o, 1.0, _lib.SCALE_SCORES, "bnhd", phase, cam_scores)
-
-
-def core_torch(t, cam_o, cam_scores=None, phase=VALUES | SCORES):
-    """The same in plain torch ops (``matmul2.relprop`` then ``matmul1.relprop``, both ``RelPropSimple``, each result halved)."""
-    bh = lambda x: x.permute(0, 2, 1, 3)                                     # noqa: E731  [B, N, H, D] -> [B, H, N, D]
-    back = lambda x: x.permute(0, 2, 1, 3).contiguous()                      # noqa: E731
-    q, k, v, o, probs = bh(t["q"]), bh(t["k"]), bh(t["v"]), bh(t["o"]), t["probs"]
-    cam_p = cam_q = cam_k = cam_v = None
-    if phase & VALUES:
-        S = lrp.safe_divide(bh(cam_o), o)
-        cam_p = probs * torch.matmul(S, v.transpose(-1, -2)) / 2
-        cam_v = back(v * torch.matmul(probs.transpose(-1, -2), S) / 2)
-    if phase & SCORES:
-        S1 = lrp.safe_divide(cam_p if cam_scores is None else cam_scores, torch.matmul(q, k.transpose(-1, -2)))
-        cam_q = back(q * torch.matmul(S1, k) / 2)
-        cam_k = back(k * torch.matmul(S1.transpose(-1, -2), q) / 2)
-    return cam_p, cam_q, cam_k, cam_v
 
 
 def _mask_add_relprop(cam_p, t):

@@ -14,6 +14,7 @@ built from, those vector-Jacobian products are plain matrix products, written ou
                              (``RelPropSimple``, layers.py:54-66) run in the HIP kernels of ``csrc/attention_lrp.hip``
                              (``ops.attn_relprop``) on the tiles the capture op uses; ``mha_relprop`` below is the module-level
                              schedule around them (out_proj / q_proj / k_proj / v_proj relprops and the q/k rescale branch).
+                             (The CPU test suite passes the plain-torch referee of ``oracle/lrp_torch.py`` as ``attn_core``.)
 LayerNorm, ReLU / GELU, Softmax, Dropout and ``WithPosEmbd`` pass relevance through unchanged (``RelProp.relprop``,
 layers.py:46-47, 110-111).  Everything is sync-free (global sums stay device scalars).
 """
@@ -108,23 +109,3 @@ def mha_relprop(cam_out, tape, weights, attn_core):
     cam_k = torch.where(rescale, cam_k * safe_divide(kf, ks), cam_k)
     cam_q = torch.where(rescale, cam_q * safe_divide(qf, qs), cam_q)
     return cam_q, cam_k, cam_v, cam_probs
-
-
-def attn_core_torch(tape):
-    """The attention core of ``mha_relprop`` in plain torch ops (``einsum2.relprop`` then ``einsum1.relprop``, both
-    ``RelPropSimple``, each result halved: layers.py:773-781).  NOT the product path (``ops.attn_relprop`` is): the referee of
-    the CPU test suite, which pins this module's rule arithmetic on the reference's own outputs without a GPU."""
-    q, k, v, o, probs, scale = (tape[n] for n in ("q", "k", "v", "o", "probs", "scale"))
-    bh = lambda t: t.permute(0, 2, 1, 3)                                    # [B, N, H, D] -> [B, H, N, D]
-    qs, kk, vv, oo = bh(q) * scale, bh(k), bh(v), bh(o)
-
-    def core(cam_o):
-        S = safe_divide(bh(cam_o), oo)
-        cam_p = probs * torch.matmul(S, vv.transpose(-1, -2)) / 2
-        cam_v = vv * torch.matmul(probs.transpose(-1, -2), S) / 2
-        S1 = safe_divide(cam_p, torch.matmul(qs, kk.transpose(-1, -2)))
-        cam_q = qs * torch.matmul(S1, kk) / 2
-        cam_k = kk * torch.matmul(S1.transpose(-1, -2), qs) / 2
-        back = lambda t: t.permute(0, 2, 1, 3).contiguous()
-        return cam_p, back(cam_q), back(cam_k), back(cam_v)
-    return core
