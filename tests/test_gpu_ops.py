@@ -373,6 +373,8 @@ def test_small_linear_routes_the_few_row_square_projections(ops, rows, E, bias):
         lin.weight.mul_(2.0)                                             # in-place update: the cached transposed copy is refreshed
     want2 = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double() if bias else None)
     close(ops.small_linear(x, lin), want2.detach().float().cpu().numpy(), atol=1e-5)
+    xg = x.clone().requires_grad_(True)                                  # an input with a graph: the module itself, graph kept
+    assert ops.small_linear(xg, lin).grad_fn is not None
 
 
 @pytest.mark.parametrize("shape", [(4928, 2048), (7, 13), (1, 3), (3, 4)])

@@ -184,8 +184,11 @@ __device__ __forceinline__ void tiles_kd(f32x4 (&acc)[NTK], const float* Xs, con
     }
 }
 
-// out[td] += A . Y with the A operand straight from accumulator-layout registers: k-step (t, r) pairs areg[t][r] with row
-// 16t + 4g + r of Y (LDS, stride LS, ds_read_b32 at columns 16td + c16); the B operands are fetched one k-step ahead.
+// out[td] += (A . Y)^T with the A operand straight from accumulator-layout registers: k-step (t, r) pairs areg[t][r] with row
+// 16t + 4g + r of Y (LDS, stride LS, ds_read_b32 at columns 16td + c16); the Y operands are fetched one k-step ahead.
+// The registers go in as the MFMA's B operand and Y as its A operand, i.e. the tile comes out TRANSPOSED: lane (c16, g) holds
+// columns 16td + 4g .. + 3 of ITS OWN row c16 -- four consecutive floats of one output row, one 16-byte store
+// (store_rows16) instead of four 4-byte stores to four rows.  Same products, same contraction order.
 template <int DP, int NTK, int LS>
 __device__ __forceinline__ void tiles_from_regs(f32x4 (&out)[DP / 16], const f32x4 (&areg)[NTK], const float* Ys, int c16, int g) {
     constexpr int KK = DP / 16;
@@ -202,13 +205,25 @@ __device__ __forceinline__ void tiles_from_regs(f32x4 (&out)[DP / 16], const f32
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int td = 0; td < KK; ++td) out[td] = mfma16x16x4(areg[s >> 2][s & 3], cur[td], out[td]);
+        for (int td = 0; td < KK; ++td) out[td] = mfma16x16x4(cur[td], areg[s >> 2][s & 3], out[td]);
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < NTK * 4) {
 #pragma unroll
             for (int td = 0; td < KK; ++td) cur[td] = nxt[td];
         }
     }
+}
+
+// Transposed-layout tiles (tiles_from_regs, phase C of the backward) -> global: row `row` of a strided [N, D] matrix, columns
+// 16td + 4g .. + 3 per tile, times mul.  D % 4 == 0 (eligibility), so a chunk is either whole or beyond D.
+template <int DP>
+__device__ __forceinline__ void store_rows16(float* base, int64_t sn, int row, bool row_valid, int D, int g,
+                                             const f32x4 (&acc)[DP / 16], float mul) {
+    if (!row_valid) return;
+    float* p = base + static_cast<int64_t>(row) * sn + 4 * g;
+#pragma unroll
+    for (int td = 0; td < DP / 16; ++td)
+        if (td * 16 + 4 * g < D) stg4_u(p + td * 16, acc[td] * mul);
 }
 
 // Dispatch "round" r of this workgroup (how many workgroups the hardware has probably placed on the same CU before it):
@@ -306,18 +321,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_head_kernel(const AttnFwdArgs a
 #pragma unroll
     for (int td = 0; td < KK; ++td) oacc[td] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!(skip & 8)) tiles_from_regs<DP, NTK, LSV>(oacc, acc, Vs, c16, g);
-    float* ob = a.o + b * a.os.sb + h * a.os.sh;
-#pragma unroll
-    for (int td = 0; td < KK; ++td) {
-        const int d = td * 16 + c16;
-        if (d < a.D) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wave * 16 + 4 * g + r;
-                if (row < a.Nq && (!(skip & 16) || oacc[td][r] == 12345.f)) ob[static_cast<int64_t>(row) * a.os.sn + d] = oacc[td][r];
-            }
-        }
-    }
+    store_rows16<DP>(a.o + b * a.os.sb + h * a.os.sh, a.os.sn, q, qv && (!(skip & 16) || oacc[0][0] == 12345.f), a.D, g, oacc, 1.f);
 }
 
 // ------------------------------------------------------------------------------------------------------- backward
@@ -387,19 +391,7 @@ __global__ __launch_bounds__(NTK >= 7 ? 512 : 1024) void attn_bwd_head_kernel(co
 #pragma unroll
         for (int td = 0; td < KK; ++td) dq[td] = f32x4{0.f, 0.f, 0.f, 0.f};
         tiles_from_regs<DP, NTK, LSB>(dq, acc, Ks, c16, g);
-        float* dqb = a.dq + b * a.dqs.sb + h * a.dqs.sh;
-        const float mul = q_first ? a.scale : 1.f;
-#pragma unroll
-        for (int td = 0; td < KK; ++td) {
-            const int d = td * 16 + c16;
-            if (d < a.D) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = wave * 16 + 4 * g + r;
-                    if (row < a.Nq) dqb[static_cast<int64_t>(row) * a.dqs.sn + d] = dq[td][r] * mul;
-                }
-            }
-        }
+        store_rows16<DP>(a.dq + b * a.dqs.sb + h * a.dqs.sh, a.dqs.sn, q, qv, a.D, g, dq, q_first ? a.scale : 1.f);
     }
 
     // ---- phase C: dK = dS^T.Q' (pass 0), dV = P^T.dO (pass 1); contraction over q = across waves, through LDS
@@ -416,30 +408,34 @@ __global__ __launch_bounds__(NTK >= 7 ? 512 : 1024) void attn_bwd_head_kernel(co
         float* outb = pass == 0 ? a.dk + b * a.dks.sb + h * a.dks.sh : a.dv + b * a.dvs.sb + h * a.dvs.sh;
         const int64_t osn = pass == 0 ? a.dks.sn : a.dvs.sn;
         for (int kt = wave; kt < NTK; kt += NTQ) {
+            // out^T tile (keys 16kt .. + 15 as the MFMA's N index): k-step s = (tq, r) pairs row 16tq + 4g + r of Ts (column
+            // 16kt + c16) with the same row of Bs; the operands of step s + 1 are fetched before the MFMAs of step s
             f32x4 o[KK];
 #pragma unroll
             for (int td = 0; td < KK; ++td) o[td] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int tq = 0; tq < NTQ; ++tq) {
+            const float* t0 = Ts + 4 * g * SS + kt * 16 + c16;
+            const float* b0 = Bs + 4 * g * LSB + c16;
+            const int steps = NTQ * 4;
+            float a_cur = t0[0], a_nxt, b_cur[KK], b_nxt[KK];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = tq * 16 + 4 * g + r;
-                    const float av = Ts[row * SS + kt * 16 + c16];
-                    const float* br = Bs + row * LSB + c16;
+            for (int td = 0; td < KK; ++td) b_cur[td] = b0[td * 16];
+#pragma unroll 4
+            for (int s = 0; s < steps; ++s) {
+                const int sn = s + 1 < steps ? s + 1 : s;
+                const int rown = (sn >> 2) * 16 + (sn & 3);
+                a_nxt = t0[rown * SS];
 #pragma unroll
-                    for (int td = 0; td < KK; ++td) o[td] = mfma16x16x4(av, br[td * 16], o[td]);
-                }
+                for (int td = 0; td < KK; ++td) b_nxt[td] = b0[rown * LSB + td * 16];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int td = 0; td < KK; ++td) o[td] = mfma16x16x4(b_cur[td], a_cur, o[td]);
+                __builtin_amdgcn_sched_barrier(0);
+                a_cur = a_nxt;
+#pragma unroll
+                for (int td = 0; td < KK; ++td) b_cur[td] = b_nxt[td];
             }
-#pragma unroll
-            for (int td = 0; td < KK; ++td) {
-                const int d = td * 16 + c16;
-                if (d < a.D) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kt * 16 + 4 * g + r;
-                        if (key < a.Nk) outb[static_cast<int64_t>(key) * osn + d] = o[td][r];
-                    }
-                }
-            }
+            const int key = kt * 16 + c16;
+            store_rows16<DP>(outb, osn, key, key < a.Nk, a.D, g, o, 1.f);
         }
     }
 }

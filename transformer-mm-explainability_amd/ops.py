@@ -505,9 +505,11 @@ def rows_add_(dense, rows, vals):
 def small_linear(x, lin):
     """``lin(x)`` for an ``nn.Linear`` applied to a FEW rows (a shared forward's 100 decoder queries) with a SQUARE weight of at
     most 256: the one shape family where the library's heuristic leaves the chip idle (a 256-row tile for 100 rows: 3
-    workgroups, 30 us; ``mmx_linear_f32``: 9 us).  Anything else goes to ``lin`` itself."""
+    workgroups, 30 us; ``mmx_linear_f32``: 9 us).  Anything else goes to ``lin`` itself -- also an ``x`` that carries an
+    autograd graph (the kernel records none: this is an op of the tape passes, which differentiate by hand)."""
     rows = x.numel() // x.shape[-1]
-    if not (x.is_cuda and x.dtype == torch.float32 and rows <= 128 and lin.in_features == lin.out_features <= 256):
+    if not (x.is_cuda and x.dtype == torch.float32 and rows <= 128 and lin.in_features == lin.out_features <= 256) or \
+            (torch.is_grad_enabled() and x.requires_grad):
         return lin(x)
     x2 = _f32c(x).view(rows, lin.in_features)
     out = torch.empty(rows, lin.out_features, dtype=torch.float32, device=x.device)
