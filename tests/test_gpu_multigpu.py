@@ -19,11 +19,11 @@ def _need_two_gpus():
         pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
 
 
-def _launch(script_args, nproc, port):
+def _launch(script_args, nproc, port, **env):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(port)] + script_args
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900,
-                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]            # rank 0 prints ONE JSON line
@@ -34,6 +34,16 @@ def test_bench_two_ranks_over_rccl():
     _need_two_gpus()
     line = _launch(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--headline-only"], 2,
                    29500 + os.getpid() % 400)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 128
+    assert abs(line["value"] - 128 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """The N > 1 code path of ``bench.py`` on a 1-GPU box: two ranks share ``cuda:0`` (``MMX_BENCH_SHARE_DEVICE``) and the
+    exchange step runs over gloo (``MMX_BENCH_BACKEND``; RCCL refuses two ranks per device) -- barriers, the max over ranks, the
+    gather of every rank's maps, ONE JSON line from rank 0 with whole-job units.  A functional check, not a rate."""
+    line = _launch(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--headline-only"], 2,
+                   30700 + os.getpid() % 400, MMX_BENCH_SHARE_DEVICE="1", MMX_BENCH_BACKEND="gloo")
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 128
     assert abs(line["value"] - 128 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
 
