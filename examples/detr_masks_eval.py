@@ -67,13 +67,9 @@ def main():
                     help="images explained BEFORE the clock starts (hipGraph capture, first-touch allocations); 0: time everything")
     ap.add_argument("--no-tuned-gemms", action="store_true", help="keep the default hipBLASLt / rocBLAS heuristic for the body's GEMMs")
     args = ap.parse_args()
-    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
-    torch.cuda.set_device(dev)
+    rank, world, dev, gather_dev = sharding.init_evaluator_process()
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from transformer_mm_explainability_amd import detr_model, tuned_gemms
     from transformer_mm_explainability_amd.detr_explainability import MaskGenerator
 
@@ -103,12 +99,12 @@ def main():
     queries[0] = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    table = evaluate(ids, masks_of, store=store, device=dev)
+    table = evaluate(ids, masks_of, store=store, device=gather_dev)
     mg.check_diag()                              # the handle_residual word of the last image's passes
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:

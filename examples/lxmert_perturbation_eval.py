@@ -94,13 +94,9 @@ def main():
     if per_item:
         args.max_batch, args.bucket_by_length = 1, True                # one item per explain call, its own length
     rule_flags = BATCHED_METHODS.get(args.method, {})
-    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
-    torch.cuda.set_device(dev)
+    rank, world, dev, gather_dev = sharding.init_evaluator_process()
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = lm.LxmertConfig()
     torch.manual_seed(0)
@@ -160,11 +156,11 @@ def main():
     t0 = time.perf_counter()
     length_of = (lambda k: item(k)["input_ids"].numel()) if args.bucket_by_length else (lambda k: 0)   # 0: one bucket
     per_sample = sharding.evaluate_sharded(indices, length_of, process_batch,
-                                           len(lp.PERT_STEPS), max_batch=args.max_batch, store=store, device=dev)
+                                           len(lp.PERT_STEPS), max_batch=args.max_batch, store=store, device=gather_dev)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     acc = sharding.mean_step_accuracy(per_sample)

@@ -72,13 +72,9 @@ def main():
     ap.add_argument("--resume-dir", default=None)
     args = ap.parse_args()
     args.text, args.positive = args.is_text_pert, args.is_positive_pert
-    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
-    torch.cuda.set_device(dev)
+    rank, world, dev, gather_dev = sharding.init_evaluator_process()
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from transformer_mm_explainability_amd import visualbert_explainability as vb
     from transformer_mm_explainability_amd import visualbert_model as vm
     from transformer_mm_explainability_amd import visualbert_perturbation as vp
@@ -105,11 +101,11 @@ def main():
     ids = list(range(args.dataset_len))         # the loader order (mmf's sampler is sequential for evaluation)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    table, printed = evaluate(ids, step_accuracies_of, args.num_samples, args.reference_exact, store=store, device=dev)
+    table, printed = evaluate(ids, step_accuracies_of, args.num_samples, args.reference_exact, store=store, device=gather_dev)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:

@@ -48,6 +48,26 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert abs(line["value"] - 128 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
 
 
+SHARED = dict(MMX_EVAL_SHARE_DEVICE="1", MMX_EVAL_BACKEND="gloo")
+
+
+@pytest.mark.parametrize("script, args, same", [
+    ("lxmert_perturbation_eval.py", ["--num-samples", "40", "--max-batch", "8", "--method", "ours_no_lrp"], ("samples", "step_accuracy_percent")),
+    ("visualbert_pert_eval.py", ["--num-samples", "12"], ("samples", "step_accuracy_percent")),
+    ("detr_masks_eval.py", ["--num-images", "6", "--graph-slots", "8", "--warmup-images", "1"], ("images", "mean_kept", "mean_mask_area")),
+])
+def test_evaluators_two_ranks_on_one_gpu_equal_one_rank(script, args, same):
+    """The three sharded evaluators with their REAL model legs, two ranks sharing ``cuda:0`` and the one exchange step over gloo
+    (``sharding.init_evaluator_process`` test hooks) against a single process: same sample list, rank-strided shards, results
+    gathered back into loader order -> identical tables."""
+    port = 31100 + os.getpid() % 300
+    one = _launch([os.path.join("examples", script)] + args, 1, port)
+    two = _launch([os.path.join("examples", script)] + args, 2, port + 301, **SHARED)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    for key in same:
+        assert one[key] == two[key], (key, one[key], two[key])
+
+
 def test_lxmert_evaluator_two_ranks_equal_one_rank():
     _need_two_gpus()
     args = ["examples/lxmert_perturbation_eval.py", "--num-samples", "96", "--max-batch", "16", "--method", "ours_no_lrp"]

@@ -24,6 +24,27 @@ def world():
     return 0, 1
 
 
+def init_evaluator_process():
+    """Set up one evaluator process of a one-process-per-GPU launch (``python -m torch.distributed.run --nproc-per-node N
+    examples/..._eval.py``; a plain ``python`` run is world size 1): picks ``cuda:LOCAL_RANK``, joins the RCCL group when
+    ``WORLD_SIZE > 1``.  Returns ``(rank, world_size, device, gather_device)``; ``gather_device`` is where the per-sample
+    score table lives for the one exchange step (the GPU with RCCL).
+
+    Test hooks for 1-GPU boxes, never set by a launcher: ``MMX_EVAL_SHARE_DEVICE=1`` puts every rank on ``cuda:0`` and
+    ``MMX_EVAL_BACKEND=gloo`` swaps RCCL (which refuses two ranks per device) for gloo with the table on the host."""
+    rank, world_size = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    backend = os.environ.get("MMX_EVAL_BACKEND", "nccl")
+    device = torch.device("cuda", 0 if os.environ.get("MMX_EVAL_SHARE_DEVICE") else int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(device)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world_size)
+    return rank, world_size, device, device if backend == "nccl" else torch.device("cpu")
+
+
 def perturbation_sample_indices(dataset_len, num_samples, seed=1234):
     """The reference's sample selection (perturbation.py:205-210): ``random.seed(1234)``, shuffle ``range(len)``,
     keep the first ``num_samples``.  Identical on every rank."""
