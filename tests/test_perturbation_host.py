@@ -187,3 +187,35 @@ def test_clip_body_dtype_switch():
     import pytest
     with pytest.raises(ValueError):
         m.set_body_dtype(torch.float16)
+
+
+def test_batched_keep_builders_equal_the_per_sample_ones():
+    """``image_keep_masks`` on ``[B, I]`` and ``text_keep_batches`` on a padded batch of ragged questions (a few launches for the
+    whole batch) against the one-sample calls pinned above -- including tied scores (stable ranking: lower index first)."""
+    g = torch.Generator().manual_seed(3)
+    cams = torch.rand(5, 36, generator=g)
+    cams[1, 7] = cams[1, 20] = cams[1, 3]                                   # ties
+    cams[2] = 0.5                                                            # all equal
+    for positive in (False, True):
+        got = lp.image_keep_masks(cams, is_positive_pert=positive)
+        assert got.shape == (5, 9, 36)
+        for b in range(5):
+            assert torch.equal(got[b], lp.image_keep_masks(cams[b], is_positive_pert=positive))
+    P, lens = 20, [20, 14, 6, 3, 9]
+    ids = torch.randint(5, 1000, (5, P), generator=g)
+    types = torch.randint(0, 2, (5, P), generator=g)
+    cam_t = torch.rand(5, P, generator=g)
+    cam_t[4, 2] = cam_t[4, 5] = cam_t[4, 3]
+    for b, n in enumerate(lens):
+        ids[b, n:] = 0
+        types[b, n:] = 0
+        cam_t[b, n:] = 0
+    for positive in (False, True):
+        got = lp.text_keep_batches(ids, types, cam_t, is_positive_pert=positive, n_tokens=lens)
+        for b, n in enumerate(lens):
+            want = lp.text_keep_batch(ids[b:b + 1], types[b:b + 1], cam_t[b], is_positive_pert=positive, n_tokens=n)
+            for k in range(3):
+                assert torch.equal(got[k][9 * b: 9 * b + 9], want[k]), (positive, b, k)
+            # and the one-sample form on the UNPADDED question gives the same kept tokens (reference: no padding at all)
+            short = lp.text_keep_batch(ids[b:b + 1, :n], types[b:b + 1, :n], cam_t[b, :n], is_positive_pert=positive)
+            assert torch.equal(want[0][:, :n], short[0]) and torch.equal(want[2][:, :n], short[2]) and want[0][:, n:].abs().sum() == 0

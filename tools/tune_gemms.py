@@ -1,7 +1,10 @@
 """Make ``tuning/tunableop_gfx950_<workload>.csv`` on an MI355X: run a workload's passes eagerly with PyTorch TunableOp
 tuning ON (every distinct GEMM shape is timed against the hipBLASLt / rocBLAS solutions once), write the selection.
 
-    python tools/tune_gemms.py detr|lxmert|cfg5 <out.csv>
+    python tools/tune_gemms.py detr|lxmert|lxmert_pert|cfg5 <out.csv>
+
+``lxmert_pert``: the perturbation re-runs only (eager no-grad forwards at 8-9x the batch); rows below 2048 are dropped from the
+file afterwards -- small shapes also occur in the CAPTURED explain pass, which must not meet a tuned solution.
 """
 import os
 import sys
@@ -45,6 +48,20 @@ elif work == "lxmert":
         cam_image, cam_text = lp.normalize_cams_batch(R_t_t, R_t_i, batch["attention_mask"])
         pert.perturbation_image(batch, cam_image, False)
         pert.perturbation_text(batch, cam_text, False)
+elif work == "lxmert_pert":
+    from transformer_mm_explainability_amd import lxmert_model as lm
+    from transformer_mm_explainability_amd import lxmert_perturbation as lp
+    cfg = lm.LxmertConfig()
+    model = lm.LxmertForQuestionAnswering(cfg).cuda().eval()
+    pert = lp.LxmertPerturbation(model, tuned=False)
+    B = 32
+    for T in (14, 20):            # bench.py's cfg-4 leg (T = 14) and the evaluator's padded questions (T = 20)
+        batch = dict(input_ids=torch.randint(1, cfg.vocab_size, (B, T), device="cuda"), attention_mask=torch.ones(B, T, device="cuda"),
+                     token_type_ids=torch.zeros(B, T, dtype=torch.long, device="cuda"),
+                     visual_feats=torch.randn(B, 36, cfg.visual_feat_dim, device="cuda"), visual_pos=torch.rand(B, 36, 4, device="cuda"))
+        pert.perturbation_image(batch, torch.rand(B, 36, device="cuda"), False)
+        if T == 20:
+            pert.perturbation_text(batch, torch.rand(B, T, device="cuda"), False)
 elif work == "cfg5":
     from transformer_mm_explainability_amd import clip_explainability as ce
     from transformer_mm_explainability_amd import clip_model
@@ -58,4 +75,9 @@ else:
     raise SystemExit("unknown workload " + work)
 torch.cuda.synchronize()
 torch.cuda.tunable.write_file(out) if hasattr(torch.cuda, "tunable") else None
+if work == "lxmert_pert":
+    rows = open(out).read().splitlines()
+    keep = [r for r in rows if r.startswith("Validator") or int(r.split(",")[1].split("_")[2]) >= 2048]
+    open(out, "w").write("\n".join(keep) + "\n")
+    print("kept %d of %d entries (rows >= 2048)" % (len(keep), len(rows)))
 print("wrote", out)

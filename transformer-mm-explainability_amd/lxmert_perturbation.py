@@ -25,7 +25,11 @@ of the same order.  With distinct scores (any real relevancy map) this equals th
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
+
+from . import tuned_gemms
 
 PERT_STEPS = (0, 0.25, 0.5, 0.75, 0.8, 0.85, 0.9, 0.95, 1)
 
@@ -59,15 +63,47 @@ def ranking(scores):
     return torch.sort(scores, dim=-1, descending=True, stable=True).indices
 
 
+def _ranks(order):
+    """Inverse of a ranking: ``rank[..., i]`` = position of element ``i`` in ``order`` (``[..., n]`` index rows)."""
+    pos = torch.arange(order.shape[-1], device=order.device).expand_as(order)
+    return torch.empty_like(order).scatter_(-1, order, pos)
+
+
 def image_keep_masks(cam_image, steps=PERT_STEPS, is_positive_pert=False):
-    """``[S, I]`` float 0/1: row s keeps the ``int((1 - step_s) * I)`` top-scoring regions (``perturbation.py:114-117``)."""
+    """``[S, I]`` float 0/1 (``[B, S, I]`` for ``cam_image [B, I]``): row s keeps the ``int((1 - step_s) * I)`` top-scoring
+    regions (``perturbation.py:114-117``).  Every step keeps a prefix of ONE ranking, so region i stays in step s iff its rank
+    is below that step's count: a handful of launches for the whole batch."""
     cam = -cam_image if is_positive_pert else cam_image
     n = cam.shape[-1]
-    keep = torch.zeros(len(steps), n, dtype=torch.float32, device=cam.device)
-    order = ranking(cam)                                      # every step keeps a prefix of ONE ranking
-    for s, step in enumerate(steps):
-        keep[s, order[: int((1 - step) * n)]] = 1.0
-    return keep
+    counts = torch.tensor([int((1 - step) * n) for step in steps], device=cam.device)          # host arithmetic, as the reference
+    rank = _ranks(ranking(cam))                                                                 # [..., I]
+    return (rank.unsqueeze(-2) < counts.unsqueeze(-1)).to(torch.float32)                        # [..., S, I]
+
+
+def text_keep_batches(input_ids, token_type_ids, cam_text, steps=PERT_STEPS, is_positive_pert=False, n_tokens=None):
+    """``text_keep_batch`` for B questions at once: ``input_ids`` / ``token_type_ids`` / ``cam_text [B, P]``, ``n_tokens`` a
+    list of the B real lengths (``None``: all ``P``).  Returns ``(ids, token_types, attention_mask)`` ``[B * S, P]``, the S
+    perturbed copies of a question adjacent."""
+    cam = -cam_text if is_positive_pert else cam_text
+    B, P = cam.shape
+    S = len(steps)
+    lens = [P if n is None else int(n) for n in (n_tokens if n_tokens is not None else [None] * B)]
+    dev = cam.device
+    T = torch.tensor(lens, device=dev).unsqueeze(1)                                             # [B, 1]
+    counts = torch.tensor([[int((1 - step) * (t - 2)) for step in steps] for t in lens], device=dev)   # [B, S] host arithmetic
+    pos = torch.arange(P, device=dev).expand(B, P)
+    inner = (pos >= 1) & (pos < T - 1)
+    # one stable ranking per question: inner tokens by descending score (ties: lower index first), everything else behind them
+    rank = _ranks(ranking(torch.where(inner, cam, torch.full_like(cam, float("-inf")))))
+    keep = (inner.unsqueeze(1) & (rank.unsqueeze(1) < counts.unsqueeze(2))) | (pos == 0).unsqueeze(1) | (pos == T - 1).unsqueeze(1)
+    keep = keep.reshape(B * S, P)
+    # stable left-alignment: kept positions sorted by index first, dropped ones after
+    posr = torch.arange(P, device=dev).expand(B * S, P)
+    perm = torch.argsort(torch.where(keep, posr, posr + P), dim=1)
+    mask = torch.gather(keep, 1, perm)
+    ids = torch.gather(input_ids.repeat_interleave(S, dim=0), 1, perm) * mask
+    types = torch.gather(token_type_ids.repeat_interleave(S, dim=0), 1, perm) * mask
+    return ids, types, mask.to(torch.float32)
 
 
 def text_keep_batch(input_ids, token_type_ids, cam_text, steps=PERT_STEPS, is_positive_pert=False, n_tokens=None):
@@ -75,23 +111,8 @@ def text_keep_batch(input_ids, token_type_ids, cam_text, steps=PERT_STEPS, is_po
     ``int((1 - step) * (T - 2))`` top-scoring inner tokens stay in their original order, the rest is dropped.
     Returns ``(ids [S, T], token_types [S, T], attention_mask [S, T])`` with the kept tokens left-aligned.
     ``n_tokens``: the question's real length when ``input_ids`` is padded to a longer ``T`` ([SEP] sits at ``n_tokens - 1``)."""
-    cam = -cam_text if is_positive_pert else cam_text
-    P = cam.shape[-1]                       # padded length
-    T = P if n_tokens is None else int(n_tokens)
-    inner = cam[1:T - 1]
-    order = ranking(inner) + 1
-    S = len(steps)
-    keep = torch.zeros(S, P, dtype=torch.bool, device=cam.device)
-    keep[:, 0] = keep[:, T - 1] = True
-    for s, step in enumerate(steps):
-        keep[s, order[: int((1 - step) * (T - 2))]] = True
-    # stable left-alignment: kept positions sorted by index first, dropped ones after
-    pos = torch.arange(P, device=cam.device).expand(S, P)
-    perm = torch.argsort(torch.where(keep, pos, pos + P), dim=1)
-    mask = torch.gather(keep, 1, perm)
-    ids = torch.gather(input_ids.expand(S, P), 1, perm) * mask
-    types = torch.gather(token_type_ids.expand(S, P), 1, perm) * mask
-    return ids, types, mask.to(torch.float32)
+    return text_keep_batches(input_ids.reshape(1, -1), token_type_ids.reshape(1, -1), cam_text.reshape(1, -1), steps,
+                             is_positive_pert, None if n_tokens is None else [n_tokens])
 
 
 class LxmertPerturbation:
@@ -105,9 +126,13 @@ class LxmertPerturbation:
     soft accuracies (``label_scores[argmax]``, ``perturbation.py:134-136``).
     """
 
-    def __init__(self, model, steps=PERT_STEPS):
+    def __init__(self, model, steps=PERT_STEPS, tuned=True):
+        """``tuned``: run the re-runs' library GEMMs (8-9x the batch: thousands of rows) with the pre-tuned hipBLASLt / rocBLAS
+        selection of ``tuned_gemms`` ("lxmert_pert"; on for the duration of a call only, ignored when the file does not match
+        the box)."""
         self.model = model
         self.steps = tuple(steps)
+        self.tuned = tuned
 
     def _scores(self, **kw):
         """Answer scores of one batched re-run: the body's grad-free fast forward when it has one."""
@@ -118,13 +143,21 @@ class LxmertPerturbation:
     def _rep(x, S):
         return x.repeat_interleave(S, dim=0)
 
-    @torch.no_grad()
     def perturbation_image(self, inputs, cam_image, is_positive_pert=False):
+        with tuned_gemms.scope("lxmert_pert") if self.tuned else contextlib.nullcontext():
+            return self._perturbation_image(inputs, cam_image, is_positive_pert)
+
+    def perturbation_text(self, inputs, cam_text, is_positive_pert=False):
+        with tuned_gemms.scope("lxmert_pert") if self.tuned else contextlib.nullcontext():
+            return self._perturbation_text(inputs, cam_text, is_positive_pert)
+
+    @torch.no_grad()
+    def _perturbation_image(self, inputs, cam_image, is_positive_pert=False):
         single = cam_image.dim() == 1
         cams = cam_image.reshape(-1, cam_image.shape[-1])
         B, I = cams.shape
         S = len(self.steps)
-        keep = torch.stack([image_keep_masks(c, self.steps, is_positive_pert) for c in cams])      # [B, S, I]
+        keep = image_keep_masks(cams, self.steps, is_positive_pert)                                 # [B, S, I]
         counts = [int((1 - step) * I) for step in self.steps]                                       # host arithmetic only
         live = [s for s, c in enumerate(counts) if c > 0]
         scores = None
@@ -154,16 +187,15 @@ class LxmertPerturbation:
         return scores[0] if single else scores
 
     @torch.no_grad()
-    def perturbation_text(self, inputs, cam_text, is_positive_pert=False):
+    def _perturbation_text(self, inputs, cam_text, is_positive_pert=False):
         single = cam_text.dim() == 1
         cams = cam_text.reshape(-1, cam_text.shape[-1])
         B, S = cams.shape[0], len(self.steps)
         # per-sample question lengths (a padded batch): one device->host read for the whole batch
         mask = inputs.get("attention_mask")
         lens = mask.sum(dim=1).tolist() if mask is not None and mask.shape[1] == cams.shape[1] else [None] * B
-        parts = [text_keep_batch(inputs["input_ids"][b:b + 1], inputs["token_type_ids"][b:b + 1], cams[b], self.steps,
-                                 is_positive_pert, n_tokens=lens[b]) for b in range(B)]
-        ids, types, mask = (torch.cat([p[k] for p in parts]) for k in range(3))                     # [B*S, T]
+        ids, types, mask = text_keep_batches(inputs["input_ids"], inputs["token_type_ids"], cams, self.steps, is_positive_pert,
+                                             n_tokens=lens)                                         # [B*S, T]
         if hasattr(self.model, "scores_no_grad") and inputs["visual_feats"].shape[1] > 0:
             # the regions are the same in all S re-runs of a sample: their own 5 layers run once per sample (visn_repeat)
             out = self.model.scores_no_grad(input_ids=ids, attention_mask=mask, token_type_ids=types,

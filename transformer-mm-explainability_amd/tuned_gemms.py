@@ -8,6 +8,7 @@ CUs).  ``tuning/*.csv`` hold the solutions TunableOp selected on an MI355X for e
 in it use the tuned solution and everything else the default.  PyTorch ignores a file whose validators (ROCm / hipBLASLt
 version, architecture) do not match the box.  Process-wide (it changes every GEMM of the process), hence opt-in.
 """
+import contextlib
 import os
 
 import torch
@@ -15,8 +16,11 @@ import torch
 _DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning")
 # (LXMERT: a selection was made too, but with it the capture of GraphedGenerateOursBatch died with
 #  hipErrorStreamCaptureUnsupported inside a library call -- not shipped; `tools/tune_gemms.py lxmert` reproduces it.)
+#  What IS shipped for LXMERT is the selection for the perturbation re-runs only ("lxmert_pert": eager no-grad forwards at 8-9x
+#  the batch, rows >= 2048 -- shapes no captured explain pass has), used through ``scope``.)
 WORKLOADS = {"clip_vitb32_b64": "tunableop_gfx950_clip_vitb32_b64.csv", "detr": "tunableop_gfx950_detr_r50.csv",
-             "clip_vitl14_336_bf16": "tunableop_gfx950_clip_vitl14_336_bf16.csv"}
+             "clip_vitl14_336_bf16": "tunableop_gfx950_clip_vitl14_336_bf16.csv", "lxmert_pert": "tunableop_gfx950_lxmert_pert.csv"}
+_LOADED = {}
 
 
 def available(workload):
@@ -32,3 +36,24 @@ def enable(workload):
     tun.tuning_enable(False)
     tun.record_untuned_enable(False) if hasattr(tun, "record_untuned_enable") else None
     return bool(tun.read_file(os.path.join(_DIR, WORKLOADS[workload])))
+
+
+@contextlib.contextmanager
+def scope(workload):
+    """TunableOp on, with ``workload``'s selection, for the duration of the block only; the previous on / off state comes back
+    afterwards (yields whether the selection is in effect).  For eager passes that sit next to captured ones in one process: a
+    hipGraph capture must not run into a tuned solution (some allocate inside the library call), so nothing is switched while
+    the current stream is capturing."""
+    if not available(workload) or torch.cuda.is_current_stream_capturing():
+        yield False
+        return
+    tun = torch.cuda.tunable
+    was = tun.is_enabled()
+    if workload not in _LOADED:
+        _LOADED[workload] = enable(workload)
+    else:
+        tun.enable(True)
+    try:
+        yield _LOADED[workload]
+    finally:
+        tun.enable(was)
