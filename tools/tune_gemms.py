@@ -74,10 +74,12 @@ elif work == "cfg5":
 else:
     raise SystemExit("unknown workload " + work)
 torch.cuda.synchronize()
-torch.cuda.tunable.write_file(out) if hasattr(torch.cuda, "tunable") else None
+# this PyTorch streams the results into <stem><device ordinal><ext> as they are found (there is no write_file any more)
+stem, ext = os.path.splitext(out)
+rows = open(stem + "0" + ext).read().splitlines()
 if work == "lxmert_pert":
-    rows = open(out).read().splitlines()
     keep = [r for r in rows if r.startswith("Validator") or int(r.split(",")[1].split("_")[2]) >= 2048]
-    open(out, "w").write("\n".join(keep) + "\n")
     print("kept %d of %d entries (rows >= 2048)" % (len(keep), len(rows)))
+    rows = keep
+open(out, "w").write("\n".join(rows) + "\n")
 print("wrote", out)
