@@ -3,7 +3,6 @@ argument validation that needs no GPU returns the documented error codes."""
 import ctypes as C
 import os
 import subprocess
-import sys
 
 import pytest
 

@@ -11,8 +11,6 @@ Tolerances: the pass divides by layer outputs (``safe_divide``), which makes the
 The yardstick is that distance: a result must be as close to the reference's float64 values as the reference's float32 values
 are, within a factor (``within_reference_noise``).  (On the CPU these closed forms reproduce the reference's fp32 values bit
 for bit in this image; the bound does not rely on it.)"""
-import math
-import types
 
 import numpy as np
 import pytest

@@ -3,7 +3,6 @@ against (a) the reference's own outputs on a tiny CLIP (golden fixture) and (b) 
 ViT-B/32 shapes.  Tolerance 1e-5 abs on relevancy maps (north_star), fp32."""
 import json
 
-import numpy as np
 import pytest
 import torch
 

@@ -3,7 +3,6 @@
 ``DETR/modules/layers.py`` (``MultiheadAttention.relprop`` :770-801 and the layer rules) and
 ``DETR/models/transformer.py`` / ``DETR/models/detr.py:79-92`` driven by the reference ``Generator`` with its DEFAULT
 arguments (``use_lrp=True``).  Fixtures: ``lrp_layers.npz``, ``detr_transformer_lrp.npz`` (``tests/golden/make_golden.py``)."""
-import numpy as np
 import pytest
 import torch
 from parity import close
@@ -44,7 +43,7 @@ def test_attn_relprop_kernel_vs_torch_referee(B, H, Nq, Nk, D):
     THE REFERENCE TOO: the yardstick is the referee itself -- evaluated in fp32 and in fp64 on the same inputs -- and the
     kernel's largest distance to the fp64 values must stay within 8x the fp32 referee's own (plus 1e-6 of the tensor's
     largest entry).  cam_P (what the rules read) and cam_V are well conditioned: ~1e-7 of the largest entry, measured."""
-    from transformer_mm_explainability_amd import lrp, ops
+    from transformer_mm_explainability_amd import ops
     g = torch.Generator().manual_seed(B * 1000 + Nq + Nk)
     q, k, v = (torch.randn(B, n, H, D, generator=g).cuda() for n in (Nq, Nk, Nk))
     scale = D ** -0.5
@@ -135,7 +134,7 @@ def in_noise(got, g, key, what):
 def test_attn_relprop_phases(B, H, Nq, Nk, D):
     """``mmx_attn_relprop_phase``: VALUES then SCORES fed with cam_P reproduces the fused call bit for bit; SCORES with another
     relevance of the scores equals the plain-torch referee (``oracle/lrp_torch.py``) within its own fp32 noise."""
-    from transformer_mm_explainability_amd import _lib, bert_lrp, ops
+    from transformer_mm_explainability_amd import _lib, ops
     g = torch.Generator().manual_seed(B + Nq * 7 + Nk)
     q, k, v = (torch.randn(B, n, H, D, generator=g).cuda() for n in (Nq, Nk, Nk))
     probs = torch.softmax(torch.einsum("bthd,bshd->bhts", q, k) / D ** 0.5, dim=-1).contiguous()

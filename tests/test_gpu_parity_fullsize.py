@@ -9,7 +9,6 @@
     ``oracle/attention_torch`` and the rule schedule vs ``oracle/relevancy_np.detr_generate_ours_chain`` on the slabs.
 Tolerances are the north star's: relevancy maps 1e-5 abs; probabilities 2e-6, gradients 2e-5.
 """
-import numpy as np
 import pytest
 import torch
 

@@ -1,6 +1,5 @@
 """-m gpu: ViT body on the HIP capture op + generate_relevance (notebook path) + the batched-target variant
  against the torch CPU oracle (oracle/vit_torch.py; model body parity is unpinned, see there)."""
-import numpy as np
 import pytest
 import torch
 

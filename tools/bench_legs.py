@@ -16,7 +16,6 @@ from __future__ import annotations
 
 import time
 import traceback
-import types
 
 import torch
 

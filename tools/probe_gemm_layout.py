@@ -1,7 +1,6 @@
 """Library fp32 GEMM layouts for the input-gradient products dX = dY . W (W = nn.Linear.weight [out, in]): the NN form
 ``matmul(dY, W)`` against the NT form ``F.linear(dY, W^T contiguous)`` and the accumulating ``addmm_`` of both -- which kernel the
 hipBLASLt heuristic picks differs per layout.  Shapes: DETR K = 10 / 20 (M = 9500 / 19000), LXMERT B = 32 (M = 448 / 1152)."""
-import sys
 
 import torch
 import torch.nn.functional as F
