@@ -219,3 +219,37 @@ def test_batched_keep_builders_equal_the_per_sample_ones():
             # and the one-sample form on the UNPADDED question gives the same kept tokens (reference: no padding at all)
             short = lp.text_keep_batch(ids[b:b + 1, :n], types[b:b + 1, :n], cam_t[b, :n], is_positive_pert=positive)
             assert torch.equal(want[0][:, :n], short[0]) and torch.equal(want[2][:, :n], short[2]) and want[0][:, n:].abs().sum() == 0
+
+
+def test_perturbation_driver_on_a_stand_in_model():
+    """``LxmertPerturbation`` end to end on the host with a stand-in body whose score is an order-independent function of the
+    regions it may attend to: 9 steps of B samples in one masked batch == the reference's loop over steps with the removed
+    regions dropped; the zero-region step takes the region-free forward; the scoped GEMM selection is a no-op without a GPU."""
+    import types
+
+    from transformer_mm_explainability_amd import tuned_gemms
+
+    class Body:
+        def __call__(self, input_ids, visual_feats, visual_pos, attention_mask=None, token_type_ids=None, visual_attention_mask=None):
+            m = torch.ones(visual_feats.shape[:2]) if visual_attention_mask is None else visual_attention_mask
+            s = (visual_feats * m[..., None]).sum(1)[:, :5] + (visual_pos * m[..., None]).sum(1)[:, :1] + input_ids.float().sum(1, keepdim=True)
+            return types.SimpleNamespace(question_answering_score=s)
+
+    with tuned_gemms.scope("lxmert_pert") as on:
+        assert on is False
+    B, I = 3, 12
+    g = torch.Generator().manual_seed(5)
+    inputs = dict(input_ids=torch.randint(1, 50, (B, 7), generator=g), attention_mask=torch.ones(B, 7),
+                  token_type_ids=torch.zeros(B, 7, dtype=torch.long), visual_feats=torch.randn(B, I, 8, generator=g),
+                  visual_pos=torch.rand(B, I, 4, generator=g))
+    cams = torch.rand(B, I, generator=g)
+    body = Body()
+    got = lp.LxmertPerturbation(body).perturbation_image(inputs, cams)
+    assert got.shape == (B, 9, 5)
+    for b in range(B):
+        for s, step in enumerate(lp.PERT_STEPS):
+            idx = cams[b].topk(k=int((1 - step) * I)).indices                      # perturbation.py:114-117
+            want = body(inputs["input_ids"][b:b + 1], inputs["visual_feats"][b:b + 1, idx], inputs["visual_pos"][b:b + 1, idx])
+            assert torch.allclose(got[b, s], want.question_answering_score[0], atol=1e-5)
+    one = lp.LxmertPerturbation(body).perturbation_image({k: v[:1] for k, v in inputs.items()}, cams[0])
+    assert one.shape == (9, 5) and torch.allclose(one, got[0], atol=1e-5)

@@ -44,7 +44,7 @@ def scope(workload):
     afterwards (yields whether the selection is in effect).  For eager passes that sit next to captured ones in one process: a
     hipGraph capture must not run into a tuned solution (some allocate inside the library call), so nothing is switched while
     the current stream is capturing."""
-    if not available(workload) or torch.cuda.is_current_stream_capturing():
+    if not torch.cuda.is_available() or not available(workload) or torch.cuda.is_current_stream_capturing():
         yield False
         return
     tun = torch.cuda.tunable
