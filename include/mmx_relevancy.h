@@ -72,6 +72,8 @@ const char* mmx_last_error(void);
  *   "self_chain_groups"  0 auto | 1..8 layer groups per sample of the fused chain kernel (1 = strict sequential order)
  *   "self_chain_big"     2: N > 128 (<= 1152, no second right-hand side) runs the ONE-launch persistent team kernel |
  *                        0 / 1 (default): the per-layer split path, which measures 1.7-2x faster on MI355X
+ *   "linear_stream"      0 (default) | 1: small-M products (mmx_bmm_f32 with batch 1, mmx_linear_f32; K % 16 == 0, N % 4 == 0, M <= 2048) on the
+ *                        K-split streaming kernel of csrc/linear_stream.hip (no LDS staging; deterministic)
  *   "attn_head"          1 (default) register-resident whole-head attention kernels (Nk <= 128, Nq <= 256) | 0 never
  *   "attn_small"         1 (default) whole-head-in-LDS attention kernels where the head fits | 0 never
  *   "attn_stream"        1 (default) long-sequence streaming attention kernels | 0 first-generation tiled kernels

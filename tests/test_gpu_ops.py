@@ -377,6 +377,37 @@ def test_small_linear_routes_the_few_row_square_projections(ops, rows, E, bias):
     assert ops.small_linear(xg, lin).grad_fn is not None
 
 
+@pytest.mark.parametrize("M,K,N", [(197, 768, 768), (197, 768, 2304), (197, 3072, 768), (448, 768, 3072), (1152, 3072, 768),
+                                   (100, 256, 256), (950, 256, 2048), (7, 16, 4), (33, 48, 100), (209, 64, 68), (1, 1024, 1000)])
+def test_linear_stream_small_m_gemm(ops, M, K, N):
+    """Option ``linear_stream`` (``csrc/linear_stream.hip``: K split over the waves of a workgroup, operands global -> registers in
+    MFMA layout, no LDS staging) behind ``mmx_bmm_f32`` / ``mmx_linear_f32``: plain product, accumulate form and bias row against
+    float64; deterministic (two launches agree bit for bit); row / column / K-split edges."""
+    from transformer_mm_explainability_amd import _lib
+    g = torch.Generator().manual_seed(M * 7 + K + N)
+    a = (torch.randn(M, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(K, N, generator=g).cuda()
+    c0 = torch.randn(M, N, generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    want = a.double() @ b.double()
+    ops.set_option("linear_stream", 1)
+    try:
+        got = ops.matmul(a, b)
+        again = ops.matmul(a, b)
+        acc = ops.matmul(a, b, add_to=c0)
+        lin = torch.empty(M, N, device="cuda")
+        _lib.check(_lib.lib().mmx_linear_f32(a.data_ptr(), b.data_ptr(), bias.data_ptr(), lin.data_ptr(), M, N, K,
+                                             torch.cuda.current_stream().cuda_stream), "mmx_linear_f32")
+    finally:
+        ops.set_option("linear_stream", 0)
+    old = ops.matmul(a, b)
+    assert torch.equal(got, again)
+    close(got, want.float().cpu().numpy(), atol=2e-5)
+    close(acc, (want + c0.double()).float().cpu().numpy(), atol=2e-5)
+    close(lin, (want + bias.double()).float().cpu().numpy(), atol=2e-5)
+    close(old, want.float().cpu().numpy(), atol=2e-5)
+
+
 @pytest.mark.parametrize("shape", [(4928, 2048), (7, 13), (1, 3), (3, 4)])
 def test_quick_gelu_fused(ops, shape):
     g = torch.Generator().manual_seed(sum(shape))

@@ -1,7 +1,7 @@
 """Make ``tuning/tunableop_gfx950_<workload>.csv`` on an MI355X: run a workload's passes eagerly with PyTorch TunableOp
 tuning ON (every distinct GEMM shape is timed against the hipBLASLt / rocBLAS solutions once), write the selection.
 
-    python tools/tune_gemms.py detr|lxmert|lxmert_pert|cfg5 <out.csv>
+    python tools/tune_gemms.py detr|lxmert|lxmert_pert|vit_b16|cfg5 <out.csv>
 
 ``lxmert_pert``: the perturbation re-runs only (eager no-grad forwards at 8-9x the batch); rows below 2048 are dropped from the
 file afterwards -- small shapes also occur in the CAPTURED explain pass, which must not meet a tuned solution.
@@ -62,6 +62,14 @@ elif work == "lxmert_pert":
         pert.perturbation_image(batch, torch.rand(B, 36, device="cuda"), False)
         if T == 20:
             pert.perturbation_text(batch, torch.rand(B, T, device="cuda"), False)
+elif work == "vit_b16":
+    from transformer_mm_explainability_amd import vit_model
+    model = vit_model.vit_base_patch16_224().float().eval().cuda()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(1, 3, 224, 224, device="cuda")
+    for K in (1, 8):              # one image: 197-row forward; 197- / 1576-row backward (bench.py's cfg-1 leg: 1 and 8 targets)
+        vit_model.generate_relevance_multi(model, x, indices=list(range(K)))
 elif work == "cfg5":
     from transformer_mm_explainability_amd import clip_explainability as ce
     from transformer_mm_explainability_amd import clip_model

@@ -204,6 +204,8 @@ inline size_t dtype_size(int dt) { return dt == MMX_F32 ? 4 : 2; }
 
 void set_error(const char* fmt, ...);
 void attn_small_enable(int on);
+void linear_stream_enable(int on);
+int linear_stream_try(const float* A, const float* B, const float* Cin, float* C, int M, int N, int K, int cin_is_row, hipStream_t s);
 void attn_head_enable(int on);
 void chain_big_enable(int on);
 size_t self_chain_big_workspace(int B, int N);

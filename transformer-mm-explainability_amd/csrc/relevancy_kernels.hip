@@ -707,6 +707,7 @@ static int g_bmm_tile = 64;   // 128: try the 128 x 128 tiling where the grid is
 
 static void launch_bmm(const float* A, const float* B, const float* Cin, float* C, int batch, int M, int N, int K,
                        int trans_a, int64_t sa, int64_t sb, int64_t sc, int nan_to_zero, hipStream_t s, int cin_is_row = 0) {
+    if (batch == 1 && !trans_a && !nan_to_zero && linear_stream_try(A, B, Cin, C, M, N, K, cin_is_row, s)) return;
     const int64_t wgs64 = static_cast<int64_t>((N + 63) / 64) * ((M + 63) / 64) * batch;
     const int64_t wgs128 = static_cast<int64_t>((N + 127) / 128) * ((M + 127) / 128) * batch;
     if (wgs128 >= 512 && g_bmm_tile == 128) {
@@ -1069,6 +1070,10 @@ extern "C" int mmx_set_option(const char* key, int value) {
     }
     if (key && strcmp(key, "attn_small") == 0) {
         attn_small_enable(value);
+        return MMX_OK;
+    }
+    if (key && strcmp(key, "linear_stream") == 0 && value >= 0 && value <= 1) {
+        linear_stream_enable(value);
         return MMX_OK;
     }
     if (key && strcmp(key, "bmm_tile") == 0) {
