@@ -162,6 +162,16 @@ size_t mmx_chain_vecmat_workspace_bytes(int B, int N);
 int mmx_chain_vecmat(const void* A_dev, const void* x_dev, const void* base_dev, void* out_dev, int B, int N,
                      void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* One layer of the row-vector chain without materialising A_bar (ViT nb cell 7:27-33 carried as ONE row, top layer down):
+ *   out[b] = base[b] + x[b] . mean_h clamp(grad[b, h] * attn[b, h], 0),   x / base / out [B, N] fp32, slabs [B, H, N, N] of `dtype`
+ * (attn_batch_stride: 0 = one forward shared by the batch, < 0 or H*N*N = per sample).  Two launches (partials per 4 slab rows, then
+ * their sum in workgroup order: deterministic) instead of mmx_avg_heads + mmx_chain_vecmat's three; out may not alias x;
+ * workspace 16-byte aligned, mmx_avg_heads_vecmat_workspace_bytes. */
+size_t mmx_avg_heads_vecmat_workspace_bytes(int B, int N);
+int mmx_avg_heads_vecmat(const void* attn_dev, const void* grad_dev, const void* x_dev, const void* base_dev, void* out_dev,
+                         int B, int H, int N, int dtype, int64_t attn_batch_stride, void* workspace_dev,
+                         size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * eq. 8-9: out = (R - I) / rowsum(R - I) + I  (0/0 rows -> NaN like the reference).
  * replaces handle_residual (DETR/.../ExplanationGenerator.py:46-53, lxmert/.../ExplanationGenerator.py:45-54).

@@ -377,6 +377,38 @@ def test_small_linear_routes_the_few_row_square_projections(ops, rows, E, bias):
     assert ops.small_linear(xg, lin).grad_fn is not None
 
 
+@pytest.mark.parametrize("B,H,N,shared", [(1, 12, 197, False), (8, 12, 197, True), (3, 4, 33, False), (2, 2, 5, False), (1, 3, 1, False),
+                                          (2, 12, 50, True), (2, 8, 260, False)])
+def test_avg_heads_vecmat_fused_row_rule(ops, B, H, N, shared):
+    """``mmx_avg_heads_vecmat``: ``base + x . mean_h clamp(G * A, 0)`` in two launches, against the oracle's head average followed
+    by a float64 vector-matrix product; shared-forward slabs, ragged last column chunk / row chunk, 16-bit slabs, NaN policy."""
+    g = torch.Generator().manual_seed(B * 100 + H + N)
+    cam = torch.randn((1 if shared else B) * H, N, N, generator=g).softmax(-1)
+    grad = torch.randn(B * H, N, N, generator=g)
+    x, base = torch.rand(B, N, generator=g), torch.randn(B, N, generator=g)
+    cam_full = cam.repeat(B, 1, 1) if shared else cam
+    abar = onp.avg_heads_batched(cam_full.numpy(), grad.numpy(), B).astype(np.float64)
+    want = base.double().numpy() + np.einsum("bi,bij->bj", x.double().numpy(), abar)
+    got = ops.avg_heads_vecmat(x.cuda(), cam.cuda(), grad.cuda(), batch_size=B, shared_attn=shared, base=base.cuda())
+    close(got, want.astype(np.float32), atol=1e-5)
+    two = ops.chain_vecmat(x.cuda(), ops.avg_heads(cam.cuda(), grad.cuda(), batch_size=B, shared_attn=shared), base=base.cuda())
+    close(got, two.cpu().numpy(), atol=1e-5)
+    close(ops.avg_heads_vecmat(x.cuda(), cam.cuda(), grad.cuda(), batch_size=B, shared_attn=shared), (want - base.double().numpy()
+                                                                                                    + x.double().numpy()).astype(np.float32), atol=1e-5)
+    for dt in (torch.bfloat16, torch.float16):
+        c16, g16 = cam.to(dt), grad.to(dt)
+        c16_full = c16.repeat(B, 1, 1) if shared else c16
+        ab = onp.avg_heads_batched(c16_full.float().numpy(), g16.float().numpy(), B).astype(np.float64)
+        w16 = base.double().numpy() + np.einsum("bi,bij->bj", x.double().numpy(), ab)
+        close(ops.avg_heads_vecmat(x.cuda(), c16.cuda(), g16.cuda(), batch_size=B, shared_attn=shared, base=base.cuda()),
+              w16.astype(np.float32), atol=1e-5)
+    if N > 2:
+        gn = grad.clone()
+        gn[0, 1, 2] = float("nan")                                  # NaN propagates like clamp() does: column 2 of sample 0
+        out = ops.avg_heads_vecmat(x.cuda(), cam.cuda(), gn.cuda(), batch_size=B, shared_attn=shared, base=base.cuda()).cpu()
+        assert torch.isnan(out[0, 2]) and torch.isnan(out).sum() == 1
+
+
 @pytest.mark.parametrize("M,K,N", [(197, 768, 768), (197, 768, 2304), (197, 3072, 768), (448, 768, 3072), (1152, 3072, 768),
                                    (100, 256, 256), (950, 256, 2048), (7, 16, 4), (33, 48, 100), (209, 64, 68), (1, 1024, 1000)])
 def test_linear_stream_small_m_gemm(ops, M, K, N):

@@ -68,6 +68,8 @@ _PROTOTYPES = {
     "mmx_chain_matvec": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mmx_chain_vecmat_workspace_bytes": (_sz, [_i, _i]),
     "mmx_chain_vecmat": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "mmx_avg_heads_vecmat_workspace_bytes": (_sz, [_i, _i]),
+    "mmx_avg_heads_vecmat": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _vp, _sz, _vp]),
     "mmx_quick_gelu_fwd": (_i, [_vp, _vp, _i64, _vp]),
     "mmx_quick_gelu_bwd": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "mmx_quick_gelu_bwd_bcast": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),

@@ -544,6 +544,27 @@ def chain_vecmat(x, A, base=None):
     return out
 
 
+def avg_heads_vecmat(x, cam, grad, batch_size=1, shared_attn=False, base=None):
+    """``base + x @ mean_h(clamp(grad * cam, 0))`` for ``x`` / ``base [B, N]`` fp32 (``base`` defaults to ``x``) and square slabs
+    ``[B * H, N, N]``: ``chain_vecmat(x, avg_heads(cam, grad))`` without the ``[B, N, N]`` intermediate, two launches instead of
+    three (``mmx_avg_heads_vecmat``).  ``shared_attn`` as in ``avg_heads``."""
+    _dev(cam, grad, x, base)
+    cam, grad, x = _capture(cam), _capture(grad), _f32c(x)
+    base = x if base is None else _f32c(base)
+    B, N = x.shape
+    bh = grad.numel() // (N * N)
+    ok = cam.numel() * batch_size == grad.numel() if shared_attn else cam.shape == grad.shape
+    if not ok or B != batch_size or bh % B or tuple(grad.shape[-2:]) != (N, N) or cam.dtype != grad.dtype:
+        raise MMXError("avg_heads_vecmat: x %s, cam %s/%s, grad %s/%s, batch %d" % (tuple(x.shape), tuple(cam.shape), cam.dtype,
+                                                                                     tuple(grad.shape), grad.dtype, batch_size))
+    out = torch.empty_like(x)
+    need = lib().mmx_avg_heads_vecmat_workspace_bytes(B, N)
+    ws = _workspace(need, x.device, "ahv")
+    check(lib().mmx_avg_heads_vecmat(_p(cam), _p(grad), _p(x), _p(base), _p(out), B, bh // B, N, _DTYPES[cam.dtype],
+                                     0 if shared_attn else -1, _p(ws), need, _stream()), "mmx_avg_heads_vecmat")
+    return out
+
+
 # ------------------------------------------------------------------------------------------- eq. 8-9
 def handle_residual(R, check_diag=True):
     """Eq. 8-9 on ``[.., N, N]``.  ``check_diag``: ``True`` asserts ``min diag(R - I) >= 0`` now, like the reference's

@@ -255,11 +255,11 @@ def generate_relevance_multi(model, input, indices=None, top_k=None):
 
     def layer_rule(l):
         if side is main:
-            row[0] = ops.chain_vecmat(row[0], ops.avg_heads(buf.probs[l], buf.grads[l], batch_size=K, shared_attn=K > 1))
+            row[0] = ops.avg_heads_vecmat(row[0], buf.probs[l], buf.grads[l], batch_size=K, shared_attn=K > 1)
             return
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            row[0] = ops.chain_vecmat(row[0], ops.avg_heads(buf.probs[l], buf.grads[l], batch_size=K, shared_attn=K > 1))
+            row[0] = ops.avg_heads_vecmat(row[0], buf.probs[l], buf.grads[l], batch_size=K, shared_attn=K > 1)
 
     model.backward_shared(state, d_logits, layer_rule)
     if side is not main:
