@@ -245,3 +245,62 @@ def test_row_vector_chain_equals_the_reference_rows(golden):
     B = g["texts"].shape[0]
     for tag, sl in (("last", len(g["img_attn"]) - 1), ("all", 0), ("mid", 1)):
         close(onp.self_chain_row(list(g["img_attn"]), list(g["img_grad"]), B, 0, sl)[:, 1:], g["R_image_" + tag], atol=1e-6)
+
+
+def _sd(g, prefix="w__"):
+    import torch
+    return {k[len(prefix):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix)}
+
+
+def test_detr_torch_oracle(golden):
+    """``oracle/detr_torch.py`` (independent autograd body: encoder-decoder, heads, ``generate_ours``) == the reference's own
+    ``DETR/models/transformer.py`` + ``Generator.generate_ours(use_lrp=False)`` (detr_transformer.npz): logits, the returned
+    rows, and the per-query loop of ``mask_generator.py`` on the single-target fixture of the LRP file's sibling."""
+    import torch
+    from oracle import detr_torch as dt
+    g = golden("detr_transformer")
+    heads = int(g["dims"][1])
+    sd = dt.prepare_state_dict(_sd(g))
+    feats, pos = torch.from_numpy(g["features"]), torch.from_numpy(g["pos"])
+    out, st = dt.generate_ours(sd, feats, pos, g["target_index"], heads, with_state=True)
+    close(st["pred_logits"], g["pred_logits"])
+    close(out, g["out"])
+    # sine position embedding of the oracle itself (the full-size GPU test feeds it)
+    mask = torch.from_numpy(g["sine_mask"])
+    d = int(g["dims"][0])
+    np.testing.assert_allclose(dt.position_embedding_sine(mask, d // 2, normalize=True).numpy(), g["sine_pos"], atol=1e-6)
+    np.testing.assert_allclose(dt.position_embedding_sine(mask, d // 2, normalize=False).numpy(), g["sine_pos_raw"], atol=1e-6)
+    # per-query loop == one call per target
+    rows, _ = dt.generate_ours_per_query(sd, feats, pos, g["target_index"], heads)
+    for j, t in enumerate(g["target_index"]):
+        close(rows[j], dt.generate_ours(sd, feats, pos, [int(t)], heads)[0, 0, 0])
+
+
+def test_lxmert_torch_oracle(golden):
+    """``oracle/lxmert_torch.py`` (independent autograd body: embeddings, 3 + 2 + 3 layers with the shared cross-attention
+    weights, pooler, answer head, ``generate_ours``) == the reference's own ``lxmert_lrp.py`` layers + ``GeneratorOurs``
+    (lxmert_model.npz): answer scores and both returned maps."""
+    import torch
+    from oracle import lxmert_torch as lt
+    g = golden("lxmert_model")
+    heads = int(g["dims"][1])
+    sd = lt.prepare_state_dict(_sd(g))
+    inputs = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("in__")}
+    R_t_t, R_t_i, st = lt.generate_ours(sd, heads, inputs, with_state=True)
+    close(st["score"], g["score"])
+    close(R_t_t, g["R_t_t"])
+    close(R_t_i, g["R_t_i"])
+
+
+def test_visualbert_torch_oracle(golden):
+    """``oracle/visualbert_torch.py`` == the reference's own ``BERT_ours`` stack + ``SelfAttentionGenerator.generate_ours``
+    (visualbert_model.npz): scores and the returned row."""
+    import torch
+    from oracle import visualbert_torch as vt
+    g = golden("visualbert_model")
+    heads = int(g["dims"][1])
+    sd = vt.prepare_state_dict(_sd(g))
+    out, st = vt.generate_ours(sd, heads, torch.from_numpy(g["input_ids"]), torch.from_numpy(g["input_mask"]),
+                               torch.from_numpy(g["image_feature_0"]), with_state=True)
+    close(st["scores"], g["scores"])
+    close(out, g["out"])
