@@ -69,6 +69,7 @@ const char* mmx_last_error(void);
  *                        next batch of 8 16-byte loads in flight across the head reduction, the LDS write and the per-layer barrier)
  *                        with up to 4 KB contiguous per (head, array) and wave | 2 / 1: at most 2 / 1 KB contiguous |
  *                        0 the plain chunk loop of rounds 1-2.  Same arithmetic, bit-identical results
+ *   "self_chain_nt"      0 (default) | 1: the pipelined stream waves load the read-once slabs with the nt (streaming) cache policy; same results
  *   "self_chain_groups"  0 auto | 1..8 layer groups per sample of the fused chain kernel (1 = strict sequential order)
  *   "self_chain_big"     2: N > 128 (<= 1152, no second right-hand side) runs the ONE-launch persistent team kernel |
  *                        0 / 1 (default): the per-layer split path, which measures 1.7-2x faster on MI355X

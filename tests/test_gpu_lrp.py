@@ -219,3 +219,31 @@ def test_visualbert_lrp_methods_run_on_the_bodys_own_pass(golden):
     one_hot = torch.zeros_like(out)
     one_hot[0, int(g["index"])] = 1
     in_noise(model.relprop(one_hot, alpha=1), g, "cam_input", "visualbert cam_input")
+
+
+def test_lrp_tapes_do_not_outlive_their_forward(golden):
+    """an LRP tape references the module's probability slab; a later forward that does not renew it (``no_grad``
+    inference, the hand-written tape path) overwrites that slab, so ``relprop`` must RAISE instead of mixing a stale tape's
+    q / k / v / o with new probabilities -- and a ``no_grad`` forward pins no activations."""
+    from test_gpu_generators import _lxmert_from_golden
+    gm, g = golden("lxmert_model"), golden("lxmert_model_lrp")
+    model, usage = _lxmert_from_golden(gm)
+    out = usage.forward(None).question_answering_score
+    one_hot = torch.zeros_like(out)
+    one_hot[0, int(g["index"])] = 1
+    torch.sum(one_hot * out).backward()
+    model.relprop(one_hot.clone(), alpha=1)                                 # fresh tapes: runs
+    att = model.lxmert.encoder.layer[0].attention.self
+    assert att._lrp_tape is not None
+    with torch.no_grad():
+        usage.forward(None)
+    assert att._lrp_tape is None and model.lxmert.encoder.layer[0].intermediate._lrp_tape is None
+    with pytest.raises(RuntimeError, match="no LRP tape"):
+        model.relprop(one_hot.clone(), alpha=1)
+    usage.forward(None)                                                     # grad mode: tapes are back
+    assert att._lrp_tape is not None
+    inputs = {k[4:]: cu(v) for k, v in gm.items() if k.startswith("in__")}
+    model.forward_tape(**inputs)                                            # the tape path rewrites the slabs
+    assert att._lrp_tape is None
+    with pytest.raises(RuntimeError, match="no LRP tape"):
+        model.relprop(one_hot.clone(), alpha=1)

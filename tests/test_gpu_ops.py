@@ -686,6 +686,25 @@ def test_detr_decoder_rows_kernels_vs_per_layer_ops(ops, K, H, Q, Ni, L, shared)
     assert float((s[poisoned[0]].double() - want[poisoned[0]]).abs().max()) <= 2e-6 * scale
 
 
+def test_detr_decoder_rows_diag_word_carries_nan(ops):
+    """a NaN on the diagonal of R_qq - I must reach the ``diag_min`` word (the reference's ``assert diag.min() >= 0``
+    fails on NaN; ``fminf`` would drop it) so that ``MaskGenerator.check_diag`` / the deferred assert fire."""
+    K, H, Q, Ni, L = 3, 2, 10, 40, 3
+    g = torch.Generator().manual_seed(5)
+    sm = lambda *s: torch.softmax(torch.randn(*s, generator=g), -1).cuda()          # noqa: E731
+    gr = lambda *s: (torch.randn(*s, generator=g) * 0.3).cuda()                      # noqa: E731
+    self_pairs = [(sm(K * H, Q, Q), gr(K * H, Q, Q)) for _ in range(L)]
+    cross_pairs = [(sm(K * H, Q, Ni), gr(K * H, Q, Ni)) for _ in range(L)]
+    targets = torch.randint(0, Q, (K,), generator=g).cuda()
+    _, clean = ops.detr_decoder_rows(self_pairs, cross_pairs, targets, shared_attn=False)
+    assert float(clean) == float(clean)                                              # finite on clean slabs
+    self_pairs[1][1].view(K, H, Q, Q)[1, 0, 4, 4] = float("nan")                      # poisons diag(R_qq) of sample 1
+    s, dmin = ops.detr_decoder_rows(self_pairs, cross_pairs, targets, shared_attn=False)
+    assert torch.isnan(dmin).all(), "the NaN was dropped by the diag reduction"
+    assert not (float(dmin) >= 0)                                                    # what the deferred assert evaluates
+    assert torch.isfinite(s).all()                                                   # NaN policy: that layer contributes nothing
+
+
 def test_graph_capture_holds_the_garbage_collector_off(ops):
     """Every ``Graphed*`` wrapper captures through ``ops.graph_capture``: Python's cyclic collector must not run inside a
     capture (it may destroy an earlier wrapper's CUDAGraph, whose pool release is illegal while a stream is capturing and

@@ -255,6 +255,7 @@ class BertStyleAttention(_SlabOwner):
         self.value = nn.Linear(ctx_dim, hidden_size)
 
     def forward(self, hidden_states, context=None, attention_mask=None, output_attentions=False):
+        self._lrp_tape = None            # (also on the empty-stream early return and under no_grad: nothing stale stays pinned)
         context = hidden_states if context is None else context
         B, Nq, _ = hidden_states.shape
         Nk = context.shape[1]

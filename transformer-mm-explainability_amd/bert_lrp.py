@@ -40,6 +40,18 @@ from . import _lib, lrp, ops
 VALUES, SCORES = _lib.LRP_VALUES, _lib.LRP_SCORES
 
 
+
+def tape_of(module):
+    """The detached activations a forward in grad mode left on ``module``; a clear error instead of a stale / missing tape
+    (every forward -- eager, ``no_grad`` or the hand-written tape path -- resets it)."""
+    t = getattr(module, "_lrp_tape", None)
+    if t is None:
+        raise RuntimeError("%s has no LRP tape: relprop needs a forward run through the module path with gradients enabled "
+                           "right before it (a no_grad forward or the tape path forward_tape() clears the tapes)"
+                           % type(module).__name__)
+    return t
+
+
 def _lin(R, X, weight):
     return lrp.linear_relprop(R, X, weight, normalize=False)
 
@@ -98,7 +110,7 @@ def ffn_relprop(inter, output, t_inter, t_out, cam):
 
 def self_layer_relprop(layer, cam, core=None):
     """``LxmertSelfAttentionLayer`` (``.self``, ``.output``) -> relevance of its input (Clone of 3: query, context, residual)."""
-    t = layer.self._lrp_tape
+    t = tape_of(layer.self)
     cam_out, cam_res = dense_add_norm_relprop(layer.output, layer._lrp_out, cam)
     cam_h, cam_k, cam_v = attention_relprop(layer.self, t, cam_out, core)
     cam_ctx = lrp.clone_relprop((cam_k, cam_v), t["context"])              # LxmertAttention's own Clone (key, value)
@@ -107,7 +119,7 @@ def self_layer_relprop(layer, cam, core=None):
 
 def cross_layer_relprop(layer, cam, core=None):
     """``LxmertCrossAttentionLayer`` (``.att``, ``.output``) -> ``(cam_input, cam_context)``."""
-    t = layer.att._lrp_tape
+    t = tape_of(layer.att)
     cam_out, cam_res = dense_add_norm_relprop(layer.output, layer._lrp_out, cam)
     cam_h, cam_k, cam_v = attention_relprop(layer.att, t, cam_out, core)
     return lrp.clone_relprop((cam_h, cam_res), t["hidden"]), lrp.clone_relprop((cam_k, cam_v), t["context"])
@@ -115,26 +127,26 @@ def cross_layer_relprop(layer, cam, core=None):
 
 def lxmert_layer_relprop(layer, cam, core=None):
     """``LxmertLayer.relprop`` (lxmert_lrp.py:601-606)."""
-    cam = ffn_relprop(layer.intermediate, layer.output, layer.intermediate._lrp_tape, layer.output._lrp_tape, cam)
+    cam = ffn_relprop(layer.intermediate, layer.output, tape_of(layer.intermediate), tape_of(layer.output), cam)
     return self_layer_relprop(layer.attention, cam, core)
 
 
 def bert_attention_relprop(att_layer, cam, core=None):
     """``BertAttention.relprop``: the module's Clone of 2 around ``BertSelfAttention``'s own Clone of 3."""
-    t = att_layer.self._lrp_tape
-    cam_out, cam_res = dense_add_norm_relprop(att_layer.output, att_layer.output._lrp_tape, cam)
+    t = tape_of(att_layer.self)
+    cam_out, cam_res = dense_add_norm_relprop(att_layer.output, tape_of(att_layer.output), cam)
     cams = attention_relprop(att_layer.self, t, cam_out, core, mask_rule=True)
     return lrp.clone_relprop((lrp.clone_relprop(cams, t["hidden"]), cam_res), t["hidden"])
 
 
 def bert_layer_relprop(layer, cam, core=None):
     """``BertLayer.relprop`` (BERT_ours.py:506-515)."""
-    cam = ffn_relprop(layer.intermediate, layer.output, layer.intermediate._lrp_tape, layer.output._lrp_tape, cam)
+    cam = ffn_relprop(layer.intermediate, layer.output, tape_of(layer.intermediate), tape_of(layer.output), cam)
     return bert_attention_relprop(layer.attention, cam, core)
 
 
 def pooler_relprop(pooler, cam):
     """``LxmertPooler.relprop``: Tanh passes through, the dense rule, then ``IndexSelect`` of token 0."""
-    hidden = pooler._lrp_tape
+    hidden = tape_of(pooler)
     cam = _lin(cam, hidden[:, 0], pooler.dense.weight).unsqueeze(1)
     return lrp.index_select_relprop(cam, hidden, 1, torch.zeros(1, dtype=torch.long, device=hidden.device))

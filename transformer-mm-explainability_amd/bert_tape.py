@@ -70,6 +70,7 @@ def attention_fwd(att, hidden, ctx=None, mask=None):
         kv = torch.addmm(b, ctx.reshape(B * Nk, ctx.shape[-1]), W.t()).view(B, Nk, 2, H, D)
         k, v = kv[:, :, 0], kv[:, :, 1]
     probs, grads = att._slabs(B, H, Nq, Nk, hidden.device)
+    att._lrp_tape = None     # the tape path overwrites the slab an older LRP tape's ``probs`` points to: relprop must not mix them
     o = ops.attn_capture_fwd(q, k, v, probs, math.sqrt(D), _lib.SCALE_SCORES, _mask3(mask, B, Nk), layout="bnhd")
     att.save_attn(probs)
     att.save_attn_gradients(grads)

@@ -259,9 +259,9 @@ class Transformer(nn.Module):
         if dy is None:
             if dy_rows is None or dy_row_values is None:
                 raise ValueError("backward_tape: dy=None needs dy_rows and dy_row_values")
-            B, N, E = dy_row_values.shape[0], tape[-1][0].shape[1], dy_row_values.shape[1]
-            if self.layers - 1 < first_grad_layer:
+            if self.layers - 1 < first_grad_layer:         # nothing to explain (the tape holds None for every layer)
                 return rel_row
+            B, N, E = dy_row_values.shape[0], tape[-1][0].shape[1], dy_row_values.shape[1]
         else:
             B, N, E = dy.shape
         buffers = self.buffers

@@ -42,6 +42,10 @@ struct DetrRowsArgs {
 };
 
 // LDS: R and B as [QP][LD] (QP = 16 ceil(Q / 16) rows, zero padded: the MFMA tiles read whole 16 x 4 blocks), LD = QP + 1.
+// min that CARRIES a NaN (fminf drops it): the reference's ``assert diag.min() >= 0`` fails on a NaN diagonal, and so does the
+// word the Python wrapper reads (``NaN >= 0`` is false) -- ops.handle_residual's atomic_min_float keeps NaN bits the same way.
+__device__ __forceinline__ float min_keep_nan(float m, float v) { return (m != m || v != v) ? __builtin_nanf("") : fminf(m, v); }
+
 __global__ __launch_bounds__(kVecThreads) void detr_decoder_vectors_kernel(const DetrRowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Q = a.Q, NTQ = (Q + 15) / 16, QP = NTQ * 16, LD = QP + 1, QQ = Q * Q;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(kVecThreads) void detr_decoder_vectors_kernel(const
             s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
             if (row < Q && part == 0) {
                 red[row] = s;
-                dmin = fminf(dmin, R[row * LD + row] - 1.f);
+                dmin = min_keep_nan(dmin, R[row * LD + row] - 1.f);
             }
         }
         __syncthreads();
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(kVecThreads) void detr_decoder_vectors_kernel(const
     __syncthreads();
     if (tid == 0) {
         float m = red[0];
-        for (int i = 1; i < Q; ++i) m = fminf(m, red[i]);
+        for (int i = 1; i < Q; ++i) m = min_keep_nan(m, red[i]);
         a.diag_k[k] = m;
     }
     // ---- top-down: w_l = u_l N(R_qq^(l))^T, u_(l-1) = u_l (I + B_l); 8 lanes per output element
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(256) void detr_rows_finish_kernel(const DetrRowsArg
     }
     if (a.diag_min && blockIdx.x == 0 && k == 0 && threadIdx.x == 0) {
         float m = a.diag_k[0];
-        for (int i = 1; i < a.K; ++i) m = fminf(m, a.diag_k[i]);
+        for (int i = 1; i < a.K; ++i) m = min_keep_nan(m, a.diag_k[i]);
         *a.diag_min = m;
     }
 }

@@ -436,6 +436,7 @@ __global__ __launch_bounds__(256) void rows_add_kernel(f32x4* __restrict__ dense
                                                        const f32x4* __restrict__ vals, int N, int E4) {
     const int b = blockIdx.y;
     const long long row = rows[b];
+    if (row < 0 || row >= N) return;                 // an index outside the sequence writes nothing (never out of bounds)
     f32x4* dst = dense + (static_cast<int64_t>(b) * N + row) * E4;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < E4; e += gridDim.x * 256) dst[e] = dst[e] + vals[static_cast<int64_t>(b) * E4 + e];
 }

@@ -79,6 +79,7 @@ struct ChainArgs {
     int debug;  // profiling only: bit0 = return before the hand-off/combine, bit2 = matrix waves skip the MFMAs
     int64_t attn_bstride;  // batch stride of the attention slabs in elements (H*N*N, or 0: one forward shared by the batch)
     int pipe;  // option "self_chain_pipe": software-pipelined stream waves (fp32 slabs)
+    int nt;    // option "self_chain_nt": cache policy of the pipelined slab loads (0 default policy, 1 = nt on the read-once slabs)
 };
 
 constexpr int kChainThreads = 1024;
@@ -233,8 +234,12 @@ __global__ __launch_bounds__(THREADS) void self_chain_fused_kernel(const ChainAr
             // chunks x 2 arrays, so that one batch reads CPL KB CONTIGUOUS per (head, array) instead of 1 KB from each of 8
             // streams (CPL = 1).  CPL is as large as still leaves every stream wave a block (text tower, 77 tokens: 1408 chunks
             // = 11 waves x 128 -> CPL = 2).  Heads are summed in ascending order whatever CPL: bit-identical results.
-            auto run = [&](auto cpl_tag) {
+            auto run = [&](auto cpl_tag, auto aux_tag) {
                 constexpr int CPL = decltype(cpl_tag)::value, HPB = 4 / CPL;
+                // cache policy of the slab loads (buffer aux bits: 2 = nt).  The gradient slab is read exactly once per launch;
+                // the probability slab as well unless the batch shares one forward (attn_bstride == 0: every sample re-reads it
+                // from L2, so it keeps the default policy).
+                constexpr int AUXG = decltype(aux_tag)::value, AUXA = decltype(aux_tag)::value & 1 ? 0 : decltype(aux_tag)::value;
                 constexpr int NW = LT / 64;
                 const int ws = wave - NT;                                   // this stream wave
                 const int nk = (stream_end + LT * CPL - 1) / (LT * CPL);   // rounds (lanes past the end redo the last chunk)
@@ -256,8 +261,8 @@ __global__ __launch_bounds__(THREADS) void self_chain_fused_kernel(const ChainAr
 #pragma unroll
                         for (int jj = 0; jj < CPL; ++jj) {
                             const unsigned voff = static_cast<unsigned>(min(base + jj * 64, stream_end - 1)) * 16u;
-                            av[u * CPL + jj] = __builtin_amdgcn_raw_buffer_load_b128(rA, voff, hoff, 0);
-                            gv[u * CPL + jj] = __builtin_amdgcn_raw_buffer_load_b128(rG, voff, hoff, 0);
+                            av[u * CPL + jj] = __builtin_amdgcn_raw_buffer_load_b128(rA, voff, hoff, AUXA & ~1);
+                            gv[u * CPL + jj] = __builtin_amdgcn_raw_buffer_load_b128(rG, voff, hoff, AUXG & ~1);
                         }
                     }
                 };
@@ -311,9 +316,15 @@ __global__ __launch_bounds__(THREADS) void self_chain_fused_kernel(const ChainAr
                 }
             };
             constexpr int NWs = LT / 64;
-            if (a.pipe >= 4 && stream_end >= NWs * 256) run(std::integral_constant<int, 4>{});
-            else if (a.pipe >= 2 && stream_end >= NWs * 128) run(std::integral_constant<int, 2>{});
-            else run(std::integral_constant<int, 1>{});
+            // aux tag: 0 default policy | 2 nt on both slabs | 3 nt on the gradient slab only (bit 0 = "probabilities are shared")
+            auto run_cpl = [&](auto aux_tag) {
+                if (a.pipe >= 4 && stream_end >= NWs * 256) run(std::integral_constant<int, 4>{}, aux_tag);
+                else if (a.pipe >= 2 && stream_end >= NWs * 128) run(std::integral_constant<int, 2>{}, aux_tag);
+                else run(std::integral_constant<int, 1>{}, aux_tag);
+            };
+            if (!a.nt) run_cpl(std::integral_constant<int, 0>{});
+            else if (a.attn_bstride == 0) run_cpl(std::integral_constant<int, 3>{});
+            else run_cpl(std::integral_constant<int, 2>{});
         } else
         for (int l = 0; l < L; ++l) {
             float* Ab = smem + (l & 1) * NP * S;
@@ -1152,6 +1163,7 @@ extern "C" int mmx_rollout_chain(const void* const* layers, int n_layers, int B,
 static int nt_for(int N) { return (N + 15) / 16; }
 static int g_debug_flags = 0;
 static int g_chain_pipe = 4;     // option "self_chain_pipe": software-pipelined stream waves of the fused chain (fp32 slabs)
+static int g_chain_nt = 0;       // option "self_chain_nt": nt cache policy on the read-once slab loads of the pipelined stream waves
 static int g_chain_groups = 0;  // layer groups per sample of the per-sample kernel: 0 auto, 1 = strict sequential order
 static int g_chain_algo = 0;  // 0 auto, 1 per-sample wave-specialised, 2 reduce + last-arriver chain
 
@@ -1162,6 +1174,10 @@ extern "C" int mmx_set_option(const char* key, int value) {
     }
     if (key && strcmp(key, "self_chain_pipe") == 0 && value >= 0 && value <= 4) {
         g_chain_pipe = value;            // 0 off | 1 one chunk per lane and head | 2 / 4: up to that many contiguous chunks
+        return MMX_OK;
+    }
+    if (key && strcmp(key, "self_chain_nt") == 0 && value >= 0 && value <= 1) {
+        g_chain_nt = value;
         return MMX_OK;
     }
     if (key && strcmp(key, "self_chain_groups") == 0 && value >= 0 && value <= 8) {
@@ -1365,6 +1381,7 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
         args.G = fused_groups(n_layers, B, H, N);
         args.debug = g_debug_flags;
         args.attn_bstride = attn_batch_stride;
+        args.nt = g_chain_nt;
         args.pipe = N * N >= 1600 ? g_chain_pipe : 0;   // (below ~40 tokens the pipeline's bookkeeping costs more than it hides)
         if (args.G > 1) {
             const size_t need = mmx_self_chain_workspace_bytes(n_layers, B, H, N, M, dtype);

@@ -497,6 +497,11 @@ class DETRFromFeatures(nn.Module):
         of the projected feature map ``[B, C, h, w]`` (the reference stops there too).  The decoder level that feeds
         ``pred_logits`` is the last one here (the reference hard-codes ``index_select(..., [5])`` of its 6 levels)."""
         hs, logits = _lrp_tape(self)
+        if logits.shape[0] != 1:
+            # the reference explains item 0 of a one-image batch (detr.py:85-86 seeds ``one_hot[0, ...]``) and its Linear / Add / MHA
+            # rules renormalise with WHOLE-TENSOR sums (layers.py:409-437): on a batch these would mix the samples silently
+            raise NotImplementedError("DETR relprop runs on a one-image batch, like the reference's generators (got batch %d): "
+                                      "call it per image" % logits.shape[0])
         target_index, target_class = kwargs["target_index"], kwargs.get("target_class")
         if target_class is None:
             target_class = logits.max(dim=-1)[1][0, target_index]

@@ -77,6 +77,7 @@ class LxmertAttentionOutput(nn.Module):                                # lxmert_
 
     def forward(self, hidden_states, input_tensor):
         d = self.dense(hidden_states)
+        self._lrp_tape = None                                       # a stale tape must not outlive this forward
         if torch.is_grad_enabled():                                    # Add / Linear inputs of the LRP pass (bert_lrp.py)
             self._lrp_tape = (hidden_states.detach(), d.detach(), input_tensor.detach())
         return self.LayerNorm(d + input_tensor)
@@ -125,6 +126,7 @@ class LxmertIntermediate(nn.Module):                                   # lxmert_
         self.intermediate_act_fn = _act(c.hidden_act)
 
     def forward(self, hidden_states):
+        self._lrp_tape = None                                       # a stale tape must not outlive this forward
         if torch.is_grad_enabled():
             self._lrp_tape = hidden_states.detach()
         return self.intermediate_act_fn(self.dense(hidden_states))
@@ -178,16 +180,16 @@ class LxmertXLayer(nn.Module):                                         # lxmert_
         """lxmert_lrp.py:735-740: ``relprop_output`` (:691-700), ``relprop_self`` (:672-676), ``relprop_cross`` (:657-664)."""
         core = kwargs.get("core")
         cam_lang, cam_vis = cam
-        cam_vis = bert_lrp.ffn_relprop(self.visn_inter, self.visn_output, self.visn_inter._lrp_tape, self.visn_output._lrp_tape,
+        cam_vis = bert_lrp.ffn_relprop(self.visn_inter, self.visn_output, bert_lrp.tape_of(self.visn_inter), bert_lrp.tape_of(self.visn_output),
                                        cam_vis)
-        cam_lang = bert_lrp.ffn_relprop(self.lang_inter, self.lang_output, self.lang_inter._lrp_tape,
-                                        self.lang_output._lrp_tape, cam_lang)
+        cam_lang = bert_lrp.ffn_relprop(self.lang_inter, self.lang_output, bert_lrp.tape_of(self.lang_inter),
+                                        bert_lrp.tape_of(self.lang_output), cam_lang)
         cam_vis = bert_lrp.self_layer_relprop(self.visn_self_att, cam_vis, core)
         cam_lang = bert_lrp.self_layer_relprop(self.lang_self_att, cam_lang, core)
         cam_vis2, cam_lang2 = bert_lrp.cross_layer_relprop(self.visual_attention_copy, cam_vis, core)
         cam_lang1, cam_vis1 = bert_lrp.cross_layer_relprop(self.visual_attention, cam_lang, core)
-        lang_in = self.visual_attention.att._lrp_tape["hidden"]           # the x-layer's inputs (clone1 / clone2)
-        vis_in = self.visual_attention_copy.att._lrp_tape["hidden"]
+        lang_in = bert_lrp.tape_of(self.visual_attention.att)["hidden"]           # the x-layer's inputs (clone1 / clone2)
+        vis_in = bert_lrp.tape_of(self.visual_attention_copy.att)["hidden"]
         return lrp.clone_relprop((cam_lang1, cam_lang2), lang_in), lrp.clone_relprop((cam_vis1, cam_vis2), vis_in)
 
     def forward_tape(self, lang, lang_mask, visn, visn_mask, side=None):
@@ -365,6 +367,7 @@ class LxmertPooler(nn.Module):                                         # lxmert_
         self.dense = nn.Linear(c.hidden_size, c.hidden_size)
 
     def forward(self, hidden_states):
+        self._lrp_tape = None                                       # a stale tape must not outlive this forward
         if torch.is_grad_enabled():
             self._lrp_tape = hidden_states.detach()
         return torch.tanh(self.dense(hidden_states[:, 0]))
@@ -383,13 +386,14 @@ class LxmertVisualAnswerHead(nn.Module):                               # lxmert_
     def forward(self, hidden_states):
         fc = self.logit_fc
         normed = fc[2](fc[1](fc[0](hidden_states)))
+        self._lrp_tape = None                                       # a stale tape must not outlive this forward
         if torch.is_grad_enabled():
             self._lrp_tape = (hidden_states.detach(), normed.detach())
         return fc[3](normed)
 
     def relprop(self, cam, **kwargs):
         """lxmert_lrp.py:955-958: the two Linear rules (GELU and LayerNorm pass relevance through)."""
-        x, normed = self._lrp_tape
+        x, normed = bert_lrp.tape_of(self)
         cam = lrp.linear_relprop(cam, normed, self.logit_fc[3].weight, normalize=False)
         return lrp.linear_relprop(cam, x, self.logit_fc[0].weight, normalize=False)
 

@@ -486,6 +486,8 @@ def rows_to_dense(vals, rows, n_tokens):
     """``out [B, n_tokens, E]`` = zeros with ``out[b, rows[b]] = vals[b]`` in ONE launch (``mmx_rows_to_dense``)."""
     _dev(vals, rows)
     vals, rows = _f32c(vals), rows.to(torch.long).contiguous()
+    if vals.dim() != 2 or rows.numel() != vals.shape[0]:
+        raise MMXError("rows_to_dense: vals [B, E] and rows [B] expected, got %s / %s" % (tuple(vals.shape), tuple(rows.shape)))
     B, E = vals.shape
     out = torch.empty(B, n_tokens, E, dtype=torch.float32, device=vals.device)
     check(lib().mmx_rows_to_dense(_p(vals), _p(rows), _p(out), B, n_tokens, E, _stream()), "mmx_rows_to_dense")
@@ -498,6 +500,9 @@ def rows_add_(dense, rows, vals):
     if dense.dtype != torch.float32 or not dense.is_contiguous():
         raise MMXError("rows_add_: dense must be fp32 contiguous")
     B, N, E = dense.shape
+    if tuple(vals.shape) != (B, E) or rows.numel() != B:
+        raise MMXError("rows_add_: dense [B, N, E] needs vals [B, E] and rows [B], got %s / %s / %s"
+                       % (tuple(dense.shape), tuple(vals.shape), tuple(rows.shape)))
     check(lib().mmx_rows_add(_p(dense), _p(rows.to(torch.long).contiguous()), _p(_f32c(vals)), B, N, E, _stream()), "mmx_rows_add")
     return dense
 

@@ -10,6 +10,7 @@ version, architecture) do not match the box.  Process-wide (it changes every GEM
 """
 import contextlib
 import os
+import threading
 
 import torch
 
@@ -38,22 +39,40 @@ def enable(workload):
     return bool(tun.read_file(os.path.join(_DIR, WORKLOADS[workload])))
 
 
+_LOCK = threading.Lock()
+
+
+def _flag(tun, getter):
+    fn = getattr(tun, getter, None)
+    return fn() if fn is not None else None
+
+
 @contextlib.contextmanager
 def scope(workload):
-    """TunableOp on, with ``workload``'s selection, for the duration of the block only; the previous on / off state comes back
-    afterwards (yields whether the selection is in effect).  For eager passes that sit next to captured ones in one process: a
-    hipGraph capture must not run into a tuned solution (some allocate inside the library call), so nothing is switched while
-    the current stream is capturing."""
+    """TunableOp on, with ``workload``'s selection, for the duration of the block only; the previous state -- on / off AND the
+    caller's ``tuning_enable`` / ``record_untuned_enable`` flags (a process started with ``PYTORCH_TUNABLEOP_TUNING=1`` keeps
+    tuning afterwards) -- comes back on exit (yields whether the selection is in effect).  For eager passes that sit next to
+    captured ones in one process: a hipGraph capture must not run into a tuned solution (some allocate inside the library call),
+    so nothing is switched while the current stream is capturing.  The TunableOp state is PROCESS-global: scopes are serialised
+    by a lock, and a scope must not overlap a hipGraph capture running on ANOTHER thread (this module cannot see that)."""
     if not torch.cuda.is_available() or not available(workload) or torch.cuda.is_current_stream_capturing():
         yield False
         return
     tun = torch.cuda.tunable
-    was = tun.is_enabled()
-    if workload not in _LOADED:
-        _LOADED[workload] = enable(workload)
-    else:
-        tun.enable(True)
-    try:
-        yield _LOADED[workload]
-    finally:
-        tun.enable(was)
+    with _LOCK:
+        was = tun.is_enabled()
+        was_tuning = _flag(tun, "tuning_is_enabled")
+        was_record = _flag(tun, "record_untuned_is_enabled")
+        if workload not in _LOADED:
+            _LOADED[workload] = enable(workload)
+        else:
+            tun.enable(True)
+            tun.tuning_enable(False)
+        try:
+            yield _LOADED[workload]
+        finally:
+            if was_tuning is not None:
+                tun.tuning_enable(was_tuning)
+            if was_record is not None and hasattr(tun, "record_untuned_enable"):
+                tun.record_untuned_enable(was_record)
+            tun.enable(was)

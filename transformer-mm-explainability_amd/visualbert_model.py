@@ -90,6 +90,7 @@ class _DenseAddNorm(nn.Module):                                        # BertSel
 
     def forward(self, hidden_states, input_tensor):
         d = self.dense(hidden_states)
+        self._lrp_tape = None                                       # a stale tape must not outlive this forward
         if torch.is_grad_enabled():                                    # Add / Linear inputs of the LRP pass (bert_lrp.py)
             self._lrp_tape = (hidden_states.detach(), d.detach(), input_tensor.detach())
         return self.LayerNorm(d + input_tensor)
@@ -112,6 +113,7 @@ class BertIntermediate(nn.Module):                                     # BERT_ou
         self.intermediate_act_fn = {"gelu": F.gelu, "relu": F.relu}[c.hidden_act]
 
     def forward(self, hidden_states):
+        self._lrp_tape = None                                       # a stale tape must not outlive this forward
         if torch.is_grad_enabled():
             self._lrp_tape = hidden_states.detach()
         return self.intermediate_act_fn(self.dense(hidden_states))
@@ -165,12 +167,13 @@ class BertPredictionHeadTransform(nn.Module):                          # BERT_ou
         self.transform_act_fn = {"gelu": F.gelu, "relu": F.relu}[c.hidden_act]
 
     def forward(self, hidden_states):
+        self._lrp_tape = None                                       # a stale tape must not outlive this forward
         if torch.is_grad_enabled():
             self._lrp_tape = hidden_states.detach()
         return self.LayerNorm(self.transform_act_fn(self.dense(hidden_states)))
 
     def relprop(self, cam, **kwargs):                                  # BERT_ours.py:533-537: LayerNorm / activation pass through
-        return lrp.linear_relprop(cam, self._lrp_tape, self.dense.weight, normalize=False)
+        return lrp.linear_relprop(cam, bert_lrp.tape_of(self), self.dense.weight, normalize=False)
 
 
 class VisualBERTBase(nn.Module):                                       # visual_bert.py:34-153 (no bypass_transformer)
@@ -209,6 +212,7 @@ class VisualBERTForClassification(nn.Module):                          # visual_
             index = input_mask.sum(1) - 2                              # second-to-last text token
             pooled_output = sequence_output[torch.arange(sequence_output.shape[0], device=index.device), index]
         transformed = self.classifier[0](pooled_output)
+        self._lrp_tape = None                                       # a stale tape must not outlive this forward
         if torch.is_grad_enabled():
             self._lrp_tape = (sequence_output.detach(), index if self.pooler_strategy == "vqa" else None, transformed.detach())
         return {"scores": self.classifier[1](transformed).reshape(-1, self.num_labels)}
@@ -220,7 +224,7 @@ class VisualBERTForClassification(nn.Module):                          # visual_
         reference's pass is defined for ``pooler_strategy == "vqa"`` only (it always goes through ``vqa_pooler``)."""
         if kwargs.get("alpha", 1) != 1:
             raise NotImplementedError("the generators call relprop with alpha = 1 (ExplanationGenerator.py:27)")
-        sequence_output, index, transformed = self._lrp_tape
+        sequence_output, index, transformed = bert_lrp.tape_of(self)
         if index is None:
             raise NotImplementedError("relprop: the reference's LRP pass exists for pooler_strategy == 'vqa' only")
         with torch.no_grad():
