@@ -82,21 +82,6 @@ CFG5_BATCH = 128
 CFG5_MODEL = "ViT-L/14@336"
 
 
-def cfg5_step_flops(batch):
-    """Matrix FLOPs of one cfg-5 step (CLIP ViT-L/14@336 bf16 body: image tower 24 x 1024 x 16 heads x 577 tokens with a shared
-    forward and row-relevancy backward, text tower 12 x 768 x 12 x 77), as ``step_flops`` counts them for cfg 2."""
-    def tower(L, E, N, H, m_fwd, m_bwd, attn_products):
-        gemm_fwd = L * 2 * m_fwd * 12 * E * E
-        full, top, low = 2 * m_bwd * 12 * E * E, 2 * m_bwd * 3 * E * E + 2 * batch * 9 * E * E, 2 * m_bwd * 9 * E * E
-        d = E // H
-        attn = L * 4 * (m_fwd // N) * H * N * N * d + (L - 1) * attn_products * 2 * (m_bwd // N) * H * N * N * d \
-            + 2 * (m_bwd // N) * H * N * N * d
-        return gemm_fwd + (L - 2) * full + top + low, attn
-    g_img, a_img = tower(24, 1024, 577, 16, 577, batch * 577, 5)       # dP (twice: both kernels), dQ, dK, dV
-    g_txt, a_txt = tower(12, 768, 77, 12, batch * 77, batch * 77, 4)
-    return {"gemm": g_img + g_txt, "attention": a_img + a_txt, "total": g_img + g_txt + a_img + a_txt}
-
-
 def main_cfg5(args):
     """Optional leg (``--workload cfg5``; NOT the driver's default): BASELINE.json config 5's shape on this GPU -- CLIP
     ViT-L/14@336 with the bf16 body of ``clip_model.CLIP.set_body_dtype``, batch 128 per GPU, all layers, eager."""
@@ -144,7 +129,7 @@ def main_cfg5(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms = elapsed / args.steps * 1e3
-    fl = cfg5_step_flops(CFG5_BATCH)
+    fl = bench_legs.cfg5_step_flops(CFG5_BATCH)
     # our dominant kernel pair of this step: the bf16 attention backward of one image-tower layer (stand-alone launches)
     us = kernel_time_us(attn_layer, 5, torch.cuda.current_stream())
     if rank == 0:
@@ -245,6 +230,98 @@ def cpu_baseline(sample_b=16, reps=3, timeout_s=240):
         return {"value": None, "unit": "maps/s", "cores": 0, "kind": "port", "sample": "timed out after %ds" % timeout_s}
 
 
+def cpu_leg_worker(name):
+    """Child process: the reference algorithm of one BASELINE configuration on the host cores, on a bounded sample
+    (the oracle bodies of oracle/: plain torch autograd, pinned on the reference's own code in tests/test_oracle_golden.py)."""
+    cores = min(os.cpu_count() or 1, CPU_THREADS_CAP)
+    torch.set_num_threads(cores)
+    total = os.cpu_count() or 1
+
+    def median(fn, reps):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    if name == "cfg1":
+        from oracle import vit_torch
+        from transformer_mm_explainability_amd import vit_model
+        torch.manual_seed(0)
+        sd = dict(vit_model.vit_base_patch16_224().float().state_dict())
+        x = torch.randn(1, 3, 224, 224)
+        vit_torch.generate_relevance(sd, x, 12, 5)
+        sec = median(lambda: vit_torch.generate_relevance(sd, x, 12, 5), 5)
+        out = {"value": round(1 / sec, 3), "unit": "maps/s", "sample": "oracle/vit_torch.generate_relevance (ViT-B/16 forward + one "
+               "backward + 12-layer rule chain, notebook cell 7), one 224x224 image, median of 5"}
+    elif name == "cfg3":
+        from oracle import detr_torch
+        from transformer_mm_explainability_amd import detr_model
+        torch.manual_seed(0)
+        sd = detr_torch.prepare_state_dict(detr_model.detr_resnet50_head().state_dict())
+        feats = torch.randn(1, 2048, 25, 38) * 0.5
+        pos = detr_torch.position_embedding_sine(torch.zeros(1, 25, 38, dtype=torch.bool), 128, normalize=True)
+        detr_torch.generate_ours(sd, feats, pos, [3], 8)
+        sec = median(lambda: detr_torch.generate_ours(sd, feats, pos, [3], 8), 3)
+        out = {"value": round(1 / sec, 3), "unit": "queries/s", "sample": "oracle/detr_torch.generate_ours (DETR-R50 transformer + "
+               "heads forward at 950 image tokens + one backward + the matrix-route rules 6 / 7 / 10 incl. the 950^3 encoder "
+               "chain), ONE kept query per call as DETR/mask_generator.py:90-110 runs it, median of 3"}
+    elif name == "cfg4":
+        from oracle import lxmert_torch
+        from transformer_mm_explainability_amd import lxmert_model as lm
+        torch.manual_seed(0)
+        sd = lxmert_torch.prepare_state_dict(lm.LxmertForQuestionAnswering(lm.LxmertConfig()).state_dict())
+        gb = torch.Generator().manual_seed(2)
+        T, I, n = 14, 36, 4
+        items = [dict(input_ids=torch.randint(1, 30000, (1, T), generator=gb), attention_mask=torch.ones(1, T),
+                      token_type_ids=torch.zeros(1, T, dtype=torch.long), visual_feats=torch.randn(1, I, 2048, generator=gb),
+                      visual_pos=torch.rand(1, I, 4, generator=gb)) for _ in range(n)]
+
+        def sample(it):                      # explain + the 9 re-runs of the perturbation test (perturbation.py:85-194)
+            lxmert_torch.generate_ours(sd, 12, it)
+            with torch.no_grad():
+                for _ in range(9):
+                    lxmert_torch.forward(sd, 12, **it)
+        sample(items[0])
+        sec = median(lambda: [sample(it) for it in items], 3) / n
+        out = {"value": round(1 / sec, 3), "unit": "samples/s", "sample": "oracle/lxmert_torch: generate_ours (LXMERT-base forward + "
+               "backward + 38-rule schedule) + 9 further forwards per sample (the perturbation steps; region removal itself not "
+               "restated), T = 14, I = 36, one item per call as perturbation.py runs it, %d items, median of 3" % n}
+    elif name == "cfg5":
+        from oracle import clip_torch
+        from transformer_mm_explainability_amd import clip_model
+        sd = clip_torch.prepare_state_dict(clip_model.random_init(CFG5_MODEL, seed=0).state_dict(), 12)
+        g = torch.Generator().manual_seed(1)
+        image = torch.randn(1, 3, 336, 336, generator=g)
+        texts = torch.zeros(1, 77, dtype=torch.long)
+        texts[0, 0], texts[0, 1:6], texts[0, 6] = 49406, torch.arange(1, 6), 49407
+        t0 = time.perf_counter()
+        clip_torch.interpret(sd, image, texts, 0, 0)
+        sec = time.perf_counter() - t0
+        out = {"value": round(1 / sec, 4), "unit": "maps/s", "sample": "oracle/clip_torch.interpret (the notebook's per-layer "
+               "autograd.grad loop) on CLIP ViT-L/14@336 in fp32, ONE pair, all 24 + 12 layers, a single cold run"}
+    else:
+        raise SystemExit("unknown leg " + name)
+    out.update(cores=cores, kind="port")
+    out["sample"] += "; torch fp32 CPU, %d threads of %d host cores" % (cores, total)
+    print(json.dumps(out), flush=True)
+
+
+def cpu_leg(name, timeout_s=120):
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg-worker", name], capture_output=True, text=True,
+                             timeout=timeout_s, cwd=ROOT)
+        for ln in reversed(out.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"value": None, "cores": 0, "kind": "port", "sample": "worker failed: " + out.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "cores": 0, "kind": "port", "sample": "timed out after %ds" % timeout_s}
+
+
 def log(msg):
     print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
@@ -265,11 +342,15 @@ def main():
                     help="skip the cfg 1 / 3 / 4 / 5 legs (tools/bench_legs.py) reported under \"configs\"")
     ap.add_argument("--legs", default=None, help="comma-separated subset of the config legs, e.g. cfg3,cfg5")
     ap.add_argument("--cpu-baseline-worker", nargs=2, type=int, metavar=("BATCH", "REPS"), help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-leg-worker", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--workload", default="cfg2", choices=("cfg2", "cfg5"),
                     help="cfg2 (default, BASELINE.json's metric configuration) or the optional cfg-5 shape (ViT-L/14@336 bf16 body)")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(*args.cpu_baseline_worker)
+        return
+    if args.cpu_leg_worker:
+        cpu_leg_worker(args.cpu_leg_worker)
         return
     if args.workload == "cfg5":
         if args.steps == 100:
@@ -405,8 +486,31 @@ def main():
             return 2 * tr.layers * BATCH * tr.heads * n * n * 4 + BATCH * n * n * 4
 
         log("kernel-only timing")
-        us_txt = kernel_time_us(chain(txt), 20, stream)
-        us_img = kernel_time_us(chain(vis), 20, stream)
+        # Each tower's launch is timed over ROTATING slab sets (text 3 x 293 MB, image 4 x 185 MB: more than the 256 MiB
+        # Infinity Cache between two uses of a set), i.e. every byte comes from HBM as it does for slabs a backward pass has
+        # just written; "same_buffers" (back-to-back launches over ONE set, what rounds 1-3 reported) is kept beside it.
+        def rotating(tr, sets):
+            b = tr.buffers
+            plans = [chain(tr)]
+            keep = []
+            for _ in range(sets - 1):
+                pr, gr = [b.probs[l].clone() for l in range(tr.layers)], [b.grads[l].clone() for l in range(tr.layers)]
+                keep.append((pr, gr))
+                plans.append(ops.ChainPlan(pr, gr, BATCH).launch)
+            state = {"i": 0}
+
+            def fn():
+                plans[state["i"] % sets]()
+                state["i"] += 1
+            return fn, keep
+
+        rot_txt, keep_txt = rotating(txt, 3)
+        rot_img, keep_img = rotating(vis, 4)
+        us_txt = kernel_time_us(rot_txt, 21, stream)
+        us_img = kernel_time_us(rot_img, 20, stream)
+        us_txt_same = kernel_time_us(chain(txt), 20, stream)
+        us_img_same = kernel_time_us(chain(vis), 20, stream)
+        del keep_txt, keep_img
         by_txt, by_img = chain_bytes(txt, 77), chain_bytes(vis, 50)
         ach = by_txt / us_txt / 1e3  # GB/s
         # HBM traffic of the same launch from the PMC passes (they cannot run inside this process): the newest committed
@@ -418,13 +522,32 @@ def main():
             if pmc:
                 traffic, pmc_name = pmc["fetch_bytes"] + pmc["write_bytes"], os.path.relpath(pmc_file, ROOT)
                 break
+        # the same kernel INSIDE the replayed step (beside the other tower's GEMMs), from the newest committed rocprofv3 kernel
+        # trace of `bench.py --headline-only` (tools/gpu_round.sh): a committed file, not a measurement of this run
+        in_step = None
+        for stats in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.txt")), reverse=True):
+            for ln in open(stats):
+                if "self_chain_fused_kernel<5, 0" in ln:
+                    f = ln.split()
+                    avg = float(f[-4])
+                    in_step = {"us_per_launch": avg, "achieved": round(by_txt / avg / 1e3, 1), "frac": round(by_txt / avg / 1e3 / HBM_PEAK_GBS, 4),
+                               "source": os.path.relpath(stats, ROOT) + " (committed rocprofv3 --kernel-trace --stats summary, avg_us column)"}
+                    break
+            if in_step:
+                break
         roofline = {"bound": "hbm", "kernel": "self_chain_fused_kernel<NT=5,f32> (text tower)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "traffic_source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per "
-                    "the gfx950 correction; regenerated by tools/pmc_chain_json.py), bytes per launch" % pmc_name,
+                    "timing": "HIP events on the launch stream over 21 stand-alone launches rotating over 3 slab sets (879 MB)",
+                    "traffic": traffic, "traffic_source": "committed PMC file %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                    "this command, FETCH_SIZE x2 per the gfx950 correction; regenerated by tools/pmc_chain_json.py; NOT measured in "
+                    "this run), bytes per launch" % pmc_name,
                     "bytes_per_launch": by_txt, "us_per_launch": round(us_txt, 2),
+                    "same_buffers": {"us_per_launch": round(us_txt_same, 2), "achieved": round(by_txt / us_txt_same / 1e3, 1),
+                                     "note": "20 back-to-back launches over ONE slab set: partly served by the Infinity Cache"},
+                    "in_step": in_step,
                     "image_tower": {"kernel": "self_chain_fused_kernel<NT=4,f32>", "bytes_per_launch": by_img,
-                                    "us_per_launch": round(us_img, 2), "achieved": round(by_img / us_img / 1e3, 1)},
+                                    "us_per_launch": round(us_img, 2), "achieved": round(by_img / us_img / 1e3, 1),
+                                    "same_buffers_us_per_launch": round(us_img_same, 2)},
                     "kernel_only_maps_per_s": round(BATCH / ((us_txt + us_img) * 1e-6), 1)}
 
     fl = step_flops(BATCH)
@@ -456,6 +579,11 @@ def main():
         torch.cuda.empty_cache()
         log("config legs (cfg 1 / 3 / 4 / 5)")
         configs = bench_legs.run_all(kernel_time_us, log, only=args.legs.split(",") if args.legs else None)
+        if not args.no_cpu_baseline:
+            for name, leg in configs.items():       # the reference algorithm of each configuration on this box's host cores
+                if "error" not in leg:
+                    log("cpu baseline of %s (child process)" % name)
+                    leg["cpu_baseline"] = cpu_leg(name, 180 if name == "cfg5" else 90)
 
     if rank == 0:
         line = {

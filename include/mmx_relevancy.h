@@ -230,6 +230,23 @@ int mmx_lxmert_schedule_ex(const void* const* lang_attn, const void* const* lang
                         void* R_tt_dev, void* R_ti_dev, void* R_ii_dev, void* R_it_dev,
                         void* diag_min_dev, void* stream);
 
+/* Same schedule and arguments, two-phase form (round 4): phase 1 spreads the rule-5 head averages of every (sample, block) over
+ * the whole chip (16-byte loads, write-through A_bar blocks into `workspace`), the last-arriving workgroup of a sample runs the
+ * 38 rule applications from the L2-resident A_bar blocks on the exact-fp32 MFMA.  One kernel launch (+ one reset launch for
+ * the tickets / diag word).  workspace: mmx_lxmert_schedule_workspace_bytes(...) bytes, caller-owned, stream-ordered.
+ * Results equal mmx_lxmert_schedule_ex up to fp32 summation order (same NaN propagation, same diag word).
+ * replaces lxmert/lxmert/src/ExplanationGenerator.py:131-211 (rule helpers :18-54, 61-129). */
+size_t mmx_lxmert_schedule_workspace_bytes(int n_lang, int n_vis, int n_x, int B, int T, int I);
+int mmx_lxmert_schedule_v2(const void* const* lang_attn, const void* const* lang_grad, int n_lang,
+                           const void* const* vis_attn, const void* const* vis_grad, int n_vis,
+                           const void* const* x_lang_cross_attn, const void* const* x_lang_cross_grad,
+                           const void* const* x_img_cross_attn, const void* const* x_img_cross_grad,
+                           const void* const* x_lang_self_attn, const void* const* x_lang_self_grad,
+                           const void* const* x_img_self_attn, const void* const* x_img_self_grad, int n_x,
+                           int B, int H, int T, int I, unsigned flags, const void* text_len_dev,
+                           void* R_tt_dev, void* R_ti_dev, void* R_ii_dev, void* R_it_dev,
+                           void* diag_min_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Attention rollout: prod_{i >= start}( (A_i + I) [/ rowsum] ), left-multiplied.
  * replaces compute_rollout_attention (DETR/.../ExplanationGenerator.py:5-16, lxmert/...:5-15 with

@@ -702,7 +702,8 @@ def test_detr_decoder_rows_diag_word_carries_nan(ops):
     s, dmin = ops.detr_decoder_rows(self_pairs, cross_pairs, targets, shared_attn=False)
     assert torch.isnan(dmin).all(), "the NaN was dropped by the diag reduction"
     assert not (float(dmin) >= 0)                                                    # what the deferred assert evaluates
-    assert torch.isfinite(s).all()                                                   # NaN policy: that layer contributes nothing
+    # rules 6 / 7 have no scrub (ExplanationGenerator.py:27-30): a NaN self-attention map poisons that sample's rows, only that sample's
+    assert torch.isnan(s[1]).any() and torch.isfinite(s[0]).all() and torch.isfinite(s[2]).all()
 
 
 def test_graph_capture_holds_the_garbage_collector_off(ops):
@@ -740,3 +741,65 @@ def test_graph_capture_holds_the_garbage_collector_off(ops):
                 raise RuntimeError("inside")
     assert gc.isenabled()
     gc.collect()
+
+
+@pytest.mark.parametrize("B,H,T,I,nl,nv,nx,ragged", [
+    (32, 12, 14, 36, 9, 5, 5, False),      # cfg 4
+    (5, 4, 20, 36, 3, 2, 3, True),         # padded batch, per-sample question lengths
+    (3, 2, 48, 48, 2, 2, 2, True),         # the LDS-resident limit
+    (2, 3, 7, 12, 1, 1, 1, False),         # a single cross layer (no image side at all)
+    (1, 12, 9, 11, 3, 2, 3, False),        # one item per call, like the reference's evaluator
+    (70, 2, 6, 5, 2, 1, 2, True),          # more samples than one wave of workgroups per sample would fill
+])
+@pytest.mark.parametrize("flags", [{}, {"apply_normalization": False}, {"apply_self_in_rule_10": False}])
+def test_lxmert_schedule_two_phase_kernel_equals_one_workgroup_kernel(ops, B, H, T, I, nl, nv, nx, ragged, flags):
+    """``mmx_lxmert_schedule_v2`` (chip-wide rule 5 + last-arriver schedule on the MFMA; ops.LXMERT_SCHEDULE_ALGO = 2, the default)
+    == the one-workgroup-per-sample kernel of rounds 1-3 (itself pinned on the reference generator's outputs) up to fp32
+    summation order, incl. per-sample question lengths, both flags and the diag word."""
+    g = torch.Generator().manual_seed(B * 1000 + T * 10 + I)
+    sm = lambda *s: torch.softmax(torch.randn(*s, generator=g), -1).cuda()          # noqa: E731
+    gr = lambda *s: (torch.randn(*s, generator=g) * 0.2).cuda()                      # noqa: E731
+    pair = lambda nq, nk: (sm(B, H, nq, nk), gr(B, H, nq, nk))                       # noqa: E731
+    groups = ([pair(T, T) for _ in range(nl)], [pair(I, I) for _ in range(nv)], [pair(T, I) for _ in range(nx)],
+              [pair(I, T) for _ in range(nx - 1)], [pair(T, T) for _ in range(nx)], [pair(I, I) for _ in range(nx - 1)])
+    text_len = (torch.randint(1, T + 1, (B,), generator=g).cuda() if ragged else None)
+    got = {}
+    for algo in (1, 2):
+        ops.LXMERT_SCHEDULE_ALGO = algo
+        try:
+            got[algo] = ops.lxmert_schedule(*groups, check_diag="defer", text_len=text_len, **flags)
+        finally:
+            ops.LXMERT_SCHEDULE_ALGO = 2
+    torch.cuda.synchronize()
+    for name, a, b_ in zip(("R_tt", "R_ti", "R_ii", "R_it"), got[1], got[2]):
+        scale = max(float(a.abs().max()), 1e-30)
+        err = float((a - b_).abs().max())
+        assert err <= 2e-6 * max(scale, 1.0), (name, err, scale)
+    if got[1][4] is not None:
+        assert abs(float(got[1][4]) - float(got[2][4])) <= 1e-6
+    else:
+        assert got[2][4] is None
+
+
+def test_lxmert_schedule_two_phase_kernel_propagates_nan(ops):
+    """LXMERT's rule 10 has no NaN scrub (lxmert/lxmert/src/ExplanationGenerator.py:32-42): a NaN in a slab must reach the same
+    output entries in both kernels."""
+    B, H, T, I = 2, 3, 6, 8
+    g = torch.Generator().manual_seed(11)
+    sm = lambda *s: torch.softmax(torch.randn(*s, generator=g), -1).cuda()          # noqa: E731
+    gr = lambda *s: (torch.randn(*s, generator=g) * 0.2).cuda()                      # noqa: E731
+    pair = lambda nq, nk: (sm(B, H, nq, nk), gr(B, H, nq, nk))                       # noqa: E731
+    groups = ([pair(T, T) for _ in range(2)], [pair(I, I) for _ in range(2)], [pair(T, I) for _ in range(2)],
+              [pair(I, T) for _ in range(1)], [pair(T, T) for _ in range(2)], [pair(I, I) for _ in range(1)])
+    groups[2][0][1][1, 0, 2, 3] = float("nan")            # sample 1, first language cross block
+    outs = {}
+    for algo in (1, 2):
+        ops.LXMERT_SCHEDULE_ALGO = algo
+        try:
+            outs[algo] = ops.lxmert_schedule(*groups, check_diag="defer")
+        finally:
+            ops.LXMERT_SCHEDULE_ALGO = 2
+    for a, b_ in zip(outs[1][:4], outs[2][:4]):
+        assert torch.equal(torch.isnan(a), torch.isnan(b_))
+        assert not torch.isnan(a[0]).any()                 # sample 0 is untouched
+    assert torch.isnan(outs[2][1][1]).any()                # ... and sample 1's R_ti is poisoned

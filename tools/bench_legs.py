@@ -77,7 +77,7 @@ def leg_cfg1(kernel_time_us, reps=20):
             "multi_target": {"targets": 8, "ms": round(ms8, 3), "rate": round(8e3 / ms8, 1)},
             "kernel": _hbm("avg_heads_kernel<f32> (one layer, B = 1: 12 heads x 197^2)", 2 * H * N * N * 4 + N * N * 4, us,
                            "latency-bound at batch 1 (3.7 MB per launch); the pass itself is ~700 body launches"),
-            "source": "profiles/r03_cfg_legs.txt"}
+            "source": "profiles/r04_cfg_legs.txt"}
 
 
 def leg_cfg3(kernel_time_us, reps=10):
@@ -119,6 +119,12 @@ def leg_cfg3(kernel_time_us, reps=10):
     torch.cuda.synchronize()
     ev_ms = (time.perf_counter() - t0) / n_img * 1e3
     del mg
+    # the LRP route (use_lrp=True, the generators' DEFAULT argument): one kept query per call, as mask_generator.py:90-110 runs it
+    from transformer_mm_explainability_amd.detr_explainability import Generator
+    gen, t1 = Generator(model), torch.tensor([3], device="cuda")
+    lrp_no = _timed_ms(lambda: gen.generate_ours(feats, t1, use_lrp=False), 3)
+    lrp_yes = _timed_ms(lambda: gen.generate_ours(feats, t1), 3)
+    del gen
     # dominant kernels of OUR part: the encoder self-attention backward pair (d = 32 streaming kernels) at K = 10
     K, H, N, D = 10, 8, 950, 32
     q, k, v = (torch.randn(1, N, H, D, device="cuda") for _ in range(3))
@@ -142,7 +148,10 @@ def leg_cfg3(kernel_time_us, reps=10):
                           "queries_per_s": round(keep_top * 1e3 / ev_ms, 1),
                           "what": "forward + keep set + one K-slot pass (hipGraph, 8 slots) + Otsu masks per image, one device->host "
                                   "read per image, %d images after 2 warm-up images" % n_img},
-            "kernel": kern, "source": "profiles/r03_cfg_legs.txt"}
+            "lrp": {"ours_no_lrp_ms": round(lrp_no, 3), "ours_lrp_ms": round(lrp_yes, 3), "ratio": round(lrp_yes / lrp_no, 2),
+                    "what": "Generator.generate_ours(img, [q]) per kept query, eager, per-query route (autograd backward): "
+                            "use_lrp=False vs the default use_lrp=True (body relprop: closed-form rules + HIP attention-core kernels)"},
+            "kernel": kern, "source": "profiles/r04_cfg_legs.txt"}
 
 
 def leg_cfg4(kernel_time_us, reps=10):
@@ -165,6 +174,13 @@ def leg_cfg4(kernel_time_us, reps=10):
     cams = torch.rand(B, I, generator=gb).cuda()
     ms_pert = _timed_ms(lambda: pert.perturbation_image(batch, cams), max(3, reps // 2))
     del run
+    # the LRP route (use_lrp=True, the generators' DEFAULT argument): one item per call, as perturbation.py:216-238 runs it
+    import types
+    item = {k: v[:1] for k, v in batch.items()}
+    gen = le.GeneratorOurs(types.SimpleNamespace(model=model, text_len=T, image_boxes_len=I, forward=lambda it: model(**item)))
+    lrp_no = _timed_ms(lambda: gen.generate_ours(None, use_lrp=False), 3)
+    lrp_yes = _timed_ms(lambda: gen.generate_ours(None), 3)
+    del gen
     # the one-launch rule schedule on slabs of the same sizes
     sm = lambda *s: torch.softmax(torch.randn(*s, device="cuda"), -1)
     gr = lambda *s: torch.randn(*s, device="cuda") * 1e-2
@@ -179,9 +195,26 @@ def leg_cfg4(kernel_time_us, reps=10):
                         "(GeneratorOurs, one hipGraph) + 9-step image perturbation test (one masked batch), fp32",
             "rate": round(B / (ms_explain + ms_pert) * 1e3, 1), "unit": "samples/s", "ms": round(ms_explain + ms_pert, 3),
             "explain_ms": round(ms_explain, 3), "perturb_ms": round(ms_pert, 3),
-            "kernel": _hbm("lxmert_schedule_kernel (38 rule applications, one workgroup per sample, B = 32)", nbytes, us,
-                           "latency-bound by construction: 32 workgroups, ~2 MB of slabs each"),
-            "source": "profiles/r03_cfg_legs.txt"}
+            "lrp": {"ours_no_lrp_ms": round(lrp_no, 3), "ours_lrp_ms": round(lrp_yes, 3), "ratio": round(lrp_yes / lrp_no, 2),
+                    "what": "GeneratorOurs.generate_ours(item) per item, eager: use_lrp=False vs the default use_lrp=True"},
+            "kernel": _hbm("lxmert_schedule_v2_kernel (38 rule applications: chip-wide rule 5 + last-arriver schedule on the MFMA, "
+                           "B = 32)", nbytes, us, "2 MB of slabs per sample; the serial 38-step schedule of a sample is the floor"),
+            "source": "profiles/r04_cfg_legs.txt"}
+
+
+def cfg5_step_flops(batch):
+    """Matrix FLOPs of one cfg-5 step (CLIP ViT-L/14@336 bf16 body: image tower 24 x 1024 x 16 heads x 577 tokens with a shared
+    forward and row-relevancy backward, text tower 12 x 768 x 12 x 77), as ``step_flops`` counts them for cfg 2."""
+    def tower(L, E, N, H, m_fwd, m_bwd, attn_products):
+        gemm_fwd = L * 2 * m_fwd * 12 * E * E
+        full, top, low = 2 * m_bwd * 12 * E * E, 2 * m_bwd * 3 * E * E + 2 * batch * 9 * E * E, 2 * m_bwd * 9 * E * E
+        d = E // H
+        attn = L * 4 * (m_fwd // N) * H * N * N * d + (L - 1) * attn_products * 2 * (m_bwd // N) * H * N * N * d \
+            + 2 * (m_bwd // N) * H * N * N * d
+        return gemm_fwd + (L - 2) * full + top + low, attn
+    g_img, a_img = tower(24, 1024, 577, 16, 577, batch * 577, 5)       # dP (twice: both kernels), dQ, dK, dV
+    g_txt, a_txt = tower(12, 768, 77, 12, batch * 77, batch * 77, 4)
+    return {"gemm": g_img + g_txt, "attention": a_img + a_txt, "total": g_img + g_txt + a_img + a_txt}
 
 
 def cfg5_setup(batch, device, rank=0):
@@ -226,7 +259,12 @@ def leg_cfg5(kernel_time_us, reps=3, batch=128):
     ms_trim = _timed_ms(lambda: ce.interpret(image, texts, model, "cuda", start_layer=0, start_layer_text=0,
                                              trim_text_padding=True), reps, warm=2)
     us = kernel_time_us(attn_layer, 5, torch.cuda.current_stream())
-    return {"workload": "BASELINE config 5 shape: CLIP ViT-L/14@336 (577 image tokens), batch 128 per GPU, all 24+12 layers, "
+    fl = cfg5_step_flops(batch)
+    step_tf = fl["total"] / (ms * 1e-3) / 1e12
+    return {"roofline_step": {"bound": "mfma", "achieved": round(step_tf, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(step_tf / BF16_MFMA_PEAK_TFLOPS, 4), "flop_per_step": fl,
+                              "what": "bf16 matrix FLOPs of the step (body GEMMs forward + input-gradient, attention products) / ms"},
+            "workload": "BASELINE config 5 shape: CLIP ViT-L/14@336 (577 image tokens), batch 128 per GPU, all 24+12 layers, "
                         "bf16 body (fp32 accumulation / LayerNorm / softmax / relevancy), row-relevancy image tower, eager",
             "rate": round(batch / ms * 1e3, 1), "unit": "maps/s", "ms": round(ms, 3),
             "resident_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
@@ -236,7 +274,7 @@ def leg_cfg5(kernel_time_us, reps=3, batch=128):
                             "matrix cores: profiles/r03_cfg5_probe.txt"),
             "variant_trim_text_padding": {"ms": round(ms_trim, 3), "rate": round(batch / ms_trim * 1e3, 1),
                                           "note": "same maps (exact); NOT the headline of this leg: the reference runs all 77 positions"},
-            "source": "profiles/r03_cfg_legs.txt"}
+            "source": "profiles/r04_cfg_legs.txt"}
 
 
 LEGS = (("cfg1", leg_cfg1), ("cfg3", leg_cfg3), ("cfg4", leg_cfg4), ("cfg5", leg_cfg5))

@@ -40,6 +40,9 @@ _PROTOTYPES = {
                                  _vp, _vp, _vp, _vp, _vp, _vp]),
     "mmx_lxmert_schedule_ex": (_i, [_vpp, _vpp, _i, _vpp, _vpp, _i] + [_vpp] * 8 + [_i, _i, _i, _i, _i, _u, _vp,
                                     _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mmx_lxmert_schedule_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "mmx_lxmert_schedule_v2": (_i, [_vpp, _vpp, _i, _vpp, _vpp, _i] + [_vpp] * 8 + [_i, _i, _i, _i, _i, _u, _vp,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mmx_heatmap_bilinear_minmax": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mmx_otsu_masks": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "mmx_rollout_workspace_bytes": (_sz, [_i, _i]),
