@@ -428,6 +428,29 @@ int mmx_attn_relprop_phase(const void* q_dev, const void* k_dev, const void* v_d
                            const void* cam_scores_dev, int phase, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused elementwise halves of the alpha-beta LRP layer rules (csrc/lrp_kernels.hip).  All tensors
+ * fp32, contiguous, device pointers; stream-ordered; deterministic two-stage sums.  workspace: mmx_lrp_workspace_bytes().
+ *   mmx_lrp_split_signs    out [rows, 2n] = [clamp(x, min=0) | clamp(x, max=0)]                (Linear.relprop's px / nx,
+ *                          DETR/modules/layers.py:411-414; the same split of W is cached by the caller)
+ *   mmx_lrp_safe_divide    out = safe_divide(a, b)                                              (layers.py:11-14)
+ *   mmx_lrp_linear_combine out [rows, n] = xx[:, :n] * y[:, :n] + xx[:, n:] * y[:, n:]           (layers.py:424-430, alpha = 1);
+ *                          r_dev != NULL: then out *= safe_divide(sum(r), sum(out))             (layers.py:432, DETR flavour)
+ *   mmx_lrp_add_relprop    Add.relprop (layers.py:197-222) on [batch, per] views: the three sums per batch item (batch = 1:
+ *                          whole-tensor sums, the reference's one-sample pass)
+ *   mmx_lrp_clone_relprop  Clone.relprop (layers.py:257-267): out = x * sum_i safe_divide(r_i, x), r_list = HOST array of
+ *                          n_r <= 8 device pointers
+ */
+size_t mmx_lrp_workspace_bytes(void);
+int mmx_lrp_split_signs(const void* x_dev, void* out_dev, int64_t rows, int n, void* stream);
+int mmx_lrp_safe_divide(const void* a_dev, const void* b_dev, void* out_dev, int64_t n, void* stream);
+int mmx_lrp_linear_combine(const void* xx_dev, const void* y_dev, void* out_dev, int64_t rows, int n,
+                           const void* r_dev, int64_t r_numel, void* workspace_dev, void* stream);
+int mmx_lrp_add_relprop(const void* r_dev, const void* a_dev, const void* b_dev, void* ra_dev, void* rb_dev,
+                        int batch, int64_t per, void* workspace_dev, void* stream);
+int mmx_lrp_clone_relprop(const void* const* r_list, int n_r, const void* x_dev, void* out_dev, int64_t n, void* stream);
+
+
+/* ---------------------------------------------------------------------------------------------
  * Fused QuickGELU of the CLIP body's MLP, y = x * sigmoid(1.702 x) (CLIP/clip/model.py:162-164): one HBM pass forward,
  * one backward (dx from x and dy; nothing saved but x) instead of PyTorch's 3 + 5 elementwise kernels.
  * fp32, contiguous, 16-byte aligned, n elements.

@@ -247,3 +247,41 @@ def test_lrp_tapes_do_not_outlive_their_forward(golden):
     assert att._lrp_tape is None
     with pytest.raises(RuntimeError, match="no LRP tape"):
         model.relprop(one_hot.clone(), alpha=1)
+
+
+def _vs_f64(fn, args, name):
+    """The fused HIP rule vs the torch formulation of ``lrp.py`` (what the CPU suite pins on the reference's own layer library):
+    measured against a float64 evaluation with the float32 CPU evaluation as yardstick (the rules divide by sums that may
+    cancel, so a fixed tolerance would be wrong either way)."""
+    r64 = fn(*[a.double() for a in args])
+    r32 = fn(*args)
+    got = fn(*[a.cuda() for a in args])
+    r64, r32, got = (x if isinstance(x, tuple) else (x,) for x in (r64, r32, got))
+    for i, (a, b, c) in enumerate(zip(got, r32, r64)):
+        err, noise, top = float((a.cpu().double() - c).abs().max()), float((b.double() - c).abs().max()), float(c.abs().max())
+        assert err <= 8 * noise + 2e-6 * top, (name, i, err, noise, top)
+
+
+@pytest.mark.parametrize("shape,n_out,normalize", [((5, 3, 12), 7, True), ((2, 100, 256), 256, True), ((1, 950, 256), 2048, True),
+                                                   ((4, 14, 768), 3072, False), ((1, 36, 768), 768, False)])
+def test_fused_linear_relprop_vs_torch_formulation(shape, n_out, normalize):
+    from transformer_mm_explainability_amd import lrp
+    g = torch.Generator().manual_seed(sum(shape) + n_out)
+    X = torch.randn(*shape, generator=g)
+    X[..., 0] = 0.0                                                        # exact zeros on both sides of the sign split
+    W = torch.randn(n_out, shape[-1], generator=g) * 0.1
+    R = torch.randn(*shape[:-1], n_out, generator=g) * 0.05
+    _vs_f64(lambda r, x, w: lrp.linear_relprop(r, x, w, normalize=normalize), (R, X, W), "linear")
+
+
+@pytest.mark.parametrize("shape,per_sample", [((4, 6), False), ((1, 950, 256), False), ((3, 14, 768), True), ((2, 36, 768), True)])
+def test_fused_add_and_clone_relprop_vs_torch_formulation(shape, per_sample):
+    from transformer_mm_explainability_amd import lrp
+    g = torch.Generator().manual_seed(sum(shape))
+    a, b, R = (torch.randn(*shape, generator=g) for _ in range(3))
+    a.view(-1)[3] = 0.0
+    b.view(-1)[3] = 0.0                                                    # safe_divide's zero branch
+    _vs_f64(lambda r, x, y: lrp.add_relprop(r, x, y, per_sample=per_sample), (R, a, b), "add")
+    for n in (1, 2, 3, 6):
+        rs = [torch.randn(*shape, generator=g) for _ in range(n)]
+        _vs_f64(lambda x, *r: lrp.clone_relprop(list(r), x), (a, *rs), "clone%d" % n)

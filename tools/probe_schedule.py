@@ -44,6 +44,10 @@ def main():
             us = timed(lambda: ops.lxmert_schedule(*groups, check_diag="defer"))
             print(f"B={B:4d} algo=2 debug={dbg} ({what}): {us:8.1f} us")
         os.environ.pop("MMX_BM_DEBUG")
+        os.environ["MMX_BM_SPLIT"] = "1"
+        us = timed(lambda: ops.lxmert_schedule(*groups, check_diag="defer"))
+        print(f"B={B:4d} algo=2 two launches (phase 1: one workgroup per block; phase 2: one per sample): {us:8.1f} us")
+        os.environ["MMX_BM_SPLIT"] = "0"
     ops.LXMERT_SCHEDULE_ALGO = 2
 
 

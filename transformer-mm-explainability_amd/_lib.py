@@ -43,6 +43,12 @@ _PROTOTYPES = {
     "mmx_lxmert_schedule_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mmx_lxmert_schedule_v2": (_i, [_vpp, _vpp, _i, _vpp, _vpp, _i] + [_vpp] * 8 + [_i, _i, _i, _i, _i, _u, _vp,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mmx_lrp_workspace_bytes": (_sz, []),
+    "mmx_lrp_split_signs": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "mmx_lrp_safe_divide": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "mmx_lrp_linear_combine": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
+    "mmx_lrp_add_relprop": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    "mmx_lrp_clone_relprop": (_i, [_vpp, _i, _vp, _vp, _i64, _vp]),
     "mmx_heatmap_bilinear_minmax": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mmx_otsu_masks": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "mmx_rollout_workspace_bytes": (_sz, [_i, _i]),

@@ -22,6 +22,8 @@ from __future__ import annotations
 
 import torch
 
+from . import ops
+
 
 def safe_divide(a, b):
     """layers.py:11-14: ``a / (b + 1e-9)`` (the two clamps add up to that), 0 where ``b == 0``."""
@@ -42,6 +44,8 @@ def linear_relprop(R, X, weight, alpha=1, normalize=True):
     without DETR's closing ``R_out * safe_divide(R.sum(), R_out.sum())`` (layers.py:432)."""
     if alpha != 1:
         raise NotImplementedError("the generators call relprop with alpha = 1 (DETR/modules/ExplanationGenerator.py:148)")
+    if ops.lrp_fusable(R, X, weight):          # 2 GEMMs + 3-4 launches (csrc/lrp_kernels.hip) instead of 4 GEMMs + ~35
+        return ops.lrp_linear(R, X, weight, normalize)
     pw, nw = weight.clamp(min=0), weight.clamp(max=0)
     px, nx = X.clamp(min=0), X.clamp(max=0)
     Z = torch.matmul(px, pw.t()) + torch.matmul(nx, nw.t())
@@ -52,6 +56,10 @@ def linear_relprop(R, X, weight, alpha=1, normalize=True):
 
 def add_relprop(R, a, b, per_sample=False):
     """``Add.relprop`` (layers.py:197-222) -> ``(R_a, R_b)``.  ``per_sample``: the three whole-tensor sums per batch item."""
+    if ops.lrp_fusable(R, a, b) and R.shape == a.shape == b.shape:
+        fused = ops.lrp_add(R, a, b, per_sample)
+        if fused is not None:
+            return fused
     S = safe_divide(R, a + b)
     ra, rb = a * S, b * S
     total_of = sample_sum if per_sample else torch.sum
@@ -63,6 +71,9 @@ def add_relprop(R, a, b, per_sample=False):
 
 def clone_relprop(Rs, X):
     """``Clone.relprop`` (layers.py:257-267): ``X * sum_i safe_divide(R_i, X)``."""
+    Rs = list(Rs)
+    if 1 <= len(Rs) <= 8 and ops.lrp_fusable(X, *Rs) and all(r.shape == X.shape for r in Rs):
+        return ops.lrp_clone(Rs, X)
     C = None
     for r in Rs:
         s = safe_divide(r, X)

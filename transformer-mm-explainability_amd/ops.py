@@ -375,6 +375,70 @@ def transposed_weight(weight):
     return hit[1]
 
 
+def sign_split_weight(weight):
+    """Cached ``[clamp(W, min=0) | clamp(W, max=0)]`` (``[out, 2 in]``, until the parameter is modified in place): the weight
+    operand of both GEMMs of the fused ``Linear.relprop`` (``lrp_linear``)."""
+    per_weight = _GEMM_WEIGHTS.get(id(weight))
+    if per_weight is None:
+        per_weight = _GEMM_WEIGHTS[id(weight)] = {}
+        weakref.finalize(weight, _GEMM_WEIGHTS.pop, id(weight), None)
+    hit = per_weight.get("pn")
+    if hit is None or hit[0] != weight._version or hit[1].device != weight.device:
+        w = weight.detach().float()
+        hit = per_weight["pn"] = (weight._version, torch.cat((w.clamp(min=0), w.clamp(max=0)), dim=1).contiguous())
+    return hit[1]
+
+
+def lrp_fusable(*tensors):
+    """The fused LRP rule kernels take fp32 CUDA tensors (anything else -- the CPU suite's host-logic tests -- runs the torch
+    formulation in ``lrp.py``)."""
+    return all(t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+
+def lrp_linear(R, X, weight, normalize):
+    """``Linear.relprop`` (alpha = 1) as 2 GEMMs + 3 (4 with ``normalize``) launches: see ``csrc/lrp_kernels.hip``.
+    ``R [..., out]``, ``X [..., in]``, ``weight [out, in]`` -> ``[..., in]``."""
+    n_in, n_out = X.shape[-1], R.shape[-1]
+    Xc, Rc = X.contiguous(), R.contiguous()
+    rows = Xc.numel() // n_in
+    WW = sign_split_weight(weight)                                   # [out, 2 in]
+    st = _stream()
+    XX = torch.empty(rows, 2 * n_in, dtype=torch.float32, device=X.device)
+    check(lib().mmx_lrp_split_signs(_p(Xc), _p(XX), rows, n_in, st), "mmx_lrp_split_signs")
+    Z = torch.mm(XX, WW.t())                                         # [rows, out] = px pw^T + nx nw^T  (K = 2 in)
+    S = torch.empty_like(Z)
+    check(lib().mmx_lrp_safe_divide(_p(Rc), _p(Z), _p(S), Z.numel(), st), "mmx_lrp_safe_divide")
+    Y = torch.mm(S, WW)                                              # [rows, 2 in] = [S pw | S nw]
+    out = torch.empty(X.shape, dtype=torch.float32, device=X.device)
+    ws = _workspace(lib().mmx_lrp_workspace_bytes(), X.device, tag="lrp") if normalize else None
+    check(lib().mmx_lrp_linear_combine(_p(XX), _p(Y), _p(out), rows, n_in, _p(Rc) if normalize else None, Rc.numel(),
+                                       _p(ws), st), "mmx_lrp_linear_combine")
+    return out
+
+
+def lrp_add(R, a, b, per_sample):
+    """``Add.relprop`` in two launches -> ``(R_a, R_b)``; ``per_sample``: the rule's three sums per leading-dimension item."""
+    Rc, ac, bc = R.contiguous(), a.contiguous(), b.contiguous()
+    batch = Rc.shape[0] if (per_sample and Rc.dim() > 1) else 1
+    if batch > 64:
+        return None
+    ra, rb = torch.empty_like(Rc), torch.empty_like(Rc)
+    ws = _workspace(lib().mmx_lrp_workspace_bytes(), R.device, tag="lrp")
+    check(lib().mmx_lrp_add_relprop(_p(Rc), _p(ac), _p(bc), _p(ra), _p(rb), batch, Rc.numel() // batch, _p(ws), _stream()),
+          "mmx_lrp_add_relprop")
+    return ra, rb
+
+
+def lrp_clone(Rs, X):
+    """``Clone.relprop`` in one launch (up to 8 relevance tensors)."""
+    Xc = X.contiguous()
+    rc = [r.contiguous() for r in Rs]
+    out = torch.empty_like(Xc)
+    tbl, _k = _lib.ptr_table([r.data_ptr() for r in rc])
+    check(lib().mmx_lrp_clone_relprop(tbl, len(rc), _p(Xc), _p(out), Xc.numel(), _stream()), "mmx_lrp_clone_relprop")
+    return out
+
+
 _MM_OUT_DTYPE = [None]      # does torch.mm(a, b, out_dtype=torch.float32) work on this build / device?  probed once
 
 
