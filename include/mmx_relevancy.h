@@ -448,6 +448,12 @@ int mmx_lrp_linear_combine(const void* xx_dev, const void* y_dev, void* out_dev,
 int mmx_lrp_add_relprop(const void* r_dev, const void* a_dev, const void* b_dev, void* ra_dev, void* rb_dev,
                         int batch, int64_t per, void* workspace_dev, void* stream);
 int mmx_lrp_clone_relprop(const void* const* r_list, int n_r, const void* x_dev, void* out_dev, int64_t n, void* stream);
+/* MultiheadAttention.relprop's closing q / k rescale (DETR/modules/layers.py:791-799), two launches, in place on cam_k / cam_q:
+ * if all_zero(cam_v after its projection rule) and not all_zero(cam_v before it), cam_k *= safe_divide(|ks| / (|ks| + |qs|) *
+ * sum(cam_o), ks) and cam_q likewise (ks, qs = their sums).  n_*: element counts. */
+int mmx_lrp_mha_rescale(const void* v_pre_dev, int64_t n_vpre, const void* v_post_dev, int64_t n_vpost, void* cam_k_dev,
+                        int64_t n_k, void* cam_q_dev, int64_t n_q, const void* cam_o_dev, int64_t n_o,
+                        void* workspace_dev, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------

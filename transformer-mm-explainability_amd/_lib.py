@@ -49,6 +49,7 @@ _PROTOTYPES = {
     "mmx_lrp_linear_combine": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i64, _vp, _vp]),
     "mmx_lrp_add_relprop": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
     "mmx_lrp_clone_relprop": (_i, [_vpp, _i, _vp, _vp, _i64, _vp]),
+    "mmx_lrp_mha_rescale": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "mmx_heatmap_bilinear_minmax": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mmx_otsu_masks": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "mmx_rollout_workspace_bytes": (_sz, [_i, _i]),

@@ -101,17 +101,32 @@ __global__ __launch_bounds__(kLrpThreads) void lrp_linear_combine_kernel(const f
     }
 }
 
-// out *= safe_divide(sum R, sum out): every block adds the `nparts` partials in index order (same value in every block)
+// sum of NV interleaved-by-array partial lists (`nparts` entries each, list i at p[i * stride + j * step]) by a whole block, the
+// same value in every block and on every run: lane t adds entries t, t + 256, ... in order, then the fixed-order block tree
+template <int NV>
+__device__ __forceinline__ void partials_sum(const float* p, int nparts, int64_t stride, int step, float (&v)[NV], float* lds,
+                                             float* bcast) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = 0.f;
+    for (int j = threadIdx.x; j < nparts; j += kLrpThreads)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] += p[i * stride + static_cast<int64_t>(j) * step];
+    block_sum<NV>(v, lds);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) bcast[i] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = bcast[i];
+}
+
+// out *= safe_divide(sum R, sum out)
 __global__ __launch_bounds__(kLrpThreads) void lrp_scale_ratio_kernel(float* __restrict__ out, int64_t total,
                                                                       const float* __restrict__ partial, int nparts) {
-    __shared__ float ratio;
-    if (threadIdx.x == 0) {
-        float so = 0.f, sr = 0.f;
-        for (int i = 0; i < nparts; ++i) { so += partial[i]; sr += partial[nparts + i]; }
-        ratio = lrp_safe_divide(sr, so);
-    }
-    __syncthreads();
-    const float k = ratio;
+    __shared__ float lds[2 * kLrpThreads / 64], bc[2];
+    float v[2];
+    partials_sum<2>(partial, nparts, nparts, 1, v, lds, bc);      // v[0] = sum out, v[1] = sum R
+    const float k = lrp_safe_divide(v[1], v[0]);
     for (int64_t e = static_cast<int64_t>(blockIdx.x) * kLrpThreads + threadIdx.x; e < total;
          e += static_cast<int64_t>(gridDim.x) * kLrpThreads)
         out[e] *= k;
@@ -143,24 +158,56 @@ __global__ __launch_bounds__(kLrpThreads) void lrp_add_split_kernel(const float*
 // Add rule, second half (layers.py:207-220): ra *= safe_divide(|sa| / (|sa| + |sb|) * total, sa), rb likewise
 __global__ __launch_bounds__(kLrpThreads) void lrp_add_scale_kernel(float* __restrict__ ra, float* __restrict__ rb, int64_t per,
                                                                     const float* __restrict__ partial, int nparts) {
-    __shared__ float ka, kb;
+    __shared__ float lds[3 * kLrpThreads / 64], bc[3];
     const int64_t off = static_cast<int64_t>(blockIdx.y) * per;
-    if (threadIdx.x == 0) {
-        const float* p = partial + static_cast<int64_t>(blockIdx.y) * nparts * 3;
-        float sa = 0.f, sb = 0.f, tot = 0.f;
-        for (int i = 0; i < nparts; ++i) { sa += p[3 * i]; sb += p[3 * i + 1]; tot += p[3 * i + 2]; }
-        const float den = fabsf(sa) + fabsf(sb);
-        const float fa = lrp_safe_divide(fabsf(sa), den) * tot, fb = lrp_safe_divide(fabsf(sb), den) * tot;
-        ka = lrp_safe_divide(fa, sa);
-        kb = lrp_safe_divide(fb, sb);
-    }
-    __syncthreads();
-    const float xa = ka, xb = kb;
+    float v[3];
+    partials_sum<3>(partial + static_cast<int64_t>(blockIdx.y) * nparts * 3, nparts, 1, 3, v, lds, bc);   // sa, sb, total
+    const float den = fabsf(v[0]) + fabsf(v[1]);
+    const float fa = lrp_safe_divide(fabsf(v[0]), den) * v[2], fb = lrp_safe_divide(fabsf(v[1]), den) * v[2];
+    const float xa = lrp_safe_divide(fa, v[0]), xb = lrp_safe_divide(fb, v[1]);
     for (int64_t e = static_cast<int64_t>(blockIdx.x) * kLrpThreads + threadIdx.x; e < per;
          e += static_cast<int64_t>(gridDim.x) * kLrpThreads) {
         ra[off + e] *= xa;
         rb[off + e] *= xb;
     }
+}
+
+// MultiheadAttention.relprop's closing branch (DETR/modules/layers.py:791-799): when the value stream carried relevance INTO its
+// projection rule (cam_v_pre not all zero) but none came out (cam_v_post all zero: decoder layer 0, value = 0), the head-level
+// relevance total = sum(cam_o) is handed to the query / key streams by their shares:
+//   cam_k *= safe_divide(|ks| / (|ks| + |qs|) * total, ks),  cam_q likewise.       "all zero" = min == max == 0 (a NaN is not).
+// stage 1: partial[0..4][block] = #nonzero(v_pre), #nonzero(v_post), sum k, sum q, sum o;  stage 2: the in-place scaling.
+struct MhaRescaleArgs {
+    const float *v_pre, *v_post, *cam_o;
+    float *cam_k, *cam_q;
+    int64_t n_vpre, n_vpost, n_k, n_q, n_o;
+    float* partial;
+};
+__global__ __launch_bounds__(kLrpThreads) void lrp_mha_partials_kernel(const MhaRescaleArgs a) {
+    __shared__ float lds[5 * kLrpThreads / 64];
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * kLrpThreads + threadIdx.x, st = static_cast<int64_t>(gridDim.x) * kLrpThreads;
+    for (int64_t e = t0; e < a.n_vpre; e += st) v[0] += (a.v_pre[e] == 0.f) ? 0.f : 1.f;
+    for (int64_t e = t0; e < a.n_vpost; e += st) v[1] += (a.v_post[e] == 0.f) ? 0.f : 1.f;
+    for (int64_t e = t0; e < a.n_k; e += st) v[2] += a.cam_k[e];
+    for (int64_t e = t0; e < a.n_q; e += st) v[3] += a.cam_q[e];
+    for (int64_t e = t0; e < a.n_o; e += st) v[4] += a.cam_o[e];
+    block_sum<5>(v, lds);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) a.partial[i * gridDim.x + blockIdx.x] = v[i];
+}
+__global__ __launch_bounds__(kLrpThreads) void lrp_mha_apply_kernel(const MhaRescaleArgs a, int nparts) {
+    __shared__ float lds[5 * kLrpThreads / 64], bc[5];
+    float v[5];
+    partials_sum<5>(a.partial, nparts, nparts, 1, v, lds, bc);
+    if (!(v[1] == 0.f && v[0] != 0.f)) return;                      // rescale = all_zero(v_post) & ~all_zero(v_pre)
+    const float den = fabsf(v[2]) + fabsf(v[3]);
+    const float kf = lrp_safe_divide(fabsf(v[2]), den) * v[4], qf = lrp_safe_divide(fabsf(v[3]), den) * v[4];
+    const float xk = lrp_safe_divide(kf, v[2]), xq = lrp_safe_divide(qf, v[3]);
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * kLrpThreads + threadIdx.x, st = static_cast<int64_t>(gridDim.x) * kLrpThreads;
+    for (int64_t e = t0; e < a.n_k; e += st) a.cam_k[e] *= xk;
+    for (int64_t e = t0; e < a.n_q; e += st) a.cam_q[e] *= xq;
 }
 
 // Clone rule: out = X * (safe_divide(R_0, X) + safe_divide(R_1, X) + ...)   (summed in list order, like the reference's loop)
@@ -254,5 +301,28 @@ extern "C" int mmx_lrp_clone_relprop(const void* const* r_list, int n_r, const v
     lrp_clone_kernel<<<lrp_grid(n), kLrpThreads, 0, static_cast<hipStream_t>(stream)>>>(a, static_cast<const float*>(x_dev),
                                                                                          static_cast<float*>(out_dev), n);
     MMX_LAUNCH_CHECK("lrp_clone_kernel");
+    return MMX_OK;
+}
+
+extern "C" int mmx_lrp_mha_rescale(const void* v_pre_dev, int64_t n_vpre, const void* v_post_dev, int64_t n_vpost, void* cam_k_dev,
+                                   int64_t n_k, void* cam_q_dev, int64_t n_q, const void* cam_o_dev, int64_t n_o,
+                                   void* workspace_dev, void* stream) {
+    MMX_CHECK_ARG(v_pre_dev && v_post_dev && cam_k_dev && cam_q_dev && cam_o_dev && workspace_dev, "mmx_lrp_mha_rescale: null pointer");
+    MMX_CHECK_ARG(n_vpre > 0 && n_vpost > 0 && n_k > 0 && n_q > 0 && n_o > 0, "mmx_lrp_mha_rescale: empty tensor");
+    MhaRescaleArgs a;
+    a.v_pre = static_cast<const float*>(v_pre_dev); a.v_post = static_cast<const float*>(v_post_dev);
+    a.cam_o = static_cast<const float*>(cam_o_dev);
+    a.cam_k = static_cast<float*>(cam_k_dev); a.cam_q = static_cast<float*>(cam_q_dev);
+    a.n_vpre = n_vpre; a.n_vpost = n_vpost; a.n_k = n_k; a.n_q = n_q; a.n_o = n_o;
+    a.partial = static_cast<float*>(workspace_dev);
+    int64_t big = n_vpre;
+    for (int64_t x : {n_vpost, n_k, n_q, n_o}) big = x > big ? x : big;
+    int grid = lrp_grid(big);
+    if (grid > 256) grid = 256;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    lrp_mha_partials_kernel<<<grid, kLrpThreads, 0, s>>>(a);
+    MMX_LAUNCH_CHECK("lrp_mha_partials_kernel");
+    lrp_mha_apply_kernel<<<grid, kLrpThreads, 0, s>>>(a, grid);
+    MMX_LAUNCH_CHECK("lrp_mha_apply_kernel");
     return MMX_OK;
 }

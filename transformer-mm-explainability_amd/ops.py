@@ -375,9 +375,9 @@ def transposed_weight(weight):
     return hit[1]
 
 
-def sign_split_weight(weight):
+def sign_split_weight(weight, transposed=False):
     """Cached ``[clamp(W, min=0) | clamp(W, max=0)]`` (``[out, 2 in]``, until the parameter is modified in place): the weight
-    operand of both GEMMs of the fused ``Linear.relprop`` (``lrp_linear``)."""
+    operand of both GEMMs of the fused ``Linear.relprop`` (``lrp_linear``); ``transposed``: its contiguous ``[2 in, out]`` form."""
     per_weight = _GEMM_WEIGHTS.get(id(weight))
     if per_weight is None:
         per_weight = _GEMM_WEIGHTS[id(weight)] = {}
@@ -386,7 +386,13 @@ def sign_split_weight(weight):
     if hit is None or hit[0] != weight._version or hit[1].device != weight.device:
         w = weight.detach().float()
         hit = per_weight["pn"] = (weight._version, torch.cat((w.clamp(min=0), w.clamp(max=0)), dim=1).contiguous())
-    return hit[1]
+        per_weight.pop("pnT", None)
+    if not transposed:
+        return hit[1]
+    hit_t = per_weight.get("pnT")
+    if hit_t is None or hit_t[0] != weight._version or hit_t[1].device != weight.device:
+        hit_t = per_weight["pnT"] = (weight._version, hit[1].t().contiguous())
+    return hit_t[1]
 
 
 def lrp_fusable(*tensors):
@@ -405,15 +411,33 @@ def lrp_linear(R, X, weight, normalize):
     st = _stream()
     XX = torch.empty(rows, 2 * n_in, dtype=torch.float32, device=X.device)
     check(lib().mmx_lrp_split_signs(_p(Xc), _p(XX), rows, n_in, st), "mmx_lrp_split_signs")
-    Z = torch.mm(XX, WW.t())                                         # [rows, out] = px pw^T + nx nw^T  (K = 2 in)
-    S = torch.empty_like(Z)
+
+    def mm(a, wt_of, k, n):       # a [rows, k] . Wt [k, n]; few rows and a short contraction: the library's heuristic picks a
+        if rows <= 128 and k <= 1024:   # 256-row tile on ONE workgroup (30-40 us, r04_lrp_probe.txt) -> our 32 x 32-tile kernel
+            out_ = torch.empty(rows, n, dtype=torch.float32, device=a.device)
+            check(lib().mmx_linear_f32(_p(a), _p(wt_of()), None, _p(out_), rows, n, k, st), "mmx_linear_f32")
+            return out_
+        return torch.mm(a, wt_of())
+    Z = mm(XX, lambda: sign_split_weight(weight, transposed=True) if rows <= 128 and 2 * n_in <= 1024 else WW.t(), 2 * n_in, n_out)
+    S = torch.empty_like(Z)                                          # Z [rows, out] = px pw^T + nx nw^T  (K = 2 in)
     check(lib().mmx_lrp_safe_divide(_p(Rc), _p(Z), _p(S), Z.numel(), st), "mmx_lrp_safe_divide")
-    Y = torch.mm(S, WW)                                              # [rows, 2 in] = [S pw | S nw]
+    Y = mm(S, lambda: WW, n_out, 2 * n_in)                           # [rows, 2 in] = [S pw | S nw]
     out = torch.empty(X.shape, dtype=torch.float32, device=X.device)
     ws = _workspace(lib().mmx_lrp_workspace_bytes(), X.device, tag="lrp") if normalize else None
     check(lib().mmx_lrp_linear_combine(_p(XX), _p(Y), _p(out), rows, n_in, _p(Rc) if normalize else None, Rc.numel(),
                                        _p(ws), st), "mmx_lrp_linear_combine")
     return out
+
+
+def lrp_mha_rescale(cam_v_pre, cam_v_post, cam_k, cam_q, cam_o):
+    """The q / k rescale branch of ``MultiheadAttention.relprop`` (layers.py:791-799) in two launches; returns ``(cam_k, cam_q)``
+    (fresh contiguous tensors, scaled in place when the branch applies)."""
+    vp, vq = cam_v_pre.contiguous(), cam_v_post.contiguous()
+    ck, cq, co = cam_k.contiguous().clone(), cam_q.contiguous().clone(), cam_o.contiguous()
+    ws = _workspace(lib().mmx_lrp_workspace_bytes(), cam_k.device, tag="lrp")
+    check(lib().mmx_lrp_mha_rescale(_p(vp), vp.numel(), _p(vq), vq.numel(), _p(ck), ck.numel(), _p(cq), cq.numel(), _p(co),
+                                    co.numel(), _p(ws), _stream()), "mmx_lrp_mha_rescale")
+    return ck, cq
 
 
 def lrp_add(R, a, b, per_sample):
