@@ -383,6 +383,8 @@ def main():
     from transformer_mm_explainability_amd import clip_explainability as ce
     from transformer_mm_explainability_amd import clip_model, ops
 
+    if os.environ.get("MMX_CHAIN_NT"):          # experiment hook (tools/gpu_r04.sh chain): cache policy of the chain's slab loads
+        ops.set_option("self_chain_nt", int(os.environ["MMX_CHAIN_NT"]))
     log("imports done; building %s" % MODEL)
     model = clip_model.random_init(MODEL, seed=0)
     model = model.to(device)

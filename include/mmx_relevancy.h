@@ -69,7 +69,8 @@ const char* mmx_last_error(void);
  *                        next batch of 8 16-byte loads in flight across the head reduction, the LDS write and the per-layer barrier)
  *                        with up to 4 KB contiguous per (head, array) and wave | 2 / 1: at most 2 / 1 KB contiguous |
  *                        0 the plain chunk loop of rounds 1-2.  Same arithmetic, bit-identical results
- *   "self_chain_nt"      0 (default) | 1: the pipelined stream waves load the read-once slabs with the nt (streaming) cache policy; same results
+ *   "self_chain_nt"      1 (default) the pipelined stream waves load the read-once slabs with the nt (streaming) cache policy (a
+ *                        probability slab shared by the batch keeps the default policy) | 0: default policy everywhere.  Same results
  *   "self_chain_groups"  0 auto | 1..8 layer groups per sample of the fused chain kernel (1 = strict sequential order)
  *   "self_chain_big"     2: N > 128 (<= 1152, no second right-hand side) runs the ONE-launch persistent team kernel |
  *                        0 / 1 (default): the per-layer split path, which measures 1.7-2x faster on MI355X
@@ -462,6 +463,8 @@ int mmx_lrp_mha_rescale(const void* v_pre_dev, int64_t n_vpre, const void* v_pos
  * fp32, contiguous, 16-byte aligned, n elements.
  */
 int mmx_quick_gelu_fwd(const void* x_dev, void* y_dev, int64_t n, void* stream);
+/* x * sigmoid(1.702 x) with a bf16 result (n % 4 == 0): the activation of a bf16 body only feeds the next GEMM */
+int mmx_quick_gelu_fwd_bf16(const void* x_dev, void* y_dev, int64_t n, void* stream);
 int mmx_quick_gelu_bwd(const void* x_dev, const void* dy_dev, void* dx_dev, int64_t n, void* stream);
 /* Same with x ([x_n] elements) broadcast over the leading dimension of dy / dx ([n] elements, n % x_n == 0, x_n % 4 == 0):
  * the shared-forward backward has ONE activation tensor for B upstream gradients. */
@@ -488,6 +491,11 @@ int mmx_layernorm_bwd_add(const void* dy_dev, const void* x_dev, const void* mea
 int mmx_add_layernorm_fwd(const void* x_dev, const void* y_dev, const void* gamma_dev, const void* beta_dev,
                           void* sum_dev, void* h_dev, void* mean_dev, void* rstd_dev, int64_t rows, int E, float eps,
                           void* stream);
+/* The same with h_dtype = MMX_F32 | MMX_BF16: a bf16 body (CLIP/clip/model.py:381-402 converts the weights to half precision) feeds
+ * h to a half-precision GEMM only, so the kernel writes it as bf16 (round to nearest even) instead of a conversion pass. */
+int mmx_add_layernorm_fwd_ex(const void* x_dev, const void* y_dev, const void* gamma_dev, const void* beta_dev,
+                             void* sum_dev, void* h_dev, void* mean_dev, void* rstd_dev, int64_t rows, int E,
+                             float eps, int h_dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Kernel timing helper for bench.py: runs `fn`-independent HIP-event timing on `stream` is done in

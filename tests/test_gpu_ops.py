@@ -803,3 +803,20 @@ def test_lxmert_schedule_two_phase_kernel_propagates_nan(ops):
         assert torch.equal(torch.isnan(a), torch.isnan(b_))
         assert not torch.isnan(a[0]).any()                 # sample 0 is untouched
     assert torch.isnan(outs[2][1][1]).any()                # ... and sample 1's R_ti is poisoned
+
+
+def test_bf16_outputs_of_layernorm_and_gelu_forward(ops):
+    """Round 4: in a bf16 body the LayerNorm output and the MLP activation only feed a half-precision GEMM, so the kernels write
+    them as bf16 directly (``add_layernorm(h_dtype=bfloat16)``, ``quick_gelu_fwd(out_dtype=bfloat16)``): must equal the fp32
+    kernel's result rounded to nearest even, bit for bit; sum / statistics unchanged."""
+    g = torch.Generator().manual_seed(3)
+    for rows, E in ((5, 768), (77, 1024), (3, 3072)):
+        x = torch.randn(rows, E, generator=g).cuda()
+        y = torch.randn(rows, E, generator=g).cuda()
+        gamma, beta = torch.randn(E, generator=g).cuda(), torch.randn(E, generator=g).cuda()
+        s32, h32, m32, r32 = ops.add_layernorm(x, y, gamma, beta, 1e-5)
+        s16, h16, m16, r16 = ops.add_layernorm(x, y, gamma, beta, 1e-5, h_dtype=torch.bfloat16)
+        assert h16.dtype == torch.bfloat16 and torch.equal(h16, h32.to(torch.bfloat16))
+        assert torch.equal(s16, s32) and torch.equal(m16, m32) and torch.equal(r16, r32)
+        a32, a16 = ops.quick_gelu_fwd(x), ops.quick_gelu_fwd(x, torch.bfloat16)
+        assert a16.dtype == torch.bfloat16 and torch.equal(a16, a32.to(torch.bfloat16))

@@ -29,5 +29,36 @@ lrp)             # fused LRP rule kernels: parity (all LRP suites) + the pass ti
   python tools/prof_summary.py $OUT/trace_lrp/lrp_results.db "" 2>&1 | head -45 | cut -c1-200 > $OUT/lrp_kernels.txt; head -30 $OUT/lrp_kernels.txt
   rm -rf $OUT/trace_lrp
   ;;
+chain)           # chain kernel: SQ / TCC counters over rotating slabs, nt vs default policy inside the replayed step
+  timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT/pmc_sq -o chain -- python tools/probe_chain_nt.py > $OUT/probe_under_pmc.txt 2> $OUT/pmc_sq.log
+  python tools/pmc_sq.py $OUT/pmc_sq/chain_counter_collection.csv self_chain_fused > $OUT/chain_sq.txt 2>&1; cat $OUT/chain_sq.txt
+  timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum --kernel-trace --output-format csv -d $OUT/pmc_tcc -o chain -- python tools/probe_chain_nt.py > /dev/null 2> $OUT/pmc_tcc.log || tail -3 $OUT/pmc_tcc.log
+  python tools/pmc_sq.py $OUT/pmc_tcc/chain_counter_collection.csv self_chain_fused > $OUT/chain_tcc.txt 2>&1; cat $OUT/chain_tcc.txt
+  for NT in 0 1; do
+    MMX_CHAIN_NT=$NT timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_nt$NT -o bench -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --headline-only > $OUT/bench_nt$NT.json 2> $OUT/trace_nt$NT.log
+    python tools/prof_summary.py $OUT/trace_nt$NT/bench_results.db "self_chain" --by-grid > $OUT/chain_in_step_nt$NT.txt 2>&1; echo "nt=$NT"; cat $OUT/chain_in_step_nt$NT.txt | cut -c1-200; cut -c1-160 $OUT/bench_nt$NT.json
+  done
+  rm -rf $OUT/pmc_sq $OUT/pmc_tcc $OUT/trace_nt0 $OUT/trace_nt1
+  ;;
+cfg5)            # bf16 body: parity suites + step time + launch-count audit (kernel trace sorted by CALLS)
+  timeout 900 python -m pytest tests/test_gpu_parity_fullsize.py tests/test_gpu_clip.py tests/test_gpu_ops.py -q -k "cfg5 or bf16" 2>&1 | tail -8 | tee $OUT/pytest.txt
+  timeout 300 python -c "
+import torch, time, sys
+sys.path.insert(0, '.')
+from tools import bench_legs
+from transformer_mm_explainability_amd import clip_explainability as ce
+model, image, texts, _, _ = bench_legs.cfg5_setup(128, torch.device('cuda'))
+f = lambda: ce.interpret(image, texts, model, 'cuda', start_layer=0, start_layer_text=0)
+for _ in range(2): f()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): f()
+torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 5 * 1e3
+print('cfg5 step: %.2f ms = %.1f maps/s' % (ms, 128 / ms * 1e3))
+" 2>&1 | grep -v amdgpu.ids | tee $OUT/step.txt
+  timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/trace_cfg5 -o cfg5 -- python tools/probe_cfg5_trace.py 128 3 > /dev/null 2> $OUT/trace_cfg5.log
+  python tools/prof_summary.py $OUT/trace_cfg5/cfg5_results.db "" 2>&1 | head -40 | cut -c1-190 > $OUT/cfg5_step_kernels.txt; head -24 $OUT/cfg5_step_kernels.txt
+  python tools/prof_summary.py $OUT/trace_cfg5/cfg5_results.db "copy" 2>&1 | cut -c1-190 | tee $OUT/cfg5_copy_kernels.txt
+  rm -rf $OUT/trace_cfg5
+  ;;
 *) echo "unknown target $T"; exit 2;;
 esac

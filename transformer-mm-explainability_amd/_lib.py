@@ -81,12 +81,14 @@ _PROTOTYPES = {
     "mmx_avg_heads_vecmat_workspace_bytes": (_sz, [_i, _i]),
     "mmx_avg_heads_vecmat": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _vp, _sz, _vp]),
     "mmx_quick_gelu_fwd": (_i, [_vp, _vp, _i64, _vp]),
+    "mmx_quick_gelu_fwd_bf16": (_i, [_vp, _vp, _i64, _vp]),
     "mmx_quick_gelu_bwd": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "mmx_quick_gelu_bwd_bcast": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "mmx_quick_gelu_bwd_bcast_bf16": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "mmx_layernorm_bwd_add_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     "mmx_layernorm_bwd_add": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     "mmx_add_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
+    "mmx_add_layernorm_fwd_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _vp]),
     "mmx_event_create": (_i, [_vpp]),
     "mmx_event_destroy": (_i, [_vp]),
     "mmx_event_record": (_i, [_vp, _vp]),

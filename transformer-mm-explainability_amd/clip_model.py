@@ -203,7 +203,9 @@ class Transformer(nn.Module):
         mma = bool(getattr(self, "attention_mma_bf16", False)) and N > 128
         # every LayerNorm but the first is fused with the residual add that produces its input
         first = blocks[0].ln_1
-        _, h1, mean1, rstd1 = ops.add_layernorm(x, None, first.weight, first.bias, first.eps)
+        # bf16 body: what only feeds a GEMM (LayerNorm outputs, the MLP activation) leaves its kernel as bf16 -- no conversion passes
+        hd = torch.bfloat16 if getattr(self, "forward_gemm_dtype", torch.float32) == torch.bfloat16 else torch.float32
+        _, h1, mean1, rstd1 = ops.add_layernorm(x, None, first.weight, first.bias, first.eps, h_dtype=hd)
         for l, blk in enumerate(blocks):
             at = blk.attn
             qkv = self._linear(h1, at.in_proj_weight, at.in_proj_bias).view(Bx, N, 3, at.num_heads, at.head_dim)
@@ -213,22 +215,22 @@ class Transformer(nn.Module):
                 ar = torch.arange(Bx, device=x.device)
                 x1, h2, mean2, rstd2 = ops.add_layernorm(
                     x[ar, out_rows], self._linear(o.view(Bx, N, E)[ar, out_rows], at.out_proj.weight, at.out_proj.bias),
-                    blk.ln_2.weight, blk.ln_2.bias, blk.ln_2.eps)
+                    blk.ln_2.weight, blk.ln_2.bias, blk.ln_2.eps, h_dtype=hd)
                 m = self._linear(h2, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
-                mlp_out = self._linear(ops.quick_gelu_fwd(m), blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
+                mlp_out = self._linear(ops.quick_gelu_fwd(m, hd), blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
                 # (x1, mean2, rstd2, m hold the Bx selected rows only: what _top_block_rows reads)
                 tape.append((x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o, out_rows) if l >= first_grad_layer else None)
                 blk.attn_probs, blk.attn_grad = buffers.layer_probs(l), buffers.layer_grads(l)
                 return x1 + mlp_out, tape
             x1, h2, mean2, rstd2 = ops.add_layernorm(x, self._linear(o.view(Bx, N, E), at.out_proj.weight, at.out_proj.bias),
-                                                     blk.ln_2.weight, blk.ln_2.bias, blk.ln_2.eps)
+                                                     blk.ln_2.weight, blk.ln_2.bias, blk.ln_2.eps, h_dtype=hd)
             m = self._linear(h2, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
-            mlp_out = self._linear(ops.quick_gelu_fwd(m), blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
+            mlp_out = self._linear(ops.quick_gelu_fwd(m, hd), blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
             tape.append((x, mean1, rstd1, qkv, x1, mean2, rstd2, m, o) if l >= first_grad_layer else None)
             blk.attn_probs, blk.attn_grad = buffers.layer_probs(l), buffers.layer_grads(l)
             if l + 1 < len(blocks):
                 nxt = blocks[l + 1].ln_1
-                x, h1, mean1, rstd1 = ops.add_layernorm(x1, mlp_out, nxt.weight, nxt.bias, nxt.eps)
+                x, h1, mean1, rstd1 = ops.add_layernorm(x1, mlp_out, nxt.weight, nxt.bias, nxt.eps, h_dtype=hd)
             else:
                 x = x1 + mlp_out
         return x, tape
@@ -272,7 +274,11 @@ class Transformer(nn.Module):
         # bf16 body on the streaming kernels: the gradients BETWEEN the GEMMs are bf16 (what the bf16 GEMMs produce and
         # consume; the elementwise kernels and the attention backward read / write bf16 directly -- no conversion
         # passes), the residual gradient stream (dx, d_x1) stays fp32
-        stream16 = mma and getattr(self, "backward_gemm_dtype", torch.float32) == torch.bfloat16
+        # A short tower of a bf16 body (CLIP's 77-token text side: register-resident fp32 head kernels) runs the same bf16 stream with
+        # two small conversions around its attention (d_o -> fp32, dq | dk | dv -> bf16) instead of an fp32 -> bf16 pass in front of
+        # every GEMM (the widest of them 4 E columns).
+        stream16 = getattr(self, "backward_gemm_dtype", torch.float32) == torch.bfloat16
+        att16 = stream16 and mma
         dx_h = None
         for l in range(top, first_grad_layer - 1, -1):
             blk = self.resblocks[l]
@@ -286,7 +292,7 @@ class Transformer(nn.Module):
                 g = dy_row_values if dy_row_values is not None else dy[torch.arange(B, device=dy_rows.device), dy_rows]
                 d_x1_r, d_o = self._top_block_rows(blk, tape[l], g, dy_rows, shared, N)
                 d_x1, top_rows = None, (dy_rows, d_x1_r)
-                if stream16:
+                if att16:
                     d_o = d_o.to(torch.bfloat16)
             elif stream16:
                 if dx_h is None:
@@ -304,6 +310,8 @@ class Transformer(nn.Module):
                 d_x1 = ops.layernorm_bwd_add(d_h2, x1, mean2, rstd2, blk.ln_2.weight, dx)   # dx + LN2'(d_h2), one pass
                 # attention branch: x1 = x + out_proj(attn(ln_1(x)))
                 d_o = self._gemm(d_x1, at.out_proj.weight)
+            if stream16 and not att16 and d_o.dtype != torch.float32:
+                d_o = d_o.float()
             d_o = d_o.view(B, N, at.num_heads, at.head_dim)
             need = l > first_grad_layer                                       # nothing below needs gradients
             dqkv = torch.empty(B, N, 3, at.num_heads, at.head_dim, dtype=d_o.dtype, device=d_o.device) if need else None
@@ -317,7 +325,8 @@ class Transformer(nn.Module):
             if not need:
                 break
             if stream16:
-                d_h1 = ops.backward_gemm_bf16(dqkv.view(B, N, 3 * E), at.in_proj_weight)
+                dq_in = dqkv.view(B, N, 3 * E)
+                d_h1 = ops.backward_gemm_bf16(dq_in if att16 else dq_in.to(torch.bfloat16), at.in_proj_weight)
                 dx, dx_h = ops.layernorm_bwd_add_bf16(d_h1, x, mean1, rstd1, blk.ln_1.weight, d_x1)
             else:
                 d_h1 = self._gemm(dqkv.view(B, N, 3 * E), at.in_proj_weight)

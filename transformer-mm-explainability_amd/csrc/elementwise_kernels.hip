@@ -6,6 +6,16 @@
 
 namespace mmx {
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf_pack(float a, float b) {        // round to nearest even (v_cvt_pk_bf16_f32)
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    bf2 r;
+    r[0] = static_cast<__bf16>(a);
+    r[1] = static_cast<__bf16>(b);
+    return __builtin_bit_cast(unsigned, r);
+}
+
+
 __device__ __forceinline__ float sigmoid_f(float z) { return 1.f / (1.f + expf(-z)); }
 
 __global__ __launch_bounds__(256) void quick_gelu_fwd_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int64_t n4,
@@ -18,6 +28,17 @@ __global__ __launch_bounds__(256) void quick_gelu_fwd_kernel(const f32x4* __rest
         y[i] = o;
     }
     if (blockIdx.x == 0 && threadIdx.x < tail) yt[threadIdx.x] = xt[threadIdx.x] * sigmoid_f(1.702f * xt[threadIdx.x]);
+}
+
+// the same with a bf16 result: the activation only feeds the next GEMM of a bf16 body (no conversion pass)
+__global__ __launch_bounds__(256) void quick_gelu_fwd_bf16_kernel(const f32x4* __restrict__ x, u32x2* __restrict__ y, int64_t n4) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += static_cast<int64_t>(gridDim.x) * 256) {
+        const f32x4 v = x[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[e] * sigmoid_f(1.702f * v[e]);
+        y[i] = u32x2{bf_pack(o[0], o[1]), bf_pack(o[2], o[3])};
+    }
 }
 
 // x_n4: number of 16-byte groups of x; x_n4 < n4 broadcasts x over the leading (batch) dimension of dy -- the shared-forward
@@ -169,7 +190,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __r
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float* __restrict__ sum_out, float* __restrict__ h_out,
                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                                int64_t rows, int E, float eps) {
+                                                                int64_t rows, int E, float eps, unsigned short* __restrict__ h_bf16) {
     const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const int lane = threadIdx.x & 63, n4 = E >> 2;
@@ -207,38 +228,60 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __r
     const f32x4* gm = reinterpret_cast<const f32x4*>(gamma);
     const f32x4* bt = reinterpret_cast<const f32x4*>(beta);
     f32x4* so = (sum_out && yr) ? reinterpret_cast<f32x4*>(sum_out + r * E) : nullptr;
-    f32x4* ho = reinterpret_cast<f32x4*>(h_out + r * E);
+    f32x4* ho = h_bf16 ? nullptr : reinterpret_cast<f32x4*>(h_out + r * E);
+    u32x2* hb = h_bf16 ? reinterpret_cast<u32x2*>(h_bf16 + r * E) : nullptr;   // bf16 body: h only feeds the next GEMM
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int i = lane + 64 * j;
         if (i < n4) {
             if (so) so[i] = v[j];
-            ho[i] = (v[j] - mu) * rs * gm[i] + bt[i];
+            const f32x4 h = (v[j] - mu) * rs * gm[i] + bt[i];
+            if (hb) hb[i] = u32x2{bf_pack(h[0], h[1]), bf_pack(h[2], h[3])};
+            else ho[i] = h;
         }
     }
 }
 
 }  // namespace mmx
 
-extern "C" int mmx_add_layernorm_fwd(const void* x_dev, const void* y_dev, const void* gamma_dev, const void* beta_dev,
-                                     void* sum_dev, void* h_dev, void* mean_dev, void* rstd_dev, int64_t rows, int E,
-                                     float eps, void* stream) {
+extern "C" int mmx_add_layernorm_fwd_ex(const void* x_dev, const void* y_dev, const void* gamma_dev, const void* beta_dev,
+                                        void* sum_dev, void* h_dev, void* mean_dev, void* rstd_dev, int64_t rows, int E,
+                                        float eps, int h_dtype, void* stream) {
     MMX_CHECK_ARG(x_dev && gamma_dev && beta_dev && h_dev && mean_dev && rstd_dev, "mmx_add_layernorm_fwd: null pointer");
     MMX_CHECK_ARG(!y_dev || sum_dev, "mmx_add_layernorm_fwd: the sum x + y needs an output buffer");
     MMX_CHECK_ARG(rows > 0 && E > 0 && E % 4 == 0 && E <= 4096, "mmx_add_layernorm_fwd: rows=%ld E=%d (E %% 4 == 0, E <= 4096)",
                   static_cast<long>(rows), E);
+    MMX_CHECK_ARG(h_dtype == MMX_F32 || h_dtype == MMX_BF16, "mmx_add_layernorm_fwd: h is fp32 or bf16");
     const unsigned grid = static_cast<unsigned>((rows + 3) / 4);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float *x = static_cast<const float*>(x_dev), *y = static_cast<const float*>(y_dev);
     const float *g = static_cast<const float*>(gamma_dev), *b = static_cast<const float*>(beta_dev);
-    float *so = static_cast<float*>(sum_dev), *ho = static_cast<float*>(h_dev);
+    float *so = static_cast<float*>(sum_dev), *ho = h_dtype == MMX_F32 ? static_cast<float*>(h_dev) : nullptr;
+    unsigned short* hb = h_dtype == MMX_BF16 ? static_cast<unsigned short*>(h_dev) : nullptr;
     float *mo = static_cast<float*>(mean_dev), *ro = static_cast<float*>(rstd_dev);
-    if (E <= 256) mmx::add_layernorm_fwd_kernel<1><<<grid, 256, 0, s>>>(x, y, g, b, so, ho, mo, ro, rows, E, eps);
-    else if (E <= 512) mmx::add_layernorm_fwd_kernel<2><<<grid, 256, 0, s>>>(x, y, g, b, so, ho, mo, ro, rows, E, eps);
-    else if (E <= 1024) mmx::add_layernorm_fwd_kernel<4><<<grid, 256, 0, s>>>(x, y, g, b, so, ho, mo, ro, rows, E, eps);
-    else if (E <= 2048) mmx::add_layernorm_fwd_kernel<8><<<grid, 256, 0, s>>>(x, y, g, b, so, ho, mo, ro, rows, E, eps);
-    else mmx::add_layernorm_fwd_kernel<16><<<grid, 256, 0, s>>>(x, y, g, b, so, ho, mo, ro, rows, E, eps);
+    if (E <= 256) mmx::add_layernorm_fwd_kernel<1><<<grid, 256, 0, s>>>(x, y, g, b, so, ho, mo, ro, rows, E, eps, hb);
+    else if (E <= 512) mmx::add_layernorm_fwd_kernel<2><<<grid, 256, 0, s>>>(x, y, g, b, so, ho, mo, ro, rows, E, eps, hb);
+    else if (E <= 1024) mmx::add_layernorm_fwd_kernel<4><<<grid, 256, 0, s>>>(x, y, g, b, so, ho, mo, ro, rows, E, eps, hb);
+    else if (E <= 2048) mmx::add_layernorm_fwd_kernel<8><<<grid, 256, 0, s>>>(x, y, g, b, so, ho, mo, ro, rows, E, eps, hb);
+    else mmx::add_layernorm_fwd_kernel<16><<<grid, 256, 0, s>>>(x, y, g, b, so, ho, mo, ro, rows, E, eps, hb);
     MMX_LAUNCH_CHECK("add_layernorm_fwd_kernel");
+    return MMX_OK;
+}
+
+extern "C" int mmx_add_layernorm_fwd(const void* x_dev, const void* y_dev, const void* gamma_dev, const void* beta_dev,
+                                     void* sum_dev, void* h_dev, void* mean_dev, void* rstd_dev, int64_t rows, int E,
+                                     float eps, void* stream) {
+    return mmx_add_layernorm_fwd_ex(x_dev, y_dev, gamma_dev, beta_dev, sum_dev, h_dev, mean_dev, rstd_dev, rows, E, eps, MMX_F32,
+                                    stream);
+}
+
+extern "C" int mmx_quick_gelu_fwd_bf16(const void* x_dev, void* y_dev, int64_t n, void* stream) {
+    MMX_CHECK_ARG(x_dev && y_dev && n > 0 && n % 4 == 0, "mmx_quick_gelu_fwd_bf16: bad argument (n %% 4 == 0)");
+    MMX_CHECK_ARG((reinterpret_cast<uintptr_t>(x_dev) & 15u) == 0 && (reinterpret_cast<uintptr_t>(y_dev) & 7u) == 0,
+                  "mmx_quick_gelu_fwd_bf16: x must be 16-byte, y 8-byte aligned");
+    mmx::quick_gelu_fwd_bf16_kernel<<<gelu_grid(n / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const mmx::f32x4*>(x_dev), static_cast<mmx::u32x2*>(y_dev), n / 4);
+    MMX_LAUNCH_CHECK("quick_gelu_fwd_bf16_kernel");
     return MMX_OK;
 }
 
@@ -252,17 +295,10 @@ extern "C" int mmx_add_layernorm_fwd(const void* x_dev, const void* y_dev, const
 namespace mmx {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
 
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
-__device__ __forceinline__ unsigned bf_pack(float a, float b) {        // round to nearest even (v_cvt_pk_bf16_f32)
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    bf2 r;
-    r[0] = static_cast<__bf16>(a);
-    r[1] = static_cast<__bf16>(b);
-    return __builtin_bit_cast(unsigned, r);
-}
 
 __global__ __launch_bounds__(256) void quick_gelu_bwd_bf16_kernel(const f32x4* __restrict__ x, const u32x4* __restrict__ dy,
                                                                   u32x4* __restrict__ dx, int64_t n8, int64_t x_n8) {

@@ -262,10 +262,15 @@ def quick_gelu(x):
     return _QuickGELU.apply(x)
 
 
-def quick_gelu_fwd(x):
-    """``x * sigmoid(1.702 x)``, no autograd (the hand-written backward passes keep ``x`` themselves)."""
+def quick_gelu_fwd(x, out_dtype=torch.float32):
+    """``x * sigmoid(1.702 x)``, no autograd (the hand-written backward passes keep ``x`` themselves).  ``out_dtype=torch.bfloat16``
+    (a bf16 body: the activation only feeds the next GEMM): the kernel writes bf16, no conversion pass."""
     _dev(x)
     x = _f32c(x)
+    if out_dtype == torch.bfloat16 and x.numel() % 4 == 0:
+        y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        check(lib().mmx_quick_gelu_fwd_bf16(_p(x), _p(y), x.numel(), _stream()), "mmx_quick_gelu_fwd_bf16")
+        return y
     y = torch.empty_like(x)
     check(lib().mmx_quick_gelu_fwd(_p(x), _p(y), x.numel(), _stream()), "mmx_quick_gelu_fwd")
     return y
@@ -295,9 +300,10 @@ def quick_gelu_bwd(x, dy):
     return dx
 
 
-def add_layernorm(x, y, gamma, beta, eps=1e-5):
+def add_layernorm(x, y, gamma, beta, eps=1e-5, h_dtype=torch.float32):
     """``s = x + y; h = LayerNorm(s)`` in one pass -> ``(s, h, mean, rstd)`` (``y=None``: ``s`` is ``x`` itself).
-    ``mean`` / ``rstd``: ``[rows]`` fp32, what ``layernorm_bwd_add`` takes."""
+    ``mean`` / ``rstd``: ``[rows]`` fp32, what ``layernorm_bwd_add`` takes.  ``h_dtype=torch.bfloat16``: ``h`` leaves the kernel
+    as bf16 (a bf16 body feeds it to a half-precision GEMM only)."""
     _dev(x, y, gamma, beta)
     x = _f32c(x)
     E = x.shape[-1]
@@ -307,11 +313,12 @@ def add_layernorm(x, y, gamma, beta, eps=1e-5):
         if y.shape != x.shape:
             raise MMXError("add_layernorm: x %s vs y %s" % (tuple(x.shape), tuple(y.shape)))
     s = torch.empty_like(x) if y is not None else x
-    h = torch.empty_like(x)
+    h = torch.empty(x.shape, dtype=h_dtype, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    check(lib().mmx_add_layernorm_fwd(_p(x), _p(y), _p(_f32c(gamma)), _p(_f32c(beta)), _p(s) if y is not None else _p(None),
-                                      _p(h), _p(mean), _p(rstd), rows, E, float(eps), _stream()), "mmx_add_layernorm_fwd")
+    check(lib().mmx_add_layernorm_fwd_ex(_p(x), _p(y), _p(_f32c(gamma)), _p(_f32c(beta)), _p(s) if y is not None else _p(None),
+                                         _p(h), _p(mean), _p(rstd), rows, E, float(eps), _DTYPES[h_dtype], _stream()),
+          "mmx_add_layernorm_fwd")
     return s, h, mean, rstd
 
 
