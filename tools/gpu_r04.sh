@@ -60,5 +60,22 @@ print('cfg5 step: %.2f ms = %.1f maps/s' % (ms, 128 / ms * 1e3))
   python tools/prof_summary.py $OUT/trace_cfg5/cfg5_results.db "copy" 2>&1 | cut -c1-190 | tee $OUT/cfg5_copy_kernels.txt
   rm -rf $OUT/trace_cfg5
   ;;
+attn5)           # cfg-5 attention backward pair stand-alone + equivalence tests + the step
+  timeout 600 python -m pytest tests/test_gpu_parity_fullsize.py -q -k "third_generation or cfg5_bf16_body or bf16_error_by_depth" 2>&1 | tail -5 | tee $OUT/pytest.txt
+  timeout 300 python tools/probe_attn_v3.py 128 2>&1 | grep -v amdgpu.ids | tee $OUT/attn_v3_probe.txt
+  timeout 300 python -c "
+import torch, time, sys
+sys.path.insert(0, '.')
+from tools import bench_legs
+from transformer_mm_explainability_amd import clip_explainability as ce
+model, image, texts, _, _ = bench_legs.cfg5_setup(128, torch.device('cuda'))
+f = lambda: ce.interpret(image, texts, model, 'cuda', start_layer=0, start_layer_text=0)
+for _ in range(2): f()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): f()
+torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 5 * 1e3
+print('cfg5 step: %.2f ms = %.1f maps/s' % (ms, 128 / ms * 1e3))
+" 2>&1 | grep -v amdgpu.ids | tee $OUT/step.txt
+  ;;
 *) echo "unknown target $T"; exit 2;;
 esac

@@ -152,17 +152,19 @@ __device__ __forceinline__ void store_row_major(bf16_t* tile, const u32x2v (&row
 // the same block of a TRANSPOSED image [d][row] (row stride Np): raw[dd] = rows row0 + r4 .. + 3 of d = c + dd.  The image
 // pointer is wave-uniform: written as (uniform base of row d) + (ONE 32-bit lane offset) the four loads share a single address
 // VGPR (scalar-base addressing); as four 64-bit lane pointers they cost 8 registers that the kernel spilled inside the loop.
-__device__ __forceinline__ const char* uniform_ptr(const void* p) {      // tell the compiler the pointer is wave-uniform (SGPRs)
-    const uint64_t u = reinterpret_cast<uint64_t>(p);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(u));
-    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(u >> 32));
-    return reinterpret_cast<const char*>((static_cast<uint64_t>(hi) << 32) | lo);
-}
+// The uniform part is a 32-bit byte OFFSET pinned to an SGPR (readfirstlane) and added to the image pointer by ordinary pointer
+// arithmetic.  Round 3 rebuilt the POINTER from two readfirstlane halves instead: an integer -> pointer cast loses the global
+// address space, hipcc emitted FLAT loads for three of the four rows and -- flat and global loads return out of order -- put an
+// s_waitcnt vmcnt(0) in front of each: three serialised memory round trips per tile on the staging waves of both kernels
+// (found in round 4 in the ISA, tools/isa_mix.py; 1190 -> 1121 us per layer pair, profiles/r04_cfg5_probe.txt).
 __device__ __forceinline__ void fetch_transposed(RawBlock& blk, const bf16_t* imgT, int Np, int row0, int st) {
-    const unsigned voff = (4u * (st & 15) * static_cast<unsigned>(Np) + 4u * (st >> 4)) * 2u;      // bytes
+    const unsigned voff = (4u * (st & 15) * static_cast<unsigned>(Np) + 4u * (st >> 4)) * 2u;      // bytes, per lane
+    const char* img = reinterpret_cast<const char*>(imgT);
 #pragma unroll
-    for (int dd = 0; dd < 4; ++dd)
-        blk.raw[dd] = *reinterpret_cast<const u32x2v*>(uniform_ptr(imgT + row0 + static_cast<int64_t>(dd) * Np) + voff);
+    for (int dd = 0; dd < 4; ++dd) {
+        const unsigned soff = static_cast<unsigned>(__builtin_amdgcn_readfirstlane((row0 + dd * Np) * 2));   // bytes, wave-uniform
+        blk.raw[dd] = *reinterpret_cast<const u32x2v*>(img + soff + voff);
+    }
 }
 __device__ __forceinline__ void store_transposed_raw(bf16_t* tile, const u32x2v (&cols)[4], int st) {
     const int c = 4 * (st & 15);
