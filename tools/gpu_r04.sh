@@ -77,5 +77,16 @@ torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 5 * 1e3
 print('cfg5 step: %.2f ms = %.1f maps/s' % (ms, 128 / ms * 1e3))
 " 2>&1 | grep -v amdgpu.ids | tee $OUT/step.txt
   ;;
+counters2)       # second counter set (matrix-pipe busy, instruction counts, instruction fetch, vmem level) on the cfg-5 pair and the schedule
+  C2="SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_IFETCH SQ_INST_LEVEL_VMEM"
+  timeout 300 rocprofv3 --pmc $C2 --kernel-trace --output-format csv -d $OUT/pmc_v3 -o v3 -- python tools/probe_attn_v3.py 16 2 > /dev/null 2> $OUT/pmc_v3.log
+  python tools/pmc_sq.py $OUT/pmc_v3/v3_counter_collection.csv _v3_ > $OUT/attn_v3_counters2.txt 2>&1; cat $OUT/attn_v3_counters2.txt
+  C3="SQ_WAVE_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_WAVES"
+  timeout 300 rocprofv3 --pmc $C3 --kernel-trace --output-format csv -d $OUT/pmc_v3b -o v3 -- python tools/probe_attn_v3.py 16 2 > /dev/null 2> $OUT/pmc_v3b.log
+  python tools/pmc_sq.py $OUT/pmc_v3b/v3_counter_collection.csv _v3_ > $OUT/attn_v3_counters3.txt 2>&1; cat $OUT/attn_v3_counters3.txt
+  timeout 300 rocprofv3 --pmc $C2 --kernel-trace --output-format csv -d $OUT/pmc_sched -o s -- python tools/probe_schedule.py > /dev/null 2> $OUT/pmc_sched.log
+  python tools/pmc_sq.py $OUT/pmc_sched/s_counter_collection.csv lxmert_schedule > $OUT/schedule_counters2.txt 2>&1; cat $OUT/schedule_counters2.txt
+  rm -rf $OUT/pmc_v3 $OUT/pmc_v3b $OUT/pmc_sched
+  ;;
 *) echo "unknown target $T"; exit 2;;
 esac

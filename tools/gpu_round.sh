@@ -1,13 +1,13 @@
 #!/bin/bash
 # One GPU-box round: gpu tests, smoke, bench (JSON line), rocprofv3 kernel trace + PMC passes. Outputs under gpurun_out/$TAG.
 #   $2 = "notest" skips the pytest / smoke legs (profiles only); "lite" keeps them and skips the cfg-5 / DETR side traces at the end
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 nproc > $OUT/nproc.txt
 if [ "$2" != "notest" ]; then
-timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -6 | tee $OUT/pytest_gpu.txt
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -12 | tee $OUT/pytest_gpu.txt
 cp gpurun_out/parity_errors.json $OUT/parity.json 2>/dev/null
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.txt
 fi
@@ -25,6 +25,10 @@ cat $OUT/pmc_fetch.txt $OUT/pmc_write.txt
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_full -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $OUT/trace_full.log
 python tools/prof_summary.py $OUT/trace_full/bench_results.db "self_chain" --by-grid > $OUT/chain_kernel_trace.txt 2>&1; cat $OUT/chain_kernel_trace.txt | cut -c1-200
 python tools/prof_summary.py $OUT/trace_full/bench_results.db "" --by-grid 2>&1 | grep -E "kernel  |mmx" | head -70 | cut -c1-200 > $OUT/cfg_legs.txt
+# round 4: the bi-modal schedule kernel (one workgroup per sample vs two-phase) and the LRP route's cost
+timeout 200 python tools/probe_schedule.py 2>&1 | grep -v amdgpu.ids > $OUT/schedule_probe.txt; cat $OUT/schedule_probe.txt
+timeout 200 python tools/probe_lrp.py both 5 2>&1 | grep -v amdgpu.ids > $OUT/lrp_probe.txt; cat $OUT/lrp_probe.txt
+rocprofv3 --list-avail > $OUT/counters_avail.txt 2>&1
 if [ "$2" == "lite" ]; then rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/trace $OUT/trace_full; exit 0; fi
 # cfg 5: the step's kernel split, the attention backward pair alone (v2 vs v3), SQ counters of the v3 kernels
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/trace_cfg5 -o cfg5 -- python tools/probe_cfg5_trace.py 128 3 > /dev/null 2> $OUT/trace_cfg5.log
