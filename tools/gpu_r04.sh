@@ -88,5 +88,33 @@ counters2)       # second counter set (matrix-pipe busy, instruction counts, ins
   python tools/pmc_sq.py $OUT/pmc_sched/s_counter_collection.csv lxmert_schedule > $OUT/schedule_counters2.txt 2>&1; cat $OUT/schedule_counters2.txt
   rm -rf $OUT/pmc_v3 $OUT/pmc_v3b $OUT/pmc_sched
   ;;
+counters3)       # memory-side counters of the cfg-5 pair (vector L1 / texture addresser / L2), third- and fourth-generation key side
+  CA="SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_ANY"
+  CB="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum"
+  CC="TA_BUSY_avr TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum TD_TD_BUSY_sum"
+  CD="TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_TAG_STALL_sum TCC_BUSY_avr TCC_READ_sum TCC_EA0_RDREQ_sum TCC_CYCLE_sum"
+  i=0
+  for C in "$CA" "$CB" "$CC" "$CD"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$i -o v -- python tools/probe_attn_v3.py 16 2,3 > /dev/null 2> $OUT/pmc_$i.log
+    python tools/pmc_sq.py $OUT/pmc_$i/v_counter_collection.csv attn_bwd_ > $OUT/attn_counters_mem_$i.txt 2>&1 || tail -5 $OUT/pmc_$i.log
+    cat $OUT/attn_counters_mem_$i.txt
+    rm -rf $OUT/pmc_$i
+  done
+  ;;
+ablate)          # timing ablations of the cfg-5 pair (library built with -DMMX_ATTN_ABLATE; results of the ablated kernels are garbage)
+  for A in 0 1 2 3 4 6 7; do
+    MMX_ATTN_ABLATE=$A timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/abl_$A -o a -- python tools/probe_attn_v3.py 128 2,3 > $OUT/abl_$A.txt 2> $OUT/abl_$A.log
+    echo "== ablation $A" | tee -a $OUT/ablate.txt
+    grep -v amdgpu.ids $OUT/abl_$A.txt | tee -a $OUT/ablate.txt
+    python - $OUT/abl_$A/a_kernel_stats.csv <<'PY' | tee -a $OUT/ablate.txt
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if "attn_bwd" in r["Name"] or "prep_" in r["Name"] or "rel_row" in r["Name"]:
+        print("    %-70s calls %4s  avg %9.1f us" % (r["Name"].replace("void mmx::(anonymous namespace)::", "")[:70], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY
+    rm -rf $OUT/abl_$A
+  done
+  ;;
 *) echo "unknown target $T"; exit 2;;
 esac

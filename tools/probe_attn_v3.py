@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from transformer_mm_explainability_amd import ops  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-modes = [int(m) for m in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2]
+modes = [int(m) for m in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3]
 H, N, D = 16, 577, 64
 qkv = torch.randn(1, N, 3, H, D, device="cuda")
 q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]

@@ -11,7 +11,10 @@
 //     64-bit address each (key side: a lane owns a key, its 16 query rows are a strided column of the slab).
 // Here two small PREP kernels run once per call on the shared operands (a few MB, L2-resident afterwards):
 //   Vb  [H][Np][64]  V rows, bf16                     KbT / QbT [H][64][Np]  K / (scale q) transposed, bf16
-//   Pq  [H][Np][Np]  P rows, zero padded to Np = 64 ceil(N / 64)             PT [H][Np][Np]  P transposed (row = key)
+//   Pq / PT  P and its transpose, zero padded to Np = 64 ceil(N / 64), in OPERAND-BLOCKED order (p_block_offset below): the 8
+//            words a lane needs of a (16 rows x 32 columns) half tile are 16 contiguous bytes and a wave's 64 lanes are 1 KB
+//            contiguous.  (Row-major images made every 8-byte lane load of a wave a gather over 16 cache lines, 32 bytes used
+//            of each: dense loads took 14 % off both kernels in the round-4 timing ablation, profiles/r04_cfg5_ablation.txt.)
 // so that in the main kernels every LDS tile is a raw 8-byte copy of its global image (no ALU, no masks: the padding is
 // zero), a lane's probabilities of a tile are four ALIGNED 8-byte loads on both sides, and on the key side those raw words
 // ARE the bf16 A operand of dV = P^T . dO.  The padded row images also end the over-read of the 16-bit slab the second
@@ -21,6 +24,7 @@
 #include "mmx_common.h"
 #include "attention_args.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace mmx {
@@ -35,7 +39,8 @@ typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;
 
-int g_attn_bf16_v3 = 2;       // 0: off (second generation), 1: 4-wave workgroups, 2: 8-wave workgroups (4 waves / SIMD on both kernels)
+int g_attn_bf16_v3 = 2;       // 0: off (second generation), 1: 4-wave workgroups, 2: 8-wave workgroups (4 waves / SIMD on both kernels),
+                              // 3: query side as 2, key side fourth generation (5 key blocks per wave, 4-wave workgroups)
 
 struct V3Images {
     const bf16_t *Vb, *KbT, *QbT, *Pq, *PT;
@@ -95,7 +100,14 @@ __global__ __launch_bounds__(256) void prep_qkv_kernel(const AttnBwdArgs a, bf16
     }
 }
 
-// P slab [H][N][N] (16-bit elements, any alignment) -> Pq [H][Np][Np] (zero padded rows) and PT (its transpose)
+// Operand-blocked image of a matrix M [Np][Np] of head h: block (rb = row / 16, ct = column / 64, pp) holds, for lane = 16 g + i,
+// the 8 elements M[16 rb + i][64 ct + 16 (2 pp + hh) + 4 g + r] in the order (hh, r) -- lane (i, g)'s words of the two 16 x 16
+// sub-tiles of half pp, i.e. one bf16x8 MFMA operand.  Offsets in elements.
+__host__ __device__ __forceinline__ int64_t p_block_offset(int h, int rb, int ct, int Np) {
+    return ((static_cast<int64_t>(h) * (Np / 16) + rb) * (Np / kT) + ct) * (2 * 64 * 8);
+}
+
+// P slab [H][N][N] (16-bit elements, any alignment) -> Pq (blocked image of P, zero padded) and PT (blocked image of P^T)
 __global__ __launch_bounds__(256) void prep_p_kernel(const bf16_t* __restrict__ P, bf16_t* __restrict__ Pq, bf16_t* __restrict__ PT,
                                                      int N, int Np) {
     __shared__ bf16_t tile[kT][kT + 2];
@@ -106,12 +118,25 @@ __global__ __launch_bounds__(256) void prep_p_kernel(const bf16_t* __restrict__ 
         bf16_t v = 0;
         if (q0 + r < N && k0 + c < N) v = src[static_cast<int64_t>(q0 + r) * N + k0 + c];
         tile[r][c] = v;
-        Pq[(static_cast<int64_t>(h) * Np + q0 + r) * Np + k0 + c] = v;
     }
     __syncthreads();
-    for (int idx = tid; idx < kT * kT; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;                              // r: key within the tile, c: query within the tile
-        PT[(static_cast<int64_t>(h) * Np + k0 + r) * Np + q0 + c] = tile[c][r];
+    // 4 row blocks x 2 halves x 64 lanes = 512 operand words of 16 bytes per image: two per thread and image
+#pragma unroll
+    for (int e = tid; e < 512; e += 256) {
+        const int rbl = e >> 7, pp = (e >> 6) & 1, lane = e & 63, i = lane & 15, g = lane >> 4;
+        bf16_t wq[8], wt[8];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * rbl + i, col = 16 * (2 * pp + hh) + 4 * g + r;
+                wq[4 * hh + r] = tile[row][col];
+                wt[4 * hh + r] = tile[col][row];
+            }
+        const int64_t oq = p_block_offset(h, q0 / 16 + rbl, k0 / kT, Np) + (pp * 64 + lane) * 8;
+        const int64_t ot = p_block_offset(h, k0 / 16 + rbl, q0 / kT, Np) + (pp * 64 + lane) * 8;
+        *reinterpret_cast<u32x4v*>(Pq + oq) = *reinterpret_cast<const u32x4v*>(wq);
+        *reinterpret_cast<u32x4v*>(PT + ot) = *reinterpret_cast<const u32x4v*>(wt);
     }
 }
 
@@ -181,7 +206,7 @@ __device__ __forceinline__ void store_transposed_raw(bf16_t* tile, const u32x2v 
 // shared operands were 3.3 GB of L2 -> CU traffic per launch at one sample per workgroup (4.7 TB/s, i.e. what bounded it).
 // Loads run TWO tiles ahead of their use (two register sets, loop unrolled by two): with one set the fetch of tile t + 2 could
 // only be issued after the wait for tile t + 1, so at most one tile per workgroup was ever in flight.
-template <int NW, int NS>
+template <int NW, int NS, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_q_v3_kernel(const AttnBwdArgs a, const V3Images im) {
     constexpr int NB = kD / 16, R = 16 * NW, NOP = NW == 4 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -222,7 +247,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_q_v3_kernel
         delta[s] = q_ok ? part : 0.f;
         if (g == 0 && q_ok && b0 + s < a.B) a.delta[(static_cast<int64_t>(b) * a.H + h) * a.Nq + q] = delta[s];
     }
-    const bf16_t* prow = im.Pq + (static_cast<int64_t>(h) * im.Np + qc) * im.Np;     // zero padded beyond Nk
+    // this wave's row block of the blocked P image (key tile kt: + 1024 kt elements); a block past the image repeats the last one
+    const bf16_t* prow = im.Pq + p_block_offset(h, min(rt * (R / 16) + wave, im.Np / 16 - 1), 0, im.Np) + 8 * lane;
     const bf16_t* vimg = im.Vb + static_cast<int64_t>(h) * im.Np * kD;
     const bf16_t* kimg = im.KbT + static_cast<int64_t>(h) * kD * im.Np;
     const int ntiles = (a.Nk + kT - 1) / kT;
@@ -236,7 +262,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_q_v3_kernel
 
     // NW == 4: every thread stages a block of V and one of K; NW == 8: waves 0-3 stage V, waves 4-7 K (ONE block per set)
     RawBlock rs[2][NOP];
-    u32x2v ps[2][4];
+    u32x4v ps[2][2];                                                  // [set][half pp]: the words of sub-tiles 2 pp, 2 pp + 1
     auto fetch = [&](int kt, auto set) {
         constexpr int S = decltype(set)::value;
         if constexpr (NW == 4) {
@@ -257,15 +283,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_q_v3_kernel
             else store_transposed_raw(Kt + buf * kD * kLT, rs[S][0].raw, st);
         }
     };
-    auto p_issue = [&](u32x2v (&raw)[4], int kt) {
+    auto p_issue = [&](u32x4v (&raw)[2], int kt) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) raw[t] = *reinterpret_cast<const u32x2v*>(prow + kt * kT + 16 * t + 4 * g);
+        for (int pp = 0; pp < 2; ++pp) raw[pp] = *reinterpret_cast<const u32x4v*>(prow + kt * 1024 + pp * 512);
     };
     // tile kt: LDS buffer / register set / probability set kt & 1 (= PAR)
     auto body = [&](int kt, auto par) {
         constexpr int PAR = decltype(par)::value;
-        if (kt + 2 < ntiles) fetch(kt + 2, par);                       // this set's tile kt went to LDS one iteration ago
-        if (kt + 1 < ntiles) stage(1 - PAR, std::integral_constant<int, 1 - PAR>{});   // waits for THAT set only
+        if (ABL != 2 && ABL != 6 && kt + 2 < ntiles) fetch(kt + 2, par);   // this set's tile kt went to LDS one iteration ago
+        if (ABL != 2 && ABL != 6 && kt + 1 < ntiles) stage(1 - PAR, std::integral_constant<int, 1 - PAR>{});   // waits for THAT set only
         const bf16_t* Vcur = Vt + PAR * kT * kLR;
         const bf16_t* Kcur = Kt + PAR * kD * kLT + tlane;
 #pragma unroll
@@ -282,7 +308,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_q_v3_kernel
                         dpT[hh] = mfma16x16x32_bf16(op, dob[s][pr], dpT[hh]);
                     }
                 // dS[q][key] = P * (dP - delta) for keys 16 t + 4 g + r, t = 2 pp + hh (scale_mode Q_FIRST: no further factor)
-                dsb[s] = pack8(unpack4(ps[PAR][2 * pp]) * (dpT[0] - delta[s]), unpack4(ps[PAR][2 * pp + 1]) * (dpT[1] - delta[s]));
+                dsb[s] = pack8(unpack4(u32x2v{ps[PAR][pp][0], ps[PAR][pp][1]}) * (dpT[0] - delta[s]),
+                               unpack4(u32x2v{ps[PAR][pp][2], ps[PAR][pp][3]}) * (dpT[1] - delta[s]));
                 // the V operands are RE-READ from LDS for the next sample (16 registers the budget of 4 waves / SIMD does not
                 // have): the clobber keeps the compiler from carrying them over
                 asm volatile("" ::: "memory");
@@ -326,7 +353,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_q_v3_kernel
 // ===================================================================================================== key side
 // per 16 NW keys: dP recomputed, dV = P^T . dO, dK = dS^T . Q (DKV), and the row-relevancy partial of this head
 // rel_part[b][h][key] = sum_q rel_v[b][q] * clamp(dP * P, 0)[q][key]
-template <int NW, bool DKV>
+template <int NW, bool DKV, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kernel(const AttnBwdArgs a, const V3Images im) {
     constexpr int NB = kD / 16, R = 16 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -346,7 +373,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
     const bool key_ok = key < a.Nk;
     const int keyc = min(key, a.Nk - 1);
     const int64_t head = static_cast<int64_t>(b) * a.H + h;
-    const bf16_t* pcol = im.PT + (static_cast<int64_t>(h) * im.Np + keyc) * im.Np;   // this key's column of P: queries contiguous
+    // this wave's key block of the blocked P^T image (query tile qt: + 1024 qt elements); a block past the image repeats the last
+    const bf16_t* pcol = im.PT + p_block_offset(h, min(kw / 16, im.Np / 16 - 1), 0, im.Np) + 8 * lane;
     const bf16_t* qimg = im.QbT + static_cast<int64_t>(h) * kD * im.Np;
     const bf16_t* dobase = reinterpret_cast<const bf16_t*>(a.dout) + b * a.os.sb + h * a.os.sh;
 
@@ -398,10 +426,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
             vl[buf * kT + tid] = vlreg;                                // (rows past Nq: p is zero there)
         }
     };
-    u32x2v p_cur[4], p_nxt[4];
-    auto p_issue = [&](u32x2v (&raw)[4], int qt) {
+    u32x4v p_cur[2], p_nxt[2];                                        // [half pp]: the words of sub-tiles 2 pp, 2 pp + 1
+    auto p_issue = [&](u32x4v (&raw)[2], int qt) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) raw[t] = *reinterpret_cast<const u32x2v*>(pcol + qt * kT + 16 * t + 4 * g);
+        for (int pp = 0; pp < 2; ++pp) raw[pp] = *reinterpret_cast<const u32x4v*>(pcol + qt * 1024 + pp * 512);
     };
     fetch(0);
     stage(0);
@@ -411,9 +439,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
     for (int qt = 0; qt < ntiles; ++qt) {
         const int cur = qt & 1;
         if (qt + 1 < ntiles) {
-            stage(cur ^ 1);
+            if (ABL != 2 && ABL != 6) stage(cur ^ 1);
             p_issue(p_nxt, qt + 1);
-            if (qt + 2 < ntiles) fetch(qt + 2);
+            if (ABL != 2 && ABL != 6 && qt + 2 < ntiles) fetch(qt + 2);
         }
         const bf16_t* dOrc = dOr + cur * kT * kLR;
         const bf16_t* dOtc = dOt + cur * kD * kLT + tlane;
@@ -432,10 +460,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int t = 2 * pp + hh;
-                const f32x4 p = unpack4(p_cur[t]);
+                const f32x4 p = unpack4(u32x2v{p_cur[pp][2 * hh], p_cur[pp][2 * hh + 1]});
                 const f32x4 vv = *reinterpret_cast<const f32x4*>(vl + cur * kT + 16 * t + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) racc += vv[r] * relu_nan(p[r] * dp[hh][r]);
+                for (int r = 0; r < 4; ++r) {
+                    if (ABL == 3 || ABL == 7) racc += dp[hh][r];
+                    else racc += vv[r] * relu_nan(p[r] * dp[hh][r]);
+                }
                 if constexpr (DKV) {
                     const f32x4 dlv = *reinterpret_cast<const f32x4*>(dl + cur * kT + 16 * t + 4 * g);
                     ds[hh] = p * (dp[hh] - dlv);
@@ -443,8 +474,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
             }
             if constexpr (DKV) {
                 // the raw probability words of the two sub-tiles ARE the bf16 A operand of dV = P^T . dO
-                const bf16x8 p_op = as_bf16x8(u32x4v{p_cur[2 * pp][0], p_cur[2 * pp][1], p_cur[2 * pp + 1][0], p_cur[2 * pp + 1][1]});
-                const bf16x8 ds_op = pack8(ds[0], ds[1]);
+                const bf16x8 p_op = as_bf16x8(p_cur[pp]);
+                const bf16x8 ds_op = ABL == 4 || ABL == 7 ? p_op : pack8(ds[0], ds[1]);
 #pragma unroll
                 for (int dt = 0; dt < NB; ++dt) {
                     vacc[dt] = mfma16x16x32_bf16(p_op, transposed_operand(dOtc, dt, pp), vacc[dt]);
@@ -458,7 +489,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
         }
         if (qt + 1 < ntiles) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) p_cur[t] = p_nxt[t];
+            for (int t = 0; t < 2; ++t) p_cur[t] = p_nxt[t];
         }
         lds_barrier();
     }
@@ -492,6 +523,205 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
     }
 }
 
+// ===================================================================================================== key side, fourth generation
+// Round 4.  The counters of the third-generation pair (profiles/r04_cfg5_probe.txt) say no pipe bounds it -- matrix pipe 19 %, VALU
+// 49 %, waves parked 50 % -- and taking 10-16 % of its work away did not move the time: every 64-row query tile is a global ->
+// register -> LDS staging step behind two barriers with only 24 MFMAs per wave between them, repeated by the five workgroups that
+// share a (sample, head).  Here a wave owns KB = 5 blocks of 16 keys (a workgroup of 4 waves: 320 keys, two per head at 577 tokens):
+// the staged dO / dO^T / Q^T tile and its LDS operand reads are used for FIVE key blocks -- 120 MFMAs per wave between two barriers
+// -- and each half tile's shared operands (dO rows, dO^T, Q^T: 12 operand registers) are read from LDS once, not once per key block.
+// The dK / dV accumulators (KB x 8 x f32x4 = 160 registers) and two tiles of probability words (80) put a wave near 400 registers: one
+// wave per SIMD, which the 5 x longer barrier interval is meant to pay for.  Same arithmetic, same orientation and accumulator layouts
+// as the third generation (results equal up to the fp32 summation order of the relevancy partial, which is unchanged per key).
+template <int KB, bool DKV, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void attn_bwd_kv_v4_kernel(const AttnBwdArgs a, const V3Images im) {
+    constexpr int NB = kD / 16, NW = 4, R = 16 * NW * KB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* dOr = reinterpret_cast<bf16_t*>(smem_raw);                // [2][kT][kLR]   dO rows (row-major)
+    bf16_t* dOt = dOr + 2 * kT * kLR;                                 // [2][kD][kLT]   dO transposed
+    bf16_t* Qt = dOt + 2 * kD * kLT;                                  // [2][kD][kLT]   (scale q) transposed
+    float* dl = reinterpret_cast<float*>(Qt + 2 * kD * kLT);          // [2][kT]        delta of the staged query rows
+    float* vl = dl + 2 * kT;                                          // [2][kT]        rel_v of the staged query rows
+    bf16_t* Vl = reinterpret_cast<bf16_t*>(vl + 2 * kT);              // [R][kLR]       V rows of the workgroup's keys, resident
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int st = tid;
+    const int nkt = (a.Nk + R - 1) / R;
+    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int b = (wg / nkt) % a.B, h = wg / (nkt * a.B);          // key chunk fastest, then the sample, the head slowest
+    const int k0 = (wg % nkt) * R;
+    const int kw = k0 + wave * 16 * KB;                               // first key of this wave; block kb: keys kw + 16 kb + i
+    const int64_t head = static_cast<int64_t>(b) * a.H + h;
+    // the launcher takes this kernel only when R divides Np: every key / query row touched exists in the padded images (rows past
+    // N are zero), so no load below is clamped or masked
+    const bf16_t* pcol0 = im.PT + p_block_offset(h, kw / 16, 0, im.Np) + 8 * lane;    // key block kb: + kb (Np / 64) 1024 elements
+    const bf16_t* qimg = im.QbT + static_cast<int64_t>(h) * kD * im.Np;
+    const bf16_t* dobase = reinterpret_cast<const bf16_t*>(a.dout) + b * a.os.sb + h * a.os.sh;
+
+    {   // V rows of the R keys -> LDS (B operand of dP = dO . V^T; kept out of the register file: KB x 8 registers)
+        const bf16_t* vsrc = im.Vb + (static_cast<int64_t>(h) * im.Np + k0) * kD;
+#pragma unroll
+        for (int e = 0; e < R * kD / 8 / 256; ++e) {
+            const int chunk = tid + 256 * e, row = chunk >> 3, c8 = chunk & 7;
+            *reinterpret_cast<u32x4v*>(Vl + row * kLR + 8 * c8) = *reinterpret_cast<const u32x4v*>(vsrc + row * kD + 8 * c8);
+        }
+    }
+    const bf16_t* vlane = Vl + (wave * 16 * KB + i) * kLR + 8 * g;    // block kb, half pr: + 16 kb kLR + 32 pr
+
+    f32x4 kacc[KB][NB], vacc[KB][NB];
+    float racc[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        racc[kb] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < NB; ++dt) kacc[kb][dt] = vacc[kb][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int ntiles = (a.Nq + kT - 1) / kT;
+    const int tlane = transposed_lane_base(i, g);
+    RawBlock doreg, qreg;
+    int do_row0 = 0;
+    float dlreg = 0.f, vlreg = 0.f;
+    auto fetch = [&](int qt) {                                        // every thread: one 4 x 4 block of dO and one of Q^T
+        const int r4 = 4 * (st >> 4), c = 4 * (st & 15);
+        do_row0 = qt * kT;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            doreg.raw[e] = *reinterpret_cast<const u32x2v*>(dobase + static_cast<int64_t>(min(qt * kT + r4 + e, a.Nq - 1)) * a.os.sn + c);
+        if constexpr (DKV) fetch_transposed(qreg, qimg, im.Np, qt * kT, st);
+        const int row = min(qt * kT + lane, a.Nq - 1);               // (every wave loads them: no branch around a load)
+        if constexpr (DKV) dlreg = a.delta[head * a.Nq + row];
+        vlreg = a.rel_v[static_cast<int64_t>(b) * a.Nq + row];
+    };
+    auto stage = [&](int buf) {
+        const int r4 = 4 * (st >> 4);
+        u32x2v rows[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rows[e] = do_row0 + r4 + e < a.Nq ? doreg.raw[e] : u32x2v{0u, 0u};
+        store_row_major(dOr + buf * kT * kLR, rows, st);
+        if constexpr (DKV) {
+            u32x2v cols[4];
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) cols[dd] = column_of(rows, dd);
+            store_transposed_raw(dOt + buf * kD * kLT, cols, st);
+            store_transposed_raw(Qt + buf * kD * kLT, qreg.raw, st);
+        }
+        if (tid < kT) {
+            if constexpr (DKV) dl[buf * kT + tid] = dlreg;
+            vl[buf * kT + tid] = vlreg;                                // (rows past Nq: p is zero there)
+        }
+    };
+    // probability words, prefetched one HALF tile (32 query rows) ahead: ps[pp][kb][hh] = rows 16 (2 pp + hh) + 4 g .. + 3 of key i
+    // (one 16-byte word per key block: lane (i, g)'s A operand of dV = P^T . dO, straight from the blocked image)
+    u32x4v ps[2][KB];
+    auto p_issue = [&](u32x4v (&raw)[KB], int half) {                // half = 2 qt + pp
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) raw[kb] = *reinterpret_cast<const u32x4v*>(pcol0 + kb * (im.Np / kT) * 1024 + half * 512);
+    };
+    fetch(0);
+    stage(0);
+    p_issue(ps[0], 0);
+    if (ntiles > 1) fetch(1);
+    __syncthreads();
+    for (int qt = 0; qt < ntiles; ++qt) {
+        const int cur = qt & 1;
+        if (ABL != 2 && ABL != 6 && qt + 1 < ntiles) {
+            stage(cur ^ 1);
+            if (qt + 2 < ntiles) fetch(qt + 2);
+        }
+        const bf16_t* dOrc = dOr + cur * kT * kLR;
+        const bf16_t* dOtc = dOt + cur * kD * kLT + tlane;
+        const bf16_t* Qtc = Qt + cur * kD * kLT + tlane;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {                               // query rows 32 pp .. + 31 of the tile
+            if (pp == 0) p_issue(ps[1], 2 * qt + 1);                   // (the second half always exists in the padded image)
+            else if (qt + 1 < ntiles) p_issue(ps[0], 2 * qt + 2);
+            // this half's shared operands, read from LDS ONCE for all KB key blocks
+            bf16x8 dor[2][kD / 32], dot[NB], qtt[NB];
+            f32x4 vv[2], dlv[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                for (int pr = 0; pr < kD / 32; ++pr)
+                    dor[hh][pr] = *reinterpret_cast<const bf16x8*>(dOrc + (16 * (2 * pp + hh) + i) * kLR + 32 * pr + 8 * g);
+                vv[hh] = *reinterpret_cast<const f32x4*>(vl + cur * kT + 16 * (2 * pp + hh) + 4 * g);
+                if constexpr (DKV) dlv[hh] = *reinterpret_cast<const f32x4*>(dl + cur * kT + 16 * (2 * pp + hh) + 4 * g);
+            }
+            if constexpr (DKV) {
+#pragma unroll
+                for (int dt = 0; dt < NB; ++dt) {
+                    dot[dt] = transposed_operand(dOtc, dt, pp);
+                    qtt[dt] = transposed_operand(Qtc, dt, pp);
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                f32x4 dp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // dp[hh][r] = dP[16 t + 4 g + r][key i of block kb]
+#pragma unroll
+                for (int pr = 0; pr < kD / 32; ++pr) {
+                    const bf16x8 vop = *reinterpret_cast<const bf16x8*>(vlane + 16 * kb * kLR + 32 * pr);
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) dp[hh] = mfma16x16x32_bf16(dor[hh][pr], vop, dp[hh]);
+                }
+                f32x4 ds[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const f32x4 p = unpack4(u32x2v{ps[pp][kb][2 * hh], ps[pp][kb][2 * hh + 1]});
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (ABL == 3 || ABL == 7) racc[kb] += dp[hh][r];
+                        else racc[kb] += vv[hh][r] * relu_nan(p[r] * dp[hh][r]);
+                    }
+                    if constexpr (DKV) ds[hh] = p * (dp[hh] - dlv[hh]);
+                }
+                if constexpr (DKV) {
+                    const bf16x8 p_op = as_bf16x8(ps[pp][kb]);
+                    const bf16x8 ds_op = ABL == 4 || ABL == 7 ? p_op : pack8(ds[0], ds[1]);
+#pragma unroll
+                    for (int dt = 0; dt < NB; ++dt) {
+                        vacc[kb][dt] = mfma16x16x32_bf16(p_op, dot[dt], vacc[kb][dt]);
+                        kacc[kb][dt] = mfma16x16x32_bf16(ds_op, qtt[dt], kacc[kb][dt]);
+                    }
+                }
+            }
+        }
+        lds_barrier();
+    }
+    const int64_t dk0 = b * a.dks.sb + h * a.dks.sh, dv0 = b * a.dvs.sb + h * a.dvs.sh;
+    const bool odd = i & 1;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int kbase = kw + 16 * kb;
+        float rs = racc[kb];
+        rs += __shfl_xor(rs, 16);
+        rs += __shfl_xor(rs, 32);                                  // the 4 row groups of the tile rows: all queries of key i
+        if (g == 0 && kbase + i < a.Nk) a.rel_part[head * a.Nk + kbase + i] = rs;
+        if constexpr (DKV) {
+            // accumulators: lane (d = 16 dt + i), rows key = kbase + 4 g + r; lanes i / i ^ 1 pair up so that every store is 4 bytes
+#pragma unroll
+            for (int dt = 0; dt < NB; ++dt) {
+                const int d = 16 * dt + i;
+#pragma unroll
+                for (int rp = 0; rp < 2; ++rp) {
+                    const int r = 2 * rp + (odd ? 1 : 0);
+                    const int j = kbase + 4 * g + r, c0 = d - (odd ? 1 : 0);
+                    const float km = odd ? kacc[kb][dt][2 * rp + 1] : kacc[kb][dt][2 * rp];
+                    const float vm = odd ? vacc[kb][dt][2 * rp + 1] : vacc[kb][dt][2 * rp];
+                    const float ko = __int_as_float(__builtin_amdgcn_update_dpp(
+                        0, __float_as_int(odd ? kacc[kb][dt][2 * rp] : kacc[kb][dt][2 * rp + 1]), 0xB1, 0xF, 0xF, false));
+                    const float vo = __int_as_float(__builtin_amdgcn_update_dpp(
+                        0, __float_as_int(odd ? vacc[kb][dt][2 * rp] : vacc[kb][dt][2 * rp + 1]), 0xB1, 0xF, 0xF, false));
+                    if (j < a.Nk) {
+                        bf16_t* dk = reinterpret_cast<bf16_t*>(a.dk) + dk0 + static_cast<int64_t>(j) * a.dks.sn + c0;
+                        bf16_t* dv = reinterpret_cast<bf16_t*>(a.dv) + dv0 + static_cast<int64_t>(j) * a.dvs.sn + c0;
+                        *reinterpret_cast<unsigned*>(dk) = odd ? pk2(ko, km) : pk2(km, ko);
+                        *reinterpret_cast<unsigned*>(dv) = odd ? pk2(vo, vm) : pk2(vm, vo);
+                    }
+                }
+            }
+        }
+    }
+}
+
 constexpr size_t kQLds = sizeof(bf16_t) * (2 * kT * kLR + 2 * kD * kLT);
 constexpr size_t kKvLds = sizeof(bf16_t) * (2 * kT * kLR + 4 * kD * kLT) + sizeof(float) * 4 * kT;
 
@@ -508,6 +738,36 @@ int launch_v3(K kern, const AttnBwdArgs& a, const V3Images& im, dim3 grid, int t
     return MMX_OK;
 }
 
+constexpr int kV4KB = 5;
+constexpr size_t kKv4Lds = kKvLds + sizeof(bf16_t) * 16 * 4 * kV4KB * kLR;
+template <int NW>
+int run_v3(const AttnBwdArgs& a, const V3Images& im, hipStream_t s);
+int run_v4(const AttnBwdArgs& a, const V3Images& im, hipStream_t s) {
+    if (im.Np % (16 * 4 * kV4KB) != 0) return run_v3<8>(a, im, s);     // the key chunks must tile the padded images
+    // query side: third generation (8-wave workgroups, two samples each); key side: fourth generation (5 key blocks per wave)
+    constexpr int RQ = 16 * 8, NS = 2, RK = 16 * 4 * kV4KB;
+    dim3 gq(((a.Nq + RQ - 1) / RQ) * a.H * ((a.B + NS - 1) / NS)), gk(((a.Nk + RK - 1) / RK) * a.H * a.B);
+    int rc = MMX_OK;
+    if (a.need_dqkv) {
+        rc = launch_v3(attn_bwd_q_v3_kernel<8, NS>, a, im, gq, 64 * 8, kQLds, s, "attn_bwd_q_v3_kernel");
+        if (rc) return rc;
+#ifdef MMX_ATTN_ABLATE
+        static const int abl = getenv("MMX_ATTN_ABLATE") ? atoi(getenv("MMX_ATTN_ABLATE")) : 0;
+        auto kern = abl == 1 ? attn_bwd_kv_v4_kernel<kV4KB, true, 1> : abl == 2 ? attn_bwd_kv_v4_kernel<kV4KB, true, 2>
+                  : abl == 3 ? attn_bwd_kv_v4_kernel<kV4KB, true, 3> : abl == 4 ? attn_bwd_kv_v4_kernel<kV4KB, true, 4>
+                  : abl == 6 ? attn_bwd_kv_v4_kernel<kV4KB, true, 6> : abl == 7 ? attn_bwd_kv_v4_kernel<kV4KB, true, 7>
+                                                                                 : attn_bwd_kv_v4_kernel<kV4KB, true, 0>;
+        rc = launch_v3(kern, a, im, gk, 256, kKv4Lds, s, "attn_bwd_kv_v4_kernel");
+#else
+        rc = launch_v3(attn_bwd_kv_v4_kernel<kV4KB, true>, a, im, gk, 256, kKv4Lds, s, "attn_bwd_kv_v4_kernel");
+#endif
+    } else {
+        rc = launch_v3(attn_bwd_kv_v4_kernel<kV4KB, false>, a, im, gk, 256, kKv4Lds, s, "attn_bwd_kv_v4_kernel<rel only>");
+    }
+    if (rc) return rc;
+    return rel_row_update(a.rel_v, a.rel_part, a.rel_out, a.B, a.H, a.Nk, 1.0f / a.H, s);
+}
+
 template <int NW>
 int run_v3(const AttnBwdArgs& a, const V3Images& im, hipStream_t s) {
     constexpr int R = 16 * NW;
@@ -515,9 +775,22 @@ int run_v3(const AttnBwdArgs& a, const V3Images& im, hipStream_t s) {
     dim3 gq(((a.Nq + R - 1) / R) * a.H * ((a.B + NS - 1) / NS)), gk(((a.Nk + R - 1) / R) * a.H * a.B);
     int rc = MMX_OK;
     if (a.need_dqkv) {
+#ifdef MMX_ATTN_ABLATE
+        static const int abl = getenv("MMX_ATTN_ABLATE") ? atoi(getenv("MMX_ATTN_ABLATE")) : 0;
+        auto qk = abl == 1 ? attn_bwd_q_v3_kernel<NW, NS, 1> : abl == 2 ? attn_bwd_q_v3_kernel<NW, NS, 2>
+                : abl == 6 ? attn_bwd_q_v3_kernel<NW, NS, 6> : attn_bwd_q_v3_kernel<NW, NS, 0>;
+        rc = launch_v3(qk, a, im, gq, 64 * NW, kQLds, s, "attn_bwd_q_v3_kernel");
+        if (rc) return rc;
+        auto kern = abl == 1 ? attn_bwd_kv_v3_kernel<NW, true, 1> : abl == 2 ? attn_bwd_kv_v3_kernel<NW, true, 2>
+                  : abl == 3 ? attn_bwd_kv_v3_kernel<NW, true, 3> : abl == 4 ? attn_bwd_kv_v3_kernel<NW, true, 4>
+                  : abl == 6 ? attn_bwd_kv_v3_kernel<NW, true, 6> : abl == 7 ? attn_bwd_kv_v3_kernel<NW, true, 7>
+                                                                                 : attn_bwd_kv_v3_kernel<NW, true, 0>;
+        rc = launch_v3(kern, a, im, gk, 64 * NW, kKvLds, s, "attn_bwd_kv_v3_kernel");
+#else
         rc = launch_v3(attn_bwd_q_v3_kernel<NW, NS>, a, im, gq, 64 * NW, kQLds, s, "attn_bwd_q_v3_kernel");
         if (rc) return rc;
         rc = launch_v3(attn_bwd_kv_v3_kernel<NW, true>, a, im, gk, 64 * NW, kKvLds, s, "attn_bwd_kv_v3_kernel");
+#endif
     } else {
         rc = launch_v3(attn_bwd_kv_v3_kernel<NW, false>, a, im, gk, 64 * NW, kKvLds, s, "attn_bwd_kv_v3_kernel<rel only>");
     }
@@ -568,7 +841,7 @@ int attn_bwd_bf16_v3_try(const AttnBwdArgs& a, void* prep, size_t prep_bytes, hi
     e = hipGetLastError();
     if (e != hipSuccess) { *rc_out = hip_fail(e, "prep_p_kernel"); return 1; }
     const V3Images im{Vb, KbT, QbT, Pq, PT, Np};
-    *rc_out = g_attn_bf16_v3 == 2 ? run_v3<8>(a, im, s) : run_v3<4>(a, im, s);
+    *rc_out = g_attn_bf16_v3 == 3 ? run_v4(a, im, s) : g_attn_bf16_v3 == 2 ? run_v3<8>(a, im, s) : run_v3<4>(a, im, s);
     return 1;
 }
 
