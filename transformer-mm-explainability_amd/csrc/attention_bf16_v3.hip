@@ -10,7 +10,7 @@
 //   * the probabilities were 12-byte unaligned loads + funnel shifts (query side) and SIXTEEN 2-byte loads with a clamped
 //     64-bit address each (key side: a lane owns a key, its 16 query rows are a strided column of the slab).
 // Here two small PREP kernels run once per call on the shared operands (a few MB, L2-resident afterwards):
-//   Vb  [H][Np][64]  V rows, bf16                     KbT / QbT [H][64][Np]  K / (scale q) transposed, bf16
+//   Vb  [H][Np][64]  V rows, bf16                     KbT / QbT  K / (scale q) transposed, bf16, staging-blocked (prep_qkv_kernel)
 //   Pq / PT  P and its transpose, zero padded to Np = 64 ceil(N / 64), in OPERAND-BLOCKED order (p_block_offset below): the 8
 //            words a lane needs of a (16 rows x 32 columns) half tile are 16 contiguous bytes and a wave's 64 lanes are 1 KB
 //            contiguous.  (Row-major images made every 8-byte lane load of a wave a gather over 16 cache lines, 32 bytes used
@@ -94,9 +94,12 @@ __global__ __launch_bounds__(256) void prep_qkv_kernel(const AttnBwdArgs a, bf16
             *reinterpret_cast<u32x2v*>(Vb + (static_cast<int64_t>(h) * Np + row0 + r4 + e) * kD + c) = rows[e];
     } else {
         bf16_t* out = which == 1 ? KbT : QbT;
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd)
-            *reinterpret_cast<u32x2v*>(out + (static_cast<int64_t>(h) * kD + c + dd) * Np + row0 + r4) = column_of(rows, dd);
+        // transposed images, staging-blocked: the 4 (d) x 4 (rows) block a staging thread moves per tile is 32 contiguous bytes
+        // at [h][tile][thread][dd][4 rows] -- a wave's fetch is 2 KB contiguous (as [d][row] it was a 16-line gather per load)
+        u32x4v* dst = reinterpret_cast<u32x4v*>(out + ((static_cast<int64_t>(h) * (Np / kT) + blockIdx.x) * 256 + tid) * 16);
+        const u32x2v c0 = column_of(rows, 0), c1 = column_of(rows, 1), c2 = column_of(rows, 2), c3 = column_of(rows, 3);
+        dst[0] = u32x4v{c0[0], c0[1], c1[0], c1[1]};
+        dst[1] = u32x4v{c2[0], c2[1], c3[0], c3[1]};
     }
 }
 
@@ -174,22 +177,17 @@ __device__ __forceinline__ void store_row_major(bf16_t* tile, const u32x2v (&row
 #pragma unroll
     for (int e = 0; e < 4; ++e) *reinterpret_cast<u32x2v*>(tile + (r4 + e) * kLR + c) = rows[e];
 }
-// the same block of a TRANSPOSED image [d][row] (row stride Np): raw[dd] = rows row0 + r4 .. + 3 of d = c + dd.  The image
-// pointer is wave-uniform: written as (uniform base of row d) + (ONE 32-bit lane offset) the four loads share a single address
-// VGPR (scalar-base addressing); as four 64-bit lane pointers they cost 8 registers that the kernel spilled inside the loop.
-// The uniform part is a 32-bit byte OFFSET pinned to an SGPR (readfirstlane) and added to the image pointer by ordinary pointer
-// arithmetic.  Round 3 rebuilt the POINTER from two readfirstlane halves instead: an integer -> pointer cast loses the global
-// address space, hipcc emitted FLAT loads for three of the four rows and -- flat and global loads return out of order -- put an
-// s_waitcnt vmcnt(0) in front of each: three serialised memory round trips per tile on the staging waves of both kernels
-// (found in round 4 in the ISA, tools/isa_mix.py; 1190 -> 1121 us per layer pair, profiles/r04_cfg5_probe.txt).
+// the same block of a TRANSPOSED operand: raw[dd] = rows row0 + r4 .. + 3 of d = c + dd, from the staging-blocked image
+// [tile][thread][dd][4 rows] of one head (prep_qkv_kernel): 32 contiguous bytes per thread.  (Rounds 3-4 kept a [d][row] image:
+// four 8-byte loads per thread, each a 16-line gather per wave -- and, until round 4, FLAT loads with an s_waitcnt vmcnt(0) in
+// front of each, because the wave-uniform base was rebuilt through an integer -> pointer cast; profiles/r04_cfg5_probe.txt.)
 __device__ __forceinline__ void fetch_transposed(RawBlock& blk, const bf16_t* imgT, int Np, int row0, int st) {
-    const unsigned voff = (4u * (st & 15) * static_cast<unsigned>(Np) + 4u * (st >> 4)) * 2u;      // bytes, per lane
-    const char* img = reinterpret_cast<const char*>(imgT);
-#pragma unroll
-    for (int dd = 0; dd < 4; ++dd) {
-        const unsigned soff = static_cast<unsigned>(__builtin_amdgcn_readfirstlane((row0 + dd * Np) * 2));   // bytes, wave-uniform
-        blk.raw[dd] = *reinterpret_cast<const u32x2v*>(img + soff + voff);
-    }
+    const u32x4v* src = reinterpret_cast<const u32x4v*>(imgT + (static_cast<int64_t>(row0 / kT) * 256 + st) * 16);
+    const u32x4v lo = src[0], hi = src[1];
+    blk.raw[0] = u32x2v{lo[0], lo[1]};
+    blk.raw[1] = u32x2v{lo[2], lo[3]};
+    blk.raw[2] = u32x2v{hi[0], hi[1]};
+    blk.raw[3] = u32x2v{hi[2], hi[3]};
 }
 __device__ __forceinline__ void store_transposed_raw(bf16_t* tile, const u32x2v (&cols)[4], int st) {
     const int c = 4 * (st & 15);
