@@ -103,7 +103,7 @@ counters3)       # memory-side counters of the cfg-5 pair (vector L1 / texture a
   done
   ;;
 ablate)          # timing ablations of the cfg-5 pair (library built with -DMMX_ATTN_ABLATE; results of the ablated kernels are garbage)
-  for A in 0 1 2 3 4 6 7; do
+  for A in ${ABLS:-0 2 3 4 7}; do
     MMX_ATTN_ABLATE=$A timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/abl_$A -o a -- python tools/probe_attn_v3.py 128 2,3 > $OUT/abl_$A.txt 2> $OUT/abl_$A.log
     echo "== ablation $A" | tee -a $OUT/ablate.txt
     grep -v amdgpu.ids $OUT/abl_$A.txt | tee -a $OUT/ablate.txt

@@ -40,7 +40,7 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;
 
 int g_attn_bf16_v3 = 2;       // 0: off (second generation), 1: 4-wave workgroups, 2: 8-wave workgroups (4 waves / SIMD on both kernels),
-                              // 3: query side as 2, key side fourth generation (5 key blocks per wave, 4-wave workgroups)
+                              // 3: query side as 2, key side fourth generation (KB key blocks per wave, 4-wave workgroups; experiment)
 
 struct V3Images {
     const bf16_t *Vb, *KbT, *QbT, *Pq, *PT;
@@ -163,6 +163,17 @@ __device__ __forceinline__ bf16x8 transposed_operand(const bf16_t* tile_lane, in
     const u32x2v lo = *reinterpret_cast<const u32x2v*>(tile_lane + 16 * dt * kLT + 16 * (dt ^ (2 * p)));
     const u32x2v hi = *reinterpret_cast<const u32x2v*>(tile_lane + 16 * dt * kLT + 16 * (dt ^ (2 * p + 1)));
     return as_bf16x8(u32x4v{lo[0], lo[1], hi[0], hi[1]});
+}
+
+// The same operand with its two 8-byte pieces in ADDRESS order (one ds_read2_b64, no register shuffle): for odd dt the swizzle puts
+// the rows of sub-tile 2 p + 1 below those of sub-tile 2 p, so the k-slots come out as (hi, lo) -- the OTHER operand of that MFMA must
+// then be given with its halves exchanged too.  (transposed_operand makes the compiler swap the halves with four v_mov per operand:
+// 32 of the ~180 VALU instructions per tile of the key-side kernel.)
+__device__ __forceinline__ bf16x8 transposed_operand_sorted(const bf16_t* tile_lane, int dt, int p) {
+    const int o0 = 16 * (dt ^ (2 * p)), o1 = 16 * (dt ^ (2 * p + 1));
+    const u32x2v a = *reinterpret_cast<const u32x2v*>(tile_lane + 16 * dt * kLT + (o0 < o1 ? o0 : o1));
+    const u32x2v b = *reinterpret_cast<const u32x2v*>(tile_lane + 16 * dt * kLT + (o0 < o1 ? o1 : o0));
+    return as_bf16x8(u32x4v{a[0], a[1], b[0], b[1]});
 }
 
 // a [64 x 64] bf16 tile of a row-major image (row stride `sn` elements): thread st (0..255) owns a 4 x 4 block
@@ -472,12 +483,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
             }
             if constexpr (DKV) {
                 // the raw probability words of the two sub-tiles ARE the bf16 A operand of dV = P^T . dO
+                // (odd dt: the transposed operands arrive with their k-slot halves exchanged -- transposed_operand_sorted -- and
+                // meet the exchanged copies of the A operands: 4 moves + 4 conversions per half tile instead of 16 moves)
                 const bf16x8 p_op = as_bf16x8(p_cur[pp]);
+                const bf16x8 p_sw = as_bf16x8(u32x4v{p_cur[pp][2], p_cur[pp][3], p_cur[pp][0], p_cur[pp][1]});
                 const bf16x8 ds_op = ABL == 4 || ABL == 7 ? p_op : pack8(ds[0], ds[1]);
+                const bf16x8 ds_sw = ABL == 4 || ABL == 7 ? p_sw : pack8(ds[1], ds[0]);
 #pragma unroll
                 for (int dt = 0; dt < NB; ++dt) {
-                    vacc[dt] = mfma16x16x32_bf16(p_op, transposed_operand(dOtc, dt, pp), vacc[dt]);
-                    kacc[dt] = mfma16x16x32_bf16(ds_op, transposed_operand(Qtc, dt, pp), kacc[dt]);
+                    vacc[dt] = mfma16x16x32_bf16(dt & 1 ? p_sw : p_op, transposed_operand_sorted(dOtc, dt, pp), vacc[dt]);
+                    kacc[dt] = mfma16x16x32_bf16(dt & 1 ? ds_sw : ds_op, transposed_operand_sorted(Qtc, dt, pp), kacc[dt]);
                 }
             }
             // pin this half's share of the relevancy sum here: left alone the compiler sinks all 16 multiply / clamp / fma
@@ -522,17 +537,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
 }
 
 // ===================================================================================================== key side, fourth generation
-// Round 4.  The counters of the third-generation pair (profiles/r04_cfg5_probe.txt) say no pipe bounds it -- matrix pipe 19 %, VALU
-// 49 %, waves parked 50 % -- and taking 10-16 % of its work away did not move the time: every 64-row query tile is a global ->
-// register -> LDS staging step behind two barriers with only 24 MFMAs per wave between them, repeated by the five workgroups that
-// share a (sample, head).  Here a wave owns KB = 5 blocks of 16 keys (a workgroup of 4 waves: 320 keys, two per head at 577 tokens):
-// the staged dO / dO^T / Q^T tile and its LDS operand reads are used for FIVE key blocks -- 120 MFMAs per wave between two barriers
-// -- and each half tile's shared operands (dO rows, dO^T, Q^T: 12 operand registers) are read from LDS once, not once per key block.
-// The dK / dV accumulators (KB x 8 x f32x4 = 160 registers) and two tiles of probability words (80) put a wave near 400 registers: one
-// wave per SIMD, which the 5 x longer barrier interval is meant to pay for.  Same arithmetic, same orientation and accumulator layouts
-// as the third generation (results equal up to the fp32 summation order of the relevancy partial, which is unchanged per key).
+// Round 4 experiment, kept selectable (attn_bf16_v3 = 3) and tested, NOT the default.  A wave owns KB blocks of 16 keys: the staged
+// dO / dO^T / Q^T tile and its LDS operand reads (dO rows, dO^T, Q^T: read once per half tile) serve KB key blocks, so a tile carries
+// KB x 24 MFMAs per wave between two barriers instead of 24.  Measured at the cfg-5 shape (16 heads x 577 tokens, B = 128; pair time
+// per layer with the third-generation query side, the third-generation key side at 855 us):
+//   KB = 5, 4 waves, V operands in LDS, accumulators in AGPRs (404 registers, ONE wave / SIMD): 980 us.  The staging is amortised
+//           (ablation: -70 us without it, third generation -199 us) but every LDS / MFMA -> VALU latency is exposed, and the dP
+//           results take a v_accvgpr_read each on their way to the VALU (the compiler keeps every MFMA result in AGPRs once the
+//           kernel needs more than 256 registers).
+//   KB = 2, 4 waves, V operands in registers (230 registers, TWO waves / SIMD; the instantiated one): 882 us.  Half the LDS operand
+//           reads and shared-operand VALU work per MFMA, half the waves to hide latency with: a wash.
+// Same arithmetic, orientation and accumulator layouts as the third generation; taken only when its key chunks tile the padded
+// images (Np % (64 KB) == 0), else the launcher falls back.  profiles/r04_cfg5_ablation.txt, r04_cfg5_probe.txt.
 template <int KB, bool DKV, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void attn_bwd_kv_v4_kernel(const AttnBwdArgs a, const V3Images im) {
+__global__ __launch_bounds__(256, KB <= 2 ? 2 : 1) void attn_bwd_kv_v4_kernel(const AttnBwdArgs a, const V3Images im) {
     constexpr int NB = kD / 16, NW = 4, R = 16 * NW * KB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* dOr = reinterpret_cast<bf16_t*>(smem_raw);                // [2][kT][kLR]   dO rows (row-major)
@@ -540,7 +558,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_v4_kernel(const AttnBwdArg
     bf16_t* Qt = dOt + 2 * kD * kLT;                                  // [2][kD][kLT]   (scale q) transposed
     float* dl = reinterpret_cast<float*>(Qt + 2 * kD * kLT);          // [2][kT]        delta of the staged query rows
     float* vl = dl + 2 * kT;                                          // [2][kT]        rel_v of the staged query rows
-    bf16_t* Vl = reinterpret_cast<bf16_t*>(vl + 2 * kT);              // [R][kLR]       V rows of the workgroup's keys, resident
+    constexpr bool VREG = KB <= 2;                                    // few key blocks: their V operands stay in registers
+    bf16_t* Vl = reinterpret_cast<bf16_t*>(vl + 2 * kT);              // [R][kLR]       V rows of the workgroup's keys, resident (!VREG)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
     const int st = tid;
     const int nkt = (a.Nk + R - 1) / R;
@@ -555,7 +574,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_v4_kernel(const AttnBwdArg
     const bf16_t* qimg = im.QbT + static_cast<int64_t>(h) * kD * im.Np;
     const bf16_t* dobase = reinterpret_cast<const bf16_t*>(a.dout) + b * a.os.sb + h * a.os.sh;
 
-    {   // V rows of the R keys -> LDS (B operand of dP = dO . V^T; kept out of the register file: KB x 8 registers)
+    bf16x8 vreg[VREG ? KB : 1][kD / 32];
+    if constexpr (VREG) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+            load_rows8(vreg[kb], im.Vb + static_cast<int64_t>(h) * im.Np * kD, kD, kw + 16 * kb + i, true, g);
+    } else {   // V rows of the R keys -> LDS (B operand of dP = dO . V^T; kept out of the register file: KB x 8 registers)
         const bf16_t* vsrc = im.Vb + (static_cast<int64_t>(h) * im.Np + k0) * kD;
 #pragma unroll
         for (int e = 0; e < R * kD / 8 / 256; ++e) {
@@ -656,7 +680,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_v4_kernel(const AttnBwdArg
                 f32x4 dp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // dp[hh][r] = dP[16 t + 4 g + r][key i of block kb]
 #pragma unroll
                 for (int pr = 0; pr < kD / 32; ++pr) {
-                    const bf16x8 vop = *reinterpret_cast<const bf16x8*>(vlane + 16 * kb * kLR + 32 * pr);
+                    const bf16x8 vop = VREG ? vreg[VREG ? kb : 0][pr] : *reinterpret_cast<const bf16x8*>(vlane + 16 * kb * kLR + 32 * pr);
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh) dp[hh] = mfma16x16x32_bf16(dor[hh][pr], vop, dp[hh]);
                 }
@@ -736,13 +760,13 @@ int launch_v3(K kern, const AttnBwdArgs& a, const V3Images& im, dim3 grid, int t
     return MMX_OK;
 }
 
-constexpr int kV4KB = 5;
-constexpr size_t kKv4Lds = kKvLds + sizeof(bf16_t) * 16 * 4 * kV4KB * kLR;
+constexpr int kV4KB = 2;                                                  // key blocks per wave of the fourth-generation key side
+constexpr size_t kKv4Lds = kKvLds + (kV4KB <= 2 ? 0 : sizeof(bf16_t) * 16 * 4 * kV4KB * kLR);
 template <int NW>
 int run_v3(const AttnBwdArgs& a, const V3Images& im, hipStream_t s);
 int run_v4(const AttnBwdArgs& a, const V3Images& im, hipStream_t s) {
     if (im.Np % (16 * 4 * kV4KB) != 0) return run_v3<8>(a, im, s);     // the key chunks must tile the padded images
-    // query side: third generation (8-wave workgroups, two samples each); key side: fourth generation (5 key blocks per wave)
+    // query side: third generation (8-wave workgroups, two samples each); key side: fourth generation (kV4KB key blocks per wave)
     constexpr int RQ = 16 * 8, NS = 2, RK = 16 * 4 * kV4KB;
     dim3 gq(((a.Nq + RQ - 1) / RQ) * a.H * ((a.B + NS - 1) / NS)), gk(((a.Nk + RK - 1) / RK) * a.H * a.B);
     int rc = MMX_OK;
