@@ -406,8 +406,9 @@ def gen_visualbert_chain_lrp():
 
 
 # ----------------------------------------------------------------------------- real hooked modules
-def gen_clip_tiny():
-    aux = load_by_path("clip_ref_pkg.auxilary", os.path.join(REF, "CLIP/clip/auxilary.py"))
+def _clip_tiny_reference():
+    """The reference's CLIP class (CLIP/clip/model.py) at a tiny configuration + the inputs of the clip_tiny fixtures."""
+    load_by_path("clip_ref_pkg.auxilary", os.path.join(REF, "CLIP/clip/auxilary.py"))
     pkg = types.ModuleType("clip_ref_pkg")
     pkg.__path__ = [os.path.join(REF, "CLIP/clip")]
     sys.modules["clip_ref_pkg"] = pkg
@@ -431,6 +432,12 @@ def gen_clip_tiny():
         texts[b, 0] = cfg["vocab_size"] - 2
         texts[b, 1:1 + n] = torch.randint(1, cfg["vocab_size"] - 2, (n,), generator=g2)
         texts[b, 1 + n] = cfg["vocab_size"] - 1  # EOT = arg-max id
+    return model_mod, model, cfg, image, texts
+
+
+def gen_clip_tiny():
+    model_mod, model, cfg, image, texts = _clip_tiny_reference()
+    B = texts.shape[0]
 
     ns = {"torch": torch, "np": np, "start_layer": -1, "start_layer_text": -1}
     exec(notebook_cell("CLIP_explainability.ipynb", 6), ns)
@@ -454,6 +461,36 @@ def gen_clip_tiny():
     arrays["txt_attn"] = torch.stack([b.attn_probs for b in txt_blocks])
     arrays["txt_grad"] = torch.stack([b.attn_grad for b in txt_blocks])
     save("clip_tiny", **arrays)
+
+
+def gen_clip_tiny_fp16():
+    """The reference's OWN half-precision mode: ``convert_weights`` (CLIP/clip/model.py:381-402: Linear / Conv / attention / projection
+    parameters to fp16; LayerNorm computes in fp32 and casts back, model.py:157-164) on the clip_tiny model -- same seed, so the fp16
+    weights are the fp32 ones of clip_tiny.npz rounded -- and notebook cell 6 unchanged: R is created in the dtype of the attention
+    probabilities (cell 6:20,43), so the whole chain runs in fp16.  Run on the CPU (fp16 GEMMs accumulate in fp32 there, as on a GPU)."""
+    model_mod, model, cfg, image, texts = _clip_tiny_reference()
+    model_mod.convert_weights(model)
+    assert model.dtype == torch.float16
+    B = texts.shape[0]
+    ns = {"torch": torch, "np": np, "start_layer": -1, "start_layer_text": -1}
+    exec(notebook_cell("CLIP_explainability.ipynb", 6), ns)
+    arrays = {}
+    for tag, sl, slt in (("last", -1, -1), ("all", 0, 0), ("mid", 1, 2)):
+        R_text, R_image = ns["interpret"](image, texts, model, "cpu", start_layer=sl, start_layer_text=slt)
+        assert R_text.dtype == torch.float16 and R_image.dtype == torch.float16
+        arrays["R_text_" + tag], arrays["R_image_" + tag] = R_text, R_image
+    logits_per_image, _ = model(image.repeat(B, 1, 1, 1), texts)
+    arrays["logits_per_image"] = logits_per_image
+    one_hot = torch.sum(torch.eye(B) * logits_per_image)
+    model.zero_grad()
+    one_hot.backward()
+    vis_blocks = list(model.visual.transformer.resblocks.children())
+    txt_blocks = list(model.transformer.resblocks.children())
+    arrays["img_attn"] = torch.stack([b.attn_probs for b in vis_blocks])
+    arrays["img_grad"] = torch.stack([b.attn_grad for b in vis_blocks])
+    arrays["txt_attn"] = torch.stack([b.attn_probs for b in txt_blocks])
+    arrays["txt_grad"] = torch.stack([b.attn_grad for b in txt_blocks])
+    save("clip_tiny_fp16", **arrays)
 
 
 def gen_detr_mha():
@@ -1109,6 +1146,8 @@ def main(which):
         # round 3
         "detr_transformer_lrp": gen_detr_transformer_lrp, "lrp_layers": gen_lrp_layers,
         "lxmert_model_lrp": gen_lxmert_model_lrp, "visualbert_model_lrp": gen_visualbert_model_lrp,
+        # round 4
+        "clip_tiny_fp16": gen_clip_tiny_fp16,
     }
     for name in (which or list(todo)):
         todo[name]()

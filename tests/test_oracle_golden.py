@@ -135,6 +135,29 @@ def test_clip_torch_oracle(golden, tag, sl, slt):
     close(R_image.numpy(), g["R_image_" + tag])
 
 
+@pytest.mark.parametrize("tag,sl,slt", [("last", -1, -1), ("all", 0, 0), ("mid", 1, 2)])
+def test_clip_torch_oracle_fp16(golden, tag, sl, slt):
+    """Half precision: the restatement with the parameters ``convert_weights`` converts rounded to fp16, fp32 LayerNorm
+    statistics and an fp16 R chain reproduces the reference's model after ``convert_weights`` (clip_tiny_fp16.npz, run on the
+    CPU) -- same ops on the same CPU kernels, so to the last fp16 place (one ulp of slack for the packed / unpacked
+    in-projection)."""
+    import json
+    import torch
+    from oracle import clip_torch
+    g, g16 = golden("clip_tiny"), golden("clip_tiny_fp16")
+    cfg = json.loads(str(g["cfg_json"]))
+    sd = clip_torch.prepare_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w__")},
+                                       cfg["transformer_heads"], dtype=torch.float16)
+    R_text, R_image = clip_torch.interpret(sd, torch.from_numpy(g["image"]), torch.from_numpy(g["texts"]), sl, slt)
+    assert R_text.dtype == torch.float16 and R_image.dtype == torch.float16
+    for got, want in ((R_text, g16["R_text_" + tag]), (R_image, g16["R_image_" + tag])):
+        want = want.astype(np.float32)
+        assert np.abs(got.float().numpy() - want).max() <= 2.0 ** -10 * np.abs(want).max()
+    # and the fp16 mode is a perturbation of the fp32 one, not a different function
+    assert np.abs(g16["R_text_" + tag].astype(np.float32) - g["R_text_" + tag]).max() <= 4e-3 * np.abs(g["R_text_" + tag]).max()
+    assert np.abs(g16["R_image_" + tag].astype(np.float32) - g["R_image_" + tag]).max() <= 4e-3 * np.abs(g["R_image_" + tag]).max()
+
+
 def test_clip_torch_oracle_capture(golden):
     import torch
     from oracle import clip_torch
