@@ -128,6 +128,17 @@ int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const void* cons
                                 const void* Rsq_init_dev, void* Rsq_out_dev, int M,
                                 void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* The same chain in the reference's HALF-PRECISION mode.  On a GPU the reference runs the CLIP model after
+ * `convert_weights` (CLIP/clip/model.py:381-402, 440) and creates R in the dtype of the fp16 attention probabilities
+ * (CLIP_explainability.ipynb cell 6:20,43), so `grad * cam`, `.clamp(min=0).mean(dim=1)`, `torch.bmm(cam, R)` and
+ * `R + ...` each produce an fp16 tensor (fp32 arithmetic inside the op, ONE rounding of its result).  This entry point
+ * applies exactly those roundings (round to nearest even, overflow to inf like torch) around the fp32 sums of the kernels.
+ *   slabs: fp32 or fp16 (`dtype`), R_out_dev: [B, N, N] fp32 storage holding fp16-representable values (R starts as I)
+ *   workspace: mmx_self_chain_workspace_bytes(n_layers, B, H, N, 0, dtype) bytes (0 for N <= 128: one fused launch) */
+int mmx_relevancy_self_chain_half(const void* const* attn_layers, const void* const* grad_layers, int n_layers,
+                                  int B, int H, int N, int dtype, int64_t attn_batch_stride, void* R_out_dev,
+                                  void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Batched fp32 matmul on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32):
  *     C[b] = (accumulate ? Cin[b] : 0) + op(A[b]) . B[b],   op = transpose if trans_a

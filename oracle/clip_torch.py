@@ -105,6 +105,19 @@ def _chain_reference_style(one_hot, probs, batch_size, start_layer):
     return R
 
 
+def chain_half(attn_layers, grad_layers, batch_size):
+    """The rule of cell 6:22-32 on given fp16 slabs ``[B*H, N, N]`` (no autograd): what the reference's chain computes once the
+    probabilities and their gradients are fp16 tensors -- every op returns fp16 (fp32 arithmetic inside, one rounding)."""
+    n = attn_layers[0].shape[-1]
+    R = torch.eye(n, dtype=torch.float16).unsqueeze(0).expand(batch_size, n, n)
+    for a, g in zip(attn_layers, grad_layers):
+        a, g = a.to(torch.float16), g.to(torch.float16)
+        cam = (g.reshape(-1, n, n) * a.reshape(-1, n, n)).reshape(batch_size, -1, n, n)
+        cam = cam.clamp(min=0).mean(dim=1)
+        R = R + torch.bmm(cam, R)
+    return R
+
+
 def _converted_by_convert_weights(name):
     """Which parameters ``convert_weights`` (model.py:381-402) rounds to fp16: nn.Linear / nn.Conv2d weights and biases, the
     attention module's packed projection, ``text_projection`` and the visual ``proj``.  LayerNorm parameters, the embeddings

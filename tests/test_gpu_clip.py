@@ -61,6 +61,35 @@ def test_capture_slabs_match_reference_hooks(golden, share):
     close(logits, g["logits_per_image"], atol=2e-5, rtol=1e-4, what="intermediate")
 
 
+@pytest.mark.parametrize("share", [True, False])
+@pytest.mark.parametrize("tag,sl,slt", [("last", -1, -1), ("all", 0, 0), ("mid", 1, 2)])
+def test_fp16_mode_matches_the_references_fp16_model(golden, tag, sl, slt, share):
+    """``set_body_dtype(torch.float16)`` -- the reference's OWN half-precision mode -- against the reference's model after
+    ``convert_weights`` (CLIP/clip/model.py:381-402) + notebook cell 6 with its fp16 R chain (clip_tiny_fp16.npz, run on the
+    CPU).  Ours rounds the same weights to fp16 and applies the chain's fp16 roundings, but keeps the residual stream, LayerNorm
+    and softmax in fp32, so it sits between the reference's fp16 and fp32 results: the bar is the distance between those two
+    (4e-3 of the largest entry; measured 6.5e-4 for R_text and 1.7e-3 for the image relevance on this fixture)."""
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    g, model = load_tiny(golden)
+    g16 = golden("clip_tiny_fp16")
+    image, texts = torch.from_numpy(g["image"]).cuda(), torch.from_numpy(g["texts"]).cuda()
+    model.set_body_dtype(torch.float16)
+    R_text, R_image = ce.interpret(image, texts, model, "cuda", start_layer=sl, start_layer_text=slt, share_image_forward=share)
+    assert R_text.dtype == torch.float16 and R_image.dtype == torch.float16          # like the reference's returns
+    for got, name in ((R_text, "R_text_" + tag), (R_image, "R_image_" + tag)):
+        want16, want32 = torch.from_numpy(g16[name]).float(), torch.from_numpy(g[name])
+        top = float(want32.abs().max())
+        err16 = float((got.float().cpu() - want16).abs().max())
+        err32 = float((got.float().cpu() - want32).abs().max())
+        assert err16 <= 4e-3 * top and err32 <= 4e-3 * top, (name, err16, err32, top)
+    # and back: the exact path is untouched by the excursion
+    model.set_body_dtype(torch.float32)
+    R_text, R_image = ce.interpret(image, texts, model, "cuda", start_layer=sl, start_layer_text=slt, share_image_forward=share)
+    assert R_text.dtype == torch.float32
+    close(R_text, g["R_text_" + tag])
+    close(R_image, g["R_image_" + tag])
+
+
 @pytest.mark.parametrize("tag,sl,slt", [("last", -1, -1), ("all", 0, 0), ("mid", 1, 2)])
 def test_interpret_trim_text_padding(golden, tag, sl, slt):
     """Running the text tower only up to the last EOT token gives the reference's full [B, 77, 77] result."""

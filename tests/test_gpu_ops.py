@@ -101,6 +101,38 @@ def test_self_chain_fused(ops, L, B, H, N, causal, algo):
     close(got, want)
 
 
+@pytest.mark.parametrize("slab_dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("L,B,H,N,causal,shared", [
+    (12, 4, 12, 50, False, False), (12, 3, 8, 77, True, False), (3, 3, 2, 12, True, False), (3, 2, 2, 17, False, True),
+    (4, 2, 4, 130, False, False), (2, 2, 3, 197, False, True),
+])
+def test_self_chain_half_vs_torch_half_chain(ops, L, B, H, N, causal, shared, slab_dtype):
+    """``mmx_relevancy_self_chain_half`` (ChainPlan(half_chain=True)): the reference's fp16 chain -- R created in the dtype of the
+    fp16 probabilities, notebook cell 6:20,43 -- against the same torch ops on fp16 CPU tensors (oracle/clip_torch.chain_half).
+    Both round every tensor-level result to fp16 and sum in fp32; only the ORDER of the fp32 sums differs (MFMA tiles vs the CPU
+    GEMM), so almost every element is equal and the rest are within two fp16 places of the largest entry.  N <= 128: the fused
+    kernel; larger: avg_heads + bmm + the rounding add."""
+    from oracle import clip_torch
+    attn, grad = make_layers(L * 7 + N, L, B, H, N, causal)
+    attn = [a.to(torch.float16) for a in attn]
+    grad = [(g * 10).to(torch.float16) for g in grad]
+    if shared:                                         # one forward shared by the batch: the probabilities of sample 0
+        attn = [a.view(B, H, N, N)[:1].expand(B, H, N, N).reshape(B * H, N, N).contiguous() for a in attn]
+    want = clip_torch.chain_half(attn, grad, B).float().numpy()
+    ca = [(a.view(B, H, N, N)[0] if shared else a).to(slab_dtype).contiguous().cuda() for a in attn]
+    cg = [g.to(slab_dtype).cuda() for g in grad]
+    plan = ops.ChainPlan(ca, cg, B, shared_attn=shared, half_chain=True)
+    for _ in range(2):
+        got = plan.launch()
+        assert got.dtype == torch.float16
+        got = got.float().cpu().numpy()
+        diff = np.abs(got - want)
+        assert diff.max() <= 2.0 ** -9 * np.abs(want).max(), (diff.max(), np.abs(want).max())
+        assert (diff == 0).mean() > 0.98, (diff == 0).mean()
+    with pytest.raises(ops.MMXError):
+        ops.ChainPlan([a.to(torch.bfloat16) for a in ca], [g.to(torch.bfloat16) for g in cg], B, shared_attn=shared, half_chain=True)
+
+
 @pytest.mark.parametrize("groups", [2, 3, 4])
 @pytest.mark.parametrize("L,B,H,N,causal,with_init", [
     (12, 4, 12, 50, False, False), (12, 3, 8, 77, True, True), (5, 2, 4, 33, False, True), (2, 2, 2, 128, False, False),

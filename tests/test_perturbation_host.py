@@ -184,9 +184,16 @@ def test_clip_body_dtype_switch():
     m.set_body_dtype(torch.float32)
     assert (vis.capture_dtype, vis.forward_gemm_dtype, vis.attention_mma_bf16, txt.forward_gemm_dtype) == \
         (torch.float32, torch.float32, False, torch.float32)
+    # the reference's own half-precision mode (convert_weights): fp16 GEMMs, fp16 long-sequence slabs, the fp16 relevancy chain
+    m.set_body_dtype(torch.float16)
+    assert (vis.capture_dtype, vis.forward_gemm_dtype, vis.backward_gemm_dtype, vis.attention_mma_bf16, vis.half_chain) == \
+        (torch.float16, torch.float16, torch.float16, False, True)
+    assert (txt.capture_dtype, txt.forward_gemm_dtype, txt.half_chain) == (torch.float32, torch.float16, True)
+    m.set_body_dtype(torch.float32)
+    assert (vis.capture_dtype, vis.forward_gemm_dtype, vis.half_chain, txt.half_chain) == (torch.float32, torch.float32, False, False)
     import pytest
     with pytest.raises(ValueError):
-        m.set_body_dtype(torch.float16)
+        m.set_body_dtype(torch.float64)
 
 
 def test_batched_keep_builders_equal_the_per_sample_ones():

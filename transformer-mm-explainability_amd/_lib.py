@@ -32,6 +32,7 @@ _PROTOTYPES = {
     "mmx_self_chain_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mmx_relevancy_self_chain": (_i, [_vpp, _vpp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "mmx_relevancy_self_chain_ex": (_i, [_vpp, _vpp, _i, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "mmx_relevancy_self_chain_half": (_i, [_vpp, _vpp, _i, _i, _i, _i, _i, _i64, _vp, _vp, _sz, _vp]),
     "mmx_bmm_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i, _vp]),
     "mmx_handle_residual": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "mmx_mm_rules_workspace_bytes": (_sz, [_i, _i]),

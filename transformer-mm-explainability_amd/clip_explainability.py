@@ -21,13 +21,15 @@ import torch
 from . import ops
 from .rules import frozen_parameters as _Frozen
 
-def _plan(buffers, first, last, batch_size, shared):
-    """Prepared chain launch, cached on the slab object (the slabs keep their addresses from call to call)."""
+def _plan(buffers, first, last, batch_size, shared, half_chain=False):
+    """Prepared chain launch, cached on the slab object (the slabs keep their addresses from call to call).  ``half_chain``:
+    the reference's fp16 chain (a model after ``set_body_dtype(torch.float16)``; ``ops.ChainPlan``)."""
     cache = buffers.__dict__.setdefault("_chain_plans", {})
-    key = (first, last, batch_size, shared)
+    key = (first, last, batch_size, shared, bool(half_chain))
     if key not in cache:
         cache[key] = ops.ChainPlan([buffers.probs[l] for l in range(first, last)],
-                                   [buffers.grads[l] for l in range(first, last)], batch_size, shared_attn=shared)
+                                   [buffers.grads[l] for l in range(first, last)], batch_size, shared_attn=shared,
+                                   half_chain=half_chain)
     return cache[key]
 
 
@@ -98,14 +100,16 @@ def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, 
         else:
             model.visual.backward_tape(img_state, image_features.grad, sl)
             if not image_chain_on_main:
-                R = _plan(vis.buffers, sl, vis.layers, batch_size, vis.buffers.shared_probs and batch_size > 1).launch()
+                R = _plan(vis.buffers, sl, vis.layers, batch_size, vis.buffers.shared_probs and batch_size > 1,
+                          getattr(vis, "half_chain", False)).launch()
                 image_relevance = R[:, 0, 1:]
     model.backward_text_tape(txt_state, text_features.grad, slt)
     txt = model.transformer
-    R_text = _plan(txt.buffers, slt, txt.layers, batch_size, False).launch()
+    R_text = _plan(txt.buffers, slt, txt.layers, batch_size, False, getattr(txt, "half_chain", False)).launch()
     main.wait_stream(side)
     if image_chain_on_main and not row_mode:
-        R = _plan(vis.buffers, sl, vis.layers, batch_size, vis.buffers.shared_probs and batch_size > 1).launch()
+        R = _plan(vis.buffers, sl, vis.layers, batch_size, vis.buffers.shared_probs and batch_size > 1,
+                  getattr(vis, "half_chain", False)).launch()
         image_relevance = R[:, 0, 1:]
     if R_text.shape[-1] != texts.shape[1]:       # trimmed run: the rest of the [B, 77, 77] matrix is the identity
         n = R_text.shape[-1]

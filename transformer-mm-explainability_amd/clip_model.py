@@ -129,12 +129,19 @@ class Transformer(nn.Module):
 
     def set_body_dtype(self, dtype):
         """``torch.bfloat16``: everything the reference's half-precision body would run in half precision (all GEMMs, the
-        attention products where the streaming kernels apply, the capture slabs); ``torch.float32``: the exact path."""
+        attention products where the streaming kernels apply, the capture slabs); ``torch.float32``: the exact path.
+        ``torch.float16``: the reference's OWN half-precision mode (``convert_weights``, CLIP/clip/model.py:381-402): every GEMM
+        on the fp16 matrix cores with the weights rounded to fp16 exactly as ``convert_weights`` rounds them (fp32 accumulate;
+        LayerNorm, softmax and the residual stream stay fp32 -- the reference computes LayerNorm in fp32 too, model.py:157-164),
+        long-sequence capture slabs in fp16, and the relevancy chain with the reference's fp16 roundings (``half_chain``: R is
+        created in the dtype of the probabilities, notebook cell 6:20,43).  Pinned on the reference's fp16 model in
+        ``tests/test_gpu_clip.py`` (fixture clip_tiny_fp16.npz)."""
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError("body dtype must be torch.float32, torch.bfloat16 or torch.float16")
         half = dtype == torch.bfloat16
-        if not half and dtype != torch.float32:
-            raise ValueError("body dtype must be torch.float32 or torch.bfloat16")
         self.backward_gemm_dtype = self.forward_gemm_dtype = dtype
         self.attention_mma_bf16 = half
+        self.half_chain = dtype == torch.float16
         if self._long_sequence_slabs_follow_body:
             self.capture_dtype = dtype
             self.buffers = None
@@ -497,7 +504,9 @@ class CLIP(nn.Module):
     def set_body_dtype(self, dtype):
         """``torch.bfloat16``: BASELINE config 5's bf16 body -- both towers' GEMMs on the bf16 matrix cores (fp32
         accumulate), the image tower's attention products too, its capture slabs in bf16; relevancy (A-bar, R) stays fp32.
-        ``torch.float32``: back to the exact path.  (The reference: ``convert_weights``, CLIP/clip/model.py:381-402.)"""
+        ``torch.float16``: the reference's own half-precision mode (``convert_weights``, CLIP/clip/model.py:381-402): fp16 GEMMs
+        and the fp16 relevancy chain of notebook cell 6:20,43 -- ``interpret`` then returns fp16 like the reference does.
+        ``torch.float32``: back to the exact path."""
         self.visual.transformer.set_body_dtype(dtype)
         self.transformer.set_body_dtype(dtype)
 

@@ -14,7 +14,12 @@ namespace mmx {
 // grid = (ceil(NN/4 / 256), B), block 256; thread owns 4 consecutive positions and walks the heads in
 // order (deterministic, same summation order as a sequential mean over dim h).
 // =====================================================================================================
-template <int DT>
+// R16: the reference's half-precision chain (notebook cell 6:20,43 with an fp16 model): the product grad * attn and the head mean
+// are each rounded to fp16 (what torch does for fp16 tensors: fp32 arithmetic inside an op, one rounding of its result).
+__device__ __forceinline__ float round_f16(float x) { return static_cast<float>(static_cast<_Float16>(x)); }
+__device__ __forceinline__ f32x4 round_f16(f32x4 v) { return f32x4{round_f16(v[0]), round_f16(v[1]), round_f16(v[2]), round_f16(v[3])}; }
+
+template <int DT, bool R16 = false>
 __global__ __launch_bounds__(256) void avg_heads_kernel(const void* __restrict__ attn,
                                                         const void* __restrict__ grad,
                                                         float* __restrict__ out, int H, int64_t NN,
@@ -34,18 +39,21 @@ __global__ __launch_bounds__(256) void avg_heads_kernel(const void* __restrict__
         for (int h = 0; h < H; ++h) {
             const f32x4 a = load4_stream<DT>(attn, base_a + h * NN);
             const f32x4 g = load4_stream<DT>(grad, base + h * NN);
-            const f32x4 x = g * a;
+            const f32x4 x = R16 ? round_f16(g * a) : g * a;
             s[0] += relu_nan(x[0]); s[1] += relu_nan(x[1]);
             s[2] += relu_nan(x[2]); s[3] += relu_nan(x[3]);
         }
         float* o = out + static_cast<int64_t>(b) * NN + p;
-        o[0] = s[0] / fH; o[1] = s[1] / fH; o[2] = s[2] / fH; o[3] = s[3] / fH;
+        const f32x4 m = R16 ? round_f16(s / fH) : s / fH;
+        o[0] = m[0]; o[1] = m[1]; o[2] = m[2]; o[3] = m[3];
     } else {
         for (int e = 0; p + e < NN; ++e) {
             float s = 0.f;
-            for (int h = 0; h < H; ++h)
-                s += relu_nan(load1_as_f32<DT>(grad, base + h * NN + e) * load1_as_f32<DT>(attn, base_a + h * NN + e));
-            out[static_cast<int64_t>(b) * NN + p + e] = s / fH;
+            for (int h = 0; h < H; ++h) {
+                const float x = load1_as_f32<DT>(grad, base + h * NN + e) * load1_as_f32<DT>(attn, base_a + h * NN + e);
+                s += relu_nan(R16 ? round_f16(x) : x);
+            }
+            out[static_cast<int64_t>(b) * NN + p + e] = R16 ? round_f16(s / fH) : s / fH;
         }
     }
 }
@@ -94,7 +102,10 @@ constexpr int kChainThreads = 1024;
 //        (text tower 75.7 us vs 77.8 / 84.6 / 82.3 / 90.4 us for 1024-EQ / 768-U8 / 768-U12 / 512-U8) -- a CU
 //        already streams at ~8 of its ~10 B/cycle HBM ceiling, more bytes in flight per lane do not raise it and
 //        fewer waves lose issue overlap.  Only the default is instantiated.
-template <int NT, int DT, int THREADS = kChainThreads, int U = 4, bool EQ = false>
+//   R16 = true: the half-precision chain of the reference's fp16 mode (round_f16 above): grad * attn, the head mean, A_bar . R and
+//        R + A_bar . R are each rounded to fp16, sums run in fp32 -- R is carried as fp32 registers holding fp16 values.  One
+//        workgroup per sample (the layer-group split re-associates the products), the plain (not software-pipelined) stream loop.
+template <int NT, int DT, int THREADS = kChainThreads, int U = 4, bool EQ = false, bool R16 = false>
 __global__ __launch_bounds__(THREADS) void self_chain_fused_kernel(const ChainArgs a) {
     constexpr int NP = NT * 16;
     constexpr int S = NP + 4;
@@ -142,21 +153,22 @@ __global__ __launch_bounds__(THREADS) void self_chain_fused_kernel(const ChainAr
             for (int h = 0; h < H; ++h) {
                 const f32x4 av = load4_as_f32<DT>(A, sampleA + h * NN + p);
                 const f32x4 gv = load4_as_f32<DT>(Gr, sample + h * NN + p);
-                const f32x4 x = gv * av;
+                const f32x4 x = R16 ? round_f16(gv * av) : gv * av;
                 s[0] += relu_nan(x[0]); s[1] += relu_nan(x[1]);
                 s[2] += relu_nan(x[2]); s[3] += relu_nan(x[3]);
             }
         } else {
             for (int e = 0; p + e < NN; ++e)
-                for (int h = 0; h < H; ++h)
-                    s[e] += relu_nan(load1_as_f32<DT>(Gr, sample + h * NN + p + e) *
-                                     load1_as_f32<DT>(A, sampleA + h * NN + p + e));
+                for (int h = 0; h < H; ++h) {
+                    const float x = load1_as_f32<DT>(Gr, sample + h * NN + p + e) * load1_as_f32<DT>(A, sampleA + h * NN + p + e);
+                    s[e] += relu_nan(R16 ? round_f16(x) : x);
+                }
         }
         int row = static_cast<int>(p / N);
         int cc = static_cast<int>(p - static_cast<int64_t>(row) * N);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (p + e < NN) Ab[row * S + cc] = s[e] / fH;
+            if (p + e < NN) Ab[row * S + cc] = R16 ? round_f16(s[e] / fH) : s[e] / fH;
             if (++cc == N) { cc = 0; ++row; }
         }
     };
@@ -200,7 +212,8 @@ __global__ __launch_bounds__(THREADS) void self_chain_fused_kernel(const ChainAr
                     acc = mfma16x16x4(av[2], Rold[t][2], acc);
                     acc = mfma16x16x4(av[3], Rold[t][3], acc);
                 }
-                Rnew[ti] = Rold[ti] + acc;  // R + (A_bar . R): same association as the reference
+                Rnew[ti] = R16 ? round_f16(Rold[ti] + round_f16(acc))   // torch.bmm rounds its result, the sum is rounded again
+                               : Rold[ti] + acc;                        // R + (A_bar . R): same association as the reference
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) Rold[t] = Rnew[t];
@@ -222,7 +235,7 @@ __global__ __launch_bounds__(THREADS) void self_chain_fused_kernel(const ChainAr
     } else {
         // ------------------------------------------------------------------ stream waves
         const int lt = tid - NT * 64;
-        if (DT == MMX_F32 && a.pipe && static_cast<int64_t>(stream_end) * 4 <= NN && stream_end > 0 &&
+        if (!R16 && DT == MMX_F32 && a.pipe && static_cast<int64_t>(stream_end) * 4 <= NN && stream_end > 0 &&
             static_cast<int64_t>(H) * NN * 4 < (1ll << 31)) {
             // Software-pipelined form (fp32 slabs, option "self_chain_pipe"): the pass is a flat sequence of load batches
             // (layer, chunk of this lane, 4 heads x 2 arrays); batch i + 1 is ISSUED before batch i is reduced, so 8 16-byte
@@ -1295,15 +1308,18 @@ static int launch_v2(ChainV2Args& args, int dtype, void* workspace, hipStream_t 
 }
 
 template <int NT>
-static int launch_fused(const ChainArgs& args, int dtype, hipStream_t s) {
+static int launch_fused(const ChainArgs& args, int dtype, hipStream_t s, bool half_chain = false) {
     constexpr int NP = NT * 16;
     const size_t lds = sizeof(float) * 2 * NP * (NP + 4);
     void (*kern)(const ChainArgs) = nullptr;
     switch (dtype) {
-        case MMX_F32: kern = self_chain_fused_kernel<NT, MMX_F32>; break;
-        case MMX_F16: kern = self_chain_fused_kernel<NT, MMX_F16>; break;
-        case MMX_BF16: kern = self_chain_fused_kernel<NT, MMX_BF16>; break;
-        default: set_error("self_chain: unsupported dtype %d", dtype); return MMX_EINVAL;
+        case MMX_F32: kern = half_chain ? self_chain_fused_kernel<NT, MMX_F32, kChainThreads, 4, false, true>
+                                        : self_chain_fused_kernel<NT, MMX_F32>; break;
+        case MMX_F16: kern = half_chain ? self_chain_fused_kernel<NT, MMX_F16, kChainThreads, 4, false, true>
+                                        : self_chain_fused_kernel<NT, MMX_F16>; break;
+        case MMX_BF16: if (!half_chain) { kern = self_chain_fused_kernel<NT, MMX_BF16>; break; }
+            [[fallthrough]];
+        default: set_error("self_chain: unsupported dtype %d%s", dtype, half_chain ? " for the fp16 chain" : ""); return MMX_EINVAL;
     }
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1460,6 +1476,81 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
             if (rc) return rc;
             SQcur = SQnxt;
         }
+    }
+    return MMX_OK;
+}
+
+// R' = round_f16(R + round_f16(P)): the two roundings of `R = R + torch.bmm(cam, R)` on fp16 tensors
+__global__ __launch_bounds__(256) void half_chain_add_kernel(const float* __restrict__ R, const float* __restrict__ P,
+                                                             float* __restrict__ out, int64_t n) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) out[i] = round_f16(R[i] + round_f16(P[i]));
+}
+
+// The reference's HALF-PRECISION chain (CLIP_explainability.ipynb cell 6:20-32, 43-55 on a model after `convert_weights`,
+// CLIP/clip/model.py:381-402: R is created in the dtype of the fp16 attention probabilities): same rule, every tensor-level result
+// rounded to fp16.  R_out: fp32 storage of fp16-representable values.  N <= 128: the fused kernel, one workgroup per sample;
+// larger N: avg_heads + bmm + a rounding add per layer (workspace: mmx_self_chain_workspace_bytes(..., M = 0)).
+extern "C" int mmx_relevancy_self_chain_half(const void* const* attn_layers, const void* const* grad_layers, int n_layers,
+                                             int B, int H, int N, int dtype, int64_t attn_batch_stride, void* R_out_dev,
+                                             void* workspace_dev, size_t workspace_bytes, void* stream) {
+    const int64_t full_stride = static_cast<int64_t>(H) * N * N;
+    if (attn_batch_stride < 0) attn_batch_stride = full_stride;
+    MMX_CHECK_ARG(attn_batch_stride == 0 || attn_batch_stride == full_stride,
+                  "mmx_relevancy_self_chain_half: attn_batch_stride must be 0 (shared forward) or H*N*N");
+    MMX_CHECK_ARG(attn_layers && grad_layers && R_out_dev, "mmx_relevancy_self_chain_half: null pointer");
+    MMX_CHECK_ARG(n_layers >= 0 && n_layers <= MMX_MAX_LAYERS, "mmx_relevancy_self_chain_half: n_layers %d not in [0, %d]",
+                  n_layers, MMX_MAX_LAYERS);
+    MMX_CHECK_ARG(B > 0 && H > 0 && N > 0, "mmx_relevancy_self_chain_half: non-positive size");
+    MMX_CHECK_ARG(dtype == MMX_F32 || dtype == MMX_F16, "mmx_relevancy_self_chain_half: slabs must be fp32 or fp16, got %d", dtype);
+    for (int l = 0; l < n_layers; ++l)
+        MMX_CHECK_ARG(attn_layers[l] && grad_layers[l], "mmx_relevancy_self_chain_half: null layer pointer %d", l);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nt = nt_for(N);
+    if (nt <= 8) {
+        ChainArgs args;
+        memset(&args, 0, sizeof(args));
+        for (int l = 0; l < n_layers; ++l) { args.attn[l] = attn_layers[l]; args.grad[l] = grad_layers[l]; }
+        args.n_layers = n_layers; args.B = B; args.H = H; args.N = N;
+        args.R_out = static_cast<float*>(R_out_dev);
+        args.G = 1;
+        args.attn_bstride = attn_batch_stride;
+        switch (nt) {
+            case 1: return launch_fused<1>(args, dtype, s, true);
+            case 2: return launch_fused<2>(args, dtype, s, true);
+            case 3: return launch_fused<3>(args, dtype, s, true);
+            case 4: return launch_fused<4>(args, dtype, s, true);
+            case 5: return launch_fused<5>(args, dtype, s, true);
+            case 6: return launch_fused<6>(args, dtype, s, true);
+            case 7: return launch_fused<7>(args, dtype, s, true);
+            default: return launch_fused<8>(args, dtype, s, true);
+        }
+    }
+    const size_t need = mmx_self_chain_workspace_bytes(n_layers, B, H, N, 0, dtype);
+    if (workspace_bytes < need || !workspace_dev) {
+        set_error("mmx_relevancy_self_chain_half: workspace %zu < %zu", workspace_bytes, need);
+        return MMX_EWORKSPACE;
+    }
+    const int64_t nn = static_cast<int64_t>(N) * N;
+    const size_t mat = align256(sizeof(float) * static_cast<size_t>(B) * N * N);
+    char* ws = static_cast<char*>(workspace_dev);
+    float* abar = reinterpret_cast<float*>(ws);
+    float* prod = reinterpret_cast<float*>(ws + mat);
+    float* R = static_cast<float*>(R_out_dev);
+    int rc = identity_async(R, B, N, s);
+    if (rc) return rc;
+    dim3 grid(static_cast<unsigned>((((nn + 3) >> 2) + 255) / 256), B);
+    for (int l = 0; l < n_layers; ++l) {
+        if (dtype == MMX_F32)
+            avg_heads_kernel<MMX_F32, true><<<grid, 256, 0, s>>>(attn_layers[l], grad_layers[l], abar, H, nn, attn_batch_stride);
+        else
+            avg_heads_kernel<MMX_F16, true><<<grid, 256, 0, s>>>(attn_layers[l], grad_layers[l], abar, H, nn, attn_batch_stride);
+        MMX_LAUNCH_CHECK("avg_heads_kernel (fp16 chain)");
+        rc = mmx_bmm_f32(abar, R, nullptr, prod, B, N, N, N, 0, nn, nn, nn, 0, stream);
+        if (rc) return rc;
+        const int64_t n = static_cast<int64_t>(B) * nn;
+        half_chain_add_kernel<<<static_cast<unsigned>((n + 255) / 256), 256, 0, s>>>(R, prod, R, n);
+        MMX_LAUNCH_CHECK("half_chain_add_kernel");
     }
     return MMX_OK;
 }

@@ -519,8 +519,11 @@ class ChainPlan:
     built once; ``launch()`` is a single C call (no per-call Python tensor plumbing).  The captured slabs of a tower
     keep their addresses from step to step, so the plan stays valid as long as the tensors it references are alive."""
 
-    def __init__(self, attn_layers, grad_layers, batch_size, shared_attn=False):
+    def __init__(self, attn_layers, grad_layers, batch_size, shared_attn=False, half_chain=False):
+        """``half_chain``: the reference's fp16 chain (``mmx_relevancy_self_chain_half``: every tensor-level result of the rule
+        rounded to fp16, like the notebook's R on a model after ``convert_weights``); ``launch`` then returns an fp16 tensor."""
         _dev(*attn_layers, *grad_layers)
+        self.half_chain = bool(half_chain)
         self.attn = [_capture(a) for a in attn_layers]
         self.grad = [_capture(g) for g in grad_layers]
         if not self.attn or len(self.attn) != len(self.grad) or len(self.attn) > _lib.MAX_LAYERS:
@@ -536,7 +539,11 @@ class ChainPlan:
                     a.numel() * (batch_size if shared_attn else 1) != g.numel():
                 raise MMXError("ChainPlan: inconsistent layer shapes/dtypes")
         self.device = g0.device
+        if self.half_chain and g0.dtype == torch.bfloat16:
+            raise MMXError("ChainPlan: the fp16 chain reads fp32 or fp16 slabs")
         self.need = lib().mmx_self_chain_workspace_bytes(len(self.attn), batch_size, self.heads, self.n, 0, self.dt)
+        if self.half_chain and self.n <= 128:
+            self.need = 0                                  # one fused launch per call, no scratch
         self.ws = torch.empty(max(self.need, 1), dtype=torch.uint8, device=g0.device)
         self.at, self._k1 = _lib.ptr_table([a.data_ptr() for a in self.attn])
         self.gt, self._k2 = _lib.ptr_table([g.data_ptr() for g in self.grad])
@@ -545,6 +552,11 @@ class ChainPlan:
         """Enqueue on torch's current stream; returns ``R [B, N, N]`` (a fresh tensor unless ``out`` is given)."""
         if out is None:
             out = torch.empty(self.batch, self.n, self.n, dtype=torch.float32, device=self.device)
+        if self.half_chain:
+            check(lib().mmx_relevancy_self_chain_half(self.at, self.gt, len(self.attn), self.batch, self.heads, self.n, self.dt,
+                                                      self.shared, _p(out), _p(self.ws), self.need, _stream()),
+                  "mmx_relevancy_self_chain_half")
+            return out.to(torch.float16)                   # lossless: the kernel rounds every result to fp16
         check(lib().mmx_relevancy_self_chain_ex(self.at, self.gt, len(self.attn), self.batch, self.heads, self.n, self.dt,
                                                 self.shared, None, _p(out), None, None, 0, _p(self.ws), self.need,
                                                 _stream()), "mmx_relevancy_self_chain_ex")
