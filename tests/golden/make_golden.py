@@ -493,6 +493,40 @@ def gen_clip_tiny_fp16():
     save("clip_tiny_fp16", **arrays)
 
 
+def gen_clip_vitb32_fp16():
+    """The reference's model at the HEADLINE geometry (CLIP ViT-B/32, 12 + 12 layers) after ``convert_weights``, notebook cell 6 on
+    a batch of 8 captions (bench.py's synthetic inputs), all layers -- fp16 and, for scale, fp32.  The weights are not stored: they
+    are ``clip_model.random_init("ViT-B/32", seed=0)`` (the product's initialiser is only a source of numbers here; the state dict
+    loads into the reference's class unchanged)."""
+    model_mod, _, _, _, _ = _clip_tiny_reference()
+    sys.path.insert(0, os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")))
+    from transformer_mm_explainability_amd import clip_model
+    sd = clip_model.random_init("ViT-B/32", seed=0).state_dict()
+    cfg = dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=32,
+               context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12)
+    B = 8
+    g = torch.Generator().manual_seed(1)                                   # tests/test_gpu_parity_fullsize.bench_inputs(8)
+    image = torch.randn(1, 3, 224, 224, generator=g)
+    texts = torch.zeros(B, 77, dtype=torch.long)
+    g2 = torch.Generator().manual_seed(2)
+    for b in range(B):
+        n = int(torch.randint(3, 11, (1,), generator=g2))
+        texts[b, 0] = 49406
+        texts[b, 1:1 + n] = torch.randint(1, 49405, (n,), generator=g2)
+        texts[b, 1 + n] = 49407
+    ns = {"torch": torch, "np": np, "start_layer": -1, "start_layer_text": -1}
+    exec(notebook_cell("CLIP_explainability.ipynb", 6), ns)
+    arrays = {"texts": texts}
+    for tag in ("fp32", "fp16"):
+        model = model_mod.CLIP(**cfg).float().eval()
+        model.load_state_dict(sd)
+        if tag == "fp16":
+            model_mod.convert_weights(model)
+        R_text, R_image = ns["interpret"](image, texts, model, "cpu", start_layer=0, start_layer_text=0)
+        arrays["R_text_" + tag], arrays["R_image_" + tag] = R_text, R_image
+    save("clip_vitb32_fp16", **arrays)
+
+
 def gen_detr_mha():
     torch.manual_seed(5)
     E, H, T, S, B = 64, 4, 6, 15, 2
@@ -1147,7 +1181,7 @@ def main(which):
         "detr_transformer_lrp": gen_detr_transformer_lrp, "lrp_layers": gen_lrp_layers,
         "lxmert_model_lrp": gen_lxmert_model_lrp, "visualbert_model_lrp": gen_visualbert_model_lrp,
         # round 4
-        "clip_tiny_fp16": gen_clip_tiny_fp16,
+        "clip_tiny_fp16": gen_clip_tiny_fp16, "clip_vitb32_fp16": gen_clip_vitb32_fp16,
     }
     for name in (which or list(todo)):
         todo[name]()

@@ -59,6 +59,44 @@ def test_cfg2_batch64_vs_oracle():
     close(R_image, want_img, what="R_image")
 
 
+def test_fp16_mode_at_vit_b32_vs_the_references_fp16_model(golden):
+    """The reference's own half-precision mode at the headline geometry (CLIP ViT-B/32, all 12 + 12 layers, B = 8):
+    ``set_body_dtype(torch.float16)`` vs the reference's model after ``convert_weights`` + notebook cell 6 (fixture
+    clip_vitb32_fp16.npz: made on the CPU by tests/golden/make_golden.py from the same ``random_init`` weights and inputs; it also
+    holds the reference's fp32 result).  Bar: 6e-3 of the largest off-diagonal entry of the map -- the reference's fp16 and fp32
+    results are themselves 2e-3 (text) / 1.5e-3 (image) apart; our body keeps the residual stream in fp32, so it lands between
+    them.  The hipGraph replay reproduces the eager call bit for bit."""
+    import faulthandler
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    from transformer_mm_explainability_amd import clip_model
+    faulthandler.dump_traceback_later(150, exit=True)                 # a hang here must name its line, not eat the GPU budget
+    try:
+        g = golden("clip_vitb32_fp16")
+        model = clip_model.random_init("ViT-B/32", seed=0).cuda()
+        image, texts = bench_inputs(8)
+        assert torch.equal(texts, torch.from_numpy(g["texts"]))
+        model.set_body_dtype(torch.float16)
+        got = ce.interpret(image.cuda(), texts.cuda(), model, "cuda", 0, 0)
+        torch.cuda.synchronize()
+        assert got[0].dtype == torch.float16 and got[1].dtype == torch.float16
+        off = torch.eye(77, dtype=torch.bool).logical_not()
+        errs = {}
+        for k, name in enumerate(("R_text", "R_image")):
+            for tag in ("fp16", "fp32"):
+                w, g_ = torch.from_numpy(g[name + "_" + tag]).float(), got[k].float().cpu()
+                if k == 0:
+                    w, g_ = w[:, off], g_[:, off]                      # (the unit diagonal would set the scale)
+                errs[(name, tag)] = float((g_ - w).abs().max()) / float(w.abs().max())
+                assert errs[(name, tag)] <= 6e-3, (name, tag, errs)
+        print("fp16 mode, relative errors:", errs, flush=True)
+        run = ce.GraphedInterpret(model, image.cuda(), texts.cuda(), start_layer=0, start_layer_text=0)
+        R_text, R_image = run()
+        torch.cuda.synchronize()
+        assert torch.equal(R_text, got[0]) and torch.equal(R_image, got[1])
+    finally:
+        faulthandler.cancel_dump_traceback_later()
+
+
 def test_cfg5_token_count_vs_oracle():
     """ViT-L/14@336 geometry (577 image tokens, width 1024 / 16 heads; text width 768 / 12 heads), 2 + 2 layers, B = 2."""
     from oracle import clip_torch

@@ -116,5 +116,11 @@ PY
     rm -rf $OUT/abl_$A
   done
   ;;
+head)            # whole-head attention kernels: stagger sweep (co-resident workgroups out of phase) + the fp16-mode full-size test
+  timeout 300 python -m pytest tests/test_gpu_parity_fullsize.py -q -s -k "fp16_mode" 2>&1 | grep -E "passed|failed|relative errors|Error" | tee $OUT/pytest.txt
+  for S in 0 100 300 600 1200; do
+    MMX_HEAD_STAGGER=$S timeout 120 python tools/probe_head_attention.py 2>&1 | grep -E "stagger|text|image" | grep -v checksums | tee -a $OUT/head_stagger.txt
+  done
+  ;;
 *) echo "unknown target $T"; exit 2;;
 esac

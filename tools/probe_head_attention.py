@@ -108,10 +108,13 @@ def run_image(B=64, H=12, N=50, D=64):
 
 def main():
     print("library: %s" % _lib.LIB_PATH)
+    if os.environ.get("MMX_HEAD_STAGGER"):          # timing hint of attention_head.hip: later dispatch rounds start N x 64 cycles late
+        ops.set_option("attn_head", 1 | (int(os.environ["MMX_HEAD_STAGGER"]) << 16))
+        print("stagger units: %s" % os.environ["MMX_HEAD_STAGGER"])
     for name, res in (("text  B=64 H=8  N=77 d=64", run_text()), ("image B=64 H=12 N=50 d=64", run_image())):
         for leg, (t, nbytes) in res.items():
             print("%s  %-30s %6.1f us  %6.1f MB  %.2f TB/s = %4.1f %% of 8 TB/s" % (name, leg, t, nbytes / 1e6, nbytes / t / 1e6, nbytes / t / 8e4))
-    if len(sys.argv) <= 2:
+    if len(sys.argv) <= 2 and not os.environ.get("MMX_HEAD_STAGGER"):
         for mb in (45, 95):
             t_copy, t_sum, t_rows = yardsticks(mb)
             print("library passes moving %3d MB per launch: copy_ %5.1f us = %.2f TB/s | flat sum %5.1f us = %.2f TB/s | row sums [n, 1024] %5.1f us = %.2f TB/s"
