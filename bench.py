@@ -471,6 +471,20 @@ def main():
                     "last_layer_only_maps_per_s": {"eager": round(last_only, 2), "hipgraph": round(last_only_graph, 2)},
                     "trim_text_padding_hipgraph_maps_per_s": round(trimmed_graph, 2),
                     "image_chain_on_main_stream_hipgraph_maps_per_s": round(chain_on_main_graph, 2)}
+        # the reference's OWN half-precision mode (convert_weights + the notebook's fp16 R chain): fp16
+        # GEMMs, fp16 chain roundings, attention on the exact-fp32 kernels.  Reported for scale only -- the headline stays fp32.
+        try:
+            model.set_body_dtype(torch.float16)
+            run_half = ce.GraphedInterpret(model, image, texts, 0, 0)
+            variants["fp16_mode_hipgraph_maps_per_s"] = round(rate(run_half, reps), 2)
+            del run_half
+        except Exception as exc:                                               # a variant must not take the line down
+            variants["fp16_mode_hipgraph_maps_per_s"] = None
+            log("fp16 variant failed: %r" % (exc,))
+        finally:
+            model.set_body_dtype(torch.float32)
+            ce.interpret(image, texts, model, device, 0, 0)                    # the fp32 slabs back in place for what follows
+            torch.cuda.synchronize()
 
     roofline = None
     if not args.headline_only:

@@ -26,17 +26,21 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_full -o bench -- pyth
 python tools/prof_summary.py $OUT/trace_full/bench_results.db "self_chain" --by-grid > $OUT/chain_kernel_trace.txt 2>&1; cat $OUT/chain_kernel_trace.txt | cut -c1-200
 python tools/prof_summary.py $OUT/trace_full/bench_results.db "" --by-grid 2>&1 | grep -E "kernel  |mmx" | head -70 | cut -c1-200 > $OUT/cfg_legs.txt
 # round 4: the bi-modal schedule kernel (one workgroup per sample vs two-phase) and the LRP route's cost
+if [ -z "$SKIP_PROBES" ]; then      # (SKIP_PROBES=1: a re-run late in a round, the probes' files are already committed)
 timeout 200 python tools/probe_schedule.py 2>&1 | grep -v amdgpu.ids > $OUT/schedule_probe.txt; cat $OUT/schedule_probe.txt
 timeout 200 python tools/probe_lrp.py both 5 2>&1 | grep -v amdgpu.ids > $OUT/lrp_probe.txt; cat $OUT/lrp_probe.txt
 rocprofv3 --list-avail > $OUT/counters_avail.txt 2>&1
+fi
 if [ "$2" == "lite" ]; then rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/trace $OUT/trace_full; exit 0; fi
 # cfg 5: the step's kernel split, the attention backward pair alone (v2 vs v3), SQ counters of the v3 kernels
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/trace_cfg5 -o cfg5 -- python tools/probe_cfg5_trace.py 128 3 > /dev/null 2> $OUT/trace_cfg5.log
 python tools/prof_summary.py $OUT/trace_cfg5/cfg5_results.db "" 2>&1 | head -30 | cut -c1-190 > $OUT/cfg5_step_kernels.txt
-timeout 300 python tools/probe_attn_v3.py 128 2>&1 | grep -v amdgpu.ids > $OUT/attn_v3_probe.txt; cat $OUT/attn_v3_probe.txt
+timeout 300 python tools/probe_attn_v3.py 128 2,3 2>&1 | grep -v amdgpu.ids > $OUT/attn_v3_probe.txt; cat $OUT/attn_v3_probe.txt
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/pmc_v3 -o v3 -- python tools/probe_attn_v3.py 16 2 > /dev/null 2> $OUT/pmc_v3.log
 python tools/pmc_sq.py $OUT/pmc_v3/v3_counter_collection.csv _v3_ > $OUT/attn_v3_sq.txt 2>&1; cat $OUT/attn_v3_sq.txt
+if [ -z "$SKIP_PROBES" ]; then
 # cfg 3: DETR K = 10 pass with the three-launch decoder rules (rows of R_q_i only)
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_detr -o detr -- python tools/probe_detr_trace.py 5 10 rows > /dev/null 2> $OUT/trace_detr.log
 python tools/prof_summary.py $OUT/trace_detr/detr_results.db "" 2>&1 | head -40 | cut -c1-190 > $OUT/detr_rows_kernels.txt
+fi
 rm -rf $OUT/trace_detr $OUT/pmc_fetch $OUT/pmc_write $OUT/trace $OUT/trace_full $OUT/trace_cfg5 $OUT/pmc_v3
