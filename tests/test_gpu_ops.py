@@ -340,6 +340,48 @@ def test_attn_capture_fwd_bwd(ops, B, H, Nq, Nk, D, mode, masked, path):
     assert torch.equal(dprobs, dprobs2)
 
 
+@pytest.mark.parametrize("B,H,N,D,shared,packed", [(4, 8, 77, 64, False, True), (3, 12, 50, 64, True, True), (2, 2, 14, 32, False, False),
+                                                    (2, 3, 128, 48, False, True), (1, 4, 33, 8, False, False)])
+def test_whole_head_backward_bf16_gradient_io(ops, B, H, N, D, shared, packed):
+    """``attention_head.hip`` with bf16 gradient I/O (a bf16 ``d_o`` without ``mma_bf16``: the bf16 gradient stream of a bf16 body
+    through a short tower): the SAME exact-fp32 arithmetic as the fp32-I/O launch on the same (bf16-representable) d_o, so dP is
+    bit-identical and dq / dk / dv are the fp32 results rounded to bf16 once.  ``packed``: outputs are views of one [B, N, 3, H, D]
+    tensor, as clip_model.backward_tape hands them in.  A long sequence without ``mma_bf16`` must refuse a bf16 d_o."""
+    g = torch.Generator().manual_seed(N * 3 + D)
+    Bf = 1 if shared else B
+    qkv = torch.randn(Bf, N, 3, H, D, generator=g).cuda()
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    d_o16 = torch.randn(B, N, H, D, generator=g).to(torch.bfloat16).cuda()
+    scale = D ** -0.5
+    mask = torch.full((N, N), float("-inf")).triu_(1).cuda()
+    probs = torch.empty(Bf, H, N, N, device="cuda")
+    o = ops.attn_capture_fwd(q, k, v, probs, scale, 0, mask)
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        d_o = d_o16.to(dt)
+        dprobs = torch.full((B, H, N, N), float("nan"), device="cuda")
+        if packed:
+            dqkv = torch.full((B, N, 3, H, D), float("nan"), dtype=dt, device="cuda")
+            out = (dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2])
+        else:
+            out = None
+        got = ops.attn_capture_bwd(q, k, v, probs, d_o, dprobs, scale, 0, out=out, batch=B if shared else None, o=o)
+        torch.cuda.synchronize()
+        assert all(t.dtype == dt for t in got)
+        res[dt] = (dprobs, [t.clone() for t in got])
+    assert torch.equal(res[torch.float32][0], res[torch.bfloat16][0])                 # the captured gradient: same bits
+    for a32, a16 in zip(res[torch.float32][1], res[torch.bfloat16][1]):
+        assert torch.isfinite(a16.float()).all()
+        assert torch.equal(a32.to(torch.bfloat16), a16)                                # one rounding of the same fp32 result
+    if N == 77:
+        long_q = torch.randn(1, 200, 3, 2, 64, device="cuda")
+        p = torch.empty(1, 2, 200, 200, device="cuda")
+        ops.attn_capture_fwd(long_q[:, :, 0], long_q[:, :, 1], long_q[:, :, 2], p, 0.125, 0, None)
+        with pytest.raises(ops.MMXError):
+            ops.attn_capture_bwd(long_q[:, :, 0], long_q[:, :, 1], long_q[:, :, 2], p,
+                                 torch.randn(1, 200, 2, 64, device="cuda").to(torch.bfloat16), torch.empty_like(p), 0.125, 0)
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,D,mode,masked", [(1, 8, 950, 950, 32, 0, False), (1, 8, 100, 950, 32, 0, False),
                                                      (1, 3, 37, 130, 20, 1, True), (2, 2, 16, 65, 32, 0, True),
                                                      (1, 1, 5, 300, 8, 0, False), (1, 12, 197, 197, 64, 1, False),

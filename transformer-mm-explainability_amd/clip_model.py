@@ -281,11 +281,13 @@ class Transformer(nn.Module):
         # bf16 body on the streaming kernels: the gradients BETWEEN the GEMMs are bf16 (what the bf16 GEMMs produce and
         # consume; the elementwise kernels and the attention backward read / write bf16 directly -- no conversion
         # passes), the residual gradient stream (dx, d_x1) stays fp32
-        # A short tower of a bf16 body (CLIP's 77-token text side: register-resident fp32 head kernels) runs the same bf16 stream with
-        # two small conversions around its attention (d_o -> fp32, dq | dk | dv -> bf16) instead of an fp32 -> bf16 pass in front of
-        # every GEMM (the widest of them 4 E columns).
+        # A short tower of a bf16 body (CLIP's 77-token text side: register-resident fp32 head kernels) runs the same bf16 stream: the
+        # whole-head backward reads a bf16 d_o and writes bf16 dq | dk | dv around its exact-fp32 arithmetic (attention_head.hip, IOH;
+        # round 4 -- before that two conversion passes per layer sat around it).
         stream16 = getattr(self, "backward_gemm_dtype", torch.float32) == torch.bfloat16
-        att16 = stream16 and mma
+        head = self.resblocks[0].attn
+        att16 = stream16 and (mma or (self.capture_dtype == torch.float32 and
+                                      ops.head_kernel_shape(N, N, head.head_dim) and head.head_dim % 8 == 0))
         dx_h = None
         for l in range(top, first_grad_layer - 1, -1):
             blk = self.resblocks[l]

@@ -226,6 +226,46 @@ __device__ __forceinline__ void store_rows16(float* base, int64_t sn, int row, b
         if (td * 16 + 4 * g < D) stg4_u(p + td * 16, acc[td] * mul);
 }
 
+// bf16 gradient I/O (IOH): the upstream gradient dO arrives as bf16 and dQ / dK / dV leave as bf16 (round to nearest even) -- the
+// bf16 gradient stream of a bf16 body (clip_model.backward_tape) through a SHORT tower: same exact-fp32 arithmetic in between, the two
+// conversion passes around the kernel (dO -> fp32, dq | dk | dv -> bf16: 33 launches and 4.5 ms per cfg-5 step) are gone.
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    bf2 r;
+    r[0] = static_cast<__bf16>(lo);
+    r[1] = static_cast<__bf16>(hi);
+    return __builtin_bit_cast(unsigned, r);
+}
+template <int DP>
+__device__ __forceinline__ void load_rows16_bf16(f32x4 (&reg)[DP / 16], const unsigned short* base, int64_t sn, int row, int N,
+                                                 int D, int g) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const bool rv = row < N;
+    const unsigned short* p = base + (rv ? static_cast<int64_t>(row) * sn : 0);
+#pragma unroll
+    for (int kk = 0; kk < DP / 16; ++kk) {
+        const int d = kk * 16 + 4 * g;
+        const bool ok = rv && d < D;
+        const u32x2 w = *reinterpret_cast<const u32x2*>(p + (ok ? d : 0));
+        reg[kk] = ok ? f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16),
+                             __uint_as_float(w[1] & 0xffff0000u)}
+                     : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+template <int DP>
+__device__ __forceinline__ void store_rows16_bf16(unsigned short* base, int64_t sn, int row, bool row_valid, int D, int g,
+                                                  const f32x4 (&acc)[DP / 16], float mul) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    if (!row_valid) return;
+    unsigned short* p = base + static_cast<int64_t>(row) * sn + 4 * g;
+#pragma unroll
+    for (int td = 0; td < DP / 16; ++td)
+        if (td * 16 + 4 * g < D) {
+            const f32x4 v = acc[td] * mul;
+            *reinterpret_cast<u32x2*>(p + td * 16) = u32x2{pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+        }
+}
+
 // Dispatch "round" r of this workgroup (how many workgroups the hardware has probably placed on the same CU before it):
 // round r > 0 waits r * units * 64 cycles before issuing its first load, so that a CU's co-resident workgroups are in
 // different phases (loading / MFMA / storing) instead of marching through them in lockstep.  A pure timing hint.
@@ -326,7 +366,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_head_kernel(const AttnFwdArgs a
 
 // ------------------------------------------------------------------------------------------------------- backward
 // (NTK >= 7 keeps 100+ live registers per lane: those instantiations are capped at 8 waves so that they get 256 VGPRs)
-template <int DP, int NTK>
+template <int DP, int NTK, bool IOH = false>
 __global__ __launch_bounds__(NTK >= 7 ? 512 : 1024) void attn_bwd_head_kernel(const AttnBwdArgs a) {
     constexpr int LSA = DP + 8, LSB = DP + 4, KK = DP / 16, NPk = NTK * 16, SS = NPk + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -347,7 +387,11 @@ __global__ __launch_bounds__(NTK >= 7 ? 512 : 1024) void attn_bwd_head_kernel(co
     stagger(a.debug >> 8);
     // this wave's rows of dO (and Q') and its chunks of P: global -> registers, issued before the LDS staging
     f32x4 doreg[KK], qreg[KK], preg[NTK];
-    load_rows16<DP>(doreg, a.dout + b * a.os.sb + h * a.os.sh, a.os.sn, q, a.Nq, a.D, g, 1.f);
+    if constexpr (IOH)
+        load_rows16_bf16<DP>(doreg, reinterpret_cast<const unsigned short*>(a.dout) + b * a.os.sb + h * a.os.sh, a.os.sn, q, a.Nq,
+                             a.D, g);
+    else
+        load_rows16<DP>(doreg, a.dout + b * a.os.sb + h * a.os.sh, a.os.sn, q, a.Nq, a.D, g, 1.f);
     const float* prow = a.probs + b * a.probs_sb + (static_cast<int64_t>(h) * a.Nq + (qv ? q : 0)) * a.Nk;
 #pragma unroll
     for (int t = 0; t < NTK; ++t) preg[t] = load_chunk(prow, t * 16 + 4 * g, a.Nk, qv);
@@ -391,7 +435,11 @@ __global__ __launch_bounds__(NTK >= 7 ? 512 : 1024) void attn_bwd_head_kernel(co
 #pragma unroll
         for (int td = 0; td < KK; ++td) dq[td] = f32x4{0.f, 0.f, 0.f, 0.f};
         tiles_from_regs<DP, NTK, LSB>(dq, acc, Ks, c16, g);
-        store_rows16<DP>(a.dq + b * a.dqs.sb + h * a.dqs.sh, a.dqs.sn, q, qv, a.D, g, dq, q_first ? a.scale : 1.f);
+        if constexpr (IOH)
+            store_rows16_bf16<DP>(reinterpret_cast<unsigned short*>(a.dq) + b * a.dqs.sb + h * a.dqs.sh, a.dqs.sn, q, qv, a.D, g, dq,
+                                  q_first ? a.scale : 1.f);
+        else
+            store_rows16<DP>(a.dq + b * a.dqs.sb + h * a.dqs.sh, a.dqs.sn, q, qv, a.D, g, dq, q_first ? a.scale : 1.f);
     }
 
     // ---- phase C: dK = dS^T.Q' (pass 0), dV = P^T.dO (pass 1); contraction over q = across waves, through LDS
@@ -406,6 +454,8 @@ __global__ __launch_bounds__(NTK >= 7 ? 512 : 1024) void attn_bwd_head_kernel(co
             *reinterpret_cast<f32x4*>(Bs + q * LSB + kk * 16 + 4 * g) = pass == 0 ? qreg[kk] : doreg[kk];
         lds_barrier();
         float* outb = pass == 0 ? a.dk + b * a.dks.sb + h * a.dks.sh : a.dv + b * a.dvs.sb + h * a.dvs.sh;
+        unsigned short* outh = pass == 0 ? reinterpret_cast<unsigned short*>(a.dk) + b * a.dks.sb + h * a.dks.sh
+                                         : reinterpret_cast<unsigned short*>(a.dv) + b * a.dvs.sb + h * a.dvs.sh;
         const int64_t osn = pass == 0 ? a.dks.sn : a.dvs.sn;
         for (int kt = wave; kt < NTK; kt += NTQ) {
             // out^T tile (keys 16kt .. + 15 as the MFMA's N index): k-step s = (tq, r) pairs row 16tq + 4g + r of Ts (column
@@ -435,7 +485,8 @@ __global__ __launch_bounds__(NTK >= 7 ? 512 : 1024) void attn_bwd_head_kernel(co
                 for (int td = 0; td < KK; ++td) b_cur[td] = b_nxt[td];
             }
             const int key = kt * 16 + c16;
-            store_rows16<DP>(outb, osn, key, key < a.Nk, a.D, g, o, 1.f);
+            if constexpr (IOH) store_rows16_bf16<DP>(outh, osn, key, key < a.Nk, a.D, g, o, 1.f);
+            else store_rows16<DP>(outb, osn, key, key < a.Nk, a.D, g, o, 1.f);
         }
     }
 }
@@ -490,17 +541,21 @@ static int fwd_head_dispatch(const AttnFwdArgs& a, int NTK, int threads, size_t 
     return MMX_ENOTSUP;
 }
 
-template <int DP>
+#define MMX_HEAD_CASE_IO(DPV, N, IO)                                                                          \
+    case N:                                                                                                    \
+        return launch_head(attn_bwd_head_kernel<DPV, N, IO>, a, threads, lds, s, "attn_bwd_head_kernel")
+
+template <int DP, bool IOH>
 static int bwd_head_dispatch(const AttnBwdArgs& a, int NTK, int threads, size_t lds, hipStream_t s) {
     switch (NTK) {
-        MMX_HEAD_CASE(attn_bwd_head_kernel, DP, 1);
-        MMX_HEAD_CASE(attn_bwd_head_kernel, DP, 2);
-        MMX_HEAD_CASE(attn_bwd_head_kernel, DP, 3);
-        MMX_HEAD_CASE(attn_bwd_head_kernel, DP, 4);
-        MMX_HEAD_CASE(attn_bwd_head_kernel, DP, 5);
-        MMX_HEAD_CASE(attn_bwd_head_kernel, DP, 6);
-        MMX_HEAD_CASE(attn_bwd_head_kernel, DP, 7);
-        MMX_HEAD_CASE(attn_bwd_head_kernel, DP, 8);
+        MMX_HEAD_CASE_IO(DP, 1, IOH);
+        MMX_HEAD_CASE_IO(DP, 2, IOH);
+        MMX_HEAD_CASE_IO(DP, 3, IOH);
+        MMX_HEAD_CASE_IO(DP, 4, IOH);
+        MMX_HEAD_CASE_IO(DP, 5, IOH);
+        MMX_HEAD_CASE_IO(DP, 6, IOH);
+        MMX_HEAD_CASE_IO(DP, 7, IOH);
+        MMX_HEAD_CASE_IO(DP, 8, IOH);
     }
     return MMX_ENOTSUP;
 }
@@ -525,13 +580,23 @@ int attn_bwd_head_try(const AttnBwdArgs& a_in, hipStream_t s, int* rc_out) {
     a.debug = g_attn_head_stagger;
     if (!g_attn_head || a.slab_dt != MMX_F32 || a.D % 4 || a.D > 64 || a.Nk > 128 || a.Nq > 256 || a.Nq < 1 || a.Nk < 1)
         return 0;
-    if (!aligned16(a.v, a.vs.sb, a.vs.sh, a.vs.sn) || !aligned16(a.dout, a.os.sb, a.os.sh, a.os.sn)) return 0;
+    // (bf16 gradient I/O: 4-element chunks are 8 bytes -- aligned16 on half the byte strides is the 8-byte test)
+    const auto io_ok = [&](const void* p, const Strides& st) {
+        return a.io_bf16 ? ((reinterpret_cast<uintptr_t>(p) | static_cast<uintptr_t>(st.sb * 2) | static_cast<uintptr_t>(st.sh * 2) |
+                             static_cast<uintptr_t>(st.sn * 2)) & 7u) == 0
+                         : aligned16(p, st.sb, st.sh, st.sn);
+    };
+    if (!aligned16(a.v, a.vs.sb, a.vs.sh, a.vs.sn) || !io_ok(a.dout, a.os)) return 0;
     if (a.need_dqkv && (!aligned16(a.q, a.qs.sb, a.qs.sh, a.qs.sn) || !aligned16(a.k, a.ks.sb, a.ks.sh, a.ks.sn)))
         return 0;
+    if (a.io_bf16 && a.need_dqkv && (!io_ok(a.dq, a.dqs) || !io_ok(a.dk, a.dks) || !io_ok(a.dv, a.dvs))) return 0;
     const int DP = a.D <= 32 ? 32 : 64, NTK = (a.Nk + 15) / 16, NTQ = (a.Nq + 15) / 16, threads = 64 * NTQ;
     const size_t lds = bwd_head_lds(DP, NTK, NTQ);
     if (lds > 160 * 1024 || (NTK >= 7 && NTQ > 8)) return 0;
-    *rc_out = DP == 32 ? bwd_head_dispatch<32>(a, NTK, threads, lds, s) : bwd_head_dispatch<64>(a, NTK, threads, lds, s);
+    if (a.io_bf16)
+        *rc_out = DP == 32 ? bwd_head_dispatch<32, true>(a, NTK, threads, lds, s) : bwd_head_dispatch<64, true>(a, NTK, threads, lds, s);
+    else
+        *rc_out = DP == 32 ? bwd_head_dispatch<32, false>(a, NTK, threads, lds, s) : bwd_head_dispatch<64, false>(a, NTK, threads, lds, s);
     return 1;
 }
 

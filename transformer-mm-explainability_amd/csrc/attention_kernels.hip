@@ -430,7 +430,7 @@ static int attn_bwd_impl(const void* q_dev, const void* k_dev, const void* v_dev
     const bool rel = rel_in_dev != nullptr;
     MMX_CHECK_ARG(v_dev && probs_dev && do_dev && (dprobs_dev || rel), "mmx_attn_capture_bwd: null pointer");
     const int io_bf16 = (slab_dtype & MMX_ATTN_IO_BF16) ? 1 : 0;
-    MMX_CHECK_ARG(!io_bf16 || (slab_dtype & MMX_ATTN_MMA_BF16), "mmx_attn_capture_bwd: MMX_ATTN_IO_BF16 needs MMX_ATTN_MMA_BF16");
+    // (MMX_ATTN_IO_BF16 without MMX_ATTN_MMA_BF16: exact-fp32 arithmetic on a bf16 gradient stream -- the whole-head kernels only)
     if (rel) {
         MMX_CHECK_ARG(rel_out_dev && Nq == Nk, "mmx_attn_capture_bwd_rowrel: needs rel_out and self-attention (Nq == Nk)");
         MMX_CHECK_ARG(slab_dtype & MMX_ATTN_MMA_BF16, "mmx_attn_capture_bwd_rowrel: MMX_ATTN_MMA_BF16 kernels only");
@@ -489,6 +489,11 @@ static int attn_bwd_impl(const void* q_dev, const void* k_dev, const void* v_dev
         return MMX_ENOTSUP;
     }
     if (attn_bwd_head_try(a, s, &rc)) return rc;    // short sequences: a wave owns 16 query rows, scores in registers
+    if (io_bf16) {
+        set_error("mmx_attn_capture_bwd: MMX_ATTN_IO_BF16 without MMX_ATTN_MMA_BF16 is served by the whole-head kernels only "
+                  "(fp32 slabs, Nk <= 128, Nq <= 256, head_dim %% 4 == 0 and <= 64, 8-byte aligned gradient rows)");
+        return MMX_ENOTSUP;
+    }
     if (attn_bwd_small_try(a, s, &rc)) return rc;   // whole head resident in LDS (first generation of the above)
     if (attn_bwd_stream_try(a, s, &rc)) return rc;  // long sequences
     dim3 gq((Nq + kTQ - 1) / kTQ, H, B), gk((Nk + 15) / 16, H, B);

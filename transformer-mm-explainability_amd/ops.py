@@ -851,6 +851,12 @@ def attn_capture_fwd(q, k, v, probs_out, scale, scale_mode=_lib.SCALE_Q_FIRST, m
     return o
 
 
+def head_kernel_shape(n_q, n_k, head_dim, slab_dtype=torch.float32):
+    """Does the register-resident whole-head backward (``attention_head.hip``) serve this shape?  (Its eligibility test, host side:
+    what decides whether a bf16 gradient stream can pass through an exact-fp32 attention without conversion passes.)"""
+    return slab_dtype == torch.float32 and n_k <= 128 and n_q <= 256 and head_dim % 4 == 0 and head_dim <= 64
+
+
 def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCALE_Q_FIRST, need_dqkv=True,
                      layout="bnhd", out=None, batch=None, o=None, mma_bf16=False, rel_row=None):
     """Writes dP into ``dprobs_out`` and returns ``(dq, dk, dv)`` (``None`` when ``need_dqkv`` is False).
@@ -883,8 +889,9 @@ def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCA
     if d_o.stride(-1) != 1:
         d_o = d_o.contiguous()
     io_bf16 = d_o.dtype == torch.bfloat16            # bf16 gradient stream: dq / dk / dv come back as bf16 too
-    if io_bf16 and not mma_bf16:
-        raise MMXError("attn_capture_bwd: a bf16 d_o needs mma_bf16=True (MMX_ATTN_IO_BF16)")
+    if io_bf16 and not mma_bf16 and not head_kernel_shape(Nq, Nk, D, probs.dtype):
+        raise MMXError("attn_capture_bwd: a bf16 d_o needs mma_bf16=True (MMX_ATTN_IO_BF16) or a whole-head shape "
+                       "(fp32 slabs, Nk <= 128, Nq <= 256, head_dim % 4 == 0 and <= 64: exact-fp32 arithmetic on the bf16 stream)")
     flags = (_lib.MMX_ATTN_MMA_BF16 if mma_bf16 else 0) | (_lib.MMX_ATTN_IO_BF16 if io_bf16 else 0)
     dq = dk = dv = None
     ws = None
