@@ -305,6 +305,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_q_v3_kernel
         const bf16_t* Kcur = Kt + PAR * kD * kLT + tlane;
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {                               // keys 32 pp .. + 31 of the tile
+            // a half tile with no real key in it (577 = 9 x 64 + 1: the second half of the last tile) has P = 0: nothing to add
+            if (pp == 1 && kt * kT + 32 >= a.Nk) break;
             bf16x8 dsb[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -457,6 +459,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
         const bf16_t* Qtc = Qt + cur * kD * kLT + tlane;
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {                               // query rows 32 pp .. + 31 of the tile
+            // a half tile with no real query row in it (577 = 9 x 64 + 1: the second half of the last tile): P = 0 and dO = 0 there
+            if (pp == 1 && qt * kT + 32 >= a.Nq) break;
             f32x4 dp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // dp[hh][r] = dP[16 t + 4 g + r][key i]
 #pragma unroll
             for (int pr = 0; pr < kD / 32; ++pr)
