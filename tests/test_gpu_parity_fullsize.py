@@ -69,7 +69,7 @@ def test_fp16_mode_at_vit_b32_vs_the_references_fp16_model(golden):
     import faulthandler
     from transformer_mm_explainability_amd import clip_explainability as ce
     from transformer_mm_explainability_amd import clip_model
-    faulthandler.dump_traceback_later(150, exit=True)                 # a hang here must name its line, not eat the GPU budget
+    faulthandler.dump_traceback_later(300, exit=False)                # a stall here names its line in the log (does not stop the run)
     try:
         g = golden("clip_vitb32_fp16")
         model = clip_model.random_init("ViT-B/32", seed=0).cuda()
