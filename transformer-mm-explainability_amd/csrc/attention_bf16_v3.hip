@@ -27,6 +27,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef MMX_MERGED_B64          // (-DMMX_MERGED_B64: the round-3 form of the transposed operand reads, for A / B runs)
+#define MMX_SPLIT_B64 1
+#endif
+
 namespace mmx {
 namespace {
 
@@ -160,8 +164,17 @@ __device__ __forceinline__ void load_rows8(bf16x8 (&op)[kD / 32], const bf16_t* 
 // (written with the XOR on the whole index the compiler kept 16-32 address registers live across the loop).
 __device__ __forceinline__ int transposed_lane_base(int i, int g) { return i * kLT + 4 * (g ^ (i >> 2)); }
 __device__ __forceinline__ bf16x8 transposed_operand(const bf16_t* tile_lane, int dt, int p) {
+#ifdef MMX_SPLIT_B64
+    // two SEPARATE ds_read_b64 (2 LDS cycles each) instead of the ds_read2_b64 hipcc merges them into (8 cycles: each of its two
+    // accesses is serviced as 4 x 16 lanes) -- and no register shuffle when the pieces come out in descending address order
+    // (volatile keeps the two loads apart; the explicit LDS address space keeps them ds_read -- a volatile generic load is a flat_load)
+    typedef const volatile __attribute__((address_space(3))) u32x2v* lds_b64_ptr;
+    const u32x2v lo = *(lds_b64_ptr)(tile_lane + 16 * dt * kLT + 16 * (dt ^ (2 * p)));
+    const u32x2v hi = *(lds_b64_ptr)(tile_lane + 16 * dt * kLT + 16 * (dt ^ (2 * p + 1)));
+#else
     const u32x2v lo = *reinterpret_cast<const u32x2v*>(tile_lane + 16 * dt * kLT + 16 * (dt ^ (2 * p)));
     const u32x2v hi = *reinterpret_cast<const u32x2v*>(tile_lane + 16 * dt * kLT + 16 * (dt ^ (2 * p + 1)));
+#endif
     return as_bf16x8(u32x4v{lo[0], lo[1], hi[0], hi[1]});
 }
 
@@ -487,16 +500,24 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
             }
             if constexpr (DKV) {
                 // the raw probability words of the two sub-tiles ARE the bf16 A operand of dV = P^T . dO
-                // (odd dt: the transposed operands arrive with their k-slot halves exchanged -- transposed_operand_sorted -- and
-                // meet the exchanged copies of the A operands: 4 moves + 4 conversions per half tile instead of 16 moves)
+                // (MMX_MERGED_B64 only: for odd dt the transposed operands arrive with their k-slot halves exchanged --
+                // transposed_operand_sorted -- and meet exchanged copies of the A operands.  The default reads the two 8-byte pieces of
+                // an operand with two SEPARATE ds_read_b64: no merge into a half-rate ds_read2_b64, no register shuffle.)
                 const bf16x8 p_op = as_bf16x8(p_cur[pp]);
-                const bf16x8 p_sw = as_bf16x8(u32x4v{p_cur[pp][2], p_cur[pp][3], p_cur[pp][0], p_cur[pp][1]});
                 const bf16x8 ds_op = ABL == 4 || ABL == 7 ? p_op : pack8(ds[0], ds[1]);
+#ifndef MMX_SPLIT_B64
+                const bf16x8 p_sw = as_bf16x8(u32x4v{p_cur[pp][2], p_cur[pp][3], p_cur[pp][0], p_cur[pp][1]});
                 const bf16x8 ds_sw = ABL == 4 || ABL == 7 ? p_sw : pack8(ds[1], ds[0]);
+#endif
 #pragma unroll
                 for (int dt = 0; dt < NB; ++dt) {
+#ifdef MMX_SPLIT_B64
+                    vacc[dt] = mfma16x16x32_bf16(p_op, transposed_operand(dOtc, dt, pp), vacc[dt]);
+                    kacc[dt] = mfma16x16x32_bf16(ds_op, transposed_operand(Qtc, dt, pp), kacc[dt]);
+#else
                     vacc[dt] = mfma16x16x32_bf16(dt & 1 ? p_sw : p_op, transposed_operand_sorted(dOtc, dt, pp), vacc[dt]);
                     kacc[dt] = mfma16x16x32_bf16(dt & 1 ? ds_sw : ds_op, transposed_operand_sorted(Qtc, dt, pp), kacc[dt]);
+#endif
                 }
             }
             // pin this half's share of the relevancy sum here: left alone the compiler sinks all 16 multiply / clamp / fma
