@@ -88,15 +88,16 @@ counters2)       # second counter set (matrix-pipe busy, instruction counts, ins
   python tools/pmc_sq.py $OUT/pmc_sched/s_counter_collection.csv lxmert_schedule > $OUT/schedule_counters2.txt 2>&1; cat $OUT/schedule_counters2.txt
   rm -rf $OUT/pmc_v3 $OUT/pmc_v3b $OUT/pmc_sched
   ;;
-counters3)       # memory-side counters of the cfg-5 pair (vector L1 / texture addresser / L2), third- and fourth-generation key side
-  CA="SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_ANY"
-  CB="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum"
-  CC="TA_BUSY_avr TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum TD_TD_BUSY_sum"
-  CD="TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_TAG_STALL_sum TCC_BUSY_avr TCC_READ_sum TCC_EA0_RDREQ_sum TCC_CYCLE_sum"
+counters3)       # memory-side counters of the cfg-5 pair (SQ LDS / VMEM view).  NOTE: the TCP / TA / TCC sets this target first carried
+                 # (8 counters of ONE block per pass) made rocprofv3 abort with "Request exceeds the capabilities of the hardware to collect"
+                 # and then sit until its timeout -- 15 GPU-minutes for nothing.  At most 4 counters of a block per pass, short timeouts.
   i=0
-  for C in "$CA" "$CB" "$CC" "$CD"; do
+  for C in "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_ANY" \
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
+           "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum" \
+           "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_TAG_STALL_sum"; do
     i=$((i+1))
-    timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$i -o v -- python tools/probe_attn_v3.py 16 2,3 > /dev/null 2> $OUT/pmc_$i.log
+    timeout 90 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$i -o v -- python tools/probe_attn_v3.py 16 2,3 > /dev/null 2> $OUT/pmc_$i.log
     python tools/pmc_sq.py $OUT/pmc_$i/v_counter_collection.csv attn_bwd_ > $OUT/attn_counters_mem_$i.txt 2>&1 || tail -5 $OUT/pmc_$i.log
     cat $OUT/attn_counters_mem_$i.txt
     rm -rf $OUT/pmc_$i
