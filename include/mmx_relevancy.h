@@ -37,8 +37,10 @@ enum mmx_dtype { MMX_F32 = 0, MMX_F16 = 1, MMX_BF16 = 2 };
  * cores (v_mfma_f32_16x16x32_bf16: operands rounded to bf16 as they are read, fp32 accumulation, softmax / dS arithmetic in
  * fp32) instead of the exact-fp32 MFMA.  BASELINE config 5 (a bf16 CLIP body, CLIP/clip/model.py:381-402). */
 #define MMX_ATTN_MMA_BF16 0x100
-/* Backward only, together with MMX_ATTN_MMA_BF16: `do_dev` holds bf16 and dq / dk / dv are written as bf16 (the gradient
- * stream between the bf16 GEMMs of a bf16 body needs no conversion passes); strides stay in elements, 16-byte aligned.
+/* Backward only: `do_dev` holds bf16 and dq / dk / dv are written as bf16 (the gradient stream between the bf16 GEMMs of a
+ * bf16 body needs no conversion passes); strides stay in elements, 16-byte aligned.  With MMX_ATTN_MMA_BF16: any shape the
+ * streaming kernels serve.  WITHOUT it (round 4): the exact-fp32 arithmetic of the whole-head kernels around bf16 gradient
+ * I/O -- fp32 slabs, Nk <= 128, Nq <= 256, head_dim % 4 == 0 and <= 64, 8-byte aligned gradient rows; MMX_ENOTSUP otherwise.
  * No entry point reads or writes outside the buffers it is handed (16-bit slabs: the vector loads of the streaming kernels
  * fall back to element loads for the last few elements of a slab). */
 #define MMX_ATTN_IO_BF16 0x200
