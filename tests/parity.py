@@ -1,5 +1,7 @@
-"""Shared parity helper of the ``-m gpu`` suites: absolute tolerance only for relevancy maps (north star: 1e-5, fp32), and
-a record of the LARGEST absolute error every comparison saw, per test, written at session end to
+"""Shared parity helper of the ``-m gpu`` suites.  Relevancy maps are judged on TWO bounds at once: the north star's absolute
+1e-5 (fp32) and -- because a map's largest entry can be as small as 5e-4 (DETR ``R_q_i`` rows), where 1e-5 is 2 % of the signal --
+``err <= RELMAX * max|reference|`` (VERDICT r04 "what's weak" #1; RELMAX = 1e-4, the measured errors are 1e-5 ... 1e-8 of the
+largest entry).  Plus a record of the LARGEST absolute error every comparison saw, per test, written at session end to
 ``gpurun_out/parity_errors.json`` (copied to ``profiles/rNN_parity.json`` by the round script) so the tolerance in a test
 is backed by a measured number, not by a constant."""
 import json
@@ -14,7 +16,7 @@ def _np(x):
     return x.detach().float().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
 
-def note(label, value, bound=None, scale=None):
+def note(label, value, bound=None, scale=None, relmax=None):
     """Remember ``value`` (max over repeated notes) under the running test's id + ``label``; ``scale`` = max |reference|
     of the compared tensor, so the record also says what the absolute error means relative to the map."""
     test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
@@ -26,19 +28,30 @@ def note(label, value, bound=None, scale=None):
     if scale:
         entry["max_abs_ref"] = float(scale)
         entry["err_over_max_ref"] = float(value) / float(scale)
+        if relmax is not None:
+            entry["relmax"] = float(relmax)
     if prev is None or prev["max_abs_err"] < entry["max_abs_err"]:
         RECORD[key] = entry
 
 
-def close(a, b, atol=1e-5, rtol=0.0, what=""):
-    """|a - b| <= atol + rtol |b| elementwise; ``rtol`` defaults to ZERO (relevancy maps are judged on the absolute 1e-5)."""
+RELMAX = 1e-4
+
+
+def close(a, b, atol=1e-5, rtol=0.0, what="", relmax=RELMAX):
+    """|a - b| <= atol + rtol |b| elementwise; ``rtol`` defaults to ZERO (relevancy maps are judged on the absolute 1e-5) and
+    then the largest error must ALSO stay below ``relmax`` x the largest |reference| entry.  ``relmax=None`` switches the second
+    bound off: only for comparisons whose tolerance is stated in another currency (a storage precision such as bf16 slabs, or the
+    reference's own fp32-vs-fp64 distance for the LRP passes) -- the call site says which."""
     a, b = _np(a), _np(b)
     assert a.shape == b.shape, (a.shape, b.shape)
     assert np.array_equal(np.isnan(a), np.isnan(b))
     fin = ~np.isnan(b)
     err = float(np.abs(a[fin] - b[fin]).max()) if fin.any() else 0.0
-    note(what, err, atol if rtol == 0.0 else None, float(np.abs(b[fin]).max()) if fin.any() else None)
+    scale = float(np.abs(b[fin]).max()) if fin.any() else None
+    note(what, err, atol if rtol == 0.0 else None, scale, relmax if rtol == 0.0 else None)
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
+    if rtol == 0.0 and relmax is not None and scale:
+        assert err <= relmax * scale, "%s: max |err| %.3e > %.0e x max |ref| (%.3e)" % (what or "map", err, relmax, scale)
 
 
 def dump(path):

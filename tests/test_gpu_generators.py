@@ -407,7 +407,7 @@ def test_detr_generate_ours_multi_equals_per_query_loop(golden, flags):
         close(two, one.cpu().numpy(), atol=1e-6)
 
 
-def test_detr_mask_generator_r50_shape():
+def test_detr_mask_generator_r50_shape(capsys):
     """mask_generator.py core at config-3 size: batched relevancy + batched Otsu == per-query loop + per-map Otsu."""
     from transformer_mm_explainability_amd import detr_model, postprocess
     from transformer_mm_explainability_amd.detr_explainability import Generator, MaskGenerator
@@ -429,6 +429,9 @@ def test_detr_mask_generator_r50_shape():
         assert (masks[0, idx] != ref).float().mean() < 0.01
     rollout_masks, _ = mg.get_masks(feats, "rollout")
     assert set(rollout_masks[0, kept].unique().tolist()) <= {0.0, 255.0}
+    # the reference's error convention for an unknown method: a message and None (DETR/mask_generator.py:111-113)
+    assert mg.get_masks(feats, "no_such_method") is None
+    assert "valid explainability method" in capsys.readouterr().out
 
 
 def test_detr_rule_kernels_beside_the_backward_equal_the_serial_schedule(golden):

@@ -59,7 +59,9 @@ def test_cfg3_detr_r50_k10_rows_hipgraph_vs_oracle_body():
                                                 dt._np(grads[ne + nd:]), np.array([t]))[0, 0, 0])
     want = np.stack(rows)
     assert out.shape == (1, 1, K, 950)
-    parity.close(out[0, 0], want, atol=1e-5, rtol=0.0, what="R_q_i rows (K=10, Ni=950)")
+    # relative bound: measured 1.4e-4 of the largest entry (7.0e-8 on 5.1e-4, profiles/r04_parity.json) -- two fp32 evaluations that
+    # sum 950-term dot products in different orders through 6 + 6 layers; 3e-4 keeps a 1 % regression out (the old bar let 2 % in)
+    parity.close(out[0, 0], want, atol=1e-5, rtol=0.0, what="R_q_i rows (K=10, Ni=950)", relmax=3e-4)
 
 
 def test_cfg4_lxmert_base_b32_tape_hipgraph_vs_oracle_body():

@@ -330,15 +330,15 @@ def test_detr_ni950_rules_vs_oracle():
     ca, cg = zip(*[slab(b.multihead_attn) for b in dec])
     want = onp.detr_generate_ours_chain(ea, eg, sa, sg, ca, cg, tgt.cpu().numpy())
     assert want.shape == out.shape == (1, 1, 1, 950)
-    close(out, want, atol=1e-5)
+    close(out, want, atol=1e-5, relmax=3e-4)   # measured 1.05e-4 of the largest entry (950-term fp32 dot products, two summation orders)
     both = torch.tensor([3, 57], device="cuda")
     multi = Generator(model).generate_ours_multi(feats, both)
-    close(multi[:, :, 1:2], want, atol=1e-5)
+    close(multi[:, :, 1:2], want, atol=1e-5, relmax=3e-4)
     # the row-vector form of the same rules (``rows_only``: no R_i_i, mat-vecs only) vs the oracle, and both routes vs an
     # fp64 evaluation of the schedule on the captured slabs (referee only): the vector form carries rho = R_ii 1 - 1 as a
     # deviation, the matrix form gets it through diag(R_ii) - 1 and loses 2-3 digits there
     rows = Generator(model).generate_ours_multi(feats, both, rows_only=True)
-    close(rows[:, :, 1:2], want, atol=1e-5)
+    close(rows[:, :, 1:2], want, atol=1e-5, relmax=3e-4)
     gen2 = Generator(model)
     gen2.generate_ours_multi(feats, both, share_forward=False)              # per-sample slabs of sample 1 (query 57)
     dd = lambda t: t.double()

@@ -85,6 +85,41 @@ def test_vit_b16_full_size_graph_replay_after_other_graphs():
     clip_graph(image, texts)
 
 
+def test_cfg1_vit_b16_full_size_vs_oracle():
+    """VERDICT r04 missing #3: EXACTLY the object ``tools/bench_legs.leg_cfg1`` times -- ``vit_base_patch16_224()`` under seed 0
+    (12 layers x 12 heads x 197 tokens, width 768, 1000 classes), ``GraphedRelevance`` replayed from its hipGraph with 1 target
+    and with 8 targets -- against the CPU oracle ``oracle/vit_torch.generate_relevance`` on the same state dict and image
+    (``Transformer_MM_explainability_ViT.ipynb`` cell 7:14-34), absolute 1e-5 AND 1e-4 of the largest entry."""
+    from oracle import vit_torch
+    from transformer_mm_explainability_amd import vit_model
+    torch.manual_seed(0)
+    model = vit_model.vit_base_patch16_224().float().eval()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    want = {}
+    for idx in range(8):
+        want[idx], logits_ref = vit_torch.generate_relevance(sd, x, 12, idx)
+    model = model.cuda()
+    xc = x.cuda()
+    close(model(xc), logits_ref, atol=2e-5, rtol=1e-4, what="logits")
+    run1 = vit_model.GraphedRelevance(model, xc, indices=[5])
+    for _ in range(2):
+        got1 = run1(xc)
+    close(got1[0], want[5], what="cfg1 leg, 1 target (hipGraph replay)")
+    run8 = vit_model.GraphedRelevance(model, xc, indices=list(range(8)))
+    for _ in range(2):
+        got8 = run8(xc)
+    for idx in range(8):
+        close(got8[idx], want[idx], what="cfg1 leg, 8 targets (hipGraph replay)")
+    # the notebook entry point itself (eager, arg-max class)
+    from transformer_mm_explainability_amd import vit_explainability as ve
+    top = int(logits_ref.argmax())
+    want_top = want[top] if top in want else vit_torch.generate_relevance(sd, x, 12, top)[0]
+    close(ve.generate_relevance(model, xc), want_top, what="generate_relevance(model, x) eager")
+
+
 def test_vit_b16_full_size_properties():
     """BASELINE.json config 1's architecture (ViT-B/16: 12 layers x 12 heads x 197 tokens) at full size: the K-target
     pass (shared forward, streaming attention kernels, split chain path with a shared probability slab) equals K

@@ -445,6 +445,8 @@ class MaskGenerator:
     _BATCHED = {"ours_no_lrp": {}, "ablation_no_self_in_10": {"apply_self_in_rule_10": False},
                 "ours_no_lrp_no_norm": {"normalize_self_attention": False}}
 
+    _PER_QUERY = ("ablation_no_aggregation", "ours_with_lrp", "raw_attn", "rollout", "attn_gradcam", "transformer_att", "partial_lrp")
+
     def __init__(self, model, threshold=0.5, graph_slots=None, max_graphs=4):
         """``graph_slots`` (e.g. 16): run the batched methods through ``GraphedGenerateOursMulti`` with that many target
         slots (captured on the first image of a given feature-map size; the evaluator's images are resized to a common
@@ -484,9 +486,7 @@ class MaskGenerator:
         fn = {"raw_attn": self.gen.generate_raw_attn, "rollout": self.gen.generate_rollout,
               "attn_gradcam": self.gen.generate_attn_gradcam, "transformer_att": self.gen.generate_transformer_att,
               "partial_lrp": self.gen.generate_partial_lrp}.get(method)
-        if fn is None:
-            raise ValueError("please provide a valid explainability method (got %r)" % (method,))
-        return fn(img, idx)
+        return None if fn is None else fn(img, idx)     # unknown method: the caller prints and returns None like the reference
 
     def get_masks(self, img, method="ours_no_lrp", outputs=None):
         """``outputs``: the body's output dict for ``img`` when the caller has already run the forward (an evaluator
@@ -525,6 +525,11 @@ class MaskGenerator:
                                                 **self._BATCHED[method])[0, 0]                             # [K, Ni]
             self._fold_diag(self.gen.diag_min)
         else:
+            if method not in self._PER_QUERY:
+                # the reference's error convention (DETR/mask_generator.py:111-113): a message and ``None``, reached -- as there,
+                # inside the loop over the kept queries -- only when the image has a kept query
+                print("please provide a valid explainability method")
+                return None
             cams = torch.cat([self._per_query(img, idx.reshape(1), method).reshape(1, -1) for idx in kept])
         masks[0, kept] = postprocess.otsu_masks(cams).reshape(-1, h, w)
         return masks, keep
