@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmmx_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mmx_relevancy.h")
 
 MMX_F32, MMX_F16, MMX_BF16 = 0, 1, 2
+MMX_ENOTSUP = -95               # shape / view outside what the kernels support (include/mmx_relevancy.h)
 MMX_ATTN_IO_BF16 = 0x200        # backward: bf16 dO in, bf16 dq / dk / dv out (with MMX_ATTN_MMA_BF16)
 MMX_ATTN_MMA_BF16 = 0x100       # OR-ed into slab_dtype of the attention *_ex entry points (bf16 matrix cores)
 MM_NORMALIZE, MM_SELF_IN_RULE10, MM_NAN_TO_ZERO = 1, 2, 4

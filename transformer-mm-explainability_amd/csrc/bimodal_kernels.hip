@@ -760,9 +760,9 @@ extern "C" int mmx_lxmert_schedule_v2(const void* const* lang_attn, const void* 
         MMX_LAUNCH_CHECK("lxmert_schedule_v2_kernel (phase 2)");
         return MMX_OK;
     }
-    // one launch: workgroups per sample so that the 256 CUs are filled once when the batch allows it (each workgroup is 512
+    // one launch: workgroups per sample so that the CUs (256 on MI355X) are filled once when the batch allows it (each workgroup is 512
     // threads and holds phase 2's LDS, i.e. one per CU)
-    int W = 256 / B;
+    int W = device_cu_count() / B;
     if (W < 1) W = 1;
     if (W > v.nblk) W = v.nblk;
     v.W = W;

@@ -221,6 +221,7 @@ int hip_fail(hipError_t e, const char* what);
 // with a corrupted 64-bit pattern once other work had run between capture and replay (every second fp32 word garbage);
 // kernel nodes carry their arguments by value and do not have that problem.  ``bytes`` must be a multiple of 4.
 int zero_async(void* dst, size_t bytes, hipStream_t s);
+int device_cu_count();   // compute units of the current device, cached
 int identity_async(float* R, int batch, int N, hipStream_t s);   // R[b] = I  (N x N, contiguous)
 
 }  // namespace mmx

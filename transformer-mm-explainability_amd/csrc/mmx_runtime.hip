@@ -19,6 +19,17 @@ int hip_fail(hipError_t e, const char* what) {
     return MMX_EHIP - static_cast<int>(e);
 }
 
+// Compute units of the current device (256 on MI355X), read once per device: grids that fill the chip "once" size themselves by it.
+int device_cu_count() {
+    static int cached[16] = {0};
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < 16 && cached[dev]) return cached[dev];
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+    if (dev >= 0 && dev < 16) cached[dev] = cus;
+    return cus;
+}
+
 __global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ dst, size_t words) {
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < words; i += stride) dst[i] = 0u;

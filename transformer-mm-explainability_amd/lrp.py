@@ -108,15 +108,20 @@ def mha_relprop(cam_out, tape, weights, attn_core):
     cam_probs, cam_q, cam_k, cam_v = attn_core(cam_o)
     cam_v, cam_k, cam_q = cam_v.reshape(B, -1, E), cam_k.reshape(B, -1, E), cam_q.reshape(B, T, E)
     cam_v_pre = cam_v
-    pre_zero = None if ops.lrp_fusable(cam_v) else _all_zero(cam_v)
+    # ONE decision for both the bookkeeping (pre_zero) and the rescale branch, taken on everything the fused launches will read:
+    # the projections below keep dtype and device, so the four streams are fusable after them iff they are now
+    fused = ops.lrp_fusable(cam_v, cam_k, cam_q, cam_o)
+    pre_zero = None if fused else _all_zero(cam_v)
     cam_v = linear_relprop(cam_v, tape["value"], Wv)
     cam_k = linear_relprop(cam_k, tape["key"], Wk)
     cam_q = linear_relprop(cam_q, tape["query"], Wq)
     # layers.py:791-799: a value stream that carries no relevance through its projection (decoder layer 0: value = 0)
     # hands the head-level relevance to the query / key streams, split by their share of the total
-    if ops.lrp_fusable(cam_v, cam_k, cam_q, cam_o):                     # two launches instead of ~35 (csrc/lrp_kernels.hip)
+    if fused and ops.lrp_fusable(cam_v, cam_k, cam_q):                  # two launches instead of ~35 (csrc/lrp_kernels.hip)
         cam_k, cam_q = ops.lrp_mha_rescale(cam_v_pre, cam_v, cam_k, cam_q, cam_o)
         return cam_q, cam_k, cam_v, cam_probs
+    if pre_zero is None:                                                # (a projection changed dtype / device: torch formulation)
+        pre_zero = _all_zero(cam_v_pre)
     rescale = _all_zero(cam_v) & ~pre_zero
     ks, qs, total = cam_k.sum(), cam_q.sum(), cam_o.sum()
     kf = safe_divide(ks.abs(), ks.abs() + qs.abs()) * total

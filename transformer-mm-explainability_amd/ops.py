@@ -412,6 +412,10 @@ def lrp_linear(R, X, weight, normalize):
     """``Linear.relprop`` (alpha = 1) as 2 GEMMs + 3 (4 with ``normalize``) launches: see ``csrc/lrp_kernels.hip``.
     ``R [..., out]``, ``X [..., in]``, ``weight [out, in]`` -> ``[..., in]``."""
     n_in, n_out = X.shape[-1], R.shape[-1]
+    # the kernels index R by X's rows and the weight by (R, X)'s last dimensions: a mismatched or broadcastable R must not reach them
+    if tuple(R.shape[:-1]) != tuple(X.shape[:-1]) or tuple(weight.shape) != (n_out, n_in):
+        raise MMXError("lrp_linear: R %s, X %s, weight %s do not describe Linear.relprop (R [..., out], X [..., in], weight "
+                       "[out, in] with equal leading dimensions)" % (tuple(R.shape), tuple(X.shape), tuple(weight.shape)))
     Xc, Rc = X.contiguous(), R.contiguous()
     rows = Xc.numel() // n_in
     WW = sign_split_weight(weight)                                   # [out, 2 in]
@@ -854,7 +858,13 @@ def attn_capture_fwd(q, k, v, probs_out, scale, scale_mode=_lib.SCALE_Q_FIRST, m
 def head_kernel_shape(n_q, n_k, head_dim, slab_dtype=torch.float32):
     """Does the register-resident whole-head backward (``attention_head.hip``) serve this shape?  (Its eligibility test, host side:
     what decides whether a bf16 gradient stream can pass through an exact-fp32 attention without conversion passes.)"""
-    return slab_dtype == torch.float32 and n_k <= 128 and n_q <= 256 and head_dim % 4 == 0 and head_dim <= 64
+    if not (slab_dtype == torch.float32 and 1 <= n_k <= 128 and 1 <= n_q <= 256 and head_dim % 4 == 0 and head_dim <= 64):
+        return False
+    # the kernel's own exclusions (attention_head.hip, attn_bwd_head_try): its LDS image must fit a CU, and the widest key
+    # side is not instantiated beyond 8 query strips
+    dp, ntk, ntq = (32 if head_dim <= 32 else 64), (n_k + 15) // 16, (n_q + 15) // 16
+    lds = 4 * max(ntk * 16 * (2 * dp + 12), ntq * 16 * (ntk * 16 + 4 + dp + 4))
+    return lds <= 160 * 1024 and not (ntk >= 7 and ntq > 8)
 
 
 def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCALE_Q_FIRST, need_dqkv=True,
@@ -922,13 +932,25 @@ def attn_capture_bwd(q, k, v, probs, d_o, dprobs_out, scale, scale_mode=_lib.SCA
             B, H, Nq, Nk, D, float(scale), scale_mode, int(need_dqkv), _p(rel_row), _p(rel_out), _p(ws), need, _stream()),
             "mmx_attn_capture_bwd_rowrel")
         return dq, dk, dv, rel_out
-    check(lib().mmx_attn_capture_bwd_ex(
-        _p(q), _p(k), _p(v), *_bhnd_strides(q, layout), *_bhnd_strides(k, layout), *_bhnd_strides(v, layout),
-        _p(probs), probs_sb, _DTYPES[probs.dtype] | flags, _p(d_o), *_bhnd_strides(d_o, layout),
-        _p(o), *(_bhnd_strides(o, layout) if o is not None else zero3), _p(dprobs_out), _p(dq), _p(dk), _p(dv),
-        *(_bhnd_strides(dq, layout) if need_dqkv else zero3), *(_bhnd_strides(dk, layout) if need_dqkv else zero3),
-        *(_bhnd_strides(dv, layout) if need_dqkv else zero3),
-        B, H, Nq, Nk, D, float(scale), scale_mode, int(need_dqkv), _p(ws), need, _stream()), "mmx_attn_capture_bwd")
+    def call(d_o_, dq_, dk_, dv_, flags_):
+        return lib().mmx_attn_capture_bwd_ex(
+            _p(q), _p(k), _p(v), *_bhnd_strides(q, layout), *_bhnd_strides(k, layout), *_bhnd_strides(v, layout),
+            _p(probs), probs_sb, _DTYPES[probs.dtype] | flags_, _p(d_o_), *_bhnd_strides(d_o_, layout),
+            _p(o), *(_bhnd_strides(o, layout) if o is not None else zero3), _p(dprobs_out), _p(dq_), _p(dk_), _p(dv_),
+            *(_bhnd_strides(dq_, layout) if need_dqkv else zero3), *(_bhnd_strides(dk_, layout) if need_dqkv else zero3),
+            *(_bhnd_strides(dv_, layout) if need_dqkv else zero3),
+            B, H, Nq, Nk, D, float(scale), scale_mode, int(need_dqkv), _p(ws), need, _stream())
+    rc = call(d_o, dq, dk, dv, flags)
+    if rc == _lib.MMX_ENOTSUP and io_bf16 and not mma_bf16:
+        # the whole-head kernel is the only exact-fp32 kernel with bf16 gradient I/O; it turned this call down at run time (a view
+        # it cannot load 8 bytes at a time, or option attn_head = 0): same arithmetic on an fp32 d_o, results rounded once to bf16
+        f32 = [torch.empty(tuple(t.shape), dtype=torch.float32, device=t.device) for t in (q, k, v)] if need_dqkv else [None] * 3
+        check(call(d_o.float(), *f32, flags & ~_lib.MMX_ATTN_IO_BF16), "mmx_attn_capture_bwd")
+        if need_dqkv:
+            for dst, src in zip((dq, dk, dv), f32):
+                dst.copy_(src)
+        return dq, dk, dv
+    check(rc, "mmx_attn_capture_bwd")
     return dq, dk, dv
 
 

@@ -39,7 +39,8 @@ def enable(workload):
     return bool(tun.read_file(os.path.join(_DIR, WORKLOADS[workload])))
 
 
-_LOCK = threading.Lock()
+_LOCK = threading.RLock()      # re-entrant: a helper may open its own scope inside a caller's (same thread)
+_DEPTH = [0]                   # nesting depth under _LOCK: only the OUTERMOST scope saves / restores the TunableOp state
 
 
 def _flag(tun, getter):
@@ -60,6 +61,16 @@ def scope(workload):
         return
     tun = torch.cuda.tunable
     with _LOCK:
+        if _DEPTH[0] > 0:          # nested on this thread: the outer scope owns the saved state; just make sure the selection is on
+            if workload not in _LOADED:
+                _LOADED[workload] = enable(workload)
+            _DEPTH[0] += 1
+            try:
+                yield _LOADED[workload]
+            finally:
+                _DEPTH[0] -= 1
+            return
+        _DEPTH[0] = 1
         was = tun.is_enabled()
         was_tuning = _flag(tun, "tuning_is_enabled")
         was_record = _flag(tun, "record_untuned_is_enabled")
@@ -71,6 +82,7 @@ def scope(workload):
         try:
             yield _LOADED[workload]
         finally:
+            _DEPTH[0] = 0
             if was_tuning is not None:
                 tun.tuning_enable(was_tuning)
             if was_record is not None and hasattr(tun, "record_untuned_enable"):
