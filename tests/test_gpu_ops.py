@@ -178,6 +178,57 @@ def test_self_chain_pipelined_stream_waves_bit_identical(ops, L, B, H, N, groups
     assert all(torch.equal(o, outs[-1]) for o in outs[:-1])
 
 
+@pytest.fixture
+def chain_options(ops):
+    """Options of the chain kernels are process-global: whatever a test sets is put back, also when it fails."""
+    yield ops
+    for key, value in (("self_chain_algo", 0), ("self_chain_groups", 0), ("self_chain_pipe", 4), ("self_chain_nt", 1),
+                       ("self_chain_relay_q", 0), ("self_chain_relay_d", 0), ("debug_flags", 0)):
+        ops.set_option(key, value)
+
+
+@pytest.mark.parametrize("L,B,H,N,causal,with_init,shared,offset", [
+    (12, 64, 8, 77, True, False, False, 0),     # cfg-2 text tower at the bench's batch: 4 streamers per sample, odd N^2
+    (12, 64, 12, 50, False, False, True, 0),    # cfg-2 image tower, one forward shared by the batch, 2 heads per round
+    (12, 5, 8, 77, True, True, False, 3),       # batch not a multiple of 8, R_init, slabs 12 bytes above a 16-byte boundary
+    (3, 2, 2, 12, False, False, False, 1), (2, 3, 4, 128, False, True, False, 0), (4, 9, 5, 33, False, False, False, 2),
+    (6, 1, 12, 112, False, False, False, 0),    # VisualBERT's shape: ONE sample spread over 16 streamers
+    (2, 2, 3, 97, False, False, False, 0),      # 7 column slabs: single A_bar buffer in the chain workgroup
+    (1, 2, 1, 7, False, False, False, 1), (3, 130, 2, 40, False, False, False, 0),
+])
+def test_self_chain_relay_bit_identical(chain_options, L, B, H, N, causal, with_init, shared, offset):
+    """K1r (``relevancy_chain_relay.hip``: position-split LDS-DMA streamers feeding one chain workgroup per sample, strict layer
+    order) == the sequential per-sample kernel BIT FOR BIT (same head order, same MFMA chain) and within 1e-5 of the oracle;
+    repeated launches reuse scratch and counters; other ring depths / streamer counts change the schedule, not the bits."""
+    ops = chain_options
+    attn, grad = make_layers(L * 13 + N + B, L, B, H, N, causal)
+    if shared:
+        attn = [a.view(B, H, N, N)[:1].expand(B, H, N, N).reshape(B * H, N, N).contiguous() for a in attn]
+    R0 = (torch.eye(N) + torch.rand(B, N, N) * 0.1) if with_init else None
+    want = np.broadcast_to(np.eye(N, dtype=np.float32), (B, N, N)).copy() if R0 is None else R0.numpy().copy()
+    for a, g in zip(attn, grad):
+        want = want + np.matmul(onp.avg_heads_batched(a.numpy(), g.numpy(), B), want)
+
+    def place(t):                                # a contiguous view `offset` elements above an aligned allocation
+        flat = torch.empty(t.numel() + 4, device="cuda")
+        flat[offset:offset + t.numel()] = t.reshape(-1).cuda()
+        return flat[offset:offset + t.numel()].view(t.shape)
+    ca = [place(a.view(B, H, N, N)[0] if shared else a) for a in attn]
+    cg = [place(g) for g in grad]
+    r0 = R0.cuda() if with_init else None
+    run = lambda: ops.relevancy_self_chain(ca, cg, B, R_init=r0, shared_attn=shared).clone()   # noqa: E731
+    ops.set_option("self_chain_algo", 1)
+    ops.set_option("self_chain_groups", 1)
+    ref = run()
+    close(ref, want)
+    ops.set_option("self_chain_algo", 3)
+    for q, d in ((0, 0), (0, 0), (1, 0), (3, 2), (0, 3)):
+        ops.set_option("self_chain_relay_q", q)
+        ops.set_option("self_chain_relay_d", d)
+        got = run()
+        assert torch.equal(got, ref), (q, d, float((got - ref).abs().max()))
+
+
 def test_self_chain_algorithms_bit_identical(ops):
     """Per-sample fused kernel and reduce + last-arriver kernel sum in the same order -> identical bits;
     repeated launches (scratch + counters reused) stay identical too."""

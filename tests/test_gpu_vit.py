@@ -113,8 +113,10 @@ def test_cfg1_vit_b16_full_size_vs_oracle():
         got8 = run8(xc)
     for idx in range(8):
         close(got8[idx], want[idx], what="cfg1 leg, 8 targets (hipGraph replay)")
-    # the notebook entry point itself (eager, arg-max class)
+    # the notebook entry point itself (eager, arg-max class; it differentiates through autograd: parameters need grads again)
     from transformer_mm_explainability_amd import vit_explainability as ve
+    for p in model.parameters():
+        p.requires_grad_(True)
     top = int(logits_ref.argmax())
     want_top = want[top] if top in want else vit_torch.generate_relevance(sd, x, 12, top)[0]
     close(ve.generate_relevance(model, xc), want_top, what="generate_relevance(model, x) eager")

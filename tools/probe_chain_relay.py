@@ -1,0 +1,81 @@
+"""Kernel-only probe (GPU box): the relay chain kernel (relevancy_chain_relay.hip, K1r) against the layer-group kernel it replaces,
+at the cfg-2 shapes over ROTATING slab sets (> 600 MB per tower: every byte from HBM), graph replay, HIP events.
+Variants: ring depth, streamers per sample, nt policy, and the phase-skip flags (1 = streamers only, 2 = chain + hand-off only)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from transformer_mm_explainability_amd import ops
+
+
+def timed(fns, iters=10, warm=2):
+    for _ in range(warm):
+        for f in fns:
+            f()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for f in fns:
+            f()
+    graph.replay()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        graph.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / (iters * len(fns)) * 1e3
+
+
+DEFAULTS = {"self_chain_algo": 0, "self_chain_groups": 0, "self_chain_nt": 1, "self_chain_relay_q": 0, "self_chain_relay_d": 0,
+            "debug_flags": 0}
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    variants = [
+        ("layer groups G=4 (r04 default)", {"self_chain_algo": 1}),
+        ("per-sample G=1", {"self_chain_algo": 1, "self_chain_groups": 1}),
+        ("relay auto", {"self_chain_algo": 3}),
+        ("relay nt=0", {"self_chain_algo": 3, "self_chain_nt": 0}),
+        ("relay D=2", {"self_chain_algo": 3, "self_chain_relay_d": 2}),
+        ("relay D=3", {"self_chain_algo": 3, "self_chain_relay_d": 3}),
+        ("relay D=4", {"self_chain_algo": 3, "self_chain_relay_d": 4}),
+        ("relay Q=2", {"self_chain_algo": 3, "self_chain_relay_q": 2}),
+        ("relay Q=3", {"self_chain_algo": 3, "self_chain_relay_q": 3}),
+        ("relay Q=6", {"self_chain_algo": 3, "self_chain_relay_q": 6}),
+        ("relay Q=8", {"self_chain_algo": 3, "self_chain_relay_q": 8}),
+        ("relay streamers only (debug 1)", {"self_chain_algo": 3, "debug_flags": 1}),
+        ("relay hand-off + chain only (debug 2)", {"self_chain_algo": 3, "debug_flags": 2}),
+    ]
+    for (L, H, N, name, sets) in [(12, 8, 77, "txt", 3), (12, 12, 50, "img", 4)]:
+        slabs = []
+        for _ in range(sets):
+            attn = [torch.rand(B * H, N, N, device="cuda").softmax(-1) for _ in range(L)]
+            grad = [torch.randn(B * H, N, N, device="cuda") * 0.01 for _ in range(L)]
+            slabs.append((attn, grad))
+        nbytes = 2 * L * B * H * N * N * 4
+        ref = None
+        for label, opts in variants:
+            for k, v in {**DEFAULTS, **opts}.items():
+                ops.set_option(k, v)
+            try:
+                rot = timed([(lambda a=a, g=g: ops.relevancy_self_chain(a, g, B)) for a, g in slabs])
+                same = timed([lambda: ops.relevancy_self_chain(slabs[0][0], slabs[0][1], B)] * sets)
+                out = ops.relevancy_self_chain(slabs[0][0], slabs[0][1], B).clone()
+            except Exception as exc:                                   # a variant that does not launch must not end the probe
+                print(f"{name}: {label:40s} FAILED: {exc}")
+                continue
+            if label.startswith("per-sample"):
+                ref = out
+            same_bits = "" if ref is None or opts.get("debug_flags") else f" | == per-sample G=1: {bool(torch.equal(out, ref))}"
+            print(f"{name} B={B}: {label:40s} rotating {rot:6.1f} us = {nbytes/rot/1e6:.3f} TB/s ({nbytes/rot/8e6:.3f} of 8 TB/s) | "
+                  f"same buffers {same:6.1f} us{same_bits}", flush=True)
+        del slabs
+        torch.cuda.empty_cache()
+    for k, v in DEFAULTS.items():
+        ops.set_option(k, v)
+
+
+if __name__ == "__main__":
+    main()

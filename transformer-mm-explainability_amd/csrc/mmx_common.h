@@ -212,6 +212,13 @@ size_t self_chain_big_workspace(int B, int N);
 int self_chain_big_try(const void* const* attn_layers, const void* const* grad_layers, int n_layers, int B, int H, int N,
                        int dtype, int64_t attn_bstride, const void* R_init, void* R_out, void* workspace,
                        size_t workspace_bytes, hipStream_t s, int* rc_out);
+// relevancy_chain_relay.hip: the chain with position-split streamers feeding one chain workgroup per sample (K1r)
+bool self_chain_relay_applies(int n_layers, int B, int H, int N);
+size_t self_chain_relay_workspace(int n_layers, int B, int H, int N);
+int self_chain_relay_launch(const void* const* attn_layers, const void* const* grad_layers, int n_layers, int B, int H, int N,
+                            int64_t attn_bstride, const void* R_init, void* R_out, void* workspace, size_t workspace_bytes,
+                            int nt_policy, int debug, hipStream_t s);
+void chain_relay_options(int q, int d);
 void attn_stream_enable(int on);
 void attn_fwd_split_enable(int on);
 void attn_bf16_v2_enable(int on);

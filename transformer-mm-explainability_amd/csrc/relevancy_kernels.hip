@@ -1179,10 +1179,18 @@ static int g_chain_pipe = 4;     // option "self_chain_pipe": software-pipelined
 static int g_chain_nt = 1;       // option "self_chain_nt": nt cache policy on the read-once slab loads of the pipelined stream waves
                                  // (default since round 4: text tower 85.8 -> 82.0 us, image 65.5 -> 63.8 us inside the replayed step)
 static int g_chain_groups = 0;  // layer groups per sample of the per-sample kernel: 0 auto, 1 = strict sequential order
-static int g_chain_algo = 0;  // 0 auto, 1 per-sample wave-specialised, 2 reduce + last-arriver chain
+static int g_chain_algo = 0;  // 0 auto, 1 per-sample wave-specialised, 2 reduce + last-arriver chain, 3 relay (position-split streamers)
 
 extern "C" int mmx_set_option(const char* key, int value) {
-    if (key && strcmp(key, "self_chain_algo") == 0 && value >= 0 && value <= 2) {
+    if (key && strcmp(key, "self_chain_relay_q") == 0 && value >= 0 && value <= 16) {
+        chain_relay_options(value, -1);
+        return MMX_OK;
+    }
+    if (key && strcmp(key, "self_chain_relay_d") == 0 && value >= 0 && value <= 8) {
+        chain_relay_options(-1, value);
+        return MMX_OK;
+    }
+    if (key && strcmp(key, "self_chain_algo") == 0 && value >= 0 && value <= 3) {
         g_chain_algo = value;
         return MMX_OK;
     }
@@ -1249,6 +1257,13 @@ static bool use_v2(int n_layers, int B, int N, int M) {
     return g_chain_algo == 2;
 }
 
+// The relay form (relevancy_chain_relay.hip, option self_chain_algo = 3): fp32 slabs, one right-hand side.  Strict layer order in one
+// launch at any batch size (bit-identical to the per-sample kernel), but measured SLOWER than the layer-group kernel at the cfg-2
+// shapes (115 vs 84 us, profiles/r05_chain_relay_probe.txt), so it is opt-in.
+static bool use_relay(int n_layers, int B, int H, int N, int M, int dtype) {
+    return g_chain_algo == 3 && dtype == MMX_F32 && M == 0 && self_chain_relay_applies(n_layers, B, H, N);
+}
+
 static int fused_groups(int n_layers, int B, int H, int N) {
     if (n_layers < 2) return 1;
     int G = g_chain_groups;
@@ -1266,6 +1281,7 @@ static size_t v2_counter_bytes(int B) { return align256(sizeof(unsigned) * stati
 extern "C" size_t mmx_self_chain_workspace_bytes(int n_layers, int B, int H, int N, int M, int dtype) {
     (void)dtype;
     if (nt_for(N) <= 8 && M == 0) {
+        if (use_relay(n_layers, B, H, N, M, dtype)) return self_chain_relay_workspace(n_layers, B, H, N);
         if (!use_v2(n_layers, B, N, M)) {
             const int G = fused_groups(n_layers, B, H, N);
             if (G == 1) return 0;  // strict-order per-sample kernel needs no scratch
@@ -1363,6 +1379,9 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nt = nt_for(N);
 
+    if (use_relay(n_layers, B, H, N, M, dtype))
+        return self_chain_relay_launch(attn_layers, grad_layers, n_layers, B, H, N, attn_batch_stride, R_init_dev, R_out_dev,
+                                       workspace_dev, workspace_bytes, g_chain_nt, g_debug_flags, s);
     if (use_v2(n_layers, B, N, M)) {
         const size_t need = mmx_self_chain_workspace_bytes(n_layers, B, H, N, M, dtype);
         if (workspace_bytes < need || !workspace_dev) {
