@@ -98,6 +98,7 @@ def main_cfg5(args):
     from tools import bench_legs
     from transformer_mm_explainability_amd import clip_explainability as ce
     model, image, texts, attn_layer, attn_flops = bench_legs.cfg5_setup(CFG5_BATCH, device, rank)
+    attn_flops = attn_flops["algorithmic"]          # 4 products per attention backward (the kernel pair executes 5)
     n_img = 576
     row = n_img + 77 * 77
     gathered = torch.empty(world * CFG5_BATCH, row, device=device) if world > 1 else None
@@ -205,12 +206,18 @@ def cpu_baseline_worker(sample_b, reps):
     clip_torch.interpret(sd, image, texts, 0, 0)  # warm-up
     times = []
     for _ in range(reps):
+        split = {}
         t0 = time.perf_counter()
-        clip_torch.interpret(sd, image, texts, 0, 0)
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
+        clip_torch.interpret(sd, image, texts, 0, 0, timings=split)
+        times.append((time.perf_counter() - t0, split))
+    times.sort(key=lambda t: t[0])
+    med, split = times[len(times) // 2]
     print(json.dumps({"value": round(sample_b / med, 3), "unit": "maps/s", "cores": cores, "kind": "port",
+                      # forward / the 24 per-layer partial backwards / the rule chain of the median run
+                      "split_s": {"forward": round(split["forward_s"], 3), "backward": round(split["backward_s"], 3),
+                                  "rule_chain": round(split["rules_s"], 3), "total": round(med, 3)},
+                      "calibration": "profiles/r05_cpu_port_calibration.txt (this port vs the reference's own CLIP/clip/model.py + "
+                                     "notebook cell 6, same weights, inputs and threads, run in the build container)",
                       "sample": "reference algorithm (hooked CLIP ViT-B/32 fwd + one autograd.grad per layer + rule "
                                 "chain, all 12+12 layers) restated in oracle/clip_torch.py, torch fp32 CPU, %d threads "
                                 "of %d host cores, batch %d of the same synthetic workload, median of %d"
@@ -613,6 +620,9 @@ def main():
                        "launch": "whole step captured once into a hipGraph and replayed",
                        "image_tower": "forward shared by the batch (the reference API repeats ONE image B times), "
                                       "backward per sample",
+                       # the headline shares ONE image-tower forward between the 64 captions (the reference's call shape); a batch of
+                       # 64 DISTINCT images runs at this rate (hipGraph replay) -- the number that must travel with the headline
+                       "distinct_images_maps_per_s": (variants or {}).get("distinct_images_hipgraph_maps_per_s"),
                        "variants": variants},
             "roofline": roofline,
             "roofline_step": roofline_step,

@@ -77,7 +77,7 @@ def leg_cfg1(kernel_time_us, reps=20):
             "multi_target": {"targets": 8, "ms": round(ms8, 3), "rate": round(8e3 / ms8, 1)},
             "kernel": _hbm("avg_heads_kernel<f32> (one layer, B = 1: 12 heads x 197^2)", 2 * H * N * N * 4 + N * N * 4, us,
                            "latency-bound at batch 1 (3.7 MB per launch); the pass itself is ~700 body launches"),
-            "source": "profiles/r04_cfg_legs.txt"}
+            "source": "profiles/r05_cfg_legs.txt"}
 
 
 def leg_cfg3(kernel_time_us, reps=10):
@@ -151,7 +151,7 @@ def leg_cfg3(kernel_time_us, reps=10):
             "lrp": {"ours_no_lrp_ms": round(lrp_no, 3), "ours_lrp_ms": round(lrp_yes, 3), "ratio": round(lrp_yes / lrp_no, 2),
                     "what": "Generator.generate_ours(img, [q]) per kept query, eager, per-query route (autograd backward): "
                             "use_lrp=False vs the default use_lrp=True (body relprop: closed-form rules + HIP attention-core kernels)"},
-            "kernel": kern, "source": "profiles/r04_cfg_legs.txt"}
+            "kernel": kern, "source": "profiles/r05_cfg_legs.txt"}
 
 
 def leg_cfg4(kernel_time_us, reps=10):
@@ -199,12 +199,15 @@ def leg_cfg4(kernel_time_us, reps=10):
                     "what": "GeneratorOurs.generate_ours(item) per item, eager: use_lrp=False vs the default use_lrp=True"},
             "kernel": _hbm("lxmert_schedule_v2_kernel (38 rule applications: chip-wide rule 5 + last-arriver schedule on the MFMA, "
                            "B = 32)", nbytes, us, "2 MB of slabs per sample; the serial 38-step schedule of a sample is the floor"),
-            "source": "profiles/r04_cfg_legs.txt"}
+            "source": "profiles/r05_cfg_legs.txt"}
 
 
-def cfg5_step_flops(batch):
+def cfg5_step_flops(batch, executed=False):
     """Matrix FLOPs of one cfg-5 step (CLIP ViT-L/14@336 bf16 body: image tower 24 x 1024 x 16 heads x 577 tokens with a shared
-    forward and row-relevancy backward, text tower 12 x 768 x 12 x 77), as ``step_flops`` counts them for cfg 2."""
+    forward and row-relevancy backward, text tower 12 x 768 x 12 x 77), as ``step_flops`` counts them for cfg 2.
+    ALGORITHMIC count: an attention backward is FOUR products (dP = dO.V^T, dV = P^T.dO, dQ = dS.K,
+    dK = dS^T.Q: 8 N^2 d per head); ``executed=True`` counts the FIVE the two-kernel image-tower design runs (both kernels
+    recompute dP)."""
     def tower(L, E, N, H, m_fwd, m_bwd, attn_products):
         gemm_fwd = L * 2 * m_fwd * 12 * E * E
         full, top, low = 2 * m_bwd * 12 * E * E, 2 * m_bwd * 3 * E * E + 2 * batch * 9 * E * E, 2 * m_bwd * 9 * E * E
@@ -212,7 +215,7 @@ def cfg5_step_flops(batch):
         attn = L * 4 * (m_fwd // N) * H * N * N * d + (L - 1) * attn_products * 2 * (m_bwd // N) * H * N * N * d \
             + 2 * (m_bwd // N) * H * N * N * d
         return gemm_fwd + (L - 2) * full + top + low, attn
-    g_img, a_img = tower(24, 1024, 577, 16, 577, batch * 577, 5)       # dP (twice: both kernels), dQ, dK, dV
+    g_img, a_img = tower(24, 1024, 577, 16, 577, batch * 577, 5 if executed else 4)
     g_txt, a_txt = tower(12, 768, 77, 12, batch * 77, batch * 77, 4)
     return {"gemm": g_img + g_txt, "attention": a_img + a_txt, "total": g_img + g_txt + a_img + a_txt}
 
@@ -245,7 +248,8 @@ def cfg5_setup(batch, device, rank=0):
     def attn_layer():
         ops.attn_capture_bwd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], probs, d_o, None, D ** -0.5, batch=batch, o=o,
                              out=(out[:, :, 0], out[:, :, 1], out[:, :, 2]), mma_bf16=True, rel_row=rel)
-    return model, image, texts, attn_layer, 5 * 2 * batch * H * N * N * D
+    # FLOPs per launch pair: ALGORITHMIC = 4 products of 2 N^2 d each per (sample, head); the pair EXECUTES 5 (dP in both kernels)
+    return model, image, texts, attn_layer, {"algorithmic": 4 * 2 * batch * H * N * N * D, "executed": 5 * 2 * batch * H * N * N * D}
 
 
 def leg_cfg5(kernel_time_us, reps=3, batch=128):
@@ -259,22 +263,67 @@ def leg_cfg5(kernel_time_us, reps=3, batch=128):
     ms_trim = _timed_ms(lambda: ce.interpret(image, texts, model, "cuda", start_layer=0, start_layer_text=0,
                                              trim_text_padding=True), reps, warm=2)
     us = kernel_time_us(attn_layer, 5, torch.cuda.current_stream())
-    fl = cfg5_step_flops(batch)
+    fl, fl_exec = cfg5_step_flops(batch), cfg5_step_flops(batch, executed=True)
     step_tf = fl["total"] / (ms * 1e-3) / 1e12
+    kernel = _mfma("attn_bwd_q_v3_kernel + attn_bwd_kv_v3_kernel (+ the two prep kernels; one image-tower layer, B = 128, "
+                   "row-relevancy mode, attention_bf16_v3.hip)", attn_flops["algorithmic"], us, BF16_MFMA_PEAK_TFLOPS,
+                   "numerator = ALGORITHMIC FLOPs (4 products); the pair executes 5 (dP in both kernels): executed_* beside it.  Bound by "
+                   "L2 -> CU movement of the shared operands and of dO, not by the matrix cores: profiles/r04_cfg5_counters_mem.txt")
+    kernel["executed_flop_per_launch"] = int(attn_flops["executed"])
+    kernel["executed_achieved"] = round(attn_flops["executed"] / us / 1e6, 1)
+    kernel["executed_frac"] = round(attn_flops["executed"] / us / 1e6 / BF16_MFMA_PEAK_TFLOPS, 4)
+    slab = _cfg5_slab_chain_variant(model, image, texts, batch, kernel_time_us)
     return {"roofline_step": {"bound": "mfma", "achieved": round(step_tf, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(step_tf / BF16_MFMA_PEAK_TFLOPS, 4), "flop_per_step": fl,
-                              "what": "bf16 matrix FLOPs of the step (body GEMMs forward + input-gradient, attention products) / ms"},
+                              "executed_flop_per_step": fl_exec["total"],
+                              "executed_frac": round(fl_exec["total"] / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                              "what": "ALGORITHMIC bf16 matrix FLOPs of the step (body GEMMs forward + input-gradient, attention "
+                                      "products: 4 per backward) / ms; executed_* counts the 5th product the two-kernel backward re-does"},
             "workload": "BASELINE config 5 shape: CLIP ViT-L/14@336 (577 image tokens), batch 128 per GPU, all 24+12 layers, "
                         "bf16 body (fp32 accumulation / LayerNorm / softmax / relevancy), row-relevancy image tower, eager",
             "rate": round(batch / ms * 1e3, 1), "unit": "maps/s", "ms": round(ms, 3),
             "resident_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-            "kernel": _mfma("attn_bwd_q_v3_kernel + attn_bwd_kv_v3_kernel (+ the two prep kernels; one image-tower layer, B = 128, "
-                            "row-relevancy mode, attention_bf16_v3.hip)", attn_flops, us, BF16_MFMA_PEAK_TFLOPS,
-                            "bound by L2 -> CU movement of the shared operands and of dO (3.3 GB per launch pair), not by the "
-                            "matrix cores: profiles/r03_cfg5_probe.txt"),
+            "kernel": kernel,
+            "variant_slab_chain": slab,
             "variant_trim_text_padding": {"ms": round(ms_trim, 3), "rate": round(batch / ms_trim * 1e3, 1),
                                           "note": "same maps (exact); NOT the headline of this leg: the reference runs all 77 positions"},
-            "source": "profiles/r04_cfg_legs.txt"}
+            "source": "profiles/r05_cfg_legs.txt"}
+
+
+def _cfg5_slab_chain_variant(model, image, texts, batch, kernel_time_us):
+    """cfg 5 on the route SURVEY section 8(d) prices (VERDICT r04 missing #4): gradient slabs captured for all 24 image-tower layers
+    (bf16) and the FULL-MATRIX chain R <- R + A_bar . R at N = 577 (avg_heads + exact-fp32 bmm per layer: N > 128) instead of the
+    row-relevancy backward.  Reports the step and, stand-alone with HIP events, the chain segment as GB/s of the slabs it reads."""
+    from transformer_mm_explainability_amd import clip_explainability as ce
+    vis = model.visual
+    try:
+        vis.row_relevancy_ok = lambda: False
+        f = lambda: ce.interpret(image, texts, model, "cuda", start_layer=0, start_layer_text=0)   # noqa: E731
+        ms = _timed_ms(f, 2, warm=1)
+        tr = vis.transformer
+        b = tr.buffers
+        L, H, N = tr.layers, tr.heads, b.probs[0].shape[-1]
+        plan = ce._plan(b, 0, L, batch, b.shared_probs and batch > 1, getattr(tr, "half_chain", False))
+        us = kernel_time_us(plan.launch, 3, torch.cuda.current_stream())
+        esz = b.grads[0].element_size()
+        shared = bool(b.shared_probs)
+        read = L * (batch * H * N * N * esz + (1 if shared else batch) * H * N * N * b.probs[0].element_size())
+        out = {"ms": round(ms, 3), "rate": round(batch / ms * 1e3, 1), "unit": "maps/s",
+               "chain_segment": {"what": "24 x (avg_heads_kernel<bf16> + bmm_f32_kernel 577^3) for the image tower, B = %d, stand-alone" % batch,
+                                 "us": round(us, 1), "slab_bytes_read": int(read), "achieved": round(read / us / 1e3, 1), "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": round(read / us / 1e3 / HBM_PEAK_GBS, 4),
+                                 "flop": int(L * batch * 2 * N * N * N), "mfma_tflops": round(L * batch * 2 * N * N * N / us / 1e6, 1),
+                                 "note": "the probability slab is ONE forward shared by the batch here (%s): bytes = every gradient slab + the "
+                                         "shared probabilities once per layer; SURVEY 8(d)'s 514.8 MB/map prices per-sample slabs of both.  "
+                                         "At 577 tokens the chain is fp32-MFMA-bound (2 N^3 per layer and sample), not HBM-bound"
+                                         % ("shared" if shared else "per sample")},
+               "note": "same maps as the row-relevancy leg within the bf16 slab rounding (tests/test_gpu_parity_fullsize.py::test_cfg5_bf16_body_vs_oracle)"}
+    except Exception as exc:                                   # a variant must not take the leg down
+        out = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    finally:
+        if "row_relevancy_ok" in vis.__dict__:
+            del vis.row_relevancy_ok
+    return out
 
 
 LEGS = (("cfg1", leg_cfg1), ("cfg3", leg_cfg3), ("cfg4", leg_cfg4), ("cfg5", leg_cfg5))
