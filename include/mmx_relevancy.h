@@ -65,8 +65,11 @@ enum mmx_status {
 int mmx_abi_version(void);
 const char* mmx_last_error(void);
 /* tuning knobs (process-wide; results stay within the parity tolerance for every setting):
- *   "self_chain_algo"    0 auto | 1 one workgroup per (sample, layer group), no scratch beyond the partial products |
- *                        2 one workgroup per (sample, layer) + last-arriver chain (bit-identical to 1 at groups = 1)
+ *   "self_chain_algo"    0 auto = 1: one workgroup per (sample, layer group); the last arriver of a sample multiplies the group
+ *                        products (re-associated at the group boundaries) | 3: relay (csrc/relevancy_chain_relay.hip): positions of
+ *                        every layer cut over streamer workgroups that feed ONE chain workgroup per sample -- strict layer order at
+ *                        any batch, bit-identical to "self_chain_groups" = 1, measured slower (profiles/r05_chain_relay_probe.txt)
+ *   "self_chain_relay_q" / "self_chain_relay_d"   0 auto | streamers per sample (<= 16) / LDS-DMA ring slots (2..8) of the relay form
  *   "self_chain_pipe"    4 (default) fused chain, fp32 slabs, N >= 40: the stream waves run a software pipeline of raw buffer loads (the
  *                        next batch of 8 16-byte loads in flight across the head reduction, the LDS write and the per-layer barrier)
  *                        with up to 4 KB contiguous per (head, array) and wave | 2 / 1: at most 2 / 1 KB contiguous |
@@ -74,16 +77,17 @@ const char* mmx_last_error(void);
  *   "self_chain_nt"      1 (default) the pipelined stream waves load the read-once slabs with the nt (streaming) cache policy (a
  *                        probability slab shared by the batch keeps the default policy) | 0: default policy everywhere.  Same results
  *   "self_chain_groups"  0 auto | 1..8 layer groups per sample of the fused chain kernel (1 = strict sequential order)
- *   "self_chain_big"     2: N > 128 (<= 1152, no second right-hand side) runs the ONE-launch persistent team kernel |
- *                        0 / 1 (default): the per-layer split path, which measures 1.7-2x faster on MI355X
- *   "linear_stream"      0 (default) | 1: small-M products (mmx_bmm_f32 with batch 1, mmx_linear_f32; K % 16 == 0, N % 4 == 0, M <= 2048) on the
- *                        K-split streaming kernel of csrc/linear_stream.hip (no LDS staging; deterministic)
  *   "attn_head"          1 (default) register-resident whole-head attention kernels (Nk <= 128, Nq <= 256) | 0 never
- *   "attn_small"         1 (default) whole-head-in-LDS attention kernels where the head fits | 0 never
- *   "attn_stream"        1 (default) long-sequence streaming attention kernels | 0 first-generation tiled kernels
+ *   "attn_stream"        1 (default) long-sequence streaming attention kernels | 0 only the general tiled kernels (any head_dim, any
+ *                        alignment: what every shape the other families turn down runs on)
+ *   "attn_bf16_v3"       non-zero (default): third-generation bf16 backward of the shared-forward row-relevancy mode | 0: second generation
+ *   "attn_bf16_v2"       1 (default) second-generation bf16 backward | 0: the streaming kernels' bf16 path
  *   "attn_fwd_split"     1 (default) streaming forward on a small grid (< 160 workgroups of 64 rows, fp32 slabs):
  *                        16-row workgroups whose waves split the keys | 0 always the 64-row kernel
  *   "debug_flags"        profiling only (phase skipping); 0 in production
+ * These are A / B switches for tests and probes (every remaining value is the default for some shape or the reference arm of an
+ * equivalence test); round 5 removed the kernel families that were nobody's default (self_chain_algo 2, self_chain_big, attn_small,
+ * linear_stream, bmm_tile, the 4-wave / fourth-generation bf16 variants, the one-workgroup bi-modal schedule).
  * Unknown keys / out-of-range values return MMX_EINVAL. */
 int mmx_set_option(const char* key, int value);
 
@@ -213,45 +217,25 @@ int mmx_mm_attention_rules(const void* R_ss_dev, const void* R_qq_dev, const voi
  *   n_lang language + n_vis vision self-attention layers, then n_x cross layers (language cross, image cross, language
  *   self, image self; the last cross layer runs its language half only), finally R_tt[0,0] = 0.
  * replaces the rule schedule of GeneratorOurs.generate_ours (lxmert/lxmert/src/ExplanationGenerator.py:131-211 with the
- * helpers :18-54, 61-129).  One workgroup per sample keeps every relevancy matrix in LDS; needs T, I <= 48.
+ * helpers :18-54, 61-129).  Two phases in one launch: the rule-5 head averages of every (sample, block) are spread over the whole
+ * chip (16-byte loads, write-through A_bar blocks into `workspace`), the last-arriving workgroup of a sample runs the 38 rule
+ * applications from the L2-resident A_bar blocks on the exact-fp32 MFMA with every relevancy matrix in LDS; needs T, I <= 48.
  *   all tables: HOST arrays of device pointers to fp32 [B, H, Nq, Nk] slabs: lang/x_lang_self [.,.,T,T],
  *   vis/x_img_self [.,.,I,I], x_lang_cross [.,.,T,I], x_img_cross [.,.,I,T]; the image tables need n_x-1 entries.
  *   flags: MMX_MM_NORMALIZE | MMX_MM_SELF_IN_RULE10 (NaNs propagate like the reference's LXMERT variant).
  *   outputs fp32: R_tt [B,T,T], R_ti [B,T,I], optional R_ii [B,I,I], R_it [B,I,T]; diag_min_dev as in
  *   mmx_handle_residual (min over all normalisations), may be NULL.
  */
-int mmx_lxmert_schedule(const void* const* lang_attn, const void* const* lang_grad, int n_lang,
-                        const void* const* vis_attn, const void* const* vis_grad, int n_vis,
-                        const void* const* x_lang_cross_attn, const void* const* x_lang_cross_grad,
-                        const void* const* x_img_cross_attn, const void* const* x_img_cross_grad,
-                        const void* const* x_lang_self_attn, const void* const* x_lang_self_grad,
-                        const void* const* x_img_self_attn, const void* const* x_img_self_grad, int n_x,
-                        int B, int H, int T, int I, unsigned flags,
-                        void* R_tt_dev, void* R_ti_dev, void* R_ii_dev, void* R_it_dev,
-                        void* diag_min_dev, void* stream);
-/* Same, for a batch that is PADDED to T question tokens: text_len_dev = device array of B ints, the real number of question
- * tokens of every sample (1..T; NULL = all T).  The slabs keep their padded [.., T, ..] shape (padded keys carry zero
- * probability under the attention mask); sample b's rules run on its leading text_len[b] tokens only, and rows / columns
- * of R_tt / R_ti / R_it beyond them are written as zero.  One padded batch replaces the grouping of samples by question
- * length (lxmert/lxmert/perturbation.py:45-83 tokenises one question per call, so the reference never pads). */
-int mmx_lxmert_schedule_ex(const void* const* lang_attn, const void* const* lang_grad, int n_lang,
-                        const void* const* vis_attn, const void* const* vis_grad, int n_vis,
-                        const void* const* x_lang_cross_attn, const void* const* x_lang_cross_grad,
-                        const void* const* x_img_cross_attn, const void* const* x_img_cross_grad,
-                        const void* const* x_lang_self_attn, const void* const* x_lang_self_grad,
-                        const void* const* x_img_self_attn, const void* const* x_img_self_grad, int n_x,
-                        int B, int H, int T, int I, unsigned flags, const void* text_len_dev,
-                        void* R_tt_dev, void* R_ti_dev, void* R_ii_dev, void* R_it_dev,
-                        void* diag_min_dev, void* stream);
-
-/* Same schedule and arguments, two-phase form (round 4): phase 1 spreads the rule-5 head averages of every (sample, block) over
- * the whole chip (16-byte loads, write-through A_bar blocks into `workspace`), the last-arriving workgroup of a sample runs the
- * 38 rule applications from the L2-resident A_bar blocks on the exact-fp32 MFMA.  One kernel launch (+ one reset launch for
- * the tickets / diag word).  workspace: mmx_lxmert_schedule_workspace_bytes(...) bytes, caller-owned, stream-ordered.
- * Results equal mmx_lxmert_schedule_ex up to fp32 summation order (same NaN propagation, same diag word).
- * replaces lxmert/lxmert/src/ExplanationGenerator.py:131-211 (rule helpers :18-54, 61-129). */
+/* text_len_dev: for a batch that is PADDED to T question tokens, a device array of B ints, the real number of question tokens of
+ * every sample (1..T; NULL = all T).  The slabs keep their padded [.., T, ..] shape (padded keys carry zero probability under the
+ * attention mask); sample b's rules run on its leading text_len[b] tokens only, and rows / columns of R_tt / R_ti / R_it beyond
+ * them are written as zero.  One padded batch replaces the grouping of samples by question length
+ * (lxmert/lxmert/perturbation.py:45-83 tokenises one question per call, so the reference never pads).
+ * workspace: mmx_lxmert_schedule_workspace_bytes(...) bytes, caller-owned, stream-ordered.  One kernel launch (+ one reset launch
+ * for the tickets / diag word).  (Rounds 1-3 had a one-workgroup-per-sample form under this name and an `_ex` / `_v2` pair; round 5
+ * keeps the one kernel that serves every shape.) */
 size_t mmx_lxmert_schedule_workspace_bytes(int n_lang, int n_vis, int n_x, int B, int T, int I);
-int mmx_lxmert_schedule_v2(const void* const* lang_attn, const void* const* lang_grad, int n_lang,
+int mmx_lxmert_schedule(const void* const* lang_attn, const void* const* lang_grad, int n_lang,
                            const void* const* vis_attn, const void* const* vis_grad, int n_vis,
                            const void* const* x_lang_cross_attn, const void* const* x_lang_cross_grad,
                            const void* const* x_img_cross_attn, const void* const* x_img_cross_grad,

@@ -296,13 +296,14 @@ def detr_generate_ours_rows(enc_attn, enc_grad, dec_self_attn, dec_self_grad, de
 
 
 def lxmert_generate_ours_chain(lang_attn, lang_grad, vis_attn, vis_grad, x_layers,
-                               normalize_self_attention=True, apply_self_in_rule_10=True):
+                               normalize_self_attention=True, apply_self_in_rule_10=True, return_all=False):
     """Rule schedule of ``GeneratorOurs.generate_ours`` (``use_lrp=False``).
 
     Reference: lxmert/lxmert/src/ExplanationGenerator.py:61-211.
     ``x_layers``: list of dicts with keys ``lang_cross`` (visual_attention, ``[1,H,T,I]``),
     ``img_cross`` (visual_attention_copy, ``[1,H,I,T]``), ``lang_self``, ``img_self``; each a
-    ``(attn, grad)`` pair.  Returns ``(R_t_t [T,T], R_t_i [T,I])``.
+    ``(attn, grad)`` pair.  Returns ``(R_t_t [T,T], R_t_i [T,I])``; ``return_all``: also the generator's ``self.R_i_i`` and
+    ``self.R_i_t`` as the schedule leaves them (ExplanationGenerator.py:148-151 keeps all four as attributes).
     """
     T = lang_attn[0].shape[-1]
     I = vis_attn[0].shape[-1]
@@ -356,7 +357,7 @@ def lxmert_generate_ours_chain(lang_attn, lang_grad, vis_attn, vis_grad, x_layer
     R_t_t = R_t_t + tt_add
     self_lang(*blk["lang_self"])
     R_t_t[0, 0] = 0
-    return R_t_t, R_t_i
+    return (R_t_t, R_t_i, R_i_i, R_i_t) if return_all else (R_t_t, R_t_i)
 
 
 def gradcam(cam, grad):

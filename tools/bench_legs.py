@@ -197,7 +197,7 @@ def leg_cfg4(kernel_time_us, reps=10):
             "explain_ms": round(ms_explain, 3), "perturb_ms": round(ms_pert, 3),
             "lrp": {"ours_no_lrp_ms": round(lrp_no, 3), "ours_lrp_ms": round(lrp_yes, 3), "ratio": round(lrp_yes / lrp_no, 2),
                     "what": "GeneratorOurs.generate_ours(item) per item, eager: use_lrp=False vs the default use_lrp=True"},
-            "kernel": _hbm("lxmert_schedule_v2_kernel (38 rule applications: chip-wide rule 5 + last-arriver schedule on the MFMA, "
+            "kernel": _hbm("lxmert_schedule_v2_kernel = mmx_lxmert_schedule (38 rule applications: chip-wide rule 5 + last-arriver schedule on the MFMA, "
                            "B = 32)", nbytes, us, "2 MB of slabs per sample; the serial 38-step schedule of a sample is the floor"),
             "source": "profiles/r05_cfg_legs.txt"}
 

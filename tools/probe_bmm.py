@@ -1,4 +1,4 @@
-"""Probe (GPU box): exact-fp32 MFMA bmm at the long-sequence chain shapes, 64 x 64 vs 128 x 128 workgroup tiles."""
+"""Probe (GPU box): exact-fp32 MFMA bmm at the long-sequence chain shapes vs torch.baddbmm (rocBLAS / hipBLASLt fp32)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,10 +17,7 @@ for name, B, N in [("vit-l 32x577", 32, 577), ("detr-enc 10x950", 10, 950), ("vi
     a = torch.rand(B, N, N, device="cuda") / N
     r = torch.rand(B, N, N, device="cuda")
     want = torch.baddbmm(r.double(), a.double(), r.double())
-    for tile in (64, 128):
-        ops.set_option("bmm_tile", tile)
-        us = bench(lambda: ops.matmul(a, r, add_to=r))
-        err = (ops.matmul(a, r, add_to=r).double() - want).abs().max().item()
-        print(f"{name}: tile {tile:3d}: {us:8.1f} us  {2 * B * N ** 3 / us / 1e6:6.1f} TF/s  max err {err:.2e}")
+    us = bench(lambda: ops.matmul(a, r, add_to=r))
+    err = (ops.matmul(a, r, add_to=r).double() - want).abs().max().item()
+    print(f"{name}: mmx bmm: {us:8.1f} us  {2 * B * N ** 3 / us / 1e6:6.1f} TF/s  max err {err:.2e}")
     print(f"{name}: torch.baddbmm fp32: {bench(lambda: torch.baddbmm(r, a, r)):8.1f} us")
-ops.set_option("bmm_tile", 64)

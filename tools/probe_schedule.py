@@ -34,21 +34,17 @@ def main():
         groups = ([pair(T, T) for _ in range(9)], [pair(I, I) for _ in range(5)], [pair(T, I) for _ in range(5)],
                   [pair(I, T) for _ in range(5)], [pair(T, T) for _ in range(5)], [pair(I, I) for _ in range(5)])
         nbytes = sum(a.numel() * 8 for grp in groups for a, _ in grp) + B * (T * T + T * I + I * I + I * T) * 4
-        for algo in (1, 2):
-            ops.LXMERT_SCHEDULE_ALGO = algo
-            us = timed(lambda: ops.lxmert_schedule(*groups, check_diag="defer"))
-            print(f"B={B:4d} algo={algo}: {us:8.1f} us  {nbytes/us/1e3:8.1f} GB/s ({nbytes/1e6:.1f} MB)  {us/B:6.2f} us/sample")
-        ops.LXMERT_SCHEDULE_ALGO = 2
+        us = timed(lambda: ops.lxmert_schedule(*groups, check_diag="defer"))
+        print(f"B={B:4d}: {us:8.1f} us  {nbytes/us/1e3:8.1f} GB/s ({nbytes/1e6:.1f} MB)  {us/B:6.2f} us/sample")
         for dbg, what in ((1, "phase 1 only"), (2, "no MFMA tiles"), (62, "skeleton only")):
             os.environ["MMX_BM_DEBUG"] = str(dbg)
             us = timed(lambda: ops.lxmert_schedule(*groups, check_diag="defer"))
-            print(f"B={B:4d} algo=2 debug={dbg} ({what}): {us:8.1f} us")
+            print(f"B={B:4d} debug={dbg} ({what}): {us:8.1f} us")
         os.environ.pop("MMX_BM_DEBUG")
         os.environ["MMX_BM_SPLIT"] = "1"
         us = timed(lambda: ops.lxmert_schedule(*groups, check_diag="defer"))
-        print(f"B={B:4d} algo=2 two launches (phase 1: one workgroup per block; phase 2: one per sample): {us:8.1f} us")
+        print(f"B={B:4d} two launches (phase 1: one workgroup per block; phase 2: one per sample): {us:8.1f} us")
         os.environ["MMX_BM_SPLIT"] = "0"
-    ops.LXMERT_SCHEDULE_ALGO = 2
 
 
 if __name__ == "__main__":

@@ -38,12 +38,8 @@ _PROTOTYPES = {
     "mmx_handle_residual": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "mmx_mm_rules_workspace_bytes": (_sz, [_i, _i]),
     "mmx_mm_attention_rules": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _u, _vp, _vp, _sz, _vp]),
-    "mmx_lxmert_schedule": (_i, [_vpp, _vpp, _i, _vpp, _vpp, _i] + [_vpp] * 8 + [_i, _i, _i, _i, _i, _u,
-                                 _vp, _vp, _vp, _vp, _vp, _vp]),
-    "mmx_lxmert_schedule_ex": (_i, [_vpp, _vpp, _i, _vpp, _vpp, _i] + [_vpp] * 8 + [_i, _i, _i, _i, _i, _u, _vp,
-                                    _vp, _vp, _vp, _vp, _vp, _vp]),
     "mmx_lxmert_schedule_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
-    "mmx_lxmert_schedule_v2": (_i, [_vpp, _vpp, _i, _vpp, _vpp, _i] + [_vpp] * 8 + [_i, _i, _i, _i, _i, _u, _vp,
+    "mmx_lxmert_schedule": (_i, [_vpp, _vpp, _i, _vpp, _vpp, _i] + [_vpp] * 8 + [_i, _i, _i, _i, _i, _u, _vp,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mmx_lrp_workspace_bytes": (_sz, []),
     "mmx_lrp_split_signs": (_i, [_vp, _vp, _i64, _i, _vp]),

@@ -46,8 +46,6 @@ struct AttnBwdArgs {
 
 int attn_fwd_head_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out);    // attention_head.hip (register-resident)
 int attn_bwd_head_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);
-int attn_fwd_small_try(AttnFwdArgs& a, hipStream_t s, int* rc_out);
-int attn_bwd_small_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);
 int attn_fwd_stream_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out);   // attention_stream.hip
 int attn_bwd_stream_try(const AttnBwdArgs& a, hipStream_t s, int* rc_out);
 // out[b][k] = v_in[b][k] + inv_h * sum_{j < J} part[b][j][k]   (row-relevancy mode, second pass; attention_kernels.hip)

@@ -27,10 +27,6 @@
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef MMX_MERGED_B64          // (-DMMX_MERGED_B64: the round-3 form of the transposed operand reads, for A / B runs)
-#define MMX_SPLIT_B64 1
-#endif
-
 namespace mmx {
 namespace {
 
@@ -43,8 +39,10 @@ typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;
 
-int g_attn_bf16_v3 = 2;       // 0: off (second generation), 1: 4-wave workgroups, 2: 8-wave workgroups (4 waves / SIMD on both kernels),
-                              // 3: query side as 2, key side fourth generation (KB key blocks per wave, 4-wave workgroups; experiment)
+int g_attn_bf16_v3 = 2;       // 0: off (the call falls through to the second generation, attention_bf16.hip: the A / B arm of
+                              // test_bf16_backward_third_generation_equals_second), non-zero: 8-wave workgroups, 4 waves / SIMD on both kernels
+                              // (measured and removed in round 5: 4-wave workgroups; a fourth-generation key side with several key
+                              // blocks per wave -- 882-980 us vs 780 us per layer pair, profiles/r04_cfg5_probe.txt)
 
 struct V3Images {
     const bf16_t *Vb, *KbT, *QbT, *Pq, *PT;
@@ -164,29 +162,13 @@ __device__ __forceinline__ void load_rows8(bf16x8 (&op)[kD / 32], const bf16_t* 
 // (written with the XOR on the whole index the compiler kept 16-32 address registers live across the loop).
 __device__ __forceinline__ int transposed_lane_base(int i, int g) { return i * kLT + 4 * (g ^ (i >> 2)); }
 __device__ __forceinline__ bf16x8 transposed_operand(const bf16_t* tile_lane, int dt, int p) {
-#ifdef MMX_SPLIT_B64
     // two SEPARATE ds_read_b64 (2 LDS cycles each) instead of the ds_read2_b64 hipcc merges them into (8 cycles: each of its two
     // accesses is serviced as 4 x 16 lanes) -- and no register shuffle when the pieces come out in descending address order
     // (volatile keeps the two loads apart; the explicit LDS address space keeps them ds_read -- a volatile generic load is a flat_load)
     typedef const volatile __attribute__((address_space(3))) u32x2v* lds_b64_ptr;
     const u32x2v lo = *(lds_b64_ptr)(tile_lane + 16 * dt * kLT + 16 * (dt ^ (2 * p)));
     const u32x2v hi = *(lds_b64_ptr)(tile_lane + 16 * dt * kLT + 16 * (dt ^ (2 * p + 1)));
-#else
-    const u32x2v lo = *reinterpret_cast<const u32x2v*>(tile_lane + 16 * dt * kLT + 16 * (dt ^ (2 * p)));
-    const u32x2v hi = *reinterpret_cast<const u32x2v*>(tile_lane + 16 * dt * kLT + 16 * (dt ^ (2 * p + 1)));
-#endif
     return as_bf16x8(u32x4v{lo[0], lo[1], hi[0], hi[1]});
-}
-
-// The same operand with its two 8-byte pieces in ADDRESS order (one ds_read2_b64, no register shuffle): for odd dt the swizzle puts
-// the rows of sub-tile 2 p + 1 below those of sub-tile 2 p, so the k-slots come out as (hi, lo) -- the OTHER operand of that MFMA must
-// then be given with its halves exchanged too.  (transposed_operand makes the compiler swap the halves with four v_mov per operand:
-// 32 of the ~180 VALU instructions per tile of the key-side kernel.)
-__device__ __forceinline__ bf16x8 transposed_operand_sorted(const bf16_t* tile_lane, int dt, int p) {
-    const int o0 = 16 * (dt ^ (2 * p)), o1 = 16 * (dt ^ (2 * p + 1));
-    const u32x2v a = *reinterpret_cast<const u32x2v*>(tile_lane + 16 * dt * kLT + (o0 < o1 ? o0 : o1));
-    const u32x2v b = *reinterpret_cast<const u32x2v*>(tile_lane + 16 * dt * kLT + (o0 < o1 ? o1 : o0));
-    return as_bf16x8(u32x4v{a[0], a[1], b[0], b[1]});
 }
 
 // a [64 x 64] bf16 tile of a row-major image (row stride `sn` elements): thread st (0..255) owns a 4 x 4 block
@@ -500,24 +482,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
             }
             if constexpr (DKV) {
                 // the raw probability words of the two sub-tiles ARE the bf16 A operand of dV = P^T . dO
-                // (MMX_MERGED_B64 only: for odd dt the transposed operands arrive with their k-slot halves exchanged --
-                // transposed_operand_sorted -- and meet exchanged copies of the A operands.  The default reads the two 8-byte pieces of
-                // an operand with two SEPARATE ds_read_b64: no merge into a half-rate ds_read2_b64, no register shuffle.)
+                // (the two 8-byte pieces of a transposed operand are read with two SEPARATE ds_read_b64: no merge into a half-rate
+                // ds_read2_b64, no register shuffle)
                 const bf16x8 p_op = as_bf16x8(p_cur[pp]);
                 const bf16x8 ds_op = ABL == 4 || ABL == 7 ? p_op : pack8(ds[0], ds[1]);
-#ifndef MMX_SPLIT_B64
-                const bf16x8 p_sw = as_bf16x8(u32x4v{p_cur[pp][2], p_cur[pp][3], p_cur[pp][0], p_cur[pp][1]});
-                const bf16x8 ds_sw = ABL == 4 || ABL == 7 ? p_sw : pack8(ds[1], ds[0]);
-#endif
 #pragma unroll
                 for (int dt = 0; dt < NB; ++dt) {
-#ifdef MMX_SPLIT_B64
                     vacc[dt] = mfma16x16x32_bf16(p_op, transposed_operand(dOtc, dt, pp), vacc[dt]);
                     kacc[dt] = mfma16x16x32_bf16(ds_op, transposed_operand(Qtc, dt, pp), kacc[dt]);
-#else
-                    vacc[dt] = mfma16x16x32_bf16(dt & 1 ? p_sw : p_op, transposed_operand_sorted(dOtc, dt, pp), vacc[dt]);
-                    kacc[dt] = mfma16x16x32_bf16(dt & 1 ? ds_sw : ds_op, transposed_operand_sorted(Qtc, dt, pp), kacc[dt]);
-#endif
                 }
             }
             // pin this half's share of the relevancy sum here: left alone the compiler sinks all 16 multiply / clamp / fma
@@ -561,214 +533,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
     }
 }
 
-// ===================================================================================================== key side, fourth generation
-// Round 4 experiment, kept selectable (attn_bf16_v3 = 3) and tested, NOT the default.  A wave owns KB blocks of 16 keys: the staged
-// dO / dO^T / Q^T tile and its LDS operand reads (dO rows, dO^T, Q^T: read once per half tile) serve KB key blocks, so a tile carries
-// KB x 24 MFMAs per wave between two barriers instead of 24.  Measured at the cfg-5 shape (16 heads x 577 tokens, B = 128; pair time
-// per layer with the third-generation query side, the third-generation key side at 855 us):
-//   KB = 5, 4 waves, V operands in LDS, accumulators in AGPRs (404 registers, ONE wave / SIMD): 980 us.  The staging is amortised
-//           (ablation: -70 us without it, third generation -199 us) but every LDS / MFMA -> VALU latency is exposed, and the dP
-//           results take a v_accvgpr_read each on their way to the VALU (the compiler keeps every MFMA result in AGPRs once the
-//           kernel needs more than 256 registers).
-//   KB = 2, 4 waves, V operands in registers (230 registers, TWO waves / SIMD; the instantiated one): 882 us.  Half the LDS operand
-//           reads and shared-operand VALU work per MFMA, half the waves to hide latency with: a wash.
-// Same arithmetic, orientation and accumulator layouts as the third generation; taken only when its key chunks tile the padded
-// images (Np % (64 KB) == 0), else the launcher falls back.  profiles/r04_cfg5_ablation.txt, r04_cfg5_probe.txt.
-template <int KB, bool DKV, int ABL = 0>
-__global__ __launch_bounds__(256, KB <= 2 ? 2 : 1) void attn_bwd_kv_v4_kernel(const AttnBwdArgs a, const V3Images im) {
-    constexpr int NB = kD / 16, NW = 4, R = 16 * NW * KB;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16_t* dOr = reinterpret_cast<bf16_t*>(smem_raw);                // [2][kT][kLR]   dO rows (row-major)
-    bf16_t* dOt = dOr + 2 * kT * kLR;                                 // [2][kD][kLT]   dO transposed
-    bf16_t* Qt = dOt + 2 * kD * kLT;                                  // [2][kD][kLT]   (scale q) transposed
-    float* dl = reinterpret_cast<float*>(Qt + 2 * kD * kLT);          // [2][kT]        delta of the staged query rows
-    float* vl = dl + 2 * kT;                                          // [2][kT]        rel_v of the staged query rows
-    constexpr bool VREG = KB <= 2;                                    // few key blocks: their V operands stay in registers
-    bf16_t* Vl = reinterpret_cast<bf16_t*>(vl + 2 * kT);              // [R][kLR]       V rows of the workgroup's keys, resident (!VREG)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
-    const int st = tid;
-    const int nkt = (a.Nk + R - 1) / R;
-    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
-    const int b = (wg / nkt) % a.B, h = wg / (nkt * a.B);          // key chunk fastest, then the sample, the head slowest
-    const int k0 = (wg % nkt) * R;
-    const int kw = k0 + wave * 16 * KB;                               // first key of this wave; block kb: keys kw + 16 kb + i
-    const int64_t head = static_cast<int64_t>(b) * a.H + h;
-    // the launcher takes this kernel only when R divides Np: every key / query row touched exists in the padded images (rows past
-    // N are zero), so no load below is clamped or masked
-    const bf16_t* pcol0 = im.PT + p_block_offset(h, kw / 16, 0, im.Np) + 8 * lane;    // key block kb: + kb (Np / 64) 1024 elements
-    const bf16_t* qimg = im.QbT + static_cast<int64_t>(h) * kD * im.Np;
-    const bf16_t* dobase = reinterpret_cast<const bf16_t*>(a.dout) + b * a.os.sb + h * a.os.sh;
-
-    bf16x8 vreg[VREG ? KB : 1][kD / 32];
-    if constexpr (VREG) {
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-            load_rows8(vreg[kb], im.Vb + static_cast<int64_t>(h) * im.Np * kD, kD, kw + 16 * kb + i, true, g);
-    } else {   // V rows of the R keys -> LDS (B operand of dP = dO . V^T; kept out of the register file: KB x 8 registers)
-        const bf16_t* vsrc = im.Vb + (static_cast<int64_t>(h) * im.Np + k0) * kD;
-#pragma unroll
-        for (int e = 0; e < R * kD / 8 / 256; ++e) {
-            const int chunk = tid + 256 * e, row = chunk >> 3, c8 = chunk & 7;
-            *reinterpret_cast<u32x4v*>(Vl + row * kLR + 8 * c8) = *reinterpret_cast<const u32x4v*>(vsrc + row * kD + 8 * c8);
-        }
-    }
-    const bf16_t* vlane = Vl + (wave * 16 * KB + i) * kLR + 8 * g;    // block kb, half pr: + 16 kb kLR + 32 pr
-
-    f32x4 kacc[KB][NB], vacc[KB][NB];
-    float racc[KB];
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        racc[kb] = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < NB; ++dt) kacc[kb][dt] = vacc[kb][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
-    const int ntiles = (a.Nq + kT - 1) / kT;
-    const int tlane = transposed_lane_base(i, g);
-    RawBlock doreg, qreg;
-    int do_row0 = 0;
-    float dlreg = 0.f, vlreg = 0.f;
-    auto fetch = [&](int qt) {                                        // every thread: one 4 x 4 block of dO and one of Q^T
-        const int r4 = 4 * (st >> 4), c = 4 * (st & 15);
-        do_row0 = qt * kT;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            doreg.raw[e] = *reinterpret_cast<const u32x2v*>(dobase + static_cast<int64_t>(min(qt * kT + r4 + e, a.Nq - 1)) * a.os.sn + c);
-        if constexpr (DKV) fetch_transposed(qreg, qimg, im.Np, qt * kT, st);
-        const int row = min(qt * kT + lane, a.Nq - 1);               // (every wave loads them: no branch around a load)
-        if constexpr (DKV) dlreg = a.delta[head * a.Nq + row];
-        vlreg = a.rel_v[static_cast<int64_t>(b) * a.Nq + row];
-    };
-    auto stage = [&](int buf) {
-        const int r4 = 4 * (st >> 4);
-        u32x2v rows[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rows[e] = do_row0 + r4 + e < a.Nq ? doreg.raw[e] : u32x2v{0u, 0u};
-        store_row_major(dOr + buf * kT * kLR, rows, st);
-        if constexpr (DKV) {
-            u32x2v cols[4];
-#pragma unroll
-            for (int dd = 0; dd < 4; ++dd) cols[dd] = column_of(rows, dd);
-            store_transposed_raw(dOt + buf * kD * kLT, cols, st);
-            store_transposed_raw(Qt + buf * kD * kLT, qreg.raw, st);
-        }
-        if (tid < kT) {
-            if constexpr (DKV) dl[buf * kT + tid] = dlreg;
-            vl[buf * kT + tid] = vlreg;                                // (rows past Nq: p is zero there)
-        }
-    };
-    // probability words, prefetched one HALF tile (32 query rows) ahead: ps[pp][kb][hh] = rows 16 (2 pp + hh) + 4 g .. + 3 of key i
-    // (one 16-byte word per key block: lane (i, g)'s A operand of dV = P^T . dO, straight from the blocked image)
-    u32x4v ps[2][KB];
-    auto p_issue = [&](u32x4v (&raw)[KB], int half) {                // half = 2 qt + pp
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) raw[kb] = *reinterpret_cast<const u32x4v*>(pcol0 + kb * (im.Np / kT) * 1024 + half * 512);
-    };
-    fetch(0);
-    stage(0);
-    p_issue(ps[0], 0);
-    if (ntiles > 1) fetch(1);
-    __syncthreads();
-    for (int qt = 0; qt < ntiles; ++qt) {
-        const int cur = qt & 1;
-        if (ABL != 2 && ABL != 6 && qt + 1 < ntiles) {
-            stage(cur ^ 1);
-            if (qt + 2 < ntiles) fetch(qt + 2);
-        }
-        const bf16_t* dOrc = dOr + cur * kT * kLR;
-        const bf16_t* dOtc = dOt + cur * kD * kLT + tlane;
-        const bf16_t* Qtc = Qt + cur * kD * kLT + tlane;
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {                               // query rows 32 pp .. + 31 of the tile
-            if (pp == 0) p_issue(ps[1], 2 * qt + 1);                   // (the second half always exists in the padded image)
-            else if (qt + 1 < ntiles) p_issue(ps[0], 2 * qt + 2);
-            // this half's shared operands, read from LDS ONCE for all KB key blocks
-            bf16x8 dor[2][kD / 32], dot[NB], qtt[NB];
-            f32x4 vv[2], dlv[2];
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-                for (int pr = 0; pr < kD / 32; ++pr)
-                    dor[hh][pr] = *reinterpret_cast<const bf16x8*>(dOrc + (16 * (2 * pp + hh) + i) * kLR + 32 * pr + 8 * g);
-                vv[hh] = *reinterpret_cast<const f32x4*>(vl + cur * kT + 16 * (2 * pp + hh) + 4 * g);
-                if constexpr (DKV) dlv[hh] = *reinterpret_cast<const f32x4*>(dl + cur * kT + 16 * (2 * pp + hh) + 4 * g);
-            }
-            if constexpr (DKV) {
-#pragma unroll
-                for (int dt = 0; dt < NB; ++dt) {
-                    dot[dt] = transposed_operand(dOtc, dt, pp);
-                    qtt[dt] = transposed_operand(Qtc, dt, pp);
-                }
-            }
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                f32x4 dp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // dp[hh][r] = dP[16 t + 4 g + r][key i of block kb]
-#pragma unroll
-                for (int pr = 0; pr < kD / 32; ++pr) {
-                    const bf16x8 vop = VREG ? vreg[VREG ? kb : 0][pr] : *reinterpret_cast<const bf16x8*>(vlane + 16 * kb * kLR + 32 * pr);
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) dp[hh] = mfma16x16x32_bf16(dor[hh][pr], vop, dp[hh]);
-                }
-                f32x4 ds[2];
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const f32x4 p = unpack4(u32x2v{ps[pp][kb][2 * hh], ps[pp][kb][2 * hh + 1]});
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (ABL == 3 || ABL == 7) racc[kb] += dp[hh][r];
-                        else racc[kb] += vv[hh][r] * relu_nan(p[r] * dp[hh][r]);
-                    }
-                    if constexpr (DKV) ds[hh] = p * (dp[hh] - dlv[hh]);
-                }
-                if constexpr (DKV) {
-                    const bf16x8 p_op = as_bf16x8(ps[pp][kb]);
-                    const bf16x8 ds_op = ABL == 4 || ABL == 7 ? p_op : pack8(ds[0], ds[1]);
-#pragma unroll
-                    for (int dt = 0; dt < NB; ++dt) {
-                        vacc[kb][dt] = mfma16x16x32_bf16(p_op, dot[dt], vacc[kb][dt]);
-                        kacc[kb][dt] = mfma16x16x32_bf16(ds_op, qtt[dt], kacc[kb][dt]);
-                    }
-                }
-            }
-        }
-        lds_barrier();
-    }
-    const int64_t dk0 = b * a.dks.sb + h * a.dks.sh, dv0 = b * a.dvs.sb + h * a.dvs.sh;
-    const bool odd = i & 1;
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        const int kbase = kw + 16 * kb;
-        float rs = racc[kb];
-        rs += __shfl_xor(rs, 16);
-        rs += __shfl_xor(rs, 32);                                  // the 4 row groups of the tile rows: all queries of key i
-        if (g == 0 && kbase + i < a.Nk) a.rel_part[head * a.Nk + kbase + i] = rs;
-        if constexpr (DKV) {
-            // accumulators: lane (d = 16 dt + i), rows key = kbase + 4 g + r; lanes i / i ^ 1 pair up so that every store is 4 bytes
-#pragma unroll
-            for (int dt = 0; dt < NB; ++dt) {
-                const int d = 16 * dt + i;
-#pragma unroll
-                for (int rp = 0; rp < 2; ++rp) {
-                    const int r = 2 * rp + (odd ? 1 : 0);
-                    const int j = kbase + 4 * g + r, c0 = d - (odd ? 1 : 0);
-                    const float km = odd ? kacc[kb][dt][2 * rp + 1] : kacc[kb][dt][2 * rp];
-                    const float vm = odd ? vacc[kb][dt][2 * rp + 1] : vacc[kb][dt][2 * rp];
-                    const float ko = __int_as_float(__builtin_amdgcn_update_dpp(
-                        0, __float_as_int(odd ? kacc[kb][dt][2 * rp] : kacc[kb][dt][2 * rp + 1]), 0xB1, 0xF, 0xF, false));
-                    const float vo = __int_as_float(__builtin_amdgcn_update_dpp(
-                        0, __float_as_int(odd ? vacc[kb][dt][2 * rp] : vacc[kb][dt][2 * rp + 1]), 0xB1, 0xF, 0xF, false));
-                    if (j < a.Nk) {
-                        bf16_t* dk = reinterpret_cast<bf16_t*>(a.dk) + dk0 + static_cast<int64_t>(j) * a.dks.sn + c0;
-                        bf16_t* dv = reinterpret_cast<bf16_t*>(a.dv) + dv0 + static_cast<int64_t>(j) * a.dvs.sn + c0;
-                        *reinterpret_cast<unsigned*>(dk) = odd ? pk2(ko, km) : pk2(km, ko);
-                        *reinterpret_cast<unsigned*>(dv) = odd ? pk2(vo, vm) : pk2(vm, vo);
-                    }
-                }
-            }
-        }
-    }
-}
-
 constexpr size_t kQLds = sizeof(bf16_t) * (2 * kT * kLR + 2 * kD * kLT);
 constexpr size_t kKvLds = sizeof(bf16_t) * (2 * kT * kLR + 4 * kD * kLT) + sizeof(float) * 4 * kT;
 
@@ -783,36 +547,6 @@ int launch_v3(K kern, const AttnBwdArgs& a, const V3Images& im, dim3 grid, int t
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, name);
     return MMX_OK;
-}
-
-constexpr int kV4KB = 2;                                                  // key blocks per wave of the fourth-generation key side
-constexpr size_t kKv4Lds = kKvLds + (kV4KB <= 2 ? 0 : sizeof(bf16_t) * 16 * 4 * kV4KB * kLR);
-template <int NW>
-int run_v3(const AttnBwdArgs& a, const V3Images& im, hipStream_t s);
-int run_v4(const AttnBwdArgs& a, const V3Images& im, hipStream_t s) {
-    if (im.Np % (16 * 4 * kV4KB) != 0) return run_v3<8>(a, im, s);     // the key chunks must tile the padded images
-    // query side: third generation (8-wave workgroups, two samples each); key side: fourth generation (kV4KB key blocks per wave)
-    constexpr int RQ = 16 * 8, NS = 2, RK = 16 * 4 * kV4KB;
-    dim3 gq(((a.Nq + RQ - 1) / RQ) * a.H * ((a.B + NS - 1) / NS)), gk(((a.Nk + RK - 1) / RK) * a.H * a.B);
-    int rc = MMX_OK;
-    if (a.need_dqkv) {
-        rc = launch_v3(attn_bwd_q_v3_kernel<8, NS>, a, im, gq, 64 * 8, kQLds, s, "attn_bwd_q_v3_kernel");
-        if (rc) return rc;
-#ifdef MMX_ATTN_ABLATE
-        static const int abl = getenv("MMX_ATTN_ABLATE") ? atoi(getenv("MMX_ATTN_ABLATE")) : 0;
-        auto kern = abl == 1 ? attn_bwd_kv_v4_kernel<kV4KB, true, 1> : abl == 2 ? attn_bwd_kv_v4_kernel<kV4KB, true, 2>
-                  : abl == 3 ? attn_bwd_kv_v4_kernel<kV4KB, true, 3> : abl == 4 ? attn_bwd_kv_v4_kernel<kV4KB, true, 4>
-                  : abl == 6 ? attn_bwd_kv_v4_kernel<kV4KB, true, 6> : abl == 7 ? attn_bwd_kv_v4_kernel<kV4KB, true, 7>
-                                                                                 : attn_bwd_kv_v4_kernel<kV4KB, true, 0>;
-        rc = launch_v3(kern, a, im, gk, 256, kKv4Lds, s, "attn_bwd_kv_v4_kernel");
-#else
-        rc = launch_v3(attn_bwd_kv_v4_kernel<kV4KB, true>, a, im, gk, 256, kKv4Lds, s, "attn_bwd_kv_v4_kernel");
-#endif
-    } else {
-        rc = launch_v3(attn_bwd_kv_v4_kernel<kV4KB, false>, a, im, gk, 256, kKv4Lds, s, "attn_bwd_kv_v4_kernel<rel only>");
-    }
-    if (rc) return rc;
-    return rel_row_update(a.rel_v, a.rel_part, a.rel_out, a.B, a.H, a.Nk, 1.0f / a.H, s);
 }
 
 template <int NW>
@@ -888,7 +622,7 @@ int attn_bwd_bf16_v3_try(const AttnBwdArgs& a, void* prep, size_t prep_bytes, hi
     e = hipGetLastError();
     if (e != hipSuccess) { *rc_out = hip_fail(e, "prep_p_kernel"); return 1; }
     const V3Images im{Vb, KbT, QbT, Pq, PT, Np};
-    *rc_out = g_attn_bf16_v3 == 3 ? run_v4(a, im, s) : g_attn_bf16_v3 == 2 ? run_v3<8>(a, im, s) : run_v3<4>(a, im, s);
+    *rc_out = run_v3<8>(a, im, s);
     return 1;
 }
 

@@ -355,7 +355,6 @@ extern "C" int mmx_attn_capture_fwd_ex(const void* q_dev, const void* k_dev, con
         return MMX_ENOTSUP;
     }
     if (attn_fwd_head_try(a, s, &rc)) return rc;    // short sequences: a wave owns 16 query rows, scores in registers
-    if (attn_fwd_small_try(a, s, &rc)) return rc;   // whole head resident in LDS (first generation of the above)
     if (attn_fwd_stream_try(a, s, &rc)) return rc;  // long sequences: K/V streamed, nothing of size Nk on chip
     if (D <= 32) return launch_dyn(attn_capture_fwd_kernel<32>, a, grid, attn_lds_bytes(32, Nk), s, "attn_capture_fwd_kernel<32>");
     return launch_dyn(attn_capture_fwd_kernel<64>, a, grid, attn_lds_bytes(64, Nk), s, "attn_capture_fwd_kernel<64>");
@@ -494,7 +493,6 @@ static int attn_bwd_impl(const void* q_dev, const void* k_dev, const void* v_dev
                   "(fp32 slabs, Nk <= 128, Nq <= 256, head_dim %% 4 == 0 and <= 64, 8-byte aligned gradient rows)");
         return MMX_ENOTSUP;
     }
-    if (attn_bwd_small_try(a, s, &rc)) return rc;   // whole head resident in LDS (first generation of the above)
     if (attn_bwd_stream_try(a, s, &rc)) return rc;  // long sequences
     dim3 gq((Nq + kTQ - 1) / kTQ, H, B), gk((Nk + 15) / 16, H, B);
     if (D <= 32) {

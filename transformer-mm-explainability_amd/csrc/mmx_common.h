@@ -203,15 +203,7 @@ __device__ __forceinline__ int xcd_contiguous_id(int w, int total) {
 inline size_t dtype_size(int dt) { return dt == MMX_F32 ? 4 : 2; }
 
 void set_error(const char* fmt, ...);
-void attn_small_enable(int on);
-void linear_stream_enable(int on);
-int linear_stream_try(const float* A, const float* B, const float* Cin, float* C, int M, int N, int K, int cin_is_row, hipStream_t s);
 void attn_head_enable(int on);
-void chain_big_enable(int on);
-size_t self_chain_big_workspace(int B, int N);
-int self_chain_big_try(const void* const* attn_layers, const void* const* grad_layers, int n_layers, int B, int H, int N,
-                       int dtype, int64_t attn_bstride, const void* R_init, void* R_out, void* workspace,
-                       size_t workspace_bytes, hipStream_t s, int* rc_out);
 // relevancy_chain_relay.hip: the chain with position-split streamers feeding one chain workgroup per sample (K1r)
 bool self_chain_relay_applies(int n_layers, int B, int H, int N);
 size_t self_chain_relay_workspace(int n_layers, int B, int H, int N);

@@ -429,199 +429,6 @@ __global__ __launch_bounds__(THREADS) void self_chain_fused_kernel(const ChainAr
 }
 
 // =====================================================================================================
-// K_self_chain_v2 ("reduce + last-arriver chain"): the chip-filling form of the same single launch.
-// grid = B * L workgroups of 512 threads; workgroup u = (sample b, layer l):
-//   phase 1  streams the [H, N, N] slabs of A_l[b], G_l[b] once (16-B loads, heads in order), writes
-//            A_bar_l[b] (1/(2H) of the bytes read) to a scratch slab.  Every CU streams: HBM-bound.
-//   publish  split-K style hand-off (cdna guide G16, write-through form): A_bar is stored with sc1 stores,
-//            every wave drains vmcnt, barrier, ONE lane takes a ticket on the sample's counter.
-//   phase 2  only the LAST arriver of sample b (ticket == L-1; no spinning, placement independent): one
-//            agent-scope acquire, then the sequential chain R <- R + A_bar_l . R for l = 0..L-1 with R in
-//            registers (MFMA C/D layout, as in the fused kernel) and A_bar_l prefetched global->regs->LDS one
-//            layer ahead of the MFMAs.  Same summation order as the per-sample fused kernel: results are
-//            bit-identical between the two algorithms.
-// Counters are zeroed by the host (a zero_async kernel node) before every launch.
-// =====================================================================================================
-struct ChainV2Args {
-    const void* attn[MMX_MAX_LAYERS];
-    const void* grad[MMX_MAX_LAYERS];
-    int n_layers, B, H, N;
-    float* abar;         // [L][B][N][S] LDS images, S = 16*NT + 4
-    unsigned* counters;  // [B]
-    const float* R_init;
-    float* R_out;
-    int debug;           // profiling only: bit0 = skip the chain phase, bit1 = skip the streaming phase
-    int64_t attn_bstride;  // as in ChainArgs
-};
-
-constexpr int kV2Threads = 512;
-
-template <int NT, int DT>
-__global__ __launch_bounds__(kV2Threads) void self_chain_v2_kernel(const ChainV2Args a) {
-    constexpr int NP = NT * 16;
-    constexpr int S = NP + 4;
-    constexpr int CH = (NP * S / 4 + kV2Threads - 1) / kV2Threads;   // 16-B chunks of an A_bar image per thread
-    extern __shared__ __attribute__((aligned(16))) float smem[];     // (NAB + 1) * NP * S floats
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int N = a.N, H = a.H, L = a.n_layers;
-    const int b = blockIdx.x / L, l0 = blockIdx.x - b * L;
-    const int64_t NN = static_cast<int64_t>(N) * N;
-
-    // ------------------------------------------------------------------ phase 1: head reduction of (b, l0)
-    // Output = the LDS image of A_bar (rows of S floats, zero column padding) so that phase 2 moves it with
-    // aligned 16-B copies only.  Chunks are (row, 4 columns); the global loads stay 16 B wide at any alignment.
-    const int64_t img_elems = static_cast<int64_t>(N) * S;
-    if (!(a.debug & 2)) {
-        const void* A = a.attn[l0];
-        const void* G = a.grad[l0];
-        const int64_t sample = static_cast<int64_t>(b) * H * NN;
-        const int64_t sampleA = static_cast<int64_t>(b) * a.attn_bstride;
-        const int64_t slab = static_cast<int64_t>(a.B) * H * NN;
-        float* img = a.abar + (static_cast<int64_t>(l0) * a.B + b) * img_elems;
-        const float fH = static_cast<float>(H);
-        const int cpr = (N + 3) >> 2;  // chunks per row holding real columns (the last may be partial)
-        const int nreal = N * cpr;
-        for (int r = tid; r < nreal; r += kV2Threads) {
-            const int row = r / cpr, col = (r - row * cpr) * 4;
-            const int64_t p = static_cast<int64_t>(row) * N + col;
-            const int valid = min(4, N - col);
-            f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            // 16-B loads stay inside the layer slabs (the shared-forward attention slab holds one sample only)
-            if (sample + (H - 1) * NN + p + 3 < slab && (a.attn_bstride != 0 || (H - 1) * NN + p + 3 < H * NN)) {
-#pragma unroll 4
-                for (int h = 0; h < H; ++h) {
-                    const f32x4 av = load4_as_f32<DT>(A, sampleA + h * NN + p);
-                    const f32x4 gv = load4_as_f32<DT>(G, sample + h * NN + p);
-                    const f32x4 x = gv * av;
-                    s[0] += relu_nan(x[0]); s[1] += relu_nan(x[1]);
-                    s[2] += relu_nan(x[2]); s[3] += relu_nan(x[3]);
-                }
-            } else {
-                for (int e = 0; e < valid; ++e)
-                    for (int h = 0; h < H; ++h)
-                        s[e] += relu_nan(load1_as_f32<DT>(G, sample + h * NN + p + e) *
-                                         load1_as_f32<DT>(A, sampleA + h * NN + p + e));
-            }
-            f32x2 lo = {valid > 0 ? s[0] / fH : 0.f, valid > 1 ? s[1] / fH : 0.f};
-            f32x2 hi = {valid > 2 ? s[2] / fH : 0.f, valid > 3 ? s[3] / fH : 0.f};
-            // write-through (sc1) 8-B stores: the publish below then needs no L2 write-back fence
-            unsigned long long* dst = reinterpret_cast<unsigned long long*>(img + static_cast<int64_t>(row) * S + col);
-            __hip_atomic_store(dst, __builtin_bit_cast(unsigned long long, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dst + 1, __builtin_bit_cast(unsigned long long, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const int ppr = S / 4 - cpr;  // all-padding chunks per row
-        for (int r = tid; r < N * ppr; r += kV2Threads) {
-            const int row = r / ppr, col = (cpr + r - row * ppr) * 4;
-            unsigned long long* dst = reinterpret_cast<unsigned long long*>(img + static_cast<int64_t>(row) * S + col);
-            __hip_atomic_store(dst, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dst + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    // ------------------------------------------------------------------ publish + ticket
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
-    __syncthreads();
-    unsigned* ticket_lds = reinterpret_cast<unsigned*>(smem);
-    if (tid == 0)
-        *ticket_lds = __hip_atomic_fetch_add(a.counters + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const unsigned ticket = *ticket_lds;
-    if (ticket != static_cast<unsigned>(L - 1) || (a.debug & 1)) return;
-    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-
-    // ------------------------------------------------------------------ phase 2: chain of sample b
-    // Tile-parallel: the NT x NT output tiles of A_bar_l . R are dealt round-robin to the 8 waves so every
-    // SIMD's matrix pipe carries the same number of MFMAs (NT = 5: 7/6/6/6 tiles per SIMD instead of a whole
-    // extra column slab on one).  R lives in LDS TRANSPOSED (RT[col][row]): with the k-order (t, r, lane>>4)
-    // both MFMA operands are one ds_read_b128 per 4 MFMAs and a finished tile goes back as one ds_write_b128.
-    // A_bar_{l+1}, A_bar_{l+2} are already in registers (global prefetch two layers deep, L2/MALL hits).
-    constexpr int NAB = (3 * NP * S * 4 <= 160 * 1024) ? 2 : 1;
-    constexpr int NTILES = NT * NT;
-    constexpr int NW = kV2Threads / 64;
-    constexpr int TPW = (NTILES + NW - 1) / NW;
-    float* Abuf = smem;
-    float* RT = smem + NAB * NP * S;
-    for (int i = tid; i < (NAB + 1) * NP * S; i += kV2Threads) smem[i] = 0.f;
-    __syncthreads();
-    // R_0 = I or R_init, written transposed
-    for (int idx = tid; idx < N * N; idx += kV2Threads) {
-        const int row = idx / N, cc = idx - row * N;
-        RT[cc * S + row] = a.R_init ? a.R_init[b * NN + idx] : (row == cc ? 1.f : 0.f);
-    }
-    f32x4 preA[CH], preB[CH];
-    const int nimg4 = static_cast<int>(img_elems >> 2);
-    auto fetch = [&](int l, f32x4 (&pre)[CH]) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.abar + (static_cast<int64_t>(l) * a.B + b) * img_elems);
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int c = tid + i * kV2Threads;
-            pre[i] = (c < nimg4) ? src[c] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto stash = [&](int buf, const f32x4 (&pre)[CH]) {
-        f32x4* Ab = reinterpret_cast<f32x4*>(Abuf + buf * NP * S);
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int c = tid + i * kV2Threads;
-            if (c < nimg4) Ab[c] = pre[i];
-        }
-    };
-    const int i_a = lane & 15, kq = (lane >> 4) * 4;
-    auto step = [&](int l, f32x4 (&pre)[CH]) {
-        // pre holds A_bar_{l+1}; A_bar_l is in Abuf[l % NAB]; R_l is in RT
-        const float* Ab = Abuf + (l % NAB) * NP * S;
-        f32x4 acc[TPW];
-#pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-            acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int tile = wave + q * NW;
-            if (tile < NTILES) {
-                const int w = tile / NT, ti = tile - w * NT;
-                const float* ap = Ab + (ti * 16 + i_a) * S + kq;
-                const float* bp = RT + (w * 16 + i_a) * S + kq;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f32x4 av = *reinterpret_cast<const f32x4*>(ap + t * 16);
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + t * 16);
-                    acc[q] = mfma16x16x4(av[0], bv[0], acc[q]);
-                    acc[q] = mfma16x16x4(av[1], bv[1], acc[q]);
-                    acc[q] = mfma16x16x4(av[2], bv[2], acc[q]);
-                    acc[q] = mfma16x16x4(av[3], bv[3], acc[q]);
-                }
-            }
-        }
-        lds_barrier();  // every wave is done reading R_l and A_bar_l (global prefetches stay in flight)
-#pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-            const int tile = wave + q * NW;
-            if (tile < NTILES) {
-                const int w = tile / NT, ti = tile - w * NT;
-                f32x4* rp = reinterpret_cast<f32x4*>(RT + (w * 16 + i_a) * S + ti * 16 + kq);
-                *rp = *rp + acc[q];  // R + (A_bar . R): same association as the reference
-            }
-        }
-        if (l + 1 < L) stash((l + 1) % NAB, pre);
-        if (l + 3 < L) fetch(l + 3, pre);
-        lds_barrier();
-    };
-    if (L > 0) { fetch(0, preA); stash(0, preA); }
-    if (L > 1) fetch(1, preA);
-    if (L > 2) fetch(2, preB);
-    __syncthreads();
-    for (int l = 0; l < L; l += 2) {
-        step(l, preA);
-        if (l + 1 < L) step(l + 1, preB);
-    }
-    for (int idx = tid; idx < N * N; idx += kV2Threads) {
-        const int row = idx / N, cc = idx - row * N;
-        a.R_out[b * NN + idx] = RT[cc * S + row];
-    }
-}
-
-// =====================================================================================================
 // K_bmm_f32: C[b] = (Cin ? Cin[b] : 0) + op(A[b]) . B[b] on v_mfma_f32_16x16x4_f32 (exact fp32).
 // 64x64 output tile per 256-thread workgroup (4 waves as 2x2, 32x32 each = 2x2 MFMA tiles), BK = 32.
 // The next K-slab's global loads are issued into registers before the MFMAs of the current one (the problems here
@@ -727,19 +534,12 @@ __global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ 
             }
 }
 
-static int g_bmm_tile = 64;   // 128: try the 128 x 128 tiling where the grid is large enough (A/B profiling)
-
 static void launch_bmm(const float* A, const float* B, const float* Cin, float* C, int batch, int M, int N, int K,
                        int trans_a, int64_t sa, int64_t sb, int64_t sc, int nan_to_zero, hipStream_t s, int cin_is_row = 0) {
-    if (batch == 1 && !trans_a && !nan_to_zero && linear_stream_try(A, B, Cin, C, M, N, K, cin_is_row, s)) return;
     const int64_t wgs64 = static_cast<int64_t>((N + 63) / 64) * ((M + 63) / 64) * batch;
-    const int64_t wgs128 = static_cast<int64_t>((N + 127) / 128) * ((M + 127) / 128) * batch;
-    if (wgs128 >= 512 && g_bmm_tile == 128) {
-        // 128 x 128 per workgroup (each wave 64 x 64 = 16 accumulator tiles).  Measured SLOWER than 64 x 64 at the
-        // long-sequence chain shapes (profiles/r02_bmm_probe.txt: 384 vs 281 us at [32 x 577 x 577]^2), so opt-in only.
-        bmm_f32_kernel<128><<<dim3(static_cast<unsigned>(wgs128)), 256, 0, s>>>(A, B, Cin, C, M, N, K, trans_a,
-                                                                                       sa, sb, sc, nan_to_zero, cin_is_row);
-    } else if (wgs64 >= 1024) {
+    // (a 128 x 128 tiling was measured SLOWER at the long-sequence chain shapes -- profiles/r02_bmm_probe.txt: 384 vs 281 us at
+    // [32 x 577 x 577]^2 -- and removed in round 5)
+    if (wgs64 >= 1024) {
         bmm_f32_kernel<64><<<dim3(static_cast<unsigned>(wgs64)), 256, 0, s>>>(A, B, Cin, C, M, N, K, trans_a, sa,
                                                                                     sb, sc, nan_to_zero, cin_is_row);
     } else {
@@ -1179,7 +979,7 @@ static int g_chain_pipe = 4;     // option "self_chain_pipe": software-pipelined
 static int g_chain_nt = 1;       // option "self_chain_nt": nt cache policy on the read-once slab loads of the pipelined stream waves
                                  // (default since round 4: text tower 85.8 -> 82.0 us, image 65.5 -> 63.8 us inside the replayed step)
 static int g_chain_groups = 0;  // layer groups per sample of the per-sample kernel: 0 auto, 1 = strict sequential order
-static int g_chain_algo = 0;  // 0 auto, 1 per-sample wave-specialised, 2 reduce + last-arriver chain, 3 relay (position-split streamers)
+static int g_chain_algo = 0;  // 0 auto = 1: per-sample kernel (layer groups when the batch leaves CUs idle) | 3: relay (position-split streamers)
 
 extern "C" int mmx_set_option(const char* key, int value) {
     if (key && strcmp(key, "self_chain_relay_q") == 0 && value >= 0 && value <= 16) {
@@ -1190,7 +990,7 @@ extern "C" int mmx_set_option(const char* key, int value) {
         chain_relay_options(-1, value);
         return MMX_OK;
     }
-    if (key && strcmp(key, "self_chain_algo") == 0 && value >= 0 && value <= 3) {
+    if (key && strcmp(key, "self_chain_algo") == 0 && (value == 0 || value == 1 || value == 3)) {
         g_chain_algo = value;
         return MMX_OK;
     }
@@ -1206,27 +1006,11 @@ extern "C" int mmx_set_option(const char* key, int value) {
         g_chain_groups = value;
         return MMX_OK;
     }
-    if (key && strcmp(key, "attn_small") == 0) {
-        attn_small_enable(value);
-        return MMX_OK;
-    }
-    if (key && strcmp(key, "linear_stream") == 0 && value >= 0 && value <= 1) {
-        linear_stream_enable(value);
-        return MMX_OK;
-    }
-    if (key && strcmp(key, "bmm_tile") == 0) {
-        g_bmm_tile = value;
-        return MMX_OK;
-    }
-    if (key && strcmp(key, "self_chain_big") == 0) {
-        chain_big_enable(value);
-        return MMX_OK;
-    }
     if (key && strcmp(key, "attn_head") == 0) {
         attn_head_enable(value);
         return MMX_OK;
     }
-    if (key && strcmp(key, "attn_bf16_v3") == 0 && value >= 0 && value <= 3) {
+    if (key && strcmp(key, "attn_bf16_v3") == 0 && value >= 0 && value <= 2) {
         attn_bf16_v3_enable(value);
         return MMX_OK;
     }
@@ -1250,13 +1034,6 @@ extern "C" int mmx_set_option(const char* key, int value) {
     return MMX_EINVAL;
 }
 
-static bool use_v2(int n_layers, int B, int N, int M) {
-    if (nt_for(N) > 8 || M != 0 || n_layers < 1) return false;
-    // auto = the per-sample kernel: measured faster or equal at CLIP shapes (profiles/r01_chain_probe.txt); the
-    // reduce + last-arriver form fills the chip while streaming but exposes the serial chain as a tail.
-    return g_chain_algo == 2;
-}
-
 // The relay form (relevancy_chain_relay.hip, option self_chain_algo = 3): fp32 slabs, one right-hand side.  Strict layer order in one
 // launch at any batch size (bit-identical to the per-sample kernel), but measured SLOWER than the layer-group kernel at the cfg-2
 // shapes (115 vs 84 us, profiles/r05_chain_relay_probe.txt), so it is opt-in.
@@ -1276,51 +1053,19 @@ static int fused_groups(int n_layers, int B, int H, int N) {
     return G < n_layers ? G : n_layers;
 }
 
-static size_t v2_counter_bytes(int B) { return align256(sizeof(unsigned) * static_cast<size_t>(B)); }
+static size_t group_counter_bytes(int B) { return align256(sizeof(unsigned) * static_cast<size_t>(B)); }
 
 extern "C" size_t mmx_self_chain_workspace_bytes(int n_layers, int B, int H, int N, int M, int dtype) {
     (void)dtype;
     if (nt_for(N) <= 8 && M == 0) {
         if (use_relay(n_layers, B, H, N, M, dtype)) return self_chain_relay_workspace(n_layers, B, H, N);
-        if (!use_v2(n_layers, B, N, M)) {
-            const int G = fused_groups(n_layers, B, H, N);
-            if (G == 1) return 0;  // strict-order per-sample kernel needs no scratch
-            return v2_counter_bytes(B) + align256(sizeof(float) * static_cast<size_t>(B) * G * N * N);
-        }
-        return v2_counter_bytes(B) + align256(sizeof(float) * static_cast<size_t>(n_layers) * B * N * (16 * nt_for(N) + 4));
+        const int G = fused_groups(n_layers, B, H, N);
+        if (G == 1) return 0;  // strict-order per-sample kernel needs no scratch
+        return group_counter_bytes(B) + align256(sizeof(float) * static_cast<size_t>(B) * G * N * N);
     }
     const size_t mat = align256(sizeof(float) * static_cast<size_t>(B) * N * N);
     const size_t sq = M > 0 ? align256(sizeof(float) * static_cast<size_t>(B) * N * M) : 0;
-    const size_t split = 2 * mat + sq;  // A_bar + R ping-pong [+ R_sq ping-pong]
-    const size_t big = M == 0 ? self_chain_big_workspace(B, N) : 0;   // one-launch long-sequence kernel (relevancy_chain_big.hip)
-    return split > big ? split : big;
-}
-
-template <int NT>
-static int launch_v2(ChainV2Args& args, int dtype, void* workspace, hipStream_t s) {
-    constexpr int NP = NT * 16;
-    constexpr int NAB = (3 * NP * (NP + 4) * 4 <= 160 * 1024) ? 2 : 1;  // must match the kernel
-    const size_t lds = sizeof(float) * (NAB + 1) * NP * (NP + 4);
-    void (*kern)(const ChainV2Args) = nullptr;
-    switch (dtype) {
-        case MMX_F32: kern = self_chain_v2_kernel<NT, MMX_F32>; break;
-        case MMX_F16: kern = self_chain_v2_kernel<NT, MMX_F16>; break;
-        case MMX_BF16: kern = self_chain_v2_kernel<NT, MMX_BF16>; break;
-        default: set_error("self_chain: unsupported dtype %d", dtype); return MMX_EINVAL;
-    }
-    args.counters = static_cast<unsigned*>(workspace);
-    args.abar = reinterpret_cast<float*>(static_cast<char*>(workspace) + v2_counter_bytes(args.B));
-    int zrc = zero_async(args.counters, sizeof(unsigned) * args.B, s);
-    if (zrc) return zrc;
-    hipError_t e;
-    if (lds > 48 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(lds));
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    }
-    kern<<<args.B * args.n_layers, kV2Threads, lds, s>>>(args);
-    MMX_LAUNCH_CHECK("self_chain_v2_kernel");
-    return MMX_OK;
+    return 2 * mat + sq;  // A_bar + R ping-pong [+ R_sq ping-pong]
 }
 
 template <int NT>
@@ -1382,31 +1127,6 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
     if (use_relay(n_layers, B, H, N, M, dtype))
         return self_chain_relay_launch(attn_layers, grad_layers, n_layers, B, H, N, attn_batch_stride, R_init_dev, R_out_dev,
                                        workspace_dev, workspace_bytes, g_chain_nt, g_debug_flags, s);
-    if (use_v2(n_layers, B, N, M)) {
-        const size_t need = mmx_self_chain_workspace_bytes(n_layers, B, H, N, M, dtype);
-        if (workspace_bytes < need || !workspace_dev) {
-            set_error("mmx_relevancy_self_chain: workspace %zu < %zu", workspace_bytes, need);
-            return MMX_EWORKSPACE;
-        }
-        ChainV2Args args;
-        memset(&args, 0, sizeof(args));
-        for (int l = 0; l < n_layers; ++l) { args.attn[l] = attn_layers[l]; args.grad[l] = grad_layers[l]; }
-        args.n_layers = n_layers; args.B = B; args.H = H; args.N = N;
-        args.R_init = static_cast<const float*>(R_init_dev);
-        args.R_out = static_cast<float*>(R_out_dev);
-        args.debug = g_debug_flags;
-        args.attn_bstride = attn_batch_stride;
-        switch (nt) {
-            case 1: return launch_v2<1>(args, dtype, workspace_dev, s);
-            case 2: return launch_v2<2>(args, dtype, workspace_dev, s);
-            case 3: return launch_v2<3>(args, dtype, workspace_dev, s);
-            case 4: return launch_v2<4>(args, dtype, workspace_dev, s);
-            case 5: return launch_v2<5>(args, dtype, workspace_dev, s);
-            case 6: return launch_v2<6>(args, dtype, workspace_dev, s);
-            case 7: return launch_v2<7>(args, dtype, workspace_dev, s);
-            default: return launch_v2<8>(args, dtype, workspace_dev, s);
-        }
-    }
     if (nt <= 8 && M == 0) {
         ChainArgs args;
         memset(&args, 0, sizeof(args));
@@ -1426,7 +1146,7 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
                 return MMX_EWORKSPACE;
             }
             args.counters = static_cast<unsigned*>(workspace_dev);
-            args.parts = reinterpret_cast<float*>(static_cast<char*>(workspace_dev) + v2_counter_bytes(B));
+            args.parts = reinterpret_cast<float*>(static_cast<char*>(workspace_dev) + group_counter_bytes(B));
         }
         switch (nt) {
             case 1: return launch_fused<1>(args, dtype, s);
@@ -1438,13 +1158,6 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
             case 7: return launch_fused<7>(args, dtype, s);
             default: return launch_fused<8>(args, dtype, s);
         }
-    }
-
-    if (M == 0) {   // N > 128: the persistent team kernel (one launch for all layers) when the grid fills the chip
-        int rc = MMX_OK;
-        if (self_chain_big_try(attn_layers, grad_layers, n_layers, B, H, N, dtype, attn_batch_stride, R_init_dev, R_out_dev,
-                               workspace_dev, workspace_bytes, s, &rc))
-            return rc;
     }
 
     // ---- split path: per layer  A_bar = avg_heads(A_l, G_l);  R' = R + A_bar . R  [; R_sq' = R_sq + A_bar . R_sq]

@@ -730,9 +730,6 @@ def mm_attention_rules(R_ss, R_qq, cam_sq, R_qs=None, apply_normalization=True, 
 LXMERT_FUSED_MAX_TOKENS = 48
 
 
-LXMERT_SCHEDULE_ALGO = 2     # 2: two-phase kernel (mmx_lxmert_schedule_v2, default) | 1: one workgroup per sample (round 1-3 kernel)
-
-
 def lxmert_schedule(lang, vis, x_lang_cross, x_img_cross, x_lang_self, x_img_self, apply_normalization=True,
                     apply_self_in_rule_10=True, check_diag=True, text_len=None):
     """The whole LXMERT rule schedule in one launch.  Every argument is a list of ``(attn, grad)`` pairs of fp32
@@ -775,16 +772,12 @@ def lxmert_schedule(lang, vis, x_lang_cross, x_img_cross, x_lang_self, x_img_sel
             alive.append(arr)
     flags = (_lib.MM_NORMALIZE if apply_normalization else 0) | (_lib.MM_SELF_IN_RULE10 if apply_self_in_rule_10 else 0)
     la, lg, va, vg, xlca, xlcg, xica, xicg, xlsa, xlsg, xisa, xisg = tables
-    if LXMERT_SCHEDULE_ALGO == 2:      # two-phase kernel: chip-wide head averages, last arriver runs the rules on the MFMA
-        need = lib().mmx_lxmert_schedule_workspace_bytes(len(keep[0]), len(keep[1]), n_x, B, T, I)
-        ws = _workspace(need, dev, tag="lxmert_schedule")
-        check(lib().mmx_lxmert_schedule_v2(la, lg, len(keep[0]), va, vg, len(keep[1]), xlca, xlcg, xica, xicg, xlsa, xlsg,
-                                           xisa, xisg, n_x, B, H, T, I, flags, _p(text_len), _p(R_tt), _p(R_ti), _p(R_ii),
-                                           _p(R_it), _p(dmin), _p(ws), need, _stream()), "mmx_lxmert_schedule_v2")
-    else:
-        check(lib().mmx_lxmert_schedule_ex(la, lg, len(keep[0]), va, vg, len(keep[1]), xlca, xlcg, xica, xicg, xlsa, xlsg,
-                                           xisa, xisg, n_x, B, H, T, I, flags, _p(text_len), _p(R_tt), _p(R_ti), _p(R_ii),
-                                           _p(R_it), _p(dmin), _stream()), "mmx_lxmert_schedule_ex")
+    # two phases in one launch: chip-wide head averages, the last arriver of a sample runs the rules on the MFMA
+    need = lib().mmx_lxmert_schedule_workspace_bytes(len(keep[0]), len(keep[1]), n_x, B, T, I)
+    ws = _workspace(need, dev, tag="lxmert_schedule")
+    check(lib().mmx_lxmert_schedule(la, lg, len(keep[0]), va, vg, len(keep[1]), xlca, xlcg, xica, xicg, xlsa, xlsg,
+                                    xisa, xisg, n_x, B, H, T, I, flags, _p(text_len), _p(R_tt), _p(R_ti), _p(R_ii),
+                                    _p(R_it), _p(dmin), _p(ws), need, _stream()), "mmx_lxmert_schedule")
     if check_diag == "defer":
         return R_tt, R_ti, R_ii, R_it, dmin
     if want_diag:
