@@ -178,6 +178,36 @@ def test_self_chain_pipelined_stream_waves_bit_identical(ops, L, B, H, N, groups
     assert all(torch.equal(o, outs[-1]) for o in outs[:-1])
 
 
+@pytest.mark.parametrize("B,M,N,K,cin,nan", [
+    (3, 577, 577, 577, True, False),     # ViT-L/14@336 chain product: 128 x 128 tiles, ragged edges in all three dimensions
+    (4, 197, 197, 197, True, False),     # ViT-B/16: 64 x 64 tiles
+    (2, 950, 950, 950, True, False),     # DETR encoder
+    (40, 100, 950, 950, False, True),    # rule 10 at DETR size, batched, with the NaN scrub
+    (300, 130, 100, 64, False, False),   # small tiles, many batch entries
+    (2, 1050, 1050, 1050, True, False),
+])
+def test_bmm_tiles_kernel(chain_options, B, M, N, K, cin, nan):
+    """``bmm_f32_tiles.hip`` (32 x 32 x 2 exact-fp32 MFMA, b128 operand reads, one barrier per K slab) against fp64 and against the
+    general kernel it replaces for the large plain products (option ``bmm_tiles`` = 0): same exact-fp32 products, another
+    summation order."""
+    ops = chain_options
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.rand(B, M, K, generator=g) / K).cuda()
+    b = torch.randn(B, K, N, generator=g).cuda()
+    c = torch.randn(B, M, N, generator=g).cuda() if cin else None
+    if nan:
+        a[0, 3, 5] = float("nan")
+    want = torch.bmm(a.double(), b.double()) + (c.double() if cin else 0)
+    if nan:
+        want = torch.nan_to_num(want, nan=0.0)
+    got = ops.matmul(a, b, add_to=c, nan_to_zero=nan)
+    ops.set_option("bmm_tiles", 0)
+    old = ops.matmul(a, b, add_to=c, nan_to_zero=nan)
+    scale = float(want.abs().max())
+    assert float((got.double() - want).abs().max()) <= 2e-6 * scale
+    assert float((got - old).abs().max()) <= 2e-6 * scale
+
+
 @pytest.fixture
 def attn_options(ops):
     """Options of the attention kernels are process-global: whatever a test sets is put back, also when it fails."""
@@ -191,7 +221,7 @@ def chain_options(ops):
     """Options of the chain kernels are process-global: whatever a test sets is put back, also when it fails."""
     yield ops
     for key, value in (("self_chain_algo", 0), ("self_chain_groups", 0), ("self_chain_pipe", 4), ("self_chain_nt", 1),
-                       ("self_chain_relay_q", 0), ("self_chain_relay_d", 0), ("debug_flags", 0)):
+                       ("self_chain_relay_q", 0), ("self_chain_relay_d", 0), ("debug_flags", 0), ("bmm_tiles", 1)):
         ops.set_option(key, value)
 
 
@@ -237,9 +267,11 @@ def test_self_chain_relay_bit_identical(chain_options, L, B, H, N, causal, with_
         assert torch.equal(got, ref), (q, d, float((got - ref).abs().max()))
 
 
-@pytest.mark.parametrize("N,M", [(197, 0), (130, 0), (20, 36), (100, 300)])
-def test_self_chain_split_and_rule7(ops, N, M):
-    L, B, H = 3, 2, 4
+@pytest.mark.parametrize("N,M,L", [(197, 0, 3), (130, 0, 3), (20, 36, 3), (100, 300, 3), (577, 0, 5), (197, 64, 4)])
+def test_self_chain_split_and_rule7(chain_options, N, M, L):
+    """N > 128 (or a second right-hand side): per layer avg_heads + exact-fp32 product (bmm_f32_tiles.hip for the large ones)."""
+    ops = chain_options
+    B, H = 2, 4
     attn, grad = make_layers(N + M, L, B, H, N)
     g = torch.Generator().manual_seed(7)
     R0 = torch.eye(N).expand(B, N, N).contiguous()
@@ -257,7 +289,6 @@ def test_self_chain_split_and_rule7(ops, N, M):
         close(got[1], SQ)
     else:
         close(got, R)
-
 
 def test_self_chain_bf16_capture(ops):
     L, B, H, N = 4, 2, 4, 50

@@ -16,5 +16,21 @@ relay2)    # relay kernel after the fixes: test, element-level diagnostic, timin
   timeout 300 python tools/probe_chain_relay.py 2>&1 | grep -v amdgpu.ids | tee $OUT/chain_relay.txt
   timeout 600 python -m pytest tests/test_gpu_vit.py tests/test_gpu_clip.py -q -x 2>&1 | tail -8 | tee $OUT/pytest_vit_clip.txt
   ;;
+split)     # N > 128 chain route: the new product kernel, the overlap of reductions and products
+  timeout 600 python -m pytest tests/test_gpu_ops.py -q -k "bmm_tiles or split_and_rule7 or matmul" 2>&1 | tail -8 | tee $OUT/pytest_split.txt
+  timeout 300 python tools/probe_chain_split_timing.py 2>&1 | grep -v amdgpu.ids | tee $OUT/chain_split_timing.txt
+  ;;
+bmmpmc)    # SQ counters of the tiles product kernel
+  timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc -o bmm -- python tools/probe_bmm_only.py > /dev/null 2> $OUT/pmc.log
+  python tools/pmc_sq.py $OUT/pmc/bmm_counter_collection.csv bmm_f32 > $OUT/bmm_sq.txt 2>&1; cat $OUT/bmm_sq.txt
+  timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc2 -o bmm -- python tools/probe_bmm_only.py > /dev/null 2> $OUT/pmc2.log
+  python tools/pmc_sq.py $OUT/pmc2/bmm_counter_collection.csv bmm_f32 > $OUT/bmm_sq2.txt 2>&1; cat $OUT/bmm_sq2.txt
+  grep -i "bmm_f32" $OUT/pmc2/bmm_kernel_trace.csv | head -3
+  rm -rf $OUT/pmc $OUT/pmc2
+  ;;
+suite)     # the whole GPU suite (after the pruning / parity-bound changes) + its timing
+  timeout 1500 python -m pytest tests -q -m gpu --durations=15 2>&1 | tail -45 | tee $OUT/pytest_gpu.txt
+  cp gpurun_out/parity_errors.json $OUT/parity.json 2>/dev/null
+  ;;
 *) echo "unknown target $T"; exit 2;;
 esac

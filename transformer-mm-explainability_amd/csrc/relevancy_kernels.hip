@@ -534,8 +534,11 @@ __global__ __launch_bounds__(256) void bmm_f32_kernel(const float* __restrict__ 
             }
 }
 
+static int g_bmm_tiles = 1;   // option "bmm_tiles": 1 (default) large plain products on bmm_f32_tiles.hip | 0: always the general kernel below
+
 static void launch_bmm(const float* A, const float* B, const float* Cin, float* C, int batch, int M, int N, int K,
                        int trans_a, int64_t sa, int64_t sb, int64_t sc, int nan_to_zero, hipStream_t s, int cin_is_row = 0) {
+    if (g_bmm_tiles && bmm_f32_tiles_try(A, B, Cin, C, batch, M, N, K, trans_a, sa, sb, sc, nan_to_zero, cin_is_row, s)) return;
     const int64_t wgs64 = static_cast<int64_t>((N + 63) / 64) * ((M + 63) / 64) * batch;
     // (a 128 x 128 tiling was measured SLOWER at the long-sequence chain shapes -- profiles/r02_bmm_probe.txt: 384 vs 281 us at
     // [32 x 577 x 577]^2 -- and removed in round 5)
@@ -998,6 +1001,10 @@ extern "C" int mmx_set_option(const char* key, int value) {
         g_chain_pipe = value;            // 0 off | 1 one chunk per lane and head | 2 / 4: up to that many contiguous chunks
         return MMX_OK;
     }
+    if (key && strcmp(key, "bmm_tiles") == 0 && value >= 0 && value <= 1) {
+        g_bmm_tiles = value;
+        return MMX_OK;
+    }
     if (key && strcmp(key, "self_chain_nt") == 0 && value >= 0 && value <= 1) {
         g_chain_nt = value;
         return MMX_OK;
@@ -1195,6 +1202,9 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
             if (rc) return rc;
         }
     }
+    // (Round 5 measured the head reductions on a side stream one layer ahead of the products -- A_bar_{l+1} does not depend on R_l,
+    // one kernel is an HBM stream, the other an MFMA loop -- and found NO gain at 197 / 577 / 950 tokens, with or without capping
+    // the product's workgroups per CU: profiles/r05_chain_split_roofline.txt.  One stream, two launches per layer.)
     for (int l = 0; l < n_layers; ++l) {
         int rc = avg_heads_launch(attn_layers[l], grad_layers[l], abar, B, H, N, N, dtype, attn_batch_stride, stream);
         if (rc) return rc;
