@@ -1,6 +1,6 @@
 """Kernel-only probe (GPU box): the relay chain kernel (relevancy_chain_relay.hip, K1r) against the layer-group kernel it replaces,
 at the cfg-2 shapes over ROTATING slab sets (> 600 MB per tower: every byte from HBM), graph replay, HIP events.
-Variants: ring depth, streamers per sample, nt policy, and the phase-skip flags (1 = streamers only, 2 = chain + hand-off only)."""
+Variants: workgroups per sample, nt policy, and the phase-skip flags (1 = stream waves only, 2 = chain waves only)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -38,15 +38,11 @@ def main():
         ("per-sample G=1", {"self_chain_algo": 1, "self_chain_groups": 1}),
         ("relay auto", {"self_chain_algo": 3}),
         ("relay nt=0", {"self_chain_algo": 3, "self_chain_nt": 0}),
-        ("relay D=2", {"self_chain_algo": 3, "self_chain_relay_d": 2}),
-        ("relay D=3", {"self_chain_algo": 3, "self_chain_relay_d": 3}),
-        ("relay D=4", {"self_chain_algo": 3, "self_chain_relay_d": 4}),
+        ("relay Q=1", {"self_chain_algo": 3, "self_chain_relay_q": 1}),
         ("relay Q=2", {"self_chain_algo": 3, "self_chain_relay_q": 2}),
         ("relay Q=3", {"self_chain_algo": 3, "self_chain_relay_q": 3}),
-        ("relay Q=6", {"self_chain_algo": 3, "self_chain_relay_q": 6}),
-        ("relay Q=8", {"self_chain_algo": 3, "self_chain_relay_q": 8}),
-        ("relay streamers only (debug 1)", {"self_chain_algo": 3, "debug_flags": 1}),
-        ("relay hand-off + chain only (debug 2)", {"self_chain_algo": 3, "debug_flags": 2}),
+        ("relay stream waves only (debug 1)", {"self_chain_algo": 3, "debug_flags": 1}),
+        ("relay chain waves only (debug 2)", {"self_chain_algo": 3, "debug_flags": 2}),
     ]
     for (L, H, N, name, sets) in [(12, 8, 77, "txt", 3), (12, 12, 50, "img", 4)]:
         slabs = []

@@ -1,32 +1,38 @@
-// K1r  self_chain_relay_kernel: the self-attention relevancy chain (rules 5 + 6) of ALL layers in ONE launch, strict layer
-// order, with the head reduction of a sample spread over Q "streamer" workgroups that feed one "chain" workgroup.
+// K1r  self_chain_relay_kernel: the self-attention relevancy chain (rules 5 + 6) of ALL layers in ONE launch, in strict layer
+// order, with the head reduction of a sample spread over Q workgroups -- no barrier, no LDS, no partial products.
 //
 //     R <- R_init or I;   for l = 0 .. L-1:   A_bar_l = mean_h clamp(G_l * A_l, 0);   R <- R + A_bar_l . R
 //
 // Reference sites: CLIP_explainability.ipynb cell 6:22-32 / 45-55, CLIP/example.py:22-30, ViT notebook cell 7:28-33,
 // VisualBERT/.../ExplanationGenerator.py:86-93 (include/mmx_relevancy.h, mmx_relevancy_self_chain).
 //
-// Why this shape.  The chain is an HBM stream (A and G read once, 2.7 FLOP/B at CLIP's text
-// tower) followed, per layer, by a tiny product that needs the WHOLE A_bar_l.  One workgroup per sample leaves 3/4 of the
-// chip idle at B = 64; the round-1..4 kernel therefore cut the LAYERS of a sample into 4 groups and multiplied the partial
-// products at the end -- a re-association of the reference's product and an exposed tail.  Here the
-// POSITIONS of every layer are cut instead: streamer q of sample b reduces positions [q, q+1) * NN/Q of every layer and
-// publishes its piece of A_bar_l (write-through stores, one arrival counter per (sample, layer)); the chain workgroup
-// of the sample follows the counters layer by layer with R in MFMA accumulators (the K1 trick: the B operand of
-// v_mfma_f32_16x16x4_f32 is the accumulator register the lane already holds).  Same summation order as the sequential
-// per-sample kernel: BIT-IDENTICAL to it (tests/test_gpu_ops.py::test_self_chain_relay_bit_identical).
+// The chain is an HBM stream (A and G read once: 2.7 FLOP/B at CLIP's text tower) followed, per layer, by a small product that
+// needs the WHOLE A_bar_l.  One workgroup per sample leaves 3/4 of the chip idle at B = 64; the round-1..4 kernel cut the LAYERS
+// of a sample into 4 groups and multiplied the partial products at the end -- a re-association of the reference's product and an
+// exposed tail.  Here the POSITIONS are cut instead, and every wave is on its own:
 //
-// Streamer = LDS-DMA ring.  One loader wave issues global_load_lds_dwordx4 (nt) for whole (head, array) fragments --
-// up to 7 KiB CONTIGUOUS per fragment, against 1-2 KiB per wave instruction from 8 interleaved streams in the
-// register-pipelined kernel -- into a ring of D slots; CW consumer waves read a landed slot with ds_read_b128, multiply,
-// clamp and add the heads IN ORDER into one f32x4 per lane.  One s_barrier per round; the DMA stays in flight across it.
-// Fragments are fetched from the 16-byte-aligned address below their first element (head slabs of odd N^2 start on
-// 4/8/12-byte offsets); the consumers undo the shift with a second b128 read and a wave-uniform select.
+//   stream waves   workgroup (b, q) owns positions [q, q + 1) * NN / Q of every layer of sample b.  A stream wave owns 64 of
+//                  those 4-element chunks of ONE layer of the current round (a round = as many consecutive layers as the stream
+//                  waves of a workgroup can cover), walks the heads IN ORDER with a register software pipeline of raw buffer
+//                  loads (two sets of 4 heads x 2 arrays: 16 x 16 B per lane in flight -- the VGPR file holds 3x the bytes in
+//                  flight that the LDS could: an LDS-DMA ring was built first and streamed at 3.1 TB/s, profiles/
+//                  r05_chain_relay_probe.txt), writes its 64 chunks of A_bar_l to an L2-resident scratch with write-through
+//                  stores, drains them and adds its chunk count to the arrival counter of (b, l).  Stream waves never wait.
+//   chain waves    the product is independent per COLUMN block of R: chain wave (b, w) keeps the 16-column slab w of R in MFMA
+//                  accumulators for the whole launch (the K1 trick: the B operand of v_mfma_f32_16x16x4_f32 is the accumulator
+//                  register the lane already holds), waits for counter (b, l) to reach the chunk count of a layer, streams the
+//                  A operand -- A_bar_l in 16-byte row pieces -- from the scratch through a 12-deep register ring and runs
+//                  R[:, w] <- R[:, w] + A_bar_l . R[:, w].  The NT chain waves of a sample form a workgroup of their OWN, on a CU
+//                  that runs no stream waves: a CU full of stream waves keeps ~200 KB of loads queued, and every request of a
+//                  chain wave on that CU -- a counter poll, a piece of A_bar -- waits its turn behind them (~10 us a round trip:
+//                  measured, the chain then only catches up after the streaming has ended).
 //
-// Roles are taken at run time: every workgroup of a sample draws a ticket; tickets 0 .. Q-1 stream piece `ticket`, the
-// LAST one to start (ticket Q) runs the chain.  The chain workgroup therefore only ever waits for workgroups that are
-// already running and that wait for nothing themselves: no assumption about dispatch order, placement or residency.
+// Same head order, same MFMA k order as the sequential per-sample kernel: BIT-IDENTICAL to it
+// (tests/test_gpu_ops.py::test_self_chain_relay_bit_identical).  The launch is sized so that every workgroup is resident
+// (B * (Q + 1) <= CUs, one 1024-thread workgroup per CU): chain workgroups only ever wait for stream workgroups, which wait for nothing.
 #include "mmx_common.h"
+
+#include <type_traits>
 
 namespace mmx {
 
@@ -34,28 +40,24 @@ struct RelayArgs {
     const void* attn[MMX_MAX_LAYERS];
     const void* grad[MMX_MAX_LAYERS];
     int n_layers, B, H, N;
-    int Q;         // streamers per sample
+    int Q;         // workgroups per sample
     int nchunks;   // ceil(N*N / 4): 4-element chunks of one head slab
-    int cpq;       // chunks per streamer
-    int SB, sbc;   // sub-blocks of a streamer's share, chunks per sub-block (<= 64 * CW)
-    int CW;        // consumer waves
-    int IPF;       // DMA instructions (1 KiB each) per (head, array) fragment = ceil((sbc + 1) / 64)
-    int HPR;       // heads per round (divides H)
-    int D;         // ring slots
-    int threads;
-    unsigned row_magic;   // ceil(2^32 / N)
+    int cpq;       // chunks per workgroup share
+    int CWc;       // (unused: chain waves have workgroups of their own)
+    int WPL;       // stream waves per (layer, share) = ceil(cpq / 64)
+    int V;         // layers per round
+    int BPW;       // 64-chunk blocks per stream wave and round
+    int NB;        // A_bar ring slots of a chain workgroup in LDS (1..6)
     const float* R_init;
     float* R_out;
-    float* abar;       // [B][L][nchunks * 4] dense A_bar pieces (scratch)
-    unsigned* start;   // [B] role tickets
-    unsigned* done;    // [B][L] arrivals of A_bar_l pieces
+    float* abar;       // [B][L][nchunks * 4] (+ one row of slack) dense A_bar (scratch)
+    unsigned* done;    // [B][L] chunks of A_bar_l that have arrived
     int64_t attn_bstride;   // H*N*N, or 0: one forward shared by the batch
     int nt;      // nt cache policy on the read-once slab stream
-    int debug;   // profiling only: 1 = chain workgroups exit at once (stream + publish only), 2 = streamers publish without streaming
+    int debug;   // profiling only: 1 = chain waves exit at once (stream + publish only), 2 = stream waves publish without streaming
 };
 
-constexpr int kRelayMaxThreads = 512;
-constexpr int kRelayHeader = 16;   // bytes in front of the ring / A_bar image: the role ticket
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 __device__ __forceinline__ void wait_vmcnt(int n) {
     // s_waitcnt takes an immediate: a jump table over the 6-bit field
@@ -72,372 +74,332 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
     }
 }
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-// 4 floats from dword `d` of an LDS fragment: one b128 read when d is a multiple of 4 (s == 0, wave-uniform), else four b32 reads
-// (the fragment was fetched from the aligned address below its first element: head slabs of odd N^2 start at 4 / 8 / 12 bytes)
-__device__ __forceinline__ f32x4 lds_read4(const unsigned char* frag_base, int j, int s) {
-    if (s == 0) return reinterpret_cast<const f32x4*>(frag_base)[j];
-    const float* f = reinterpret_cast<const float*>(frag_base) + 4 * j + s;
-    return f32x4{f[0], f[1], f[2], f[3]};
-}
-
-// One (head, array) fragment: IPF LDS-DMA instructions of 1 KiB each from the 16-byte-aligned address `base`; every instruction runs
-// with all 64 lanes (lanes past the fragment repeat its last unit), so the instruction count per round is exact -- the counted vmcnt
-// waits of the loader rely on it.  Raw buffer form: the address is one SGPR resource + a lane offset (2 VALU per instruction).
-template <int AUX>
-__device__ __forceinline__ void dma_fragment(const char* base, unsigned nunits, unsigned char* dst, int ipf, int lane) {
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sgpr_ptr(base)), 0, 0x7fffffff, kRawBufferFlags);
-    for (int i = 0; i < ipf; ++i) {
-        const unsigned u = min(static_cast<unsigned>(i * 64 + lane), nunits - 1);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + i * 1024), 16, u * 16u, 0, 0, AUX);
-    }
-}
+constexpr int kRelayThreads = 1024;
+constexpr int kRelayWaves = kRelayThreads / 64;
 
 template <int NT>
-__global__ __launch_bounds__(kRelayMaxThreads, 4) void self_chain_relay_kernel(const RelayArgs a) {
-    constexpr int NP = NT * 16;
-    constexpr int S = NP + 4;
-    constexpr bool PRE = NT <= 6;   // A_bar double-buffered in LDS (<= 77 KB): the next layer's piece loads fly under the MFMAs
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned* ticket_lds = reinterpret_cast<unsigned*>(smem_raw);
-    unsigned char* body = smem_raw + kRelayHeader;
-
+__global__ __launch_bounds__(kRelayThreads) void self_chain_relay_kernel(const RelayArgs a) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int N = a.N, H = a.H, L = a.n_layers, Q = a.Q;
     const int NN = N * N;
-
-    // workgroup -> sample.  Streamer candidates come first (ids < groups*8*Q), chain candidates last, and a sample's
-    // workgroups share id % 8, i.e. an XCD and its L2 (a speed hint only: the hand-off is agent-scope).
+    // workgroup -> (sample, role): the B * Q stream workgroups come first, then one chain workgroup per sample; a sample's
+    // workgroups share id % 8, i.e. an XCD and its L2 (a speed hint only)
     const int groups = (a.B + 7) >> 3;
-    int b;
-    {
-        const int id = blockIdx.x, nstream = groups * 8 * Q;
-        if (id < nstream) { const int j = id >> 3; b = (j / Q) * 8 + (id & 7); }
-        else b = id - nstream;
-    }
+    const bool chain_wg = static_cast<int>(blockIdx.x) >= groups * 8 * Q;
+    const int j = (chain_wg ? static_cast<int>(blockIdx.x) - groups * 8 * Q : static_cast<int>(blockIdx.x)) >> 3;
+    const int b = (chain_wg ? j : j / Q) * 8 + (blockIdx.x & 7), q = chain_wg ? 0 : j % Q;
     if (b >= a.B) return;
-
-    if (tid == 0) *ticket_lds = __hip_atomic_fetch_add(a.start + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int ticket = __builtin_amdgcn_readfirstlane(static_cast<int>(*ticket_lds));
     const int64_t Lb = static_cast<int64_t>(b) * L;
 
-    if (ticket < Q) {
-        // =============================================================================================== streamer
-        const int cq0 = ticket * a.cpq, cq1 = min(a.nchunks, cq0 + a.cpq);
-        const int HPR = a.HPR, HB = H / HPR, SB = a.SB, IPF = a.IPF, D = a.D;
-        const int R = (cq0 < cq1 && !(a.debug & 2)) ? L * SB * HB : 0;
-        const int IPR = HPR * 2 * IPF;                     // DMA instructions per round
-        const int frag = IPF * 1024, slot_bytes = HPR * 2 * frag;
-        if (wave > a.CW) return;
-        if (R == 0) {   // nothing to reduce (more streamers than chunks): the arrivals are still owed
-            if (wave == 0)
+    if (!chain_wg) {
+        // =============================================================================================== stream wave
+        const int ws = wave, NWs = kRelayWaves;
+        const int cq0 = q * a.cpq, cq1 = min(a.nchunks, cq0 + a.cpq);
+        const int WPL = a.WPL, V = a.V, BPW = a.BPW;
+        const int rounds = (L + V - 1) / V;
+        const int HB = (H + 3) >> 2;                       // batches of 4 heads
+        const int hstride = NN * 4;                        // bytes between heads
+        const float fH = static_cast<float>(H);
+        const int64_t sampleG = static_cast<int64_t>(b) * H * NN * 4, sampleA = static_cast<int64_t>(b) * a.attn_bstride * 4;
+        const auto rS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.abar), 0, 0x7fffffff, kRawBufferFlags);
+        if (cq0 >= cq1 || (a.debug & 2)) {
+            // nothing to reduce in this share (more workgroups than chunks); profiling (2): the chain must still see full counters
+            if (ws == 0 && q == 0 && (a.debug & 2))
                 for (int l = lane; l < L; l += 64)
-                    __hip_atomic_fetch_add(a.done + Lb + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(a.done + Lb + l, static_cast<unsigned>(a.nchunks), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
-        const uintptr_t offG = static_cast<uintptr_t>(b) * H * NN * 4, offA = static_cast<uintptr_t>(b) * a.attn_bstride * 4;
-        // Round r = (layer l, sub-block sb, head block hb), hb fastest.  Both roles walk the rounds with counters (no
-        // division per round: a round is ~0.4 us of streaming, a few dependent integer divisions are a third of that).
-        if (wave == 0) {
-            // ------------------------------------------------------------------------------------------- loader
-            int il = 0, isb = 0, ihb = 0, islot = 0;              // the NEXT fill to issue
-            uintptr_t pA = 0, pG = 0;
-            auto layer_ptrs = [&](int l) {
-                pA = reinterpret_cast<uintptr_t>(a.attn[l]) + offA;
-                pG = reinterpret_cast<uintptr_t>(a.grad[l]) + offG;
-            };
-            layer_ptrs(0);
-            // the gradient slab is read exactly once per launch; the probability slab as well unless the batch shares one
-            // forward (then every sample re-reads it from L2: default policy)
-            const bool ntG = a.nt != 0, ntA = a.nt != 0 && a.attn_bstride != 0;
-            auto issue = [&]() {
-                // (a shorter last share can leave its last sub-block empty: fetch its first chunk instead -- nobody reads it --
-                // so that every address stays inside the slab)
-                const int cs = min(cq0 + isb * a.sbc, cq1 - 1), ce = max(cs + 1, min(cq1, cq0 + (isb + 1) * a.sbc));
-                const unsigned nvalid = static_cast<unsigned>(min(4 * (ce - cs), NN - 4 * cs));       // >= 1: cs < nchunks
-                unsigned char* dst = body + islot * slot_bytes;
-                unsigned hoff = static_cast<unsigned>(ihb * HPR) * NN + 4u * cs;
-                for (int hh = 0; hh < HPR; ++hh, hoff += NN) {
-                    {
-                        const unsigned al = static_cast<unsigned>(pA >> 2) & 3u, E = al + hoff;      // elements above a 16-byte boundary
-                        const char* src = reinterpret_cast<const char*>(pA - 4u * al) + static_cast<size_t>(E >> 2) * 16;
-                        const unsigned nunits = ((E & 3u) + nvalid + 3u) >> 2;
-                        if (ntA) dma_fragment<2>(src, nunits, dst, IPF, lane); else dma_fragment<0>(src, nunits, dst, IPF, lane);
-                        dst += frag;
-                    }
-                    {
-                        const unsigned al = static_cast<unsigned>(pG >> 2) & 3u, E = al + hoff;
-                        const char* src = reinterpret_cast<const char*>(pG - 4u * al) + static_cast<size_t>(E >> 2) * 16;
-                        const unsigned nunits = ((E & 3u) + nvalid + 3u) >> 2;
-                        if (ntG) dma_fragment<2>(src, nunits, dst, IPF, lane); else dma_fragment<0>(src, nunits, dst, IPF, lane);
-                        dst += frag;
-                    }
-                }
-                if (++ihb == HB) { ihb = 0; if (++isb == SB) { isb = 0; if (++il < L) layer_ptrs(il); } }
-                if (++islot == D) islot = 0;
-            };
-            const int pro = min(D - 1, R);
-            for (int r = 0; r < pro; ++r) issue();
-            for (int r = 0; r < R; ++r) {
-                const int issued = min(r + D - 1, R);
-                wait_vmcnt((issued - 1 - r) * IPR);                 // fill r has landed
-                asm volatile("s_barrier" ::: "memory");             // consumers: slot r is yours; slot r-1 is free again
-                if (r + D - 1 < R) issue();
+        if (ws >= V * WPL) return;                         // (more stream waves than blocks in a round: nothing for this one, ever)
+        const int64_t restG = static_cast<int64_t>(a.B - b) * H * NN * 4;
+        const int bytesG = static_cast<int>(restG < 0x7fffffff ? restG : 0x7fffffff), bytesA = a.attn_bstride ? bytesG : H * NN * 4;
+        // item = one 64-chunk block of one layer; a wave's items: (round r, block slot s) -> block ws + s * NWs of the round's
+        // V * WPL blocks -> layer r * V + blk / WPL, chunks cq0 + 64 * (blk % WPL) + lane
+        struct Item { int l, c; bool wave_on, lane_on; };
+        auto item_of = [&](int it) -> Item {
+            const int r = it / BPW, s = it - r * BPW;
+            const int blk = ws + s * NWs, dl = blk / WPL;
+            const int l = r * V + dl, c = cq0 + (blk - dl * WPL) * 64 + lane;
+            const bool on = dl < V && l < L;
+            return Item{min(l, L - 1), min(c, cq1 - 1), on, on && c < cq1};
+        };
+        const int items = rounds * BPW;
+        const int total = items * HB;
+        // Software pipeline over the flat batch sequence k = item * HB + hb (4 heads x 2 arrays = 8 x 16 B per batch): batch k + 1
+        // is ISSUED before batch k is reduced.  Every issue is unconditional (a batch past the end, a head past H or a lane past
+        // the share repeats a valid address and is reduced with weight 0): with conditional issues the compiler merges the wait
+        // counts of the two paths and drains everything before each reduction.
+        auto issue = [&](int k, u32x4 (&av)[4], u32x4 (&gv)[4], auto aux_tag) {
+            constexpr int AUXG = decltype(aux_tag)::value & 2, AUXA = (decltype(aux_tag)::value & 1) ? 0 : AUXG;
+            const int it = k / HB, hb = k - it * HB;
+            const Item im = item_of(it);
+            const int lu = __builtin_amdgcn_readfirstlane(im.l);
+            // the resources end exactly at the end of the tensors and the whole offset is in the VGPR: the 16-byte load of the last,
+            // partial chunk of the last head of the last sample (N^2 % 4 != 0) reads its out-of-range dwords as zero instead of
+            // touching memory behind the slab
+            const auto rA = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(a.attn[lu]) + sampleA)), 0, bytesA, kRawBufferFlags);
+            const auto rG = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(a.grad[lu]) + sampleG)), 0, bytesG, kRawBufferFlags);
+            const unsigned voff = static_cast<unsigned>(im.c) * 16u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned off = voff + static_cast<unsigned>(min(hb * 4 + u, H - 1) * hstride);
+                av[u] = __builtin_amdgcn_raw_buffer_load_b128(rA, off, 0, AUXA);
+                gv[u] = __builtin_amdgcn_raw_buffer_load_b128(rG, off, 0, AUXG);
             }
-            asm volatile("s_barrier" ::: "memory");                 // pairs with the consumers' closing barrier
-        } else {
-            // ----------------------------------------------------------------------------------------- consumers
-            const int j = (wave - 1) * 64 + lane;                   // this lane's chunk inside the sub-block
-            const float fH = static_cast<float>(H);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.abar), 0, 0x7fffffff, kRawBufferFlags);
-            int publish = -1;                                       // layer whose pieces are stored and wait for their arrival tick
-            int l = 0, sb = 0, hb = 0, slot_i = 0;
-            unsigned alA = 0, alG = 0;
-            auto layer_align = [&](int ll) {
-                alA = static_cast<unsigned>((reinterpret_cast<uintptr_t>(a.attn[ll]) + offA) >> 2) & 3u;
-                alG = static_cast<unsigned>((reinterpret_cast<uintptr_t>(a.grad[ll]) + offG) >> 2) & 3u;
-            };
-            layer_align(0);
-            for (int r = 0; r < R; ++r) {
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (publish >= 0) {
-                    // every consumer wave drained its stores before the barrier it has just passed
-                    if (wave == 1 && lane == 0)
-                        __hip_atomic_fetch_add(a.done + Lb + publish, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    publish = -1;
-                }
-                const int cs = cq0 + sb * a.sbc, ce = min(cq1, cs + a.sbc);
-                const bool mine = j < ce - cs;
-                const unsigned char* slot = body + slot_i * slot_bytes;
-                if (mine) {
-                    unsigned off = static_cast<unsigned>(hb * HPR) * NN + 4u * cs;
-                    for (int hh = 0; hh < HPR; ++hh, off += NN) {
-                        const f32x4 av = lds_read4(slot + (hh * 2) * frag, j, static_cast<int>((alA + off) & 3u));
-                        const f32x4 gv = lds_read4(slot + (hh * 2 + 1) * frag, j, static_cast<int>((alG + off) & 3u));
-                        const f32x4 x = gv * av;
-                        acc[0] += relu_nan(x[0]); acc[1] += relu_nan(x[1]);
-                        acc[2] += relu_nan(x[2]); acc[3] += relu_nan(x[3]);
-                    }
-                }
-                const bool last_hb = hb == HB - 1, last_sb = sb == SB - 1;
-                if (last_hb) {
-                    if (mine) {
-                        const f32x4 m = acc / fH;
+        };
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        auto consume = [&](int k, bool live, const u32x4 (&av)[4], const u32x4 (&gv)[4]) {
+            const int it = k / HB, hb = k - it * HB;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float w = (live && hb * 4 + u < H) ? 1.f : 0.f;      // heads in ascending order: the sequential sum
+                const f32x4 x = __builtin_bit_cast(f32x4, gv[u]) * __builtin_bit_cast(f32x4, av[u]);
+                s[0] += relu_nan(x[0]) * w; s[1] += relu_nan(x[1]) * w;
+                s[2] += relu_nan(x[2]) * w; s[3] += relu_nan(x[3]) * w;
+            }
+            if (live && hb == HB - 1) {
+                const Item im = item_of(it);
+                if (im.wave_on) {
+                    if (im.lane_on) {
+                        const f32x4 m = s / fH;
                         // write-through (sc1): the arrival tick below then needs no L2 write-back fence (cdna guide G16, R1 form)
-                        const int64_t byte = ((Lb + l) * a.nchunks + cs + j) * 16;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), rs, static_cast<unsigned>(byte), 0, 16);
-                        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                        const int64_t byte = ((Lb + im.l) * a.nchunks + im.c) * 16;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), rS, static_cast<unsigned>(byte), 0, 16);
                     }
-                    if (last_sb) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of A_bar_l are in L2 / memory
-                        publish = l;
-                    }
+                    // this wave's pieces of A_bar_l must be in L2 / memory before the tick: loads and stores may retire out of
+                    // order with respect to each other, so the wave drains (the prefetched batch is needed next anyway)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned long long m = __ballot(im.lane_on);
+                    if (lane == 0 && m)
+                        __hip_atomic_fetch_add(a.done + Lb + im.l, static_cast<unsigned>(__popcll(m)), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (++hb == HB) { hb = 0; if (++sb == SB) { sb = 0; if (++l < L) layer_align(l); } }
-                if (++slot_i == D) slot_i = 0;
+                s = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (publish >= 0 && wave == 1 && lane == 0)
-                __hip_atomic_fetch_add(a.done + Lb + publish, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        };
+        auto run = [&](auto aux_tag) {
+            u32x4 a0[4], g0[4], a1[4], g1[4];
+            issue(0, a0, g0, aux_tag);
+            for (int k = 0; k < total; k += 2) {
+                issue(min(k + 1, total - 1), a1, g1, aux_tag);
+                consume(k, true, a0, g0);
+                issue(min(k + 2, total - 1), a0, g0, aux_tag);
+                consume(min(k + 1, total - 1), k + 1 < total, a1, g1);
+            }
+        };
+        // aux tag: 0 default policy | 2 nt on both slabs | 3 nt on the gradient slab only (the batch shares the probabilities)
+        if (!a.nt) run(std::integral_constant<int, 0>{});
+        else if (a.attn_bstride == 0) run(std::integral_constant<int, 3>{});
+        else run(std::integral_constant<int, 2>{});
         return;
     }
 
-    // =================================================================================================== chain
-    if (wave >= NT || (a.debug & 1)) return;
-    float* Ab0 = reinterpret_cast<float*>(body);
-    constexpr int NBUF = PRE ? 2 : 1;
-    constexpr int CT = NT * 64;                                         // chain threads
-    for (int i = tid; i < NBUF * NP * S; i += CT) Ab0[i] = 0.f;       // the pads must read as 0
-    const int col = wave * 16 + (lane & 15);
-    const int rq = (lane >> 4) * 4;
-    f32x4 Rold[NT], Rnew[NT];
-    if (a.R_init) {
-        const float* R0 = a.R_init + static_cast<int64_t>(b) * NN;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = t * 16 + rq + r;
-                Rold[t][r] = (row < N && col < N) ? R0[row * N + col] : 0.f;
-            }
-    } else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Rold[t][r] = (t * 16 + rq + r == col && col < N) ? 1.f : 0.f;
+    // =================================================================================================== chain workgroup
+    // CW = min(8, NT^2) waves; the NT x NT output tiles of A_bar_l . R are dealt round-robin to them, so that the exact-fp32 MFMAs of a
+    // layer (4 NT^3 of 32 cycles) spread evenly over the four matrix pipes of the CU (5 column-slab waves would put two on one pipe).
+    // R lives in LDS (two buffers of NP rows x NP + 4 floats, zero padded: ping-pong per layer), A_bar_l in a ring of NB dense copies.
+    constexpr int NP = NT * 16, SR = NP + 4, NTILE = NT * NT;
+    constexpr int CW = NTILE < 8 ? NTILE : 8;
+    if (wave >= CW || (a.debug & 1)) return;                 // (the other waves of the 1024-thread footprint leave: barriers below count CW waves)
+    extern __shared__ __attribute__((aligned(16))) unsigned char relay_smem[];
+    const int NB = a.NB;                                     // A_bar ring slots
+    const int CPI = (a.nchunks + 63) >> 6;                   // 1 KiB copy instructions per layer
+    const int buf_bytes = CPI * 1024;
+    unsigned char* abuf = relay_smem;
+    volatile unsigned* poll_lds = reinterpret_cast<volatile unsigned*>(abuf + NB * buf_bytes);     // 256 B: where a counter poll lands
+    volatile int* avail_lds = reinterpret_cast<volatile int*>(abuf + NB * buf_bytes + 256);        // wave 0 -> all: layer l has landed
+    float* Rbuf = reinterpret_cast<float*>(abuf + NB * buf_bytes + 512);                           // 2 x NP x SR floats
+    const int ctid = wave * 64 + lane;
+    for (int i = ctid; i < 2 * NP * SR; i += CW * 64) Rbuf[i] = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int i = ctid; i < NN; i += CW * 64) {
+        const int row = i / N, cc = i - row * N;
+        Rbuf[row * SR + cc] = a.R_init ? a.R_init[static_cast<int64_t>(b) * NN + i] : (row == cc ? 1.f : 0.f);
     }
-    constexpr int CH = NT;   // 16-byte pieces of A_bar per chain lane: ceil(ceil(N*N/4) / (64 NT)) <= NT
-    u32x4 pre[CH];
-    auto ready = [&](int l) -> bool {
-        const unsigned v = __hip_atomic_load(a.done + Lb + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return __builtin_amdgcn_readfirstlane(v) >= static_cast<unsigned>(Q);
-    };
-    auto wait_ready = [&](int l) {
-        while (!ready(l)) __builtin_amdgcn_s_sleep(1);
-    };
-    auto fetch = [&](int l) {   // sc1 loads: the pieces were stored write-through by other CUs, possibly of another XCD
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.abar) + (Lb + l) * a.nchunks * 4, 0, 0x7fffffff, kRawBufferFlags);
+    // from here on wave 0 counts its own vector memory operations (the R_init loads above have been consumed by the LDS stores)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Wave 0 is also the LOADER of its workgroup.  It keeps one counter poll (lane i polls the counter of layer avail + i: a round of
+    // the stream waves completes several layers at once) and up to NB - 2 layer copies in flight, all of them LDS-DMA
+    // (global_load_lds_dword / _dwordx4 sc1: A_bar, dense, 16 bytes x nchunks, lane-linear into the ring): no register is a destination
+    // of anything in flight, and since vector memory operations of one kind retire in issue order, "operation X has landed" is
+    // s_waitcnt vmcnt(operations issued after X).  All of it is inline asm: the compiler neither counts nor drains these operations (a
+    // compiler-visible poll would be waited for with vmcnt(0), i.e. together with every copy behind it).  One s_barrier per layer: the
+    // loader has seen layer l land; everybody has finished layer l - 1 (its ring slot may be refilled, its R buffer is complete).
+    // MFMA operands, k visited as (t, r, lane >> 4) like the per-sample kernel: A = A_bar[16 ti + (lane & 15)][16 t + 4 (lane >> 4) + r]
+    // (dense rows of N floats; only the LAST tile row / column reaches past N: one row mask and four column masks, as BIT masks -- what
+    // lies behind a row is the next row, behind the matrix anything), B = R[16 t + 4 (lane >> 4) + r][16 tj + (lane & 15)].
+    const unsigned expect = static_cast<unsigned>(a.nchunks);
+    const int li = lane & 15, g4 = (lane >> 4) * 4;
+    unsigned cmask[4];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int k = min(tid + i * CT, a.nchunks - 1);
-            pre[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, static_cast<unsigned>(k) * 16u, 0, 16);
+    for (int e = 0; e < 4; ++e) cmask[e] = ((NT - 1) * 16 + g4 + e < N) ? 0xffffffffu : 0u;
+    const unsigned rmask = ((NT - 1) * 16 + li < N) ? 0xffffffffu : 0u;
+    const int lane_row = min(li, N - 1) * N + g4, last_row = min((NT - 1) * 16 + li, N - 1) * N + g4;
+    int avail = 0, copied = 0;                               // loader: layers known complete / copy issued (prefixes)
+    int issued = 0;                                          // loader: vector memory operations issued so far
+    int copy_seq[8] = {0, 0, 0, 0, 0, 0, 0, 0};             // `issued` right after the copy into ring slot i
+    int poll_seq = 0, poll_base = 0;
+    bool poll_out = false;
+    auto wait_for = [&](int seq) { wait_vmcnt(min(issued - seq, 63)); };
+    // loader step: harvest / issue the poll, issue the copies the ring has room for (slots of layers < busy_from are free)
+    auto loader_step = [&](int busy_from) {
+        if (poll_out) {
+            wait_for(poll_seq);
+            poll_out = false;
+            const unsigned long long okm = __ballot(poll_lds[lane] >= expect);
+            while (avail < L && avail - poll_base < 64 && ((okm >> (avail - poll_base)) & 1ull)) ++avail;
         }
-    };
-    const unsigned magic = a.row_magic;                                // ceil(2^32 / N): row = (p * magic) >> 32, exact for p < N*N + 8
-    auto stash = [&](int buf) {
-        float* Ab = Ab0 + buf * NP * S;
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int k = tid + i * CT;
-            if (k < a.nchunks) {
-                const f32x4 v = __builtin_bit_cast(f32x4, pre[i]);
-                const int p = k * 4;
-                int row = static_cast<int>(__umulhi(static_cast<unsigned>(p), magic)), cc = p - row * N;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (p + e < NN) Ab[row * S + cc] = v[e];
-                    if (++cc == N) { cc = 0; ++row; }
-                }
+        if (avail < L) {
+            poll_base = avail;
+            const unsigned* pp = a.done + Lb + min(avail + lane, L - 1);
+            const unsigned ldst = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(abuf + NB * buf_bytes))));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(pp), "s"(ldst) : "memory");
+            poll_seq = ++issued;
+            poll_out = true;
+        }
+        while (copied < avail && copied - busy_from < NB) {
+            const char* src = reinterpret_cast<const char*>(a.abar + (Lb + copied) * a.nchunks * 4);
+            const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(abuf + (copied % NB) * buf_bytes)));
+            for (int i = 0; i < CPI; ++i) {
+                const char* gsrc = src + static_cast<size_t>(min(i * 64 + lane, a.nchunks - 1)) * 16;
+                const unsigned ldst = __builtin_amdgcn_readfirstlane(lds0 + i * 1024);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
             }
+            issued += CPI;
+            copy_seq[copied % NB] = issued;
+            ++copied;
         }
     };
-    auto chain_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    chain_barrier();            // zero fill visible
-    if (L > 0) { wait_ready(0); fetch(0); stash(0); }
-    chain_barrier();
-    constexpr int TI = NT <= 5 ? 2 : 1;   // output tiles in flight: two accumulator chains cover the 40-cycle MFMA latency (registers permitting)
     for (int l = 0; l < L; ++l) {
-        const int buf = PRE ? (l & 1) : 0;
-        bool fetched = false;
-        if (PRE && l + 1 < L && ready(l + 1)) { fetch(l + 1); fetched = true; }
-        const float* Ab = Ab0 + buf * NP * S + (lane & 15) * S + rq;
-#pragma unroll
-        for (int ti = 0; ti < NT; ti += TI) {
-            f32x4 acc[TI];
-#pragma unroll
-            for (int q = 0; q < TI; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wave == 0) {
+            // (copies may go into every ring slot except the one of layer l - 1, which the other waves may still be reading)
+            const int busy_from = l > 0 ? l - 1 : 0;
+            // every wait in this kernel is bounded: ~seconds of polling without the stream waves delivering means something outside
+            // this launch is wrong -- give up (the result is then poisoned below) instead of hanging the device
+            int turns = 0;
+            loader_step(busy_from);
+            while (copied <= l && ++turns < (1 << 21)) {
+                __builtin_amdgcn_s_sleep(4);
+                loader_step(busy_from);
+            }
+            if (copied > l) wait_for(copy_seq[l % NB]);      // layer l has landed (younger copies and the poll stay in flight)
+            if (lane == 0) *avail_lds = copied > l ? l + 1 : -1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (*avail_lds < 0) break;
+        const float* Ab = reinterpret_cast<const float*>(abuf + (l % NB) * buf_bytes);
+        const float* Rc = Rbuf + (l & 1) * NP * SR;
+        float* Rn = Rbuf + ((l + 1) & 1) * NP * SR;
+        for (int u = wave; u < NTILE; u += CW) {
+            const int ti = u / NT, tj = u - ti * NT;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* rowp = Ab + (ti == NT - 1 ? last_row : lane_row + ti * 16 * N);
+            const float* bp = Rc + g4 * SR + tj * 16 + li;
+            const bool last_ti = ti == NT - 1;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
+                u32x4 raw;
 #pragma unroll
-                for (int q = 0; q < TI; ++q) {
-                    if (ti + q < NT) {
-                        const f32x4 av = *reinterpret_cast<const f32x4*>(Ab + (ti + q) * 16 * S + t * 16);
-                        acc[q] = mfma16x16x4(av[0], Rold[t][0], acc[q]);
-                        acc[q] = mfma16x16x4(av[1], Rold[t][1], acc[q]);
-                        acc[q] = mfma16x16x4(av[2], Rold[t][2], acc[q]);
-                        acc[q] = mfma16x16x4(av[3], Rold[t][3], acc[q]);
-                    }
-                }
+                for (int e = 0; e < 4; ++e) raw[e] = __float_as_uint(rowp[t * 16 + e]);
+                if (t == NT - 1) { raw[0] &= cmask[0]; raw[1] &= cmask[1]; raw[2] &= cmask[2]; raw[3] &= cmask[3]; }
+                if (last_ti) { raw[0] &= rmask; raw[1] &= rmask; raw[2] &= rmask; raw[3] &= rmask; }
+                const f32x4 av = __builtin_bit_cast(f32x4, raw);
+                acc = mfma16x16x4(av[0], bp[(t * 16 + 0) * SR], acc);
+                acc = mfma16x16x4(av[1], bp[(t * 16 + 1) * SR], acc);
+                acc = mfma16x16x4(av[2], bp[(t * 16 + 2) * SR], acc);
+                acc = mfma16x16x4(av[3], bp[(t * 16 + 3) * SR], acc);
             }
+            // R + (A_bar . R): the reference's association; lane holds rows 16 ti + 4 (lane >> 4) + r, column 16 tj + (lane & 15)
+            const float* ro = Rc + (ti * 16 + g4) * SR + tj * 16 + li;
+            float* rn = Rn + (ti * 16 + g4) * SR + tj * 16 + li;
 #pragma unroll
-            for (int q = 0; q < TI; ++q)
-                if (ti + q < NT) Rnew[ti + q] = Rold[ti + q] + acc[q];      // R + (A_bar . R): the reference's association
-            // keep the scheduler from hoisting all NT*NT operand reads (100+ VGPRs) above the first MFMA: two workgroups share a
-            // CU only under 128 registers per lane
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) Rold[t] = Rnew[t];
-        if (l + 1 < L) {
-            if (!PRE) chain_barrier();          // single buffer: every wave is done reading A_bar_l
-            if (!fetched) { wait_ready(l + 1); fetch(l + 1); }
-            stash(PRE ? ((l + 1) & 1) : 0);
-            chain_barrier();
+            for (int r = 0; r < 4; ++r) rn[r * SR] = ro[r * SR] + acc[r];
         }
     }
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const bool failed = *avail_lds < 0;
+    const float* Rf = Rbuf + (L & 1) * NP * SR;
     float* dst = a.R_out + static_cast<int64_t>(b) * NN;
-    int rq2 = rq, col2 = col;
-    asm volatile("" : "+v"(rq2), "+v"(col2));   // recompute the store indices here instead of keeping 4 NT of them (and their predicates) live
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = t * 16 + rq2 + r;
-            if (row < N && col2 < N) dst[row * N + col2] = Rold[t][r];
-        }
+    for (int i = ctid; i < NN; i += CW * 64) {
+        const int row = i / N, cc = i - row * N;
+        dst[i] = failed ? __builtin_nanf("") : Rf[row * SR + cc];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------ host side
-static int g_relay_q = 0;     // option "self_chain_relay_q": streamers per sample (0 = auto: fill the CUs once)
-static int g_relay_d = 0;     // option "self_chain_relay_d": ring slots (0 = auto)
-void chain_relay_options(int q, int d) { if (q >= 0) g_relay_q = q; if (d >= 0) g_relay_d = d; }
+static int g_relay_q = 0;     // option "self_chain_relay_q": workgroups per sample (0 = auto: fill the CUs once)
+void chain_relay_options(int q, int d) { if (q >= 0) g_relay_q = q; (void)d; }
 
-static size_t relay_counter_bytes(int B, int L) { return ((sizeof(unsigned) * static_cast<size_t>(B) * (1 + L)) + 255) & ~static_cast<size_t>(255); }
+static size_t relay_counter_bytes(int B, int L) { return ((sizeof(unsigned) * static_cast<size_t>(B) * L) + 255) & ~static_cast<size_t>(255); }
 
 // Launch geometry for a shape; returns false when the relay form does not apply (the per-sample kernel then runs)
-static bool relay_plan(int n_layers, int B, int H, int N, RelayArgs* out, size_t* lds_out) {
+static bool relay_plan(int n_layers, int B, int H, int N, RelayArgs* out) {
     const int nt = (N + 15) / 16;
-    if (nt > 8 || n_layers < 1) return false;
+    if (nt > 8 || n_layers < 1 || B < 1) return false;
     RelayArgs r;
     memset(&r, 0, sizeof(r));
     r.n_layers = n_layers; r.B = B; r.H = H; r.N = N;
     r.nchunks = (N * N + 3) / 4;
-    int Q = g_relay_q;
-    if (Q <= 0) {
-        const int cus = device_cu_count();
-        Q = (cus + B / 2) / B;                       // streamers fill the CUs once
-    }
-    if (Q > 16) Q = 16;
-    if (Q > r.nchunks / 64) Q = r.nchunks / 64;      // a streamer's share is at least one wave of chunks
+    const int cus = device_cu_count();
+    const int groups8 = (B + 7) / 8 * 8;                           // samples are dealt to the XCDs in groups of 8
+    // every workgroup resident, one 1024-thread workgroup per CU: B * Q stream workgroups + B chain workgroups (which wait for them)
+    int Q = cus / groups8 - 1;
+    if (Q < 1) return false;
+    if (g_relay_q > 0 && g_relay_q < Q) Q = g_relay_q;
+    if (Q > 8) Q = 8;
+    if (Q > r.nchunks / 64) Q = r.nchunks / 64;                    // a share is at least one wave of chunks
     if (Q < 1) Q = 1;
     r.Q = Q;
     r.cpq = (r.nchunks + Q - 1) / Q;
-    r.SB = (r.cpq + 447) / 448;
-    r.sbc = (r.cpq + r.SB - 1) / r.SB;
-    r.CW = (r.sbc + 63) / 64;
-    r.IPF = (r.sbc + 1 + 63) / 64;
-    const int frag = r.IPF * 1024;
-    r.HPR = 1;
-    for (int h = 1; h <= H; ++h)
-        if (H % h == 0 && h * 2 * frag <= 16 * 1024 && h * 2 * r.IPF <= 21) r.HPR = h;   // <= 16 KiB slots, >= 3 fills under the vmcnt field
-    const int slot = r.HPR * 2 * frag, ipr = r.HPR * 2 * r.IPF;
-    int D = g_relay_d > 0 ? g_relay_d : 6;
-    const int ring_budget = 72 * 1024;
-    if (D > ring_budget / slot) D = ring_budget / slot;
-    if (D > 1 + 63 / ipr) D = 1 + 63 / ipr;          // (D - 2) * ipr outstanding instructions must fit the 6-bit vmcnt field ...
-    while (D > 2 && (D - 1) * ipr > 63) --D;         // ... and so must the D - 1 fills of the prologue
-    if (D < 2) return false;
-    r.D = D;
-    const int NP = nt * 16, S = NP + 4;
-    const size_t chain_lds = sizeof(float) * (nt <= 6 ? 2 : 1) * NP * S;
-    const size_t ring_lds = static_cast<size_t>(D) * slot;
-    *lds_out = kRelayHeader + (chain_lds > ring_lds ? chain_lds : ring_lds);
-    const int waves = (1 + r.CW) > nt ? (1 + r.CW) : nt;
-    r.threads = waves * 64;
-    r.row_magic = static_cast<unsigned>((0x100000000ull + N - 1) / N);
-    if (r.threads > kRelayMaxThreads) return false;
+    r.CWc = 0;
+    const int nws = kRelayWaves;
+    r.WPL = (r.cpq + 63) / 64;
+    r.V = nws / r.WPL;
+    if (r.V < 1) r.V = 1;
+    if (r.V > n_layers) r.V = n_layers;
+    r.BPW = (r.V * r.WPL + nws - 1) / nws;
+    // the chain workgroup's LDS: A_bar ring (dense copies of a layer, >= 2 slots: the one being multiplied + one to copy into) + two R
+    // buffers of NP x (NP + 4) floats; beyond ~100 tokens that no longer fits a CU and the per-sample kernel runs
+    const size_t per = static_cast<size_t>((r.nchunks + 63) / 64) * 1024;
+    const size_t rb = 2 * static_cast<size_t>(nt * 16) * (nt * 16 + 4) * sizeof(float);
+    if (rb + 2 * per + 512 > 160 * 1024) return false;
+    r.NB = static_cast<int>((160 * 1024 - 512 - rb) / per);
+    if (r.NB > 6) r.NB = 6;
     *out = r;
     return true;
 }
 
 bool self_chain_relay_applies(int n_layers, int B, int H, int N) {
-    RelayArgs r; size_t lds;
-    return relay_plan(n_layers, B, H, N, &r, &lds);
+    RelayArgs r;
+    return relay_plan(n_layers, B, H, N, &r);
 }
 
 size_t self_chain_relay_workspace(int n_layers, int B, int H, int N) {
-    RelayArgs r; size_t lds;
-    if (!relay_plan(n_layers, B, H, N, &r, &lds)) return 0;
-    return relay_counter_bytes(B, n_layers) + sizeof(float) * static_cast<size_t>(B) * n_layers * r.nchunks * 4;
+    RelayArgs r;
+    if (!relay_plan(n_layers, B, H, N, &r)) return 0;
+    // + slack: the chain waves' 16-byte pieces of the last rows reach past the dense N x N matrix
+    return relay_counter_bytes(B, n_layers) + sizeof(float) * (static_cast<size_t>(B) * n_layers * r.nchunks * 4 + 256);
 }
 
 template <int NT>
-static int relay_launch(const RelayArgs& r, size_t lds, hipStream_t s) {
-    auto kern = self_chain_relay_kernel<NT>;
+static int relay_launch(const RelayArgs& r, hipStream_t s) {
+    const int groups = (r.B + 7) / 8;
+    const size_t lds = static_cast<size_t>(r.NB) * ((r.nchunks + 63) / 64) * 1024 + 512 +
+                       2 * static_cast<size_t>(NT * 16) * (NT * 16 + 4) * sizeof(float);
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           static_cast<int>(lds));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(self_chain_relay_kernel<NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
-    const int groups = (r.B + 7) / 8;
-    const int grid = groups * 8 * r.Q + r.B;
-    kern<<<grid, r.threads, lds, s>>>(r);
+    self_chain_relay_kernel<NT><<<groups * 8 * (r.Q + 1), kRelayThreads, lds, s>>>(r);
     MMX_LAUNCH_CHECK("self_chain_relay_kernel");
     return MMX_OK;
 }
@@ -445,34 +407,36 @@ static int relay_launch(const RelayArgs& r, size_t lds, hipStream_t s) {
 int self_chain_relay_launch(const void* const* attn_layers, const void* const* grad_layers, int n_layers, int B, int H, int N,
                             int64_t attn_bstride, const void* R_init, void* R_out, void* workspace, size_t workspace_bytes,
                             int nt_policy, int debug, hipStream_t s) {
-    RelayArgs r; size_t lds;
-    if (!relay_plan(n_layers, B, H, N, &r, &lds)) { set_error("self_chain_relay: shape not supported"); return MMX_ENOTSUP; }
+    RelayArgs r;
+    if (!relay_plan(n_layers, B, H, N, &r)) { set_error("self_chain_relay: shape not supported"); return MMX_ENOTSUP; }
     const size_t need = self_chain_relay_workspace(n_layers, B, H, N);
     if (workspace_bytes < need || !workspace) {
         set_error("mmx_relevancy_self_chain: workspace %zu < %zu", workspace_bytes, need);
         return MMX_EWORKSPACE;
     }
-    if (static_cast<size_t>(B) * n_layers * r.nchunks * 16 >= (1ull << 31)) { set_error("self_chain_relay: A_bar scratch beyond 2 GiB"); return MMX_ENOTSUP; }
+    if (static_cast<size_t>(B) * n_layers * r.nchunks * 16 >= (1ull << 31) || static_cast<size_t>(H) * N * N * 4 >= (1ull << 31)) {
+        set_error("self_chain_relay: slabs beyond the 2 GiB offset range of one buffer resource");
+        return MMX_ENOTSUP;
+    }
     for (int l = 0; l < n_layers; ++l) { r.attn[l] = attn_layers[l]; r.grad[l] = grad_layers[l]; }
     r.R_init = static_cast<const float*>(R_init);
     r.R_out = static_cast<float*>(R_out);
-    r.start = static_cast<unsigned*>(workspace);
-    r.done = r.start + B;
+    r.done = static_cast<unsigned*>(workspace);
     r.abar = reinterpret_cast<float*>(static_cast<char*>(workspace) + relay_counter_bytes(B, n_layers));
     r.attn_bstride = attn_bstride;
     r.nt = nt_policy;
     r.debug = debug;
-    int zrc = zero_async(r.start, sizeof(unsigned) * static_cast<size_t>(B) * (1 + n_layers), s);
+    int zrc = zero_async(r.done, sizeof(unsigned) * static_cast<size_t>(B) * n_layers, s);
     if (zrc) return zrc;
     switch ((N + 15) / 16) {
-        case 1: return relay_launch<1>(r, lds, s);
-        case 2: return relay_launch<2>(r, lds, s);
-        case 3: return relay_launch<3>(r, lds, s);
-        case 4: return relay_launch<4>(r, lds, s);
-        case 5: return relay_launch<5>(r, lds, s);
-        case 6: return relay_launch<6>(r, lds, s);
-        case 7: return relay_launch<7>(r, lds, s);
-        default: return relay_launch<8>(r, lds, s);
+        case 1: return relay_launch<1>(r, s);
+        case 2: return relay_launch<2>(r, s);
+        case 3: return relay_launch<3>(r, s);
+        case 4: return relay_launch<4>(r, s);
+        case 5: return relay_launch<5>(r, s);
+        case 6: return relay_launch<6>(r, s);
+        case 7: return relay_launch<7>(r, s);
+        default: return relay_launch<8>(r, s);
     }
 }
 
