@@ -541,7 +541,8 @@ def main():
         # (tests/test_profiles.py checks that it matches them)
         traffic, pmc_name = None, None
         for pmc_file in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_chain.json")), reverse=True):
-            pmc = json.load(open(pmc_file)).get("self_chain_fused_kernel<5, 0>")
+            pmc = json.load(open(pmc_file))
+            pmc = pmc.get("self_chain_groups_kernel<5>") or pmc.get("self_chain_fused_kernel<5, 0>")
             if pmc:
                 traffic, pmc_name = pmc["fetch_bytes"] + pmc["write_bytes"], os.path.relpath(pmc_file, ROOT)
                 break
@@ -549,16 +550,17 @@ def main():
         # trace of `bench.py --headline-only` (tools/gpu_round.sh): a committed file, not a measurement of this run
         in_step = None
         for stats in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.txt")), reverse=True):
-            for ln in open(stats):
-                if "self_chain_fused_kernel<5, 0" in ln:
-                    f = ln.split()
-                    avg = float(f[-4])
-                    in_step = {"us_per_launch": avg, "achieved": round(by_txt / avg / 1e3, 1), "frac": round(by_txt / avg / 1e3 / HBM_PEAK_GBS, 4),
-                               "source": os.path.relpath(stats, ROOT) + " (committed rocprofv3 --kernel-trace --stats summary, avg_us column)"}
-                    break
+            lines = open(stats).read().splitlines()
+            # the text tower's launch: self_chain_groups_kernel<5> (round 5 on), self_chain_fused_kernel<5, 0, ...> in older summaries
+            for ln in [x for x in lines if "self_chain_groups_kernel<5>" in x] + [x for x in lines if "self_chain_fused_kernel<5, 0" in x]:
+                f = ln.split()
+                avg = float(f[-4])
+                in_step = {"us_per_launch": avg, "achieved": round(by_txt / avg / 1e3, 1), "frac": round(by_txt / avg / 1e3 / HBM_PEAK_GBS, 4),
+                           "source": os.path.relpath(stats, ROOT) + " (committed rocprofv3 --kernel-trace --stats summary, avg_us column)"}
+                break
             if in_step:
                 break
-        roofline = {"bound": "hbm", "kernel": "self_chain_fused_kernel<NT=5,f32> (text tower)",
+        roofline = {"bound": "hbm", "kernel": "self_chain_groups_kernel<NT=5> (text tower, fp32 slabs)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "timing": "HIP events on the launch stream over 21 stand-alone launches rotating over 3 slab sets (879 MB)",
                     "traffic": traffic, "traffic_source": "committed PMC file %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
@@ -568,7 +570,7 @@ def main():
                     "same_buffers": {"us_per_launch": round(us_txt_same, 2), "achieved": round(by_txt / us_txt_same / 1e3, 1),
                                      "note": "20 back-to-back launches over ONE slab set: partly served by the Infinity Cache"},
                     "in_step": in_step,
-                    "image_tower": {"kernel": "self_chain_fused_kernel<NT=4,f32>", "bytes_per_launch": by_img,
+                    "image_tower": {"kernel": "self_chain_groups_kernel<NT=4>", "bytes_per_launch": by_img,
                                     "us_per_launch": round(us_img, 2), "achieved": round(by_img / us_img / 1e3, 1),
                                     "same_buffers_us_per_launch": round(us_img_same, 2)},
                     "kernel_only_maps_per_s": round(BATCH / ((us_txt + us_img) * 1e-6), 1)}

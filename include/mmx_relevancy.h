@@ -65,18 +65,22 @@ enum mmx_status {
 int mmx_abi_version(void);
 const char* mmx_last_error(void);
 /* tuning knobs (process-wide; results stay within the parity tolerance for every setting):
- *   "self_chain_algo"    0 auto = 1: one workgroup per (sample, layer group); the last arriver of a sample multiplies the group
- *                        products (re-associated at the group boundaries) | 3: relay (csrc/relevancy_chain_relay.hip): positions of
- *                        every layer cut over streamer workgroups that feed ONE chain workgroup per sample -- strict layer order at
- *                        any batch, bit-identical to "self_chain_groups" = 1, measured slower (profiles/r05_chain_relay_probe.txt)
+ *   "self_chain_algo"    0 auto: one workgroup per (sample, layer group); the last arriver of a sample multiplies the group products
+ *                        (re-associated at the group boundaries).  fp32 slabs with more than one group run
+ *                        csrc/relevancy_chain_groups.hip (barrier-free stream waves, every A_bar of the group resident in LDS),
+ *                        everything else the fused kernel of relevancy_kernels.hip | 1: the fused kernel everywhere (same bits) |
+ *                        3: relay (csrc/relevancy_chain_relay.hip): positions of every layer cut over streamer workgroups that feed
+ *                        ONE chain workgroup per sample -- strict layer order at any batch, bit-identical to "self_chain_groups" = 1,
+ *                        measured slower (profiles/r05_chain_relay_probe.txt) | 4: same as 0
  *   "self_chain_relay_q" / "self_chain_relay_d"   0 auto | streamers per sample (<= 16) / LDS-DMA ring slots (2..8) of the relay form
- *   "self_chain_pipe"    4 (default) fused chain, fp32 slabs, N >= 40: the stream waves run a software pipeline of raw buffer loads (the
+ *   "self_chain_pipe"    4 (default) fused chain kernel (algo 1 / one group / 16-bit slabs), fp32 slabs, N >= 40: the stream waves run a software pipeline of raw buffer loads (the
  *                        next batch of 8 16-byte loads in flight across the head reduction, the LDS write and the per-layer barrier)
  *                        with up to 4 KB contiguous per (head, array) and wave | 2 / 1: at most 2 / 1 KB contiguous |
  *                        0 the plain chunk loop of rounds 1-2.  Same arithmetic, bit-identical results
  *   "self_chain_nt"      1 (default) the pipelined stream waves load the read-once slabs with the nt (streaming) cache policy (a
  *                        probability slab shared by the batch keeps the default policy) | 0: default policy everywhere.  Same results
- *   "self_chain_groups"  0 auto | 1..8 layer groups per sample of the fused chain kernel (1 = strict sequential order)
+ *   "self_chain_groups"  0 auto (the fewest groups that put a workgroup on ~70 % of the CUs, at most 4, never more workgroups than
+ *                        CUs; 1 below 1 MB per sample) | 1..8 layer groups per sample (1 = strict sequential order)
  *   "attn_head"          1 (default) register-resident whole-head attention kernels (Nk <= 128, Nq <= 256) | 0 never
  *   "attn_stream"        1 (default) long-sequence streaming attention kernels | 0 only the general tiled kernels (any head_dim, any
  *                        alignment: what every shape the other families turn down runs on)

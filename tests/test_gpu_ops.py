@@ -86,7 +86,8 @@ def test_avg_heads_nan_and_lowp(ops):
     (3, 2, 2, 5, False), (1, 1, 1, 1, False), (2, 5, 3, 16, False), (4, 2, 4, 17, False),
     (6, 2, 8, 100, False), (2, 1, 4, 128, False), (5, 3, 12, 36, False), (0, 2, 1, 7, False),
 ])
-@pytest.mark.parametrize("algo", [1, 3])       # 1: per-sample kernel (layer groups by batch), 3: relay (csrc/relevancy_chain_relay.hip)
+# 0: auto (layer groups by batch: relevancy_chain_groups.hip for fp32 slabs), 1: the fused kernel everywhere, 3: relay (relevancy_chain_relay.hip)
+@pytest.mark.parametrize("algo", [0, 1, 3])
 def test_self_chain_fused(chain_options, L, B, H, N, causal, algo):
     ops = chain_options
     ops.set_option("self_chain_algo", algo)
@@ -133,29 +134,37 @@ def test_self_chain_half_vs_torch_half_chain(ops, L, B, H, N, causal, shared, sl
         ops.ChainPlan([a.to(torch.bfloat16) for a in ca], [g.to(torch.bfloat16) for g in cg], B, shared_attn=shared, half_chain=True)
 
 
+@pytest.mark.parametrize("algo", [1, 4])        # 1: self_chain_fused_kernel, 4 (= auto for fp32 slabs): self_chain_groups_kernel
 @pytest.mark.parametrize("groups", [2, 3, 4])
-@pytest.mark.parametrize("L,B,H,N,causal,with_init", [
-    (12, 4, 12, 50, False, False), (12, 3, 8, 77, True, True), (5, 2, 4, 33, False, True), (2, 2, 2, 128, False, False),
+@pytest.mark.parametrize("L,B,H,N,causal,with_init,shared", [
+    (12, 4, 12, 50, False, False, False), (12, 3, 8, 77, True, True, False), (5, 2, 4, 33, False, True, False),
+    (2, 2, 2, 128, False, False, False), (12, 2, 3, 100, False, False, True), (7, 5, 5, 17, False, True, True),
+    (4, 1, 9, 91, False, False, False),
 ])
-def test_self_chain_layer_groups(ops, groups, L, B, H, N, causal, with_init):
+def test_self_chain_layer_groups(chain_options, algo, groups, L, B, H, N, causal, with_init, shared):
     """Layer-group split: partial products re-associated at the group boundaries, combined by the last arriver.
-    Same 1e-5 bar against the sequential oracle; repeated launches reuse scratch and counters."""
-    attn, grad = make_layers(L * 10 + N, L, B, H, N, causal)
+    Same 1e-5 bar against the sequential oracle; repeated launches reuse scratch and counters.  The two kernels that implement
+    it differ in how the slabs reach LDS, not in the arithmetic: their results are equal bit for bit."""
+    ops = chain_options
+    attn, grad = make_layers(L * 10 + N, L, 1 if shared else B, H, N, causal)
+    if shared:
+        grad = [torch.randn(B * H, N, N) * 0.05 for _ in range(L)]
     R0 = (torch.eye(N) + torch.rand(B, N, N) * 0.1) if with_init else None
     want = np.broadcast_to(np.eye(N, dtype=np.float32), (B, N, N)).copy() if R0 is None else R0.numpy().copy()
     for a, g in zip(attn, grad):
-        cam = onp.avg_heads_batched(a.numpy(), g.numpy(), B)
+        full = a.reshape(1, H, N, N).expand(B, H, N, N).reshape(B * H, N, N) if shared else a
+        cam = onp.avg_heads_batched(full.numpy(), g.numpy(), B)
         want = want + np.matmul(cam, want)
-    ops.set_option("self_chain_algo", 1)
+    ca, cg = [a.cuda() for a in attn], [g.cuda() for g in grad]
     ops.set_option("self_chain_groups", groups)
-    try:
-        ca, cg = [a.cuda() for a in attn], [g.cuda() for g in grad]
+    outs = {}
+    for which in sorted({1, algo}):
+        ops.set_option("self_chain_algo", which)
         for _ in range(3):
-            got = ops.relevancy_self_chain(ca, cg, B, R_init=R0.cuda() if with_init else None)
+            got = ops.relevancy_self_chain(ca, cg, B, R_init=R0.cuda() if with_init else None, shared_attn=shared)
             close(got, want)
-    finally:
-        ops.set_option("self_chain_groups", 0)
-        ops.set_option("self_chain_algo", 0)
+        outs[which] = got.clone()
+    assert torch.equal(outs[1], outs[algo])
 
 
 @pytest.mark.parametrize("L,B,H,N,groups", [(12, 8, 8, 77, 0), (12, 4, 12, 50, 0), (3, 2, 5, 44, 1), (2, 1, 16, 128, 0), (5, 3, 8, 20, 2),
@@ -168,6 +177,7 @@ def test_self_chain_pipelined_stream_waves_bit_identical(ops, L, B, H, N, groups
     attn, grad = make_layers(31 + H + N, L, B, H, N)
     outs = []
     try:
+        ops.set_option("self_chain_algo", 1)     # (the option belongs to self_chain_fused_kernel)
         ops.set_option("self_chain_groups", groups)
         for pipe in (4, 2, 1, 0):                 # up to 4 / 2 / 1 contiguous chunks per lane and head; 0: the plain loop
             ops.set_option("self_chain_pipe", pipe)
@@ -175,6 +185,7 @@ def test_self_chain_pipelined_stream_waves_bit_identical(ops, L, B, H, N, groups
     finally:
         ops.set_option("self_chain_pipe", 4)
         ops.set_option("self_chain_groups", 0)
+        ops.set_option("self_chain_algo", 0)
     assert all(torch.equal(o, outs[-1]) for o in outs[:-1])
 
 

@@ -28,6 +28,15 @@ bmmpmc)    # SQ counters of the tiles product kernel
   grep -i "bmm_f32" $OUT/pmc2/bmm_kernel_trace.csv | head -3
   rm -rf $OUT/pmc $OUT/pmc2
   ;;
+groups)    # layer-group chain kernel with barrier-free stream waves: parity / bit-identity, then timing variants
+  timeout 600 python -m pytest tests/test_gpu_ops.py -q -k "layer_groups" 2>&1 | tail -15 | tee $OUT/pytest_groups.txt
+  timeout 400 python tools/probe_chain_relay.py 2>&1 | grep -v amdgpu.ids | grep -v relay | tee $OUT/chain_groups.txt
+  ;;
+groupsB)   # the same at other batch sizes (auto rule for the number of layer groups)
+  for B in 16 32 96 128; do
+    timeout 300 python tools/probe_chain_relay.py $B 2>&1 | grep -v amdgpu.ids | grep -v "relay\|debug\|nt=0" | tee -a $OUT/chain_groups_B.txt
+  done
+  ;;
 suite)     # the whole GPU suite (after the pruning / parity-bound changes) + its timing
   timeout 1500 python -m pytest tests -q -m gpu --durations=15 2>&1 | tail -45 | tee $OUT/pytest_gpu.txt
   cp gpurun_out/parity_errors.json $OUT/parity.json 2>/dev/null

@@ -37,12 +37,13 @@ def build(tag):
            "correction": "FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; KB = 1024 B",
            "generated_by": "tools/pmc_chain_json.py %s" % tag}
     for name in sorted(fetch):
-        m = re.match(r"mmx::(self_chain\w*kernel)<(\d+), (\d+)", name)
+        m = re.match(r"mmx::(self_chain\w*kernel)<(\d+)(?:, (\d+))?", name)
         if not m or name not in write:
             continue
-        key = "%s<%s, %s>" % (m.group(1), m.group(2), m.group(3))
+        # self_chain_fused_kernel<NT, dtype, ...> (rounds 1-5) / self_chain_groups_kernel<NT> (round 5 on: the fp32 default)
+        key = "%s<%s, %s>" % (m.group(1), m.group(2), m.group(3)) if m.group(3) is not None else "%s<%s>" % (m.group(1), m.group(2))
         entry = {"fetch_bytes": fetch[name], "write_bytes": write[name]}
-        if m.group(2) in TOWERS and m.group(1) == "self_chain_fused_kernel":
+        if m.group(2) in TOWERS and m.group(1) in ("self_chain_fused_kernel", "self_chain_groups_kernel"):
             _, L, H, N = TOWERS[m.group(2)]
             entry["algorithmic_bytes"] = 2 * L * BATCH * H * N * N * 4 + BATCH * N * N * 4
         doc[key] = entry

@@ -1,4 +1,5 @@
-"""Kernel-only probe (GPU box): the relay chain kernel (relevancy_chain_relay.hip, K1r) against the layer-group kernel it replaces,
+"""Kernel-only probe (GPU box): the chain kernels against each other -- layer groups with barrier-free stream waves
+(relevancy_chain_groups.hip, K1g: the fp32 default), the fused kernel of rounds 1-4 (K1), the relay kernel (relevancy_chain_relay.hip, K1r) --
 at the cfg-2 shapes over ROTATING slab sets (> 600 MB per tower: every byte from HBM), graph replay, HIP events.
 Variants: workgroups per sample, nt policy, and the phase-skip flags (1 = stream waves only, 2 = chain waves only)."""
 import os, sys
@@ -34,8 +35,20 @@ DEFAULTS = {"self_chain_algo": 0, "self_chain_groups": 0, "self_chain_nt": 1, "s
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     variants = [
-        ("layer groups G=4 (r04 default)", {"self_chain_algo": 1}),
+        ("default (auto groups, groups kernel)", {}),
         ("per-sample G=1", {"self_chain_algo": 1, "self_chain_groups": 1}),
+        ("fused kernel G=4 (r01-r04 default)", {"self_chain_algo": 1, "self_chain_groups": 4}),
+        ("fused kernel G=3", {"self_chain_algo": 1, "self_chain_groups": 3}),
+        ("fused kernel G=2", {"self_chain_algo": 1, "self_chain_groups": 2}),
+        ("groups kernel G=4", {"self_chain_groups": 4}),
+        ("groups kernel G=3", {"self_chain_groups": 3}),
+        ("groups kernel G=2", {"self_chain_groups": 2}),
+        ("groups kernel G=4 nt=0", {"self_chain_groups": 4, "self_chain_nt": 0}),
+        ("groups kernel G=4 hand-off, no combine (debug 8)", {"self_chain_groups": 4, "debug_flags": 8}),
+        ("groups kernel G=4 no combine (debug 1)", {"self_chain_groups": 4, "debug_flags": 1}),
+        ("groups kernel G=3 no combine (debug 1)", {"self_chain_groups": 3, "debug_flags": 1}),
+        ("groups kernel G=4 no MFMA no combine (debug 5)", {"self_chain_groups": 4, "debug_flags": 5}),
+        ("fused kernel G=4 no combine (debug 1)", {"self_chain_algo": 1, "self_chain_groups": 4, "debug_flags": 1}),
         ("relay auto", {"self_chain_algo": 3}),
         ("relay nt=0", {"self_chain_algo": 3, "self_chain_nt": 0}),
         ("relay Q=1", {"self_chain_algo": 3, "self_chain_relay_q": 1}),

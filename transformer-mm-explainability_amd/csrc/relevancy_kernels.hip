@@ -982,7 +982,8 @@ static int g_chain_pipe = 4;     // option "self_chain_pipe": software-pipelined
 static int g_chain_nt = 1;       // option "self_chain_nt": nt cache policy on the read-once slab loads of the pipelined stream waves
                                  // (default since round 4: text tower 85.8 -> 82.0 us, image 65.5 -> 63.8 us inside the replayed step)
 static int g_chain_groups = 0;  // layer groups per sample of the per-sample kernel: 0 auto, 1 = strict sequential order
-static int g_chain_algo = 0;  // 0 auto = 1: per-sample kernel (layer groups when the batch leaves CUs idle) | 3: relay (position-split streamers)
+static int g_chain_algo = 0;  // 0 auto = 4: layer groups with barrier-free stream waves where they apply (fp32 slabs, G > 1), else this file's
+                              // per-sample kernel | 1: this file's kernel everywhere | 3: relay (position-split streamers)
 
 extern "C" int mmx_set_option(const char* key, int value) {
     if (key && strcmp(key, "self_chain_relay_q") == 0 && value >= 0 && value <= 16) {
@@ -993,7 +994,7 @@ extern "C" int mmx_set_option(const char* key, int value) {
         chain_relay_options(-1, value);
         return MMX_OK;
     }
-    if (key && strcmp(key, "self_chain_algo") == 0 && (value == 0 || value == 1 || value == 3)) {
+    if (key && strcmp(key, "self_chain_algo") == 0 && (value == 0 || value == 1 || value == 3 || value == 4)) {
         g_chain_algo = value;
         return MMX_OK;
     }
@@ -1052,10 +1053,20 @@ static int fused_groups(int n_layers, int B, int H, int N) {
     if (n_layers < 2) return 1;
     int G = g_chain_groups;
     if (G == 0) {
-        // auto: split only when a sample streams enough bytes to pay for the hand-off (>= 1 MB) and there are idle
-        // CUs to fill (256 on MI355X); 4 groups measured best at CLIP ViT-B/32 shapes (profiles/r01_chain_probe.txt)
+        // auto: split only when a sample streams enough bytes to pay for the hand-off (>= 1 MB).  Then the FEWEST groups that put a
+        // workgroup on ~70 % of the CUs: every further group adds an exact-fp32 product to the serial combine on ONE CU (~2.9 us each
+        // at 77 tokens) while the stream rate is flat from ~190 workgroups on; never more workgroups than CUs (a second round of
+        // workgroups costs far more than idle CUs: B = 96 / 128 at CLIP's text shape: G = 4 141 / 155 us, G = 2 96 / 120 us); at
+        // most 4.  profiles/r05_chain_groups_probe.txt (B = 16 ... 128); rounds 1-4 used 4 groups up to B = 128.
         const double sample_bytes = 8.0 * n_layers * H * N * N;
-        G = (sample_bytes >= 1e6 && B <= 128) ? 4 : 1;
+        if (sample_bytes < 1e6) {
+            G = 1;
+        } else {
+            const int cus = device_cu_count();
+            G = (7 * cus + 10 * B - 1) / (10 * B);
+            while (G > 1 && B * G > cus) --G;
+            if (G > 4) G = 4;
+        }
     }
     return G < n_layers ? G : n_layers;
 }
@@ -1154,6 +1165,10 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
             }
             args.counters = static_cast<unsigned*>(workspace_dev);
             args.parts = reinterpret_cast<float*>(static_cast<char*>(workspace_dev) + group_counter_bytes(B));
+            // fp32 slabs: the kernel with barrier-free stream waves (relevancy_chain_groups.hip) unless algo 1 asks for this file's
+            if (g_chain_algo != 1 && dtype == MMX_F32 && self_chain_groups_applies(n_layers, args.G, N))
+                return self_chain_groups_launch(attn_layers, grad_layers, n_layers, B, H, N, args.G, attn_batch_stride, R_init_dev,
+                                                R_out_dev, args.counters, args.parts, g_chain_nt, g_debug_flags, s);
         }
         switch (nt) {
             case 1: return launch_fused<1>(args, dtype, s);
