@@ -86,8 +86,9 @@ def test_avg_heads_nan_and_lowp(ops):
     (3, 2, 2, 5, False), (1, 1, 1, 1, False), (2, 5, 3, 16, False), (4, 2, 4, 17, False),
     (6, 2, 8, 100, False), (2, 1, 4, 128, False), (5, 3, 12, 36, False), (0, 2, 1, 7, False),
 ])
-# 0: auto (layer groups by batch: relevancy_chain_groups.hip for fp32 slabs), 1: the fused kernel everywhere, 3: relay (relevancy_chain_relay.hip)
-@pytest.mark.parametrize("algo", [0, 1, 3])
+# 0: auto (layer groups by batch; fp32 slabs: relevancy_chain_groups.hip / relevancy_chain_cols.hip), 1: the fused kernel everywhere,
+# 3: relay (relevancy_chain_relay.hip), 5: relevancy_chain_cols.hip wherever it applies
+@pytest.mark.parametrize("algo", [0, 1, 3, 5])
 def test_self_chain_fused(chain_options, L, B, H, N, causal, algo):
     ops = chain_options
     ops.set_option("self_chain_algo", algo)
@@ -232,7 +233,8 @@ def chain_options(ops):
     """Options of the chain kernels are process-global: whatever a test sets is put back, also when it fails."""
     yield ops
     for key, value in (("self_chain_algo", 0), ("self_chain_groups", 0), ("self_chain_pipe", 4), ("self_chain_nt", 1),
-                       ("self_chain_relay_q", 0), ("self_chain_relay_d", 0), ("debug_flags", 0), ("bmm_tiles", 1)):
+                       ("self_chain_relay_q", 0), ("self_chain_relay_d", 0), ("self_chain_cols_c", 0), ("self_chain_cols_nb", 0),
+                       ("debug_flags", 0), ("bmm_tiles", 1)):
         ops.set_option(key, value)
 
 
@@ -276,6 +278,14 @@ def test_self_chain_relay_bit_identical(chain_options, L, B, H, N, causal, with_
         ops.set_option("self_chain_relay_d", d)
         got = run()
         assert torch.equal(got, ref), (q, d, float((got - ref).abs().max()))
+    # K1c (``relevancy_chain_cols.hip``): the columns of R split over the workgroups of a sample, every workgroup reduces the full
+    # A_bar -- the same sequential chain; workgroups per sample / ring depth change the schedule, not the bits
+    ops.set_option("self_chain_algo", 5)
+    for c, nb in ((0, 0), (0, 0), (1, 0), (2, 1), (3, 2), (8, 3)):
+        ops.set_option("self_chain_cols_c", c)
+        ops.set_option("self_chain_cols_nb", nb)
+        got = run()
+        assert torch.equal(got, ref), ("cols", c, nb, float((got - ref).abs().max()))
 
 
 @pytest.mark.parametrize("N,M,L", [(197, 0, 3), (130, 0, 3), (20, 36, 3), (100, 300, 3), (577, 0, 5), (197, 64, 4)])

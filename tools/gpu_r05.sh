@@ -32,6 +32,15 @@ groups)    # layer-group chain kernel with barrier-free stream waves: parity / b
   timeout 600 python -m pytest tests/test_gpu_ops.py -q -k "layer_groups" 2>&1 | tail -15 | tee $OUT/pytest_groups.txt
   timeout 400 python tools/probe_chain_relay.py 2>&1 | grep -v amdgpu.ids | grep -v relay | tee $OUT/chain_groups.txt
   ;;
+cols)      # column-split chain kernel: bit identity, timing variants
+  timeout 600 python -m pytest tests/test_gpu_ops.py -q -k "relay_bit_identical" 2>&1 | tail -15 | tee $OUT/pytest_cols.txt
+  timeout 400 python tools/probe_chain_relay.py 2>&1 | grep -v amdgpu.ids | grep -v "relay\|fused kernel G=[23]\|groups kernel G=[24]" | tee $OUT/chain_cols.txt
+  ;;
+colsB)     # large batches: one workgroup per sample -- fused kernel vs the column kernel with C = 1
+  for B in 128 160 256; do
+    timeout 300 python tools/probe_chain_relay.py $B 2>&1 | grep -v amdgpu.ids | grep "default\|per-sample\|cols C=1\|cols auto\|cols C=2\|groups kernel G=2" | tee -a $OUT/chain_cols_B.txt
+  done
+  ;;
 groupsB)   # the same at other batch sizes (auto rule for the number of layer groups)
   for B in 16 32 96 128; do
     timeout 300 python tools/probe_chain_relay.py $B 2>&1 | grep -v amdgpu.ids | grep -v "relay\|debug\|nt=0" | tee -a $OUT/chain_groups_B.txt

@@ -28,7 +28,7 @@ def timed(fns, iters=10, warm=2):
     return s.elapsed_time(e) / (iters * len(fns)) * 1e3
 
 
-DEFAULTS = {"self_chain_algo": 0, "self_chain_groups": 0, "self_chain_nt": 1, "self_chain_relay_q": 0, "self_chain_relay_d": 0,
+DEFAULTS = {"self_chain_cols_c": 0, "self_chain_cols_nb": 0, "self_chain_algo": 0, "self_chain_groups": 0, "self_chain_nt": 1, "self_chain_relay_q": 0, "self_chain_relay_d": 0,
             "debug_flags": 0}
 
 
@@ -49,6 +49,16 @@ def main():
         ("groups kernel G=3 no combine (debug 1)", {"self_chain_groups": 3, "debug_flags": 1}),
         ("groups kernel G=4 no MFMA no combine (debug 5)", {"self_chain_groups": 4, "debug_flags": 5}),
         ("fused kernel G=4 no combine (debug 1)", {"self_chain_algo": 1, "self_chain_groups": 4, "debug_flags": 1}),
+        ("cols auto (C=1: the default for one group)", {"self_chain_algo": 5}),
+        ("cols C=4", {"self_chain_algo": 5, "self_chain_cols_c": 4}),
+        ("cols C=4 no rotation (debug 2)", {"self_chain_algo": 5, "self_chain_cols_c": 4, "debug_flags": 2}),
+        ("cols C=2", {"self_chain_algo": 5, "self_chain_cols_c": 2}),
+        ("cols C=3", {"self_chain_algo": 5, "self_chain_cols_c": 3}),
+        ("cols C=1", {"self_chain_algo": 5, "self_chain_cols_c": 1}),
+        ("cols NB=2", {"self_chain_algo": 5, "self_chain_cols_nb": 2}),
+        ("cols NB=3", {"self_chain_algo": 5, "self_chain_cols_nb": 3}),
+        ("cols C=4 stream only (debug 1)", {"self_chain_algo": 5, "self_chain_cols_c": 4, "debug_flags": 1}),
+        ("cols C=4 stream only, no rotation (debug 3)", {"self_chain_algo": 5, "self_chain_cols_c": 4, "debug_flags": 3}),
         ("relay auto", {"self_chain_algo": 3}),
         ("relay nt=0", {"self_chain_algo": 3, "self_chain_nt": 0}),
         ("relay Q=1", {"self_chain_algo": 3, "self_chain_relay_q": 1}),

@@ -211,6 +211,11 @@ int self_chain_relay_launch(const void* const* attn_layers, const void* const* g
                             int64_t attn_bstride, const void* R_init, void* R_out, void* workspace, size_t workspace_bytes,
                             int nt_policy, int debug, hipStream_t s);
 void chain_relay_options(int q, int d);
+// relevancy_chain_cols.hip: the chain split by columns of R over the workgroups of a sample, strict layer order (K1c)
+bool self_chain_cols_applies(int n_layers, int B, int H, int N);
+int self_chain_cols_launch(const void* const* attn_layers, const void* const* grad_layers, int n_layers, int B, int H, int N,
+                           int64_t attn_bstride, const void* R_init, void* R_out, int nt_policy, int debug, hipStream_t s);
+void chain_cols_options(int c, int nb);
 // relevancy_chain_groups.hip: the layer-group chain with barrier-free stream waves (K1g)
 bool self_chain_groups_applies(int n_layers, int G, int N);
 int self_chain_groups_launch(const void* const* attn_layers, const void* const* grad_layers, int n_layers, int B, int H, int N, int G,

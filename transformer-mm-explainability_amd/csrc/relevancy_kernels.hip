@@ -990,11 +990,19 @@ extern "C" int mmx_set_option(const char* key, int value) {
         chain_relay_options(value, -1);
         return MMX_OK;
     }
+    if (key && strcmp(key, "self_chain_cols_c") == 0 && value >= 0 && value <= 8) {
+        chain_cols_options(value, -1);
+        return MMX_OK;
+    }
+    if (key && strcmp(key, "self_chain_cols_nb") == 0 && value >= 0 && value <= 8) {
+        chain_cols_options(-1, value);
+        return MMX_OK;
+    }
     if (key && strcmp(key, "self_chain_relay_d") == 0 && value >= 0 && value <= 8) {
         chain_relay_options(-1, value);
         return MMX_OK;
     }
-    if (key && strcmp(key, "self_chain_algo") == 0 && (value == 0 || value == 1 || value == 3 || value == 4)) {
+    if (key && strcmp(key, "self_chain_algo") == 0 && (value == 0 || value == 1 || value == 3 || value == 4 || value == 5)) {
         g_chain_algo = value;
         return MMX_OK;
     }
@@ -1049,6 +1057,16 @@ static bool use_relay(int n_layers, int B, int H, int N, int M, int dtype) {
     return g_chain_algo == 3 && dtype == MMX_F32 && M == 0 && self_chain_relay_applies(n_layers, B, H, N);
 }
 
+static int fused_groups(int n_layers, int B, int H, int N);
+// One group, fp32 slabs, N >= 40: relevancy_chain_cols.hip with one workgroup per sample (the fused kernel's single-group form with
+// barrier-free stream waves and a ring of A_bar images; same bits).  Option self_chain_algo = 5 takes it for every shape it supports,
+// 1 never.
+static bool use_cols(int n_layers, int B, int H, int N, int M, int dtype) {
+    if (g_chain_algo == 1 || g_chain_algo == 3 || dtype != MMX_F32 || M != 0 || !self_chain_cols_applies(n_layers, B, H, N)) return false;
+    if (g_chain_algo == 5) return true;
+    return N >= 40 && fused_groups(n_layers, B, H, N) == 1;
+}
+
 static int fused_groups(int n_layers, int B, int H, int N) {
     if (n_layers < 2) return 1;
     int G = g_chain_groups;
@@ -1077,6 +1095,7 @@ extern "C" size_t mmx_self_chain_workspace_bytes(int n_layers, int B, int H, int
     (void)dtype;
     if (nt_for(N) <= 8 && M == 0) {
         if (use_relay(n_layers, B, H, N, M, dtype)) return self_chain_relay_workspace(n_layers, B, H, N);
+        if (use_cols(n_layers, B, H, N, M, dtype)) return 0;
         const int G = fused_groups(n_layers, B, H, N);
         if (G == 1) return 0;  // strict-order per-sample kernel needs no scratch
         return group_counter_bytes(B) + align256(sizeof(float) * static_cast<size_t>(B) * G * N * N);
@@ -1142,6 +1161,9 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nt = nt_for(N);
 
+    if (use_cols(n_layers, B, H, N, M, dtype))
+        return self_chain_cols_launch(attn_layers, grad_layers, n_layers, B, H, N, attn_batch_stride, R_init_dev, R_out_dev, g_chain_nt,
+                                      g_debug_flags, s);
     if (use_relay(n_layers, B, H, N, M, dtype))
         return self_chain_relay_launch(attn_layers, grad_layers, n_layers, B, H, N, attn_batch_stride, R_init_dev, R_out_dev,
                                        workspace_dev, workspace_bytes, g_chain_nt, g_debug_flags, s);
