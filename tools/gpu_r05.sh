@@ -36,6 +36,10 @@ cols)      # column-split chain kernel: bit identity, timing variants
   timeout 600 python -m pytest tests/test_gpu_ops.py -q -k "relay_bit_identical" 2>&1 | tail -15 | tee $OUT/pytest_cols.txt
   timeout 400 python tools/probe_chain_relay.py 2>&1 | grep -v amdgpu.ids | grep -v "relay\|fused kernel G=[23]\|groups kernel G=[24]" | tee $OUT/chain_cols.txt
   ;;
+bmm)       # tile shape x prefetch depth of the large exact-fp32 product
+  timeout 300 python -m pytest tests/test_gpu_ops.py -q -k "bmm_tiles or split_and_rule7 or matmul" 2>&1 | tail -5 | tee $OUT/pytest_bmm.txt
+  BMM_VARIANTS=1 timeout 400 python tools/probe_chain_split_timing.py 2>&1 | grep -v amdgpu.ids | grep -v "chain\|avg_heads" | tee $OUT/bmm_variants.txt
+  ;;
 colsB)     # large batches: one workgroup per sample -- fused kernel vs the column kernel with C = 1
   for B in 128 160 256; do
     timeout 300 python tools/probe_chain_relay.py $B 2>&1 | grep -v amdgpu.ids | grep "default\|per-sample\|cols C=1\|cols auto\|cols C=2\|groups kernel G=2" | tee -a $OUT/chain_cols_B.txt

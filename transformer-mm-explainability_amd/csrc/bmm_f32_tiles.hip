@@ -4,18 +4,18 @@
 //
 // the round-1..4 kernel (bmm_f32_kernel, relevancy_kernels.hip: 64 x 64 tiles, scalar 4-byte global loads,
 // scalar LDS stores, ds_read_b32 operands, two barriers per 32-wide K slab) ran at 32-40 % of the fp32 MFMA peak and lost to
-// rocBLAS.  This one:
-//   * TM x TN output tile per 256-thread workgroup (128 x 128 or 64 x 64), 4 waves as 2 x 2; a wave's (TM/2) x (TN/2) block is
-//     1 or 4 MFMA tiles of 32 x 32 (16 accumulator registers each); K slabs of 16.
+// rocBLAS.  This one (950 tokens: 0.597 of the peak, rocBLAS 0.587; 577: 0.507 / 0.487; 1024: 0.706 / 0.717):
+//   * TM x TN output tile per 256-thread workgroup (instantiated at 64 x 64), 4 waves as 2 x 2; a wave's (TM/2) x (TN/2) block is
+//     1 (or 4) MFMA tiles of 32 x 32 (16 accumulator registers each); K slabs of 16.
 //   * the k-order of a dot product is free: MFMA step t of the 8-wide k group j takes k = 8 j + 4 (lane >> 5) + t, so a lane's A
 //     operands of FOUR consecutive steps are one ds_read_b128 from a k-fastest A tile (rows of 20 floats: conflict-free), and the
 //     B operand is one ds_read_b32 from the n-fastest B tile (32 consecutive floats per half wave).
 //   * 16-byte global loads (dword-aligned addresses suffice on gfx950; rows of 577 floats are not 16-byte aligned), 16-byte LDS
 //     stores; edge chunks fall back to guarded scalar loads, out-of-range elements are zero.
-//   * two LDS stages, ONE barrier per slab: slab s + 1 is fetched into registers while slab s is multiplied and written to the
-//     other stage afterwards (32 MFMAs of 64 cycles per wave and slab: the barrier is < 10 % of a slab).
+//   * two LDS stages, ONE barrier per slab, PF slabs requested ahead into a ring of register sets (a slab's 0.2 us of MFMAs do
+//     not cover an L2 round trip): slab s + 1 moves from its registers to the other stage before the MFMAs of slab s.
 //   * 1-D grid, XCD-aware (xcd_contiguous_id): the tiles of one batch entry share an L2.
-// Products it does not take (transposed A, tiny M or N) stay on bmm_f32_kernel.
+// Products it does not take (transposed A, tiny M or N, grids below one workgroup per CU) stay on bmm_f32_kernel.
 #include "mmx_common.h"
 
 namespace mmx {
@@ -24,7 +24,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kTilesBK = 16;
 
-template <int TM, int TN>
+template <int TM, int TN, int PF>
 __global__ __launch_bounds__(256, 2) void bmm_f32_tiles_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                const float* Cin, float* C, int M, int N, int K, int64_t sa,
                                                                int64_t sb, int64_t sc, int nan_to_zero, int cin_is_row) {
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void bmm_f32_tiles_kernel(const float* __re
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
     // per-thread chunk addresses, fixed for the whole K loop (the slab loop only adds k0 / k0 * N and compares against K)
-    f32x4 ra[CA], rb[CB];
+    f32x4 ra[PF][CA], rb[PF][CB];      // slab t waits in register set t % PF
     const float* pa[CA];
     const float* pb[CB];
     int ka[CA], kb[CB];
@@ -76,45 +76,45 @@ __global__ __launch_bounds__(256, 2) void bmm_f32_tiles_kernel(const float* __re
         okb4[c] = nb[c] + 3 < N;
         pb[c] = Bb + static_cast<int64_t>(kb[c]) * N + (nb[c] < N ? nb[c] : 0);
     }
-    auto fetch = [&](int k0) {
+    auto fetch = [&](int k0, f32x4 (&xa)[CA], f32x4 (&xb)[CB]) {
 #pragma unroll
         for (int c = 0; c < CA; ++c) {
             if (oka[c] && k0 + ka[c] + 3 < K) {
-                ra[c] = ldg4_u(pa[c] + k0);
+                xa[c] = ldg4_u(pa[c] + k0);
             } else {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (oka[c])
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (k0 + ka[c] + e < K) v[e] = pa[c][k0 + e];
-                ra[c] = v;
+                xa[c] = v;
             }
         }
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
             const float* src = pb[c] + static_cast<int64_t>(k0) * N;
             if (okb4[c] && k0 + kb[c] < K) {
-                rb[c] = ldg4_u(src);
+                xb[c] = ldg4_u(src);
             } else {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (k0 + kb[c] < K)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (nb[c] + e < N) v[e] = src[e];
-                rb[c] = v;
+                xb[c] = v;
             }
         }
     };
-    auto stash = [&](int stage) {
+    auto stash = [&](int stage, const f32x4 (&xa)[CA], const f32x4 (&xb)[CB]) {
 #pragma unroll
         for (int c = 0; c < CA; ++c) {
             const int idx = tid + c * 256;
-            *reinterpret_cast<f32x4*>(&As[stage][(idx >> 2) * LA + (idx & 3) * 4]) = ra[c];
+            *reinterpret_cast<f32x4*>(&As[stage][(idx >> 2) * LA + (idx & 3) * 4]) = xa[c];
         }
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
             const int idx = tid + c * 256;
-            *reinterpret_cast<f32x4*>(&Bs[stage][(idx / (TN / 4)) * LB + (idx % (TN / 4)) * 4]) = rb[c];
+            *reinterpret_cast<f32x4*>(&Bs[stage][(idx / (TN / 4)) * LB + (idx % (TN / 4)) * 4]) = xb[c];
         }
     };
 
@@ -126,36 +126,46 @@ __global__ __launch_bounds__(256, 2) void bmm_f32_tiles_kernel(const float* __re
     for (int i = 0; i < WM; ++i) row_on[i] = __builtin_amdgcn_readfirstlane(m0 + wr * (TM / 2) + i * 32) < M;
 #pragma unroll
     for (int q = 0; q < WN; ++q) col_on[q] = __builtin_amdgcn_readfirstlane(n0 + wc * (TN / 2) + q * 32) < N;
-    fetch(0);
-    stash(0);
-    lds_barrier();
     const int nslab = (K + kTilesBK - 1) / kTilesBK;
-    for (int s = 0; s < nslab; ++s) {
-        const int stage = s & 1;
-        if (s + 1 < nslab) fetch((s + 1) * kTilesBK);      // in flight under the MFMAs of slab s
-        const float* Asl = &As[stage][(wr * (TM / 2) + li) * LA + 4 * lg];
-        const float* Bsl = &Bs[stage][(4 * lg) * LB + wc * (TN / 2) + li];
+    fetch(0, ra[0], rb[0]);
+    stash(0, ra[0], rb[0]);
 #pragma unroll
-        for (int j = 0; j < kTilesBK / 8; ++j) {
-            f32x4 av[WM];
+    for (int j = 1; j <= PF; ++j)                            // slabs 1 .. PF in flight (set 0 is free again)
+        if (j < nslab) fetch(j * kTilesBK, ra[j % PF], rb[j % PF]);
+    lds_barrier();
+    for (int s0 = 0; s0 < nslab; s0 += PF) {
 #pragma unroll
-            for (int i = 0; i < WM; ++i) av[i] = *reinterpret_cast<const f32x4*>(Asl + i * 32 * LA + 8 * j);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float bv[WN];
-#pragma unroll
-                for (int q = 0; q < WN; ++q) bv[q] = Bsl[(8 * j + t) * LB + q * 32];
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int q = 0; q < WN; ++q)
-                        if (row_on[i] && col_on[q])
-                            acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[q], acc[i][q], 0, 0, 0);
+        for (int j = 0; j < PF; ++j) {
+            const int s = s0 + j;
+            if (s >= nslab) break;
+            const int stage = s & 1;
+            if (s + 1 < nslab) {
+                // every wave left stage ^ 1 at the barrier that ended slab s - 1: slab s + 1 (requested PF slabs ago) moves in before
+                // the MFMAs of slab s, and its register set takes the request for slab s + 1 + PF
+                stash(stage ^ 1, ra[(j + 1) % PF], rb[(j + 1) % PF]);
+                if (s + 1 + PF < nslab) fetch((s + 1 + PF) * kTilesBK, ra[(j + 1) % PF], rb[(j + 1) % PF]);
             }
-        }
-        if (s + 1 < nslab) {
-            stash(stage ^ 1);          // every wave left that stage at the barrier that ended slab s - 1
-            lds_barrier();
+            const float* Asl = &As[stage][(wr * (TM / 2) + li) * LA + 4 * lg];
+            const float* Bsl = &Bs[stage][(4 * lg) * LB + wc * (TN / 2) + li];
+#pragma unroll
+            for (int jj = 0; jj < kTilesBK / 8; ++jj) {
+                f32x4 av[WM];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) av[i] = *reinterpret_cast<const f32x4*>(Asl + i * 32 * LA + 8 * jj);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float bv[WN];
+#pragma unroll
+                    for (int q = 0; q < WN; ++q) bv[q] = Bsl[(8 * jj + t) * LB + q * 32];
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int q = 0; q < WN; ++q)
+                            if (row_on[i] && col_on[q])
+                                acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[q], acc[i][q], 0, 0, 0);
+                }
+            }
+            if (s + 1 < nslab) lds_barrier();
         }
     }
 
@@ -179,25 +189,18 @@ __global__ __launch_bounds__(256, 2) void bmm_f32_tiles_kernel(const float* __re
 }
 
 // Takes the product if it is one of the shapes this kernel is built for (plain A, a grid that fills the chip); returns false otherwise.
+// One configuration: 64 x 64 tiles, three K slabs requested ahead.  Measured against 128 x 128 tiles and 1 / 2 slabs ahead
+// (profiles/r05_chain_split_roofline.txt): 577 tokens 0.507 vs 0.416 of the fp32 MFMA peak, 950 tokens 0.597 vs 0.447, 1024 (no
+// padding) 0.706 vs 0.702 -- 3200 small tiles leave each CU 12.5 -> 13 of them where 800 large ones leave 3.1 -> 4, and the edge
+// tiles' idle waves give their matrix-pipe time to the other workgroups of the CU.
 bool bmm_f32_tiles_try(const float* A, const float* B, const float* Cin, float* C, int batch, int M, int N, int K, int trans_a,
                        int64_t sa, int64_t sb, int64_t sc, int nan_to_zero, int cin_is_row, hipStream_t s) {
     if (trans_a || M < 96 || N < 96 || K < 32) return false;
-    const int64_t wgs128 = static_cast<int64_t>((N + 127) / 128) * ((M + 127) / 128) * batch;
-    const int64_t wgs64 = static_cast<int64_t>((N + 63) / 64) * ((M + 63) / 64) * batch;
-    // 128 x 128 tiles when they still give every CU two workgroups and do not waste more than a third of the tile area
-    const double use128 = static_cast<double>(M) * N / (static_cast<double>((M + 127) / 128 * 128) * ((N + 127) / 128 * 128));
-    const double use64 = static_cast<double>(M) * N / (static_cast<double>((M + 63) / 64 * 64) * ((N + 63) / 64 * 64));
-    if (wgs128 >= 2 * device_cu_count() && use128 >= 0.66 && use128 + 0.12 >= use64) {
-        bmm_f32_tiles_kernel<128, 128><<<dim3(static_cast<unsigned>(wgs128)), 256, 0, s>>>(A, B, Cin, C, M, N, K, sa, sb, sc,
-                                                                                          nan_to_zero, cin_is_row);
-        return true;
-    }
-    if (wgs64 >= device_cu_count()) {
-        bmm_f32_tiles_kernel<64, 64><<<dim3(static_cast<unsigned>(wgs64)), 256, 0, s>>>(A, B, Cin, C, M, N, K, sa, sb, sc,
-                                                                                        nan_to_zero, cin_is_row);
-        return true;
-    }
-    return false;
+    const int64_t wgs = static_cast<int64_t>((N + 63) / 64) * ((M + 63) / 64) * batch;
+    if (wgs < device_cu_count()) return false;
+    bmm_f32_tiles_kernel<64, 64, 3><<<dim3(static_cast<unsigned>(wgs)), 256, 0, s>>>(A, B, Cin, C, M, N, K, sa, sb, sc, nan_to_zero,
+                                                                                    cin_is_row);
+    return true;
 }
 
 }  // namespace mmx

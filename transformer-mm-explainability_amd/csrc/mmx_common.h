@@ -230,7 +230,7 @@ int hip_fail(hipError_t e, const char* what);
 // with a corrupted 64-bit pattern once other work had run between capture and replay (every second fp32 word garbage);
 // kernel nodes carry their arguments by value and do not have that problem.  ``bytes`` must be a multiple of 4.
 int zero_async(void* dst, size_t bytes, hipStream_t s);
-// bmm_f32_tiles.hip: the large exact-fp32 products (32 x 32 x 2 MFMA, 128 x 128 / 64 x 64 tiles); false = not its shape
+// bmm_f32_tiles.hip: the large exact-fp32 products (32 x 32 x 2 MFMA, 64 x 64 tiles); false = not its shape
 bool bmm_f32_tiles_try(const float* A, const float* B, const float* Cin, float* C, int batch, int M, int N, int K, int trans_a,
                        int64_t sa, int64_t sb, int64_t sc, int nan_to_zero, int cin_is_row, hipStream_t s);
 int device_cu_count();   // compute units of the current device, cached
