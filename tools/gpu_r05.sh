@@ -30,11 +30,15 @@ bmmpmc)    # SQ counters of the tiles product kernel
   ;;
 groups)    # layer-group chain kernel with barrier-free stream waves: parity / bit-identity, then timing variants
   timeout 600 python -m pytest tests/test_gpu_ops.py -q -k "layer_groups" 2>&1 | tail -15 | tee $OUT/pytest_groups.txt
-  timeout 400 python tools/probe_chain_relay.py 2>&1 | grep -v amdgpu.ids | grep -v relay | tee $OUT/chain_groups.txt
+  timeout 400 python tools/probe_chain_relay.py 2>&1 | grep -v amdgpu.ids | grep -v "relay\|cols" | tee $OUT/chain_groups.txt
   ;;
 cols)      # column-split chain kernel: bit identity, timing variants
   timeout 600 python -m pytest tests/test_gpu_ops.py -q -k "relay_bit_identical" 2>&1 | tail -15 | tee $OUT/pytest_cols.txt
   timeout 400 python tools/probe_chain_relay.py 2>&1 | grep -v amdgpu.ids | grep -v "relay\|fused kernel G=[23]\|groups kernel G=[24]" | tee $OUT/chain_cols.txt
+  ;;
+v3)        # cfg-5 attention backward pair: parity gate + timing
+  timeout 300 python -m pytest tests/test_gpu_ops.py tests/test_gpu_parity_fullsize.py -q -k "third_generation or bf16_backward or cfg5_bf16" 2>&1 | tail -5 | tee $OUT/pytest_v3.txt
+  timeout 300 python tools/probe_attn_v3.py 128 0,2 2>&1 | grep -v amdgpu.ids | tee $OUT/attn_v3_probe.txt
   ;;
 bmm)       # tile shape x prefetch depth of the large exact-fp32 product
   timeout 300 python -m pytest tests/test_gpu_ops.py -q -k "bmm_tiles or split_and_rule7 or matmul" 2>&1 | tail -5 | tee $OUT/pytest_bmm.txt

@@ -75,7 +75,10 @@ def main():
             slabs.append((attn, grad))
         nbytes = 2 * L * B * H * N * N * 4
         ref = None
+        outs = {}
         for label, opts in variants:
+            opts = dict(opts)
+            cmp_to = opts.pop("_cmp", None)
             for k, v in {**DEFAULTS, **opts}.items():
                 ops.set_option(k, v)
             try:
@@ -85,9 +88,12 @@ def main():
             except Exception as exc:                                   # a variant that does not launch must not end the probe
                 print(f"{name}: {label:40s} FAILED: {exc}")
                 continue
+            outs[label] = out
             if label.startswith("per-sample"):
                 ref = out
             same_bits = "" if ref is None or opts.get("debug_flags") else f" | == per-sample G=1: {bool(torch.equal(out, ref))}"
+            if cmp_to:
+                same_bits = f" | == {cmp_to}: {bool(torch.equal(out, outs[cmp_to]))}"
             print(f"{name} B={B}: {label:40s} rotating {rot:6.1f} us = {nbytes/rot/1e6:.3f} TB/s ({nbytes/rot/8e6:.3f} of 8 TB/s) | "
                   f"same buffers {same:6.1f} us{same_bits}", flush=True)
         del slabs

@@ -227,6 +227,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_q_v3_kernel
     const int q = rt * R + wave * 16 + i;
     const bool q_ok = q < a.Nq;
     const int qc = min(q, a.Nq - 1);
+    const bool wave_live = __builtin_amdgcn_readfirstlane(rt * R + wave * 16) < a.Nq;
 
     // per sample: the wave's dO rows as the B operand of dP^T, and delta = rowsum(dO * O) of this lane's row
     bf16x8 dob[NS][kD / 32];
@@ -300,8 +301,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_q_v3_kernel
         const bf16_t* Kcur = Kt + PAR * kD * kLT + tlane;
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {                               // keys 32 pp .. + 31 of the tile
-            // a half tile with no real key in it (577 = 9 x 64 + 1: the second half of the last tile) has P = 0: nothing to add
-            if (pp == 1 && kt * kT + 32 >= a.Nk) break;
+            // a half tile with no real key in it (577 = 9 x 64 + 1: the second half of the last tile) has P = 0: nothing to add;
+            // a wave whose 16 query rows all lie past Nq (577 = 4 x 128 + 65: three of the last workgroup's eight waves) only stages
+            if ((pp == 1 && kt * kT + 32 >= a.Nk) || !wave_live) break;
             bf16x8 dsb[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -377,6 +379,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
     const int kw = (wg % nkt) * R + wave * 16;                        // first key of this wave
     const int key = kw + i;
     const bool key_ok = key < a.Nk;
+    const bool wave_live = __builtin_amdgcn_readfirstlane(kw) < a.Nk;
     const int keyc = min(key, a.Nk - 1);
     const int64_t head = static_cast<int64_t>(b) * a.H + h;
     // this wave's key block of the blocked P^T image (query tile qt: + 1024 qt elements); a block past the image repeats the last
@@ -454,8 +457,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
         const bf16_t* Qtc = Qt + cur * kD * kLT + tlane;
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {                               // query rows 32 pp .. + 31 of the tile
-            // a half tile with no real query row in it (577 = 9 x 64 + 1: the second half of the last tile): P = 0 and dO = 0 there
-            if (pp == 1 && qt * kT + 32 >= a.Nq) break;
+            // a half tile with no real query row in it (577 = 9 x 64 + 1: the second half of the last tile): P = 0 and dO = 0 there;
+            // a wave whose 16 keys all lie past Nk only stages
+            if ((pp == 1 && qt * kT + 32 >= a.Nq) || !wave_live) break;
             f32x4 dp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // dp[hh][r] = dP[16 t + 4 g + r][key i]
 #pragma unroll
             for (int pr = 0; pr < kD / 32; ++pr)

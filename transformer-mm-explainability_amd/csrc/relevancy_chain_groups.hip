@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kGroupsThreads) void self_chain_groups_kernel(const
     __syncthreads();
     const unsigned ticket = *ticket_lds;
     if (ticket != static_cast<unsigned>(G - 1) || (a.debug & 8)) return;
-    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (skipping it when all groups share an XCD gains nothing: measured)
     __syncthreads();
     // All 16 waves multiply: the NT x NT output tiles of P_gg . X are dealt round-robin (4 NT^3 exact-fp32 MFMAs spread over the four
     // matrix pipes instead of NT column-slab waves with two on one pipe); X ping-pongs between two LDS images; up to four partial
