@@ -43,6 +43,9 @@ def main():
         ("groups kernel G=4", {"self_chain_groups": 4}),
         ("groups kernel G=3", {"self_chain_groups": 3}),
         ("groups kernel G=2", {"self_chain_groups": 2}),
+        ("groups kernel G=3, single-arriver combine (debug 16)", {"self_chain_groups": 3, "debug_flags": 16, "_cmp": "groups kernel G=3"}),
+        ("groups kernel G=4, single-arriver combine (debug 16)", {"self_chain_groups": 4, "debug_flags": 16, "_cmp": "groups kernel G=4"}),
+        ("groups kernel G=2, single-arriver combine (debug 16)", {"self_chain_groups": 2, "debug_flags": 16, "_cmp": "groups kernel G=2"}),
         ("groups kernel G=4 nt=0", {"self_chain_groups": 4, "self_chain_nt": 0}),
         ("groups kernel G=4 hand-off, no combine (debug 8)", {"self_chain_groups": 4, "debug_flags": 8}),
         ("groups kernel G=4 no combine (debug 1)", {"self_chain_groups": 4, "debug_flags": 1}),
