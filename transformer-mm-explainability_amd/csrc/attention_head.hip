@@ -31,6 +31,16 @@ namespace mmx {
 
 namespace {
 
+// -DMMX_HEAD_TIMELINE (probe builds only, tools/probe_head_timeline.py): every wave of the backward records s_memtime at its phase
+// boundaries and lane 0 writes the differences (shader cycles) over row 0 of its head's dV -- the output is garbage in such a build.
+#ifdef MMX_HEAD_TIMELINE
+#define MMX_TL_DECL long long tl_[10]; int tl_n_ = 0
+#define MMX_TL_MARK() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tl_[tl_n_++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MMX_TL_DECL
+#define MMX_TL_MARK() do { } while (0)
+#endif
+
 __device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 // 16-byte store that only assumes 4-byte alignment (rows of an odd-Nk slab)
@@ -385,6 +395,8 @@ __global__ __launch_bounds__(NTK >= 7 ? 512 : 1024) void attn_bwd_head_kernel(co
     const int64_t head = static_cast<int64_t>(b) * a.H + h;
 
     stagger(a.debug >> 8);
+    MMX_TL_DECL;
+    MMX_TL_MARK();                                                   // 0: start
     // this wave's rows of dO (and Q') and its chunks of P: global -> registers, issued before the LDS staging
     f32x4 doreg[KK], qreg[KK], preg[NTK];
     if constexpr (IOH)
@@ -403,13 +415,16 @@ __global__ __launch_bounds__(NTK >= 7 ? 512 : 1024) void attn_bwd_head_kernel(co
     } else {
         stage_one<DP, 4>(Vs, LSA, vb, a.vs.sn, a.Nk, NPk, a.D, tid, nthreads);
     }
+    MMX_TL_MARK();                                                   // 1: V / K staged (this wave's part)
     lds_barrier();
+    MMX_TL_MARK();                                                   // 2: after the first barrier
 
     // ---- phase A: dP^T tiles, dP -> slab, delta, dS (all in registers: acc[t][r] <-> [q][key = 16t + 4g + r])
     f32x4 acc[NTK];
 #pragma unroll
     for (int t = 0; t < NTK; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     tiles_kd<DP, NTK, LSA>(acc, Vs, doreg, c16, g);
+    MMX_TL_MARK();                                                   // 3: dP tiles done (waits for dO rows)
     float* dprow = a.dprobs + (head * a.Nq + (qv ? q : 0)) * a.Nk;
     float dot = 0.f;
 #pragma unroll
@@ -429,6 +444,7 @@ __global__ __launch_bounds__(NTK >= 7 ? 512 : 1024) void attn_bwd_head_kernel(co
             acc[t][r] = ds;
         }
 
+    MMX_TL_MARK();                                                   // 4: dP stored, delta reduced, dS (waits for P chunks)
     // ---- phase B: dQ = dS.K, dS straight from the accumulators
     {
         f32x4 dq[KK];
@@ -442,10 +458,12 @@ __global__ __launch_bounds__(NTK >= 7 ? 512 : 1024) void attn_bwd_head_kernel(co
             store_rows16<DP>(a.dq + b * a.dqs.sb + h * a.dqs.sh, a.dqs.sn, q, qv, a.D, g, dq, q_first ? a.scale : 1.f);
     }
 
+    MMX_TL_MARK();                                                   // 5: dQ done and stored
     // ---- phase C: dK = dS^T.Q' (pass 0), dV = P^T.dO (pass 1); contraction over q = across waves, through LDS
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         lds_barrier();                                           // previous readers of this LDS region are done
+        MMX_TL_MARK();                                               // 6 / 8: barrier passed
 #pragma unroll
         for (int t = 0; t < NTK; ++t)
             *reinterpret_cast<f32x4*>(Ts + q * SS + t * 16 + 4 * g) = pass == 0 ? acc[t] : preg[t];
@@ -488,7 +506,21 @@ __global__ __launch_bounds__(NTK >= 7 ? 512 : 1024) void attn_bwd_head_kernel(co
             if constexpr (IOH) store_rows16_bf16<DP>(outh, osn, key, key < a.Nk, a.D, g, o, 1.f);
             else store_rows16<DP>(outb, osn, key, key < a.Nk, a.D, g, o, 1.f);
         }
+        MMX_TL_MARK();                                               // 7 / 9: pass done
     }
+#ifdef MMX_HEAD_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        const long long tend = __builtin_readcyclecounter();
+        __syncthreads();
+        if (lane == 0 && wave < 5) {
+            float* out = a.dv + b * a.dvs.sb + h * a.dvs.sh + wave * 12;
+            for (int i = 1; i < 10; ++i) out[i - 1] = static_cast<float>(tl_[i] - tl_[0]);
+            out[9] = static_cast<float>(tend - tl_[0]);
+            out[10] = static_cast<float>(tl_[0] & 0xffffff);
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------- host side
