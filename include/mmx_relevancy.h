@@ -70,14 +70,11 @@ const char* mmx_last_error(void);
  *                        barrier-free stream waves -- csrc/relevancy_chain_groups.hip (several groups: every A_bar of the group
  *                        resident in LDS) / csrc/relevancy_chain_cols.hip (one group, N >= 40: ring of A_bar images) --, everything
  *                        else the fused kernel of relevancy_kernels.hip | 1: the fused kernel everywhere (same bits) |
- *                        3: relay (csrc/relevancy_chain_relay.hip): positions of every layer cut over streamer workgroups that feed
- *                        ONE chain workgroup per sample -- strict layer order at any batch, bit-identical to "self_chain_groups" = 1,
- *                        measured slower (profiles/r05_chain_relay_probe.txt) | 4: same as 0 | 5: relevancy_chain_cols.hip for every
+ *                        4: same as 0 | 5: relevancy_chain_cols.hip for every
  *                        fp32 shape (strict layer order, bit-identical to "self_chain_groups" = 1)
  *   "self_chain_cols_c" / "self_chain_cols_nb"   0 auto (1 / as many as fit, <= 6) | workgroups per sample that split the COLUMNS of R
  *                        (each reduces the full A_bar; measured slower than layer groups, profiles/r05_chain_cols_probe.txt) / LDS
  *                        images of A_bar in the ring, of relevancy_chain_cols.hip
- *   "self_chain_relay_q" / "self_chain_relay_d"   0 auto | streamers per sample (<= 16) / LDS-DMA ring slots (2..8) of the relay form
  *   "self_chain_pipe"    4 (default) fused chain kernel (algo 1 / one group / 16-bit slabs), fp32 slabs, N >= 40: the stream waves run a software pipeline of raw buffer loads (the
  *                        next batch of 8 16-byte loads in flight across the head reduction, the LDS write and the per-layer barrier)
  *                        with up to 4 KB contiguous per (head, array) and wave | 2 / 1: at most 2 / 1 KB contiguous |

@@ -87,8 +87,8 @@ def test_avg_heads_nan_and_lowp(ops):
     (6, 2, 8, 100, False), (2, 1, 4, 128, False), (5, 3, 12, 36, False), (0, 2, 1, 7, False),
 ])
 # 0: auto (layer groups by batch; fp32 slabs: relevancy_chain_groups.hip / relevancy_chain_cols.hip), 1: the fused kernel everywhere,
-# 3: relay (relevancy_chain_relay.hip), 5: relevancy_chain_cols.hip wherever it applies
-@pytest.mark.parametrize("algo", [0, 1, 3, 5])
+# 5: relevancy_chain_cols.hip wherever it applies
+@pytest.mark.parametrize("algo", [0, 1, 5])
 def test_self_chain_fused(chain_options, L, B, H, N, causal, algo):
     ops = chain_options
     ops.set_option("self_chain_algo", algo)
@@ -234,24 +234,24 @@ def chain_options(ops):
     """Options of the chain kernels are process-global: whatever a test sets is put back, also when it fails."""
     yield ops
     for key, value in (("self_chain_algo", 0), ("self_chain_groups", 0), ("self_chain_pipe", 4), ("self_chain_nt", 1),
-                       ("self_chain_relay_q", 0), ("self_chain_relay_d", 0), ("self_chain_cols_c", 0), ("self_chain_cols_nb", 0),
+                       ("self_chain_cols_c", 0), ("self_chain_cols_nb", 0),
                        ("debug_flags", 0), ("bmm_tiles", 1)):
         ops.set_option(key, value)
 
 
 @pytest.mark.parametrize("L,B,H,N,causal,with_init,shared,offset", [
-    (12, 64, 8, 77, True, False, False, 0),     # cfg-2 text tower at the bench's batch: 4 streamers per sample, odd N^2
-    (12, 64, 12, 50, False, False, True, 0),    # cfg-2 image tower, one forward shared by the batch, 2 heads per round
+    (12, 64, 8, 77, True, False, False, 0),     # cfg-2 text tower at the bench's batch, odd N^2
+    (12, 64, 12, 50, False, False, True, 0),    # cfg-2 image tower, one forward shared by the batch
     (12, 5, 8, 77, True, True, False, 3),       # batch not a multiple of 8, R_init, slabs 12 bytes above a 16-byte boundary
     (3, 2, 2, 12, False, False, False, 1), (2, 3, 4, 128, False, True, False, 0), (4, 9, 5, 33, False, False, False, 2),
-    (6, 1, 12, 112, False, False, False, 0),    # VisualBERT's shape: ONE sample spread over 16 streamers
-    (2, 2, 3, 97, False, False, False, 0),      # 7 column slabs: single A_bar buffer in the chain workgroup
+    (6, 1, 12, 112, False, False, False, 0),    # VisualBERT's shape: 7 column slabs, three ring images
+    (2, 2, 3, 97, False, False, False, 0),
     (1, 2, 1, 7, False, False, False, 1), (3, 130, 2, 40, False, False, False, 0),
 ])
-def test_self_chain_relay_bit_identical(chain_options, L, B, H, N, causal, with_init, shared, offset):
-    """K1r (``relevancy_chain_relay.hip``: position-split LDS-DMA streamers feeding one chain workgroup per sample, strict layer
-    order) == the sequential per-sample kernel BIT FOR BIT (same head order, same MFMA chain) and within 1e-5 of the oracle;
-    repeated launches reuse scratch and counters; other ring depths / streamer counts change the schedule, not the bits."""
+def test_self_chain_strict_order_bit_identical(chain_options, L, B, H, N, causal, with_init, shared, offset):
+    """K1c (``relevancy_chain_cols.hip``: barrier-free stream waves feeding a ring of A_bar images, strict layer order, optionally
+    the columns of R split over several workgroups per sample) == the fused kernel with one group BIT FOR BIT (same head order,
+    same MFMA chain) and within 1e-5 of the oracle; workgroups per sample / ring depth change the schedule, not the bits."""
     ops = chain_options
     attn, grad = make_layers(L * 13 + N + B, L, B, H, N, causal)
     if shared:
@@ -273,12 +273,6 @@ def test_self_chain_relay_bit_identical(chain_options, L, B, H, N, causal, with_
     ops.set_option("self_chain_groups", 1)
     ref = run()
     close(ref, want)
-    ops.set_option("self_chain_algo", 3)
-    for q, d in ((0, 0), (0, 0), (1, 0), (3, 2), (0, 3)):
-        ops.set_option("self_chain_relay_q", q)
-        ops.set_option("self_chain_relay_d", d)
-        got = run()
-        assert torch.equal(got, ref), (q, d, float((got - ref).abs().max()))
     # K1c (``relevancy_chain_cols.hip``): the columns of R split over the workgroups of a sample, every workgroup reduces the full
     # A_bar -- the same sequential chain; workgroups per sample / ring depth change the schedule, not the bits
     ops.set_option("self_chain_algo", 5)

@@ -4,18 +4,6 @@ T=${1:?target}; TAG=${2:-$T}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p $OUT; nproc > $OUT/nproc.txt
 case $T in
-relay)     # relay chain kernel: bit-identity test, stand-alone timing with variants, then the whole GPU suite (relative parity bound)
-  timeout 300 python -m pytest tests/test_gpu_ops.py -q -x -k "relay" 2>&1 | tail -15 | tee $OUT/pytest_relay.txt
-  timeout 300 python tools/probe_chain_relay.py 2>&1 | grep -v amdgpu.ids | tee $OUT/chain_relay.txt
-  timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -25 | tee $OUT/pytest_gpu.txt
-  cp gpurun_out/parity_errors.json $OUT/parity.json 2>/dev/null
-  ;;
-relay2)    # relay kernel after the fixes: test, element-level diagnostic, timing variants
-  timeout 300 python -m pytest tests/test_gpu_ops.py -q -k "relay" 2>&1 | tail -15 | tee $OUT/pytest_relay.txt
-  timeout 120 python tools/probe_relay_debug.py 2>&1 | grep -v amdgpu.ids | tee $OUT/relay_debug.txt
-  timeout 300 python tools/probe_chain_relay.py 2>&1 | grep -v amdgpu.ids | tee $OUT/chain_relay.txt
-  timeout 600 python -m pytest tests/test_gpu_vit.py tests/test_gpu_clip.py -q -x 2>&1 | tail -8 | tee $OUT/pytest_vit_clip.txt
-  ;;
 split)     # N > 128 chain route: the new product kernel, the overlap of reductions and products
   timeout 600 python -m pytest tests/test_gpu_ops.py -q -k "bmm_tiles or split_and_rule7 or matmul" 2>&1 | tail -8 | tee $OUT/pytest_split.txt
   timeout 300 python tools/probe_chain_split_timing.py 2>&1 | grep -v amdgpu.ids | tee $OUT/chain_split_timing.txt
@@ -30,11 +18,11 @@ bmmpmc)    # SQ counters of the tiles product kernel
   ;;
 groups)    # layer-group chain kernel with barrier-free stream waves: parity / bit-identity, then timing variants
   timeout 600 python -m pytest tests/test_gpu_ops.py -q -k "layer_groups" 2>&1 | tail -15 | tee $OUT/pytest_groups.txt
-  timeout 400 python tools/probe_chain_relay.py 2>&1 | grep -v amdgpu.ids | grep -v "relay\|cols" | tee $OUT/chain_groups.txt
+  timeout 400 python tools/probe_chain_kernels.py 2>&1 | grep -v amdgpu.ids | grep -v "relay\|cols" | tee $OUT/chain_groups.txt
   ;;
 cols)      # column-split chain kernel: bit identity, timing variants
-  timeout 600 python -m pytest tests/test_gpu_ops.py -q -k "relay_bit_identical" 2>&1 | tail -15 | tee $OUT/pytest_cols.txt
-  timeout 400 python tools/probe_chain_relay.py 2>&1 | grep -v amdgpu.ids | grep -v "relay\|fused kernel G=[23]\|groups kernel G=[24]" | tee $OUT/chain_cols.txt
+  timeout 600 python -m pytest tests/test_gpu_ops.py -q -k "strict_order_bit_identical" 2>&1 | tail -15 | tee $OUT/pytest_cols.txt
+  timeout 400 python tools/probe_chain_kernels.py 2>&1 | grep -v amdgpu.ids | grep -v "relay\|fused kernel G=[23]\|groups kernel G=[24]" | tee $OUT/chain_cols.txt
   ;;
 v3)        # cfg-5 attention backward pair: parity gate + timing
   timeout 300 python -m pytest tests/test_gpu_ops.py tests/test_gpu_parity_fullsize.py -q -k "third_generation or bf16_backward or cfg5_bf16" 2>&1 | tail -5 | tee $OUT/pytest_v3.txt
@@ -46,12 +34,12 @@ bmm)       # tile shape x prefetch depth of the large exact-fp32 product
   ;;
 colsB)     # large batches: one workgroup per sample -- fused kernel vs the column kernel with C = 1
   for B in 128 160 256; do
-    timeout 300 python tools/probe_chain_relay.py $B 2>&1 | grep -v amdgpu.ids | grep "default\|per-sample\|cols C=1\|cols auto\|cols C=2\|groups kernel G=2" | tee -a $OUT/chain_cols_B.txt
+    timeout 300 python tools/probe_chain_kernels.py $B 2>&1 | grep -v amdgpu.ids | grep "default\|per-sample\|cols C=1\|cols auto\|cols C=2\|groups kernel G=2" | tee -a $OUT/chain_cols_B.txt
   done
   ;;
 groupsB)   # the same at other batch sizes (auto rule for the number of layer groups)
   for B in 16 32 96 128; do
-    timeout 300 python tools/probe_chain_relay.py $B 2>&1 | grep -v amdgpu.ids | grep -v "relay\|debug\|nt=0" | tee -a $OUT/chain_groups_B.txt
+    timeout 300 python tools/probe_chain_kernels.py $B 2>&1 | grep -v amdgpu.ids | grep -v "relay\|debug\|nt=0" | tee -a $OUT/chain_groups_B.txt
   done
   ;;
 suite)     # the whole GPU suite (after the pruning / parity-bound changes) + its timing

@@ -1,7 +1,8 @@
 """Kernel-only probe (GPU box): the chain kernels against each other -- layer groups with barrier-free stream waves
-(relevancy_chain_groups.hip, K1g: the fp32 default), the fused kernel of rounds 1-4 (K1), the relay kernel (relevancy_chain_relay.hip, K1r) --
-at the cfg-2 shapes over ROTATING slab sets (> 600 MB per tower: every byte from HBM), graph replay, HIP events.
-Variants: workgroups per sample, nt policy, and the phase-skip flags (1 = stream waves only, 2 = chain waves only)."""
+(relevancy_chain_groups.hip, K1g: the fp32 default), the fused kernel of rounds 1-4 (K1), the strict-order / column-split kernel
+(relevancy_chain_cols.hip, K1c) -- at the cfg-2 shapes over ROTATING slab sets (> 600 MB per tower: every byte from HBM), graph
+replay, HIP events.  Variants: groups / workgroups per sample, nt policy, and the phase-skip debug flags.  (Round 5's relay kernel was
+probed with this script too -- then tools/probe_chain_relay.py -- before it was removed: profiles/r05_chain_relay_probe.txt.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -28,7 +29,7 @@ def timed(fns, iters=10, warm=2):
     return s.elapsed_time(e) / (iters * len(fns)) * 1e3
 
 
-DEFAULTS = {"self_chain_cols_c": 0, "self_chain_cols_nb": 0, "self_chain_algo": 0, "self_chain_groups": 0, "self_chain_nt": 1, "self_chain_relay_q": 0, "self_chain_relay_d": 0,
+DEFAULTS = {"self_chain_cols_c": 0, "self_chain_cols_nb": 0, "self_chain_algo": 0, "self_chain_groups": 0, "self_chain_nt": 1,
             "debug_flags": 0}
 
 
@@ -62,13 +63,6 @@ def main():
         ("cols NB=3", {"self_chain_algo": 5, "self_chain_cols_nb": 3}),
         ("cols C=4 stream only (debug 1)", {"self_chain_algo": 5, "self_chain_cols_c": 4, "debug_flags": 1}),
         ("cols C=4 stream only, no rotation (debug 3)", {"self_chain_algo": 5, "self_chain_cols_c": 4, "debug_flags": 3}),
-        ("relay auto", {"self_chain_algo": 3}),
-        ("relay nt=0", {"self_chain_algo": 3, "self_chain_nt": 0}),
-        ("relay Q=1", {"self_chain_algo": 3, "self_chain_relay_q": 1}),
-        ("relay Q=2", {"self_chain_algo": 3, "self_chain_relay_q": 2}),
-        ("relay Q=3", {"self_chain_algo": 3, "self_chain_relay_q": 3}),
-        ("relay stream waves only (debug 1)", {"self_chain_algo": 3, "debug_flags": 1}),
-        ("relay chain waves only (debug 2)", {"self_chain_algo": 3, "debug_flags": 2}),
     ]
     for (L, H, N, name, sets) in [(12, 8, 77, "txt", 3), (12, 12, 50, "img", 4)]:
         slabs = []

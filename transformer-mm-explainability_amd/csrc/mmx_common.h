@@ -204,13 +204,6 @@ inline size_t dtype_size(int dt) { return dt == MMX_F32 ? 4 : 2; }
 
 void set_error(const char* fmt, ...);
 void attn_head_enable(int on);
-// relevancy_chain_relay.hip: the chain with position-split streamers feeding one chain workgroup per sample (K1r)
-bool self_chain_relay_applies(int n_layers, int B, int H, int N);
-size_t self_chain_relay_workspace(int n_layers, int B, int H, int N);
-int self_chain_relay_launch(const void* const* attn_layers, const void* const* grad_layers, int n_layers, int B, int H, int N,
-                            int64_t attn_bstride, const void* R_init, void* R_out, void* workspace, size_t workspace_bytes,
-                            int nt_policy, int debug, hipStream_t s);
-void chain_relay_options(int q, int d);
 // relevancy_chain_cols.hip: the chain split by columns of R over the workgroups of a sample, strict layer order (K1c)
 bool self_chain_cols_applies(int n_layers, int B, int H, int N);
 int self_chain_cols_launch(const void* const* attn_layers, const void* const* grad_layers, int n_layers, int B, int H, int N,

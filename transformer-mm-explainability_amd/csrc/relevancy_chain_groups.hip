@@ -8,10 +8,11 @@
 // VisualBERT/.../ExplanationGenerator.py:86-93 (include/mmx_relevancy.h, mmx_relevancy_self_chain).
 //
 // What changed against self_chain_fused_kernel (relevancy_kernels.hip), which made stream and matrix waves meet at one s_barrier per
-// layer and let the stream waves walk a whole layer as one chunk loop: round 5's relay experiments (profiles/r05_chain_relay_probe.txt)
+// layer and let the stream waves walk a whole layer as one chunk loop: round 5's relay experiments (a strict-order kernel fed through
+// L2, since removed: profiles/r05_chain_relay_probe.txt)
 // showed that stream waves which never wait -- each with its own register software pipeline over 64-chunk blocks -- reach 0.58 of the
 // HBM peak against 0.50-0.53 for the coupled form.  Here:
-//   * every A_bar_l of the group has its OWN LDS buffer (<= 3 layers x NP x (NP + 4) floats), so a stream wave never has to wait
+//   * every A_bar_l of the group has its OWN LDS buffer (NP x (NP + 4) floats each), so a stream wave never has to wait
 //     for a buffer: it takes the blocks ws, ws + NWs, ... of the group's (layer, 64-chunk block) list in layer order, reduces the heads
 //     IN ORDER (two register sets of 4 heads x 2 arrays: 16 x 16 B per lane in flight, raw buffer loads, nt policy, resources that end
 //     at the tensor end), scatters its 64 chunks into the layer's LDS image and adds its chunk count to the layer's LDS counter;

@@ -983,13 +983,9 @@ static int g_chain_nt = 1;       // option "self_chain_nt": nt cache policy on t
                                  // (default since round 4: text tower 85.8 -> 82.0 us, image 65.5 -> 63.8 us inside the replayed step)
 static int g_chain_groups = 0;  // layer groups per sample of the per-sample kernel: 0 auto, 1 = strict sequential order
 static int g_chain_algo = 0;  // 0 auto = 4: layer groups with barrier-free stream waves where they apply (fp32 slabs, G > 1), else this file's
-                              // per-sample kernel | 1: this file's kernel everywhere | 3: relay (position-split streamers)
+                              // per-sample kernel | 1: this file's kernel everywhere | 5: relevancy_chain_cols.hip wherever it applies
 
 extern "C" int mmx_set_option(const char* key, int value) {
-    if (key && strcmp(key, "self_chain_relay_q") == 0 && value >= 0 && value <= 16) {
-        chain_relay_options(value, -1);
-        return MMX_OK;
-    }
     if (key && strcmp(key, "self_chain_cols_c") == 0 && value >= 0 && value <= 8) {
         chain_cols_options(value, -1);
         return MMX_OK;
@@ -998,11 +994,7 @@ extern "C" int mmx_set_option(const char* key, int value) {
         chain_cols_options(-1, value);
         return MMX_OK;
     }
-    if (key && strcmp(key, "self_chain_relay_d") == 0 && value >= 0 && value <= 8) {
-        chain_relay_options(-1, value);
-        return MMX_OK;
-    }
-    if (key && strcmp(key, "self_chain_algo") == 0 && (value == 0 || value == 1 || value == 3 || value == 4 || value == 5)) {
+    if (key && strcmp(key, "self_chain_algo") == 0 && (value == 0 || value == 1 || value == 4 || value == 5)) {
         g_chain_algo = value;
         return MMX_OK;
     }
@@ -1050,19 +1042,12 @@ extern "C" int mmx_set_option(const char* key, int value) {
     return MMX_EINVAL;
 }
 
-// The relay form (relevancy_chain_relay.hip, option self_chain_algo = 3): fp32 slabs, one right-hand side.  Strict layer order in one
-// launch at any batch size (bit-identical to the per-sample kernel), but measured SLOWER than the layer-group kernel at the cfg-2
-// shapes (115 vs 84 us, profiles/r05_chain_relay_probe.txt), so it is opt-in.
-static bool use_relay(int n_layers, int B, int H, int N, int M, int dtype) {
-    return g_chain_algo == 3 && dtype == MMX_F32 && M == 0 && self_chain_relay_applies(n_layers, B, H, N);
-}
-
 static int fused_groups(int n_layers, int B, int H, int N);
 // One group, fp32 slabs, N >= 40: relevancy_chain_cols.hip with one workgroup per sample (the fused kernel's single-group form with
 // barrier-free stream waves and a ring of A_bar images; same bits).  Option self_chain_algo = 5 takes it for every shape it supports,
 // 1 never.
 static bool use_cols(int n_layers, int B, int H, int N, int M, int dtype) {
-    if (g_chain_algo == 1 || g_chain_algo == 3 || dtype != MMX_F32 || M != 0 || !self_chain_cols_applies(n_layers, B, H, N)) return false;
+    if (g_chain_algo == 1 || dtype != MMX_F32 || M != 0 || !self_chain_cols_applies(n_layers, B, H, N)) return false;
     if (g_chain_algo == 5) return true;
     return N >= 40 && fused_groups(n_layers, B, H, N) == 1;
 }
@@ -1094,7 +1079,6 @@ static size_t group_counter_bytes(int B) { return align256(sizeof(unsigned) * st
 extern "C" size_t mmx_self_chain_workspace_bytes(int n_layers, int B, int H, int N, int M, int dtype) {
     (void)dtype;
     if (nt_for(N) <= 8 && M == 0) {
-        if (use_relay(n_layers, B, H, N, M, dtype)) return self_chain_relay_workspace(n_layers, B, H, N);
         if (use_cols(n_layers, B, H, N, M, dtype)) return 0;
         const int G = fused_groups(n_layers, B, H, N);
         if (G == 1) return 0;  // strict-order per-sample kernel needs no scratch
@@ -1164,9 +1148,6 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
     if (use_cols(n_layers, B, H, N, M, dtype))
         return self_chain_cols_launch(attn_layers, grad_layers, n_layers, B, H, N, attn_batch_stride, R_init_dev, R_out_dev, g_chain_nt,
                                       g_debug_flags, s);
-    if (use_relay(n_layers, B, H, N, M, dtype))
-        return self_chain_relay_launch(attn_layers, grad_layers, n_layers, B, H, N, attn_batch_stride, R_init_dev, R_out_dev,
-                                       workspace_dev, workspace_bytes, g_chain_nt, g_debug_flags, s);
     if (nt <= 8 && M == 0) {
         ChainArgs args;
         memset(&args, 0, sizeof(args));
