@@ -25,9 +25,7 @@
 // a matrix wave follows tile by tile.  Back-pressure on the ring: a stream wave about to write layer l waits until every matrix wave
 // has finished layer l - NB (progress words in LDS) -- the matrix waves need 1.3 us per layer against ~5 us of streaming, so it
 // does not wait in practice.
-#include "mmx_common.h"
-
-#include <type_traits>
+#include "chain_stream.h"
 
 namespace mmx {
 
@@ -83,104 +81,23 @@ __global__ __launch_bounds__(kColsThreads) void self_chain_cols_kernel(const Col
     const int rot = (a.debug & 2) ? 0 : (c * NBLK) / C;
 
     if (wave >= nown) {
-        // =============================================================================================== stream waves
-        const int ws = wave - nown;
-        const int NWs = kColsWaves - nown;
-        const int nitems = L * NBLK;
-        const int mine = ws < nitems ? (nitems - ws + NWs - 1) / NWs : 0;
-        const int HB = (H + 3) >> 2;                       // batches of 4 heads
-        const int hstride = NN * 4;
-        const float fH = static_cast<float>(H);
-        const int64_t sampleG = static_cast<int64_t>(b) * H * NN * 4, sampleA = static_cast<int64_t>(b) * a.attn_bstride * 4;
-        const int64_t restG = static_cast<int64_t>(a.B - b) * H * NN * 4;
-        const int bytesG = static_cast<int>(restG < 0x7fffffff ? restG : 0x7fffffff), bytesA = a.attn_bstride ? bytesG : H * NN * 4;
-        const int total = mine * HB;
-        if (total > 0) {
-            auto item_layer = [&](int i) { return (ws + i * NWs) / NBLK; };
-            auto item_chunk = [&](int i) {
-                int blk = (ws + i * NWs) % NBLK + rot;
-                if (blk >= NBLK) blk -= NBLK;
-                return blk * 64 + lane;
-            };
-            // flat batch sequence k = item * HB + hb; batch k + 1 is issued before batch k is reduced; every issue is unconditional
-            // (clamped indices, weight 0) so that the compiler keeps the wait counts of both register sets apart
-            auto issue = [&](int k, u32x4 (&av)[4], u32x4 (&gv)[4], auto aux_tag) {
-                constexpr int AUXG = decltype(aux_tag)::value & 2, AUXA = (decltype(aux_tag)::value & 1) ? 0 : AUXG;
-                const int i = k / HB, hb = k - i * HB;
-                const int lu = __builtin_amdgcn_readfirstlane(item_layer(i));
-                const auto rA = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(a.attn[lu]) + sampleA)), 0, bytesA, kRawBufferFlags);
-                const auto rG = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(a.grad[lu]) + sampleG)), 0, bytesG, kRawBufferFlags);
-                const unsigned voff = static_cast<unsigned>(min(item_chunk(i), a.nchunks - 1)) * 16u;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const unsigned off = voff + static_cast<unsigned>(min(hb * 4 + u, H - 1) * hstride);
-                    av[u] = __builtin_amdgcn_raw_buffer_load_b128(rA, off, 0, AUXA);
-                    gv[u] = __builtin_amdgcn_raw_buffer_load_b128(rG, off, 0, AUXG);
-                }
-            };
-            f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            auto consume = [&](int k, bool live, const u32x4 (&av)[4], const u32x4 (&gv)[4]) {
-                const int i = k / HB, hb = k - i * HB;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float w = (live && hb * 4 + u < H) ? 1.f : 0.f;      // heads in ascending order: the sequential sum
-                    const f32x4 x = __builtin_bit_cast(f32x4, gv[u]) * __builtin_bit_cast(f32x4, av[u]);
-                    s[0] += relu_nan(x[0]) * w; s[1] += relu_nan(x[1]) * w;
-                    s[2] += relu_nan(x[2]) * w; s[3] += relu_nan(x[3]) * w;
-                }
-                if (live && hb == HB - 1) {
-                    const int l = item_layer(i), cidx = item_chunk(i);
-                    const int slot = l % NB;
-                    if (l >= NB) {
-                        // ring back-pressure: every matrix wave must have left layer l - NB (bounded like every wait here)
-                        const unsigned need = static_cast<unsigned>(l - NB + 1);
-                        int turns = 0;
-                        while (!__all(lane >= nown ||
-                                      __hip_atomic_load(prog + (lane & 15), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) &&
-                               ++turns < (1 << 24))
-                            __builtin_amdgcn_s_sleep(1);
-                    }
-                    if (cidx < a.nchunks) {
-                        float* Ab = smem + slot * NP * S;
-                        const int p = cidx * 4;
-                        int row = static_cast<int>(__umulhi(static_cast<unsigned>(p), a.row_magic)), cc = p - row * N;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (p + e < NN) Ab[row * S + cc] = s[e] / fH;
-                            if (++cc == N) { cc = 0; ++row; }
-                        }
-                    }
-                    // Arrival counts per 16-row tile, in elements (the block [p0, p1) is contiguous in row-major order and shorter than a
-                    // tile, so it ends in tile t0 or t0 + 1); cumulative over the uses of the slot.  LDS operations of a wave execute in
-                    // issue order: the counts land after the elements they count.
-                    if (lane == 0) {
-                        const int p0 = (cidx - lane) * 4, p1 = min(NN, p0 + 256);
-                        const int t0 = static_cast<int>(__umulhi(static_cast<unsigned>(p0), a.row_magic)) >> 4;
-                        const int n0 = min(p1, (t0 + 1) * 16 * N) - p0;
-                        atomicAdd(lds_cnt + slot * NT + t0, static_cast<unsigned>(n0));
-                        if (p1 - p0 > n0) atomicAdd(lds_cnt + slot * NT + t0 + 1, static_cast<unsigned>(p1 - p0 - n0));
-                    }
-                    s = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            };
-            auto run = [&](auto aux_tag) {
-                u32x4 a0[4], g0[4], a1[4], g1[4];
-                issue(0, a0, g0, aux_tag);
-                for (int k = 0; k < total; k += 2) {
-                    issue(min(k + 1, total - 1), a1, g1, aux_tag);
-                    consume(k, true, a0, g0);
-                    issue(min(k + 2, total - 1), a0, g0, aux_tag);
-                    consume(min(k + 1, total - 1), k + 1 < total, a1, g1);
-                }
-            };
-            // aux tag: 0 default policy | 2 nt on both slabs | 3 nt on the gradient slab only (the batch shares the probabilities).
-            // With several workgroups per sample the partners re-read every line from L2: default policy.
-            if (!a.nt || C > 1) run(std::integral_constant<int, 0>{});
-            else if (a.attn_bstride == 0) run(std::integral_constant<int, 3>{});
-            else run(std::integral_constant<int, 2>{});
-        }
+        // =============================================================================================== stream waves (chain_stream.h)
+        const ChainStreamGeom gm{a.attn, a.grad, 0, NBLK, rot, a.nchunks, H, NN, b, a.B, a.attn_bstride, (a.nt && C == 1) ? 1 : 0};
+        // (with several workgroups per sample the partners re-read every line from L2: default cache policy)
+        chain_stream_wave(gm, wave - nown, kColsWaves - nown, L * NBLK, lane, [&](int l, int cidx, f32x4 mean) {
+            const int slot = l % NB;
+            if (l >= NB) {
+                // ring back-pressure: every matrix wave must have left layer l - NB (bounded like every wait here)
+                const unsigned need = static_cast<unsigned>(l - NB + 1);
+                int turns = 0;
+                while (!__all(lane >= nown ||
+                              __hip_atomic_load(prog + (lane & 15), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) &&
+                       ++turns < (1 << 24))
+                    __builtin_amdgcn_s_sleep(1);
+            }
+            // arrival counts are cumulative over the uses of the slot
+            chain_stream_deliver(smem + slot * NP * S, S, lds_cnt + slot * NT, cidx, lane, a.nchunks, N, NN, a.row_magic, mean);
+        });
     } else {
         // =============================================================================================== matrix waves
         const int slab = c + wave * C;
