@@ -210,7 +210,7 @@ int self_chain_cols_launch(const void* const* attn_layers, const void* const* gr
                            int64_t attn_bstride, const void* R_init, void* R_out, int nt_policy, int debug, hipStream_t s);
 void chain_cols_options(int c, int nb);
 // relevancy_chain_groups.hip: the layer-group chain with barrier-free stream waves (K1g)
-bool self_chain_groups_applies(int n_layers, int G, int N);
+bool self_chain_groups_applies(int n_layers, int G, int H, int N);
 int self_chain_groups_launch(const void* const* attn_layers, const void* const* grad_layers, int n_layers, int B, int H, int N, int G,
                              int64_t attn_bstride, const void* R_init, void* R_out, unsigned* counters, float* parts, int nt_policy,
                              int debug, hipStream_t s);

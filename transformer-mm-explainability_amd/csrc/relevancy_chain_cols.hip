@@ -94,6 +94,7 @@ __global__ __launch_bounds__(kColsThreads) void self_chain_cols_kernel(const Col
                               __hip_atomic_load(prog + (lane & 15), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) &&
                        ++turns < (1 << 24))
                     __builtin_amdgcn_s_sleep(1);
+                if (turns >= (1 << 24) && lane == 0) prog[15] = 1u;        // (word 15 is no wave's progress: "a wait gave up")
             }
             // arrival counts are cumulative over the uses of the slot
             chain_stream_deliver(smem + slot * NP * S, S, lds_cnt + slot * NT, cidx, lane, a.nchunks, N, NN, a.row_magic, mean);
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(kColsThreads) void self_chain_cols_kernel(const Col
                     v = a.R_init ? a.R_init[static_cast<int64_t>(b) * NN + row * N + col] : (row == col ? 1.f : 0.f);
                 Rold[t][r] = v;
             }
+        bool poisoned = false;
         for (int l = 0; l < L; ++l) {
             const int slot = l % NB;
             const unsigned uses = static_cast<unsigned>(l / NB + 1);
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(kColsThreads) void self_chain_cols_kernel(const Col
                 while (__hip_atomic_load(lds_cnt + slot * NT + ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expect &&
                        ++turns < (1 << 24))
                     __builtin_amdgcn_s_sleep(1);
+                if (turns >= (1 << 24)) poisoned = true;        // never seen; if it happens the result says so (NaN), it does not lie
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 if (!(a.debug & 1)) {
@@ -145,13 +148,14 @@ __global__ __launch_bounds__(kColsThreads) void self_chain_cols_kernel(const Col
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(prog + wave, static_cast<unsigned>(l + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        if (__hip_atomic_load(prog + 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) poisoned = true;
         float* dst = a.R_out + static_cast<int64_t>(b) * NN;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = t * 16 + rq + r;
-                if (row < N && col < N) dst[row * N + col] = Rold[t][r];
+                if (row < N && col < N) dst[row * N + col] = poisoned ? __builtin_nanf("") : Rold[t][r];
             }
     }
 }

@@ -101,6 +101,7 @@ __global__ __launch_bounds__(kGroupsThreads) void self_chain_groups_kernel(const
                     v = (a.R_init && g == 0) ? a.R_init[static_cast<int64_t>(b) * NN + row * N + col] : (row == col ? 1.f : 0.f);
                 Rold[t][r] = v;
             }
+        bool poisoned = false;
         for (int l = 0; l < L; ++l) {
             const float* Ab = smem + l * NP * S + (lane & 15) * S + rq;
 #pragma unroll
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(kGroupsThreads) void self_chain_groups_kernel(const
                 while (__hip_atomic_load(lds_cnt + l * NT + ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expect &&
                        ++turns < (1 << 24))
                     __builtin_amdgcn_s_sleep(1);
+                if (turns >= (1 << 24)) poisoned = true;        // never seen; if it happens the result says so (NaN), it does not lie
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 if (!(a.debug & 4)) {
@@ -137,7 +139,8 @@ __global__ __launch_bounds__(kGroupsThreads) void self_chain_groups_kernel(const
             for (int r = 0; r < 4; ++r) {
                 const int row = t * 16 + rq + r;
                 if (row < N && col < N)      // write-through: the hand-off below needs no L2 write-back fence
-                    __hip_atomic_store(dst + row * N + col, Rold[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + row * N + col, poisoned ? __builtin_nanf("") : Rold[t][r], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
             }
     }
     if (a.debug & 1) return;
@@ -228,9 +231,10 @@ static size_t groups_lds_bytes(int nt, int per) {
 }
 
 // fp32 slabs, G > 1, every A_bar image of a group resident in LDS
-bool self_chain_groups_applies(int n_layers, int G, int N) {
+bool self_chain_groups_applies(int n_layers, int G, int H, int N) {
     const int nt = (N + 15) / 16;
     if (nt > 8 || G < 2 || n_layers < G) return false;
+    if (static_cast<size_t>(H) * N * N * 4 >= (1ull << 31)) return false;      // 32-bit offsets inside one buffer resource
     return groups_lds_bytes(nt, (n_layers + G - 1) / G) <= 160 * 1024;
 }
 

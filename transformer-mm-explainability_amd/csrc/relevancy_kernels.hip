@@ -1169,7 +1169,7 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
             args.counters = static_cast<unsigned*>(workspace_dev);
             args.parts = reinterpret_cast<float*>(static_cast<char*>(workspace_dev) + group_counter_bytes(B));
             // fp32 slabs: the kernel with barrier-free stream waves (relevancy_chain_groups.hip) unless algo 1 asks for this file's
-            if (g_chain_algo != 1 && dtype == MMX_F32 && self_chain_groups_applies(n_layers, args.G, N))
+            if (g_chain_algo != 1 && dtype == MMX_F32 && self_chain_groups_applies(n_layers, args.G, H, N))
                 return self_chain_groups_launch(attn_layers, grad_layers, n_layers, B, H, N, args.G, attn_batch_stride, R_init_dev,
                                                 R_out_dev, args.counters, args.parts, g_chain_nt, g_debug_flags, s);
         }
