@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kColsThreads) void self_chain_cols_kernel(const Col
 
     {   // pads must read as 0; counters = 0
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const int n4 = (NB * NP * S + NB * NT + 16) >> 2;
+        const int n4 = (NB * NP * S + NB * NT + 16 + 3) >> 2;            // (rounded up: the allocation has the slack)
         for (int i = tid; i < n4; i += kColsThreads) reinterpret_cast<f32x4*>(smem)[i] = z;
     }
     __syncthreads();
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kColsThreads) void self_chain_cols_kernel(const Col
 
 // ------------------------------------------------------------------------------------------------------------ host side
 static size_t cols_lds_bytes(int nt, int nb) {
-    return sizeof(float) * (static_cast<size_t>(nb) * nt * 16 * (nt * 16 + 4) + static_cast<size_t>(nb) * nt + 16);
+    return sizeof(float) * (static_cast<size_t>(nb) * nt * 16 * (nt * 16 + 4) + static_cast<size_t>(nb) * nt + 20);
 }
 
 static int g_cols_c = 0, g_cols_nb = 0;    // 0 = auto
