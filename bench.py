@@ -192,36 +192,44 @@ def kernel_time_us(fn, iters, stream):
 
 
 CPU_THREADS_CAP = 32   # torch CPU autograd on >64 threads gets slower, not faster (256-thread box: 128 threads = 0.9 maps/s)
+CPU_THREAD_CANDIDATES = (16, 32)   # the best of these is reported: which one wins depends on the box (profiles/r02_cpu_threads.txt: 32;
+                                   # profiles/r05_cpu_threads.txt: 16 threads 9.2 maps/s vs 32 threads 3.5 at batch 8)
 
 
 def cpu_baseline_worker(sample_b, reps):
     """Runs in a child process (bounded by a timeout in the parent): the reference algorithm on host cores."""
     from oracle import clip_torch
     from transformer_mm_explainability_amd import clip_model
-    cores = min(os.cpu_count() or 1, CPU_THREADS_CAP)
-    torch.set_num_threads(cores)
     model = clip_model.random_init(MODEL, seed=0)       # parameters only; the CPU path never calls the HIP op
     sd = clip_torch.prepare_state_dict(model.state_dict(), 8)
     image, texts = synthetic_inputs(sample_b, "cpu", 0)
-    clip_torch.interpret(sd, image, texts, 0, 0)  # warm-up
-    times = []
-    for _ in range(reps):
-        split = {}
-        t0 = time.perf_counter()
-        clip_torch.interpret(sd, image, texts, 0, 0, timings=split)
-        times.append((time.perf_counter() - t0, split))
-    times.sort(key=lambda t: t[0])
-    med, split = times[len(times) // 2]
+    best, tried = None, {}
+    for cores in sorted({min(os.cpu_count() or 1, c) for c in CPU_THREAD_CANDIDATES}):
+        torch.set_num_threads(cores)
+        clip_torch.interpret(sd, image, texts, 0, 0)  # warm-up
+        times = []
+        for _ in range(reps):
+            split = {}
+            t0 = time.perf_counter()
+            clip_torch.interpret(sd, image, texts, 0, 0, timings=split)
+            times.append((time.perf_counter() - t0, split))
+        times.sort(key=lambda t: t[0])
+        med, split = times[len(times) // 2]
+        tried[cores] = round(sample_b / med, 3)
+        if best is None or med < best[0]:
+            best = (med, split, cores)
+    med, split, cores = best
     print(json.dumps({"value": round(sample_b / med, 3), "unit": "maps/s", "cores": cores, "kind": "port",
                       # SURVEY section 8(d): forward / the 24 per-layer partial backwards / the rule chain of the median run
                       "split_s": {"forward": round(split["forward_s"], 3), "backward": round(split["backward_s"], 3),
                                   "rule_chain": round(split["rules_s"], 3), "total": round(med, 3)},
+                      "maps_per_s_by_threads": tried,
                       "calibration": "profiles/r05_cpu_port_calibration.txt (this port vs the reference's own CLIP/clip/model.py + "
                                      "notebook cell 6, same weights, inputs and threads, run in the build container)",
                       "sample": "reference algorithm (hooked CLIP ViT-B/32 fwd + one autograd.grad per layer + rule "
-                                "chain, all 12+12 layers) restated in oracle/clip_torch.py, torch fp32 CPU, %d threads "
-                                "of %d host cores, batch %d of the same synthetic workload, median of %d"
-                                % (cores, os.cpu_count() or 1, sample_b, reps)}), flush=True)
+                                "chain, all 12+12 layers) restated in oracle/clip_torch.py, torch fp32 CPU, the best of %s threads "
+                                "(%d) of %d host cores, batch %d of the same synthetic workload, median of %d"
+                                % ("/".join(str(c) for c in sorted(tried)), cores, os.cpu_count() or 1, sample_b, reps)}), flush=True)
 
 
 def cpu_baseline(sample_b=16, reps=3, timeout_s=240):

@@ -140,7 +140,7 @@ def test_self_chain_half_vs_torch_half_chain(ops, L, B, H, N, causal, shared, sl
 @pytest.mark.parametrize("L,B,H,N,causal,with_init,shared", [
     (12, 4, 12, 50, False, False, False), (12, 3, 8, 77, True, True, False), (5, 2, 4, 33, False, True, False),
     (2, 2, 2, 128, False, False, False), (12, 2, 3, 100, False, False, True), (7, 5, 5, 17, False, True, True),
-    (4, 1, 9, 91, False, False, False),
+    (4, 1, 9, 91, False, False, False), (6, 11, 1, 128, False, True, False), (8, 3, 16, 16, False, False, False),
 ])
 def test_self_chain_layer_groups(chain_options, algo, groups, L, B, H, N, causal, with_init, shared):
     """Layer-group split: partial products re-associated at the group boundaries, combined by the last arriver.
@@ -166,6 +166,31 @@ def test_self_chain_layer_groups(chain_options, algo, groups, L, B, H, N, causal
             close(got, want)
         outs[which] = got.clone()
     assert torch.equal(outs[1], outs[algo])
+
+
+def test_self_chain_auto_groups(chain_options):
+    """The automatic number of layer groups, read off the scratch the C-ABI asks for (B tickets, 256-byte aligned, + B x G partial
+    products): the fewest groups that put a workgroup on ~70 % of the CUs, at most 4, never more workgroups than CUs; one group
+    (no scratch) below 1 MB per sample and when the batch alone fills the chip.  On the 256 CUs of an MI355X."""
+    from transformer_mm_explainability_amd import _lib
+    lib = _lib.lib()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+
+    def groups(L, B, H, N):
+        need = lib.mmx_self_chain_workspace_bytes(L, B, H, N, 0, _lib.MMX_F32)
+        if need == 0:
+            return 1
+        tickets = (4 * B + 255) // 256 * 256
+        per_group = (4 * B * N * N + 255) // 256 * 256
+        g, rem = divmod(need - tickets, 4 * B * N * N)
+        assert need - tickets == (4 * B * g * N * N + 255) // 256 * 256 or rem < 256, (need, tickets, per_group)
+        return g
+    if cus != 256:
+        pytest.skip("rule pinned for 256 CUs")
+    assert [groups(12, B, 8, 77) for B in (1, 16, 32, 59, 60, 64, 85, 86, 96, 128, 129, 160, 256)] == \
+        [4, 4, 4, 4, 3, 3, 3, 2, 2, 2, 1, 1, 1]
+    assert groups(12, 64, 12, 50) == 3 and groups(1, 64, 8, 77) == 1 and groups(3, 2, 2, 12) == 1 and groups(2, 64, 8, 77) == 1 \
+        and groups(4, 64, 8, 77) == 3 and groups(3, 16, 8, 77) == 3
 
 
 @pytest.mark.parametrize("L,B,H,N,groups", [(12, 8, 8, 77, 0), (12, 4, 12, 50, 0), (3, 2, 5, 44, 1), (2, 1, 16, 128, 0), (5, 3, 8, 20, 2),

@@ -42,6 +42,10 @@ groupsB)   # the same at other batch sizes (auto rule for the number of layer gr
     timeout 300 python tools/probe_chain_kernels.py $B 2>&1 | grep -v amdgpu.ids | grep -v "relay\|debug\|nt=0" | tee -a $OUT/chain_groups_B.txt
   done
   ;;
+final)     # late additions: new chain tests, then the CPU thread sweep behind CPU_THREADS_CAP (host cores of the GPU box)
+  timeout 600 python -m pytest tests/test_gpu_ops.py -q -k "chain" 2>&1 | tail -4 | tee $OUT/pytest_chain.txt
+  for t in 8 16 32 64 128; do timeout 120 python tools/probe_cpu_baseline.py $t 8 2>&1 | grep -v amdgpu.ids | tee -a $OUT/cpu_threads.txt; done
+  ;;
 suite)     # the whole GPU suite (after the pruning / parity-bound changes) + its timing
   timeout 1500 python -m pytest tests -q -m gpu --durations=15 2>&1 | tail -45 | tee $OUT/pytest_gpu.txt
   cp gpurun_out/parity_errors.json $OUT/parity.json 2>/dev/null
