@@ -386,10 +386,15 @@ def main():
     dev_index = 0 if os.environ.get("MMX_BENCH_SHARE_DEVICE") else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    # MMX_BENCH_FORCE_DIST=1 (tests/test_gpu_multigpu.py::test_rccl_world_size_one_smoke): join a WORLD-SIZE-1 RCCL group and run the
+    # exchange step anyway, so that init_process_group("nccl", device_id=...) and the packed all_gather_into_tensor of this file
+    # execute on the 1-GPU boxes the suite runs on.  Never set by the driver: a plain N = 1 run has no collective in its step.
+    dist_on = world > 1 or bool(os.environ.get("MMX_BENCH_FORCE_DIST"))
     dist = None
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -406,8 +411,8 @@ def main():
     image, texts = synthetic_inputs(BATCH, device, seed=rank)
     # the exchange step moves the FULL per-sample result: image relevancy [49] and text relevancy [77 x 77] per pair
     row = 49 + 77 * 77
-    gathered = torch.empty(world * BATCH, row, device=device) if world > 1 else None
-    packed = torch.empty(BATCH, row, device=device) if world > 1 else None
+    gathered = torch.empty(world * BATCH, row, device=device) if dist_on else None
+    packed = torch.empty(BATCH, row, device=device) if dist_on else None
 
     # The step is ~600 short launches; eager it is bound by the Python + launch path on the host, so the whole step
     # (forward, autograd backward, hand-written image backward, both chain launches) is captured ONCE into a hipGraph
@@ -416,7 +421,7 @@ def main():
 
     def step():
         R_text, R_image = run(image, texts)
-        if world > 1:   # the evaluators' exchange step: per-sample maps gathered on every rank (1.5 MB per rank)
+        if dist_on:   # the evaluators' exchange step: per-sample maps gathered on every rank (1.5 MB per rank)
             packed[:, :49] = R_image
             packed[:, 49:] = R_text.reshape(BATCH, -1)
             if backend == "nccl":
@@ -426,7 +431,7 @@ def main():
         return R_text, R_image
 
     def sync():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -440,7 +445,7 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -627,6 +632,8 @@ def main():
             "config": {"workload": "CLIP ViT-B/32 image<->text relevancy, batch=64 fp32 per GPU, all 12+12 layers "
                                    "(start_layer=0); random-init weights, synthetic image + token ids",
                        "global_batch": world * BATCH, "parallelism": "dp%d (independent batches, all-gather of maps)" % world,
+                       **({"forced_world1_collective": "%s: world-size-1 group, the exchange step ran inside every timed step" % backend}
+                          if dist_on and world == 1 else {}),
                        "launch": "whole step captured once into a hipGraph and replayed",
                        "image_tower": "forward shared by the batch (the reference API repeats ONE image B times), "
                                       "backward per sample",
@@ -643,7 +650,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
             log("cpu baseline done")
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -29,7 +29,12 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 1   /* within a version entry points are only ever ADDED (the *_ex forms); a binding checks == */
+/* Within a version entry points are only ever ADDED (the *_ex forms); a binding checks ==.
+ * 2 (round 5 / 6): mmx_lxmert_schedule_ex and mmx_lxmert_schedule_v2 removed, mmx_lxmert_schedule gained `text_len_dev`,
+ *    `workspace_dev`, `workspace_bytes` (a caller built against version 1 would pass `stream` where a pointer is expected), and
+ *    several mmx_set_option keys now return MMX_EINVAL -- an incompatible change, hence the bump.  A version-1 binding fails its
+ *    mmx_abi_version() check instead of misreading arguments. */
+#define MMX_ABI_VERSION 2
 #define MMX_MAX_LAYERS 48
 
 enum mmx_dtype { MMX_F32 = 0, MMX_F16 = 1, MMX_BF16 = 2 };
@@ -90,7 +95,9 @@ const char* mmx_last_error(void);
  *   "attn_bf16_v2"       1 (default) second-generation bf16 backward | 0: the streaming kernels' bf16 path
  *   "attn_fwd_split"     1 (default) streaming forward on a small grid (< 160 workgroups of 64 rows, fp32 slabs):
  *                        16-row workgroups whose waves split the keys | 0 always the 64-row kernel
- *   "debug_flags"        profiling only (phase skipping); 0 in production
+ *   "debug_flags"        profiling only (phase skipping), 0 in production; one meaning per bit for every chain kernel the dispatcher
+ *                        may pick: 1 return before the hand-off / combine | 4 matrix waves skip the MFMAs | 8 layer-group kernel:
+ *                        ticket without combine | 16 column kernel: no block rotation
  * These are A / B switches for tests and probes (every remaining value is the default for some shape or the reference arm of an
  * equivalence test); round 5 removed the kernel families that were nobody's default (self_chain_algo 2, self_chain_big, attn_small,
  * linear_stream, bmm_tile, the 4-wave / fourth-generation bf16 variants, the one-workgroup bi-modal schedule).

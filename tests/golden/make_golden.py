@@ -635,33 +635,47 @@ def gen_detr_transformer_lrp():
     feats = torch.randn(1, Cb, h, w, generator=g)
     body.pos = torch.randn(1, d, h, w, generator=g)
     tgt = torch.tensor([1, 4])
-    gen = detr_eg.Generator(body)
-    out = gen.generate_ours(feats, tgt)                               # DEFAULT arguments: use_lrp=True
-    enc, dec = body.transformer.encoder.layers, body.transformer.decoder.layers
-    arrays = dict(features=feats, pos=body.pos, target_index=tgt, out_default=out, R_i_i=gen.R_i_i, R_q_q=gen.R_q_q,
-                  pred_logits=body(feats)["pred_logits"],
-                  enc_cam=torch.stack([b.self_attn.get_attn_cam() for b in enc]),
-                  dself_cam=torch.stack([b.self_attn.get_attn_cam() for b in dec]),
-                  dcross_cam=torch.stack([b.multihead_attn.get_attn_cam() for b in dec]),
-                  enc_attn=torch.stack([b.self_attn.get_attn() for b in enc]),
-                  enc_grad=torch.stack([b.self_attn.get_attn_gradients() for b in enc]),
-                  dims=np.array([d, heads, Le, Ld, ff, Q, n_cls, Cb, h, w]))
-    # the relevance the pass hands back for the transformer input (conservation check + end-to-end pin of every relprop)
-    outputs = body(feats)["pred_logits"]
-    index = outputs[0, tgt, :-1].max(1)[1]
-    one_hot = torch.zeros_like(outputs)
-    one_hot[0, tgt, index] = 1
-    body.zero_grad()
-    torch.sum(one_hot * outputs).backward(retain_graph=True)
-    arrays["cam_src"] = body.relprop(one_hot.clone(), alpha=1, target_index=tgt, target_class=index)
-    arrays["target_class"] = index
-    arrays["transformer_att_out"] = detr_eg.Generator(body).generate_transformer_att(feats, tgt)
-    arrays["partial_lrp_out"] = detr_eg.Generator(body).generate_partial_lrp(feats, tgt)
-    arrays["abl_lrp_out"] = detr_eg.GeneratorAlbationNoAgg(body).generate_ours_abl(feats, tgt, use_lrp=True)
-    single = torch.tensor([4])
-    arrays["out_default_single"] = detr_eg.Generator(body).generate_ours(feats, single)
+
+    def record(feats):
+        gen = detr_eg.Generator(body)
+        out = gen.generate_ours(feats, tgt)                               # DEFAULT arguments: use_lrp=True
+        enc, dec = body.transformer.encoder.layers, body.transformer.decoder.layers
+        arrays = dict(out_default=out, R_i_i=gen.R_i_i, R_q_q=gen.R_q_q,
+                      pred_logits=body(feats)["pred_logits"],
+                      enc_cam=torch.stack([b.self_attn.get_attn_cam() for b in enc]),
+                      dself_cam=torch.stack([b.self_attn.get_attn_cam() for b in dec]),
+                      dcross_cam=torch.stack([b.multihead_attn.get_attn_cam() for b in dec]),
+                      enc_attn=torch.stack([b.self_attn.get_attn() for b in enc]),
+                      enc_grad=torch.stack([b.self_attn.get_attn_gradients() for b in enc]))
+        # the relevance the pass hands back for the transformer input (conservation check + end-to-end pin of every relprop)
+        outputs = body(feats)["pred_logits"]
+        index = outputs[0, tgt, :-1].max(1)[1]
+        one_hot = torch.zeros_like(outputs)
+        one_hot[0, tgt, index] = 1
+        body.zero_grad()
+        torch.sum(one_hot * outputs).backward(retain_graph=True)
+        arrays["cam_src"] = body.relprop(one_hot.clone(), alpha=1, target_index=tgt, target_class=index)
+        arrays["target_class"] = index
+        arrays["transformer_att_out"] = detr_eg.Generator(body).generate_transformer_att(feats, tgt)
+        arrays["partial_lrp_out"] = detr_eg.Generator(body).generate_partial_lrp(feats, tgt)
+        arrays["abl_lrp_out"] = detr_eg.GeneratorAlbationNoAgg(body).generate_ours_abl(feats, tgt, use_lrp=True)
+        single = torch.tensor([4])
+        arrays["out_default_single"] = detr_eg.Generator(body).generate_ours(feats, single)
+        return {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in arrays.items()}
+
+    arrays = dict(features=feats, pos=body.pos, target_index=tgt, dims=np.array([d, heads, Le, Ld, ff, Q, n_cls, Cb, h, w]))
+    arrays.update(record(feats))
     for name, p in body.state_dict().items():
-        arrays["w__" + name] = p
+        arrays["w__" + name] = p.detach().clone()
+    # Round 6: the same reference pass in float64 ("f64__" entries), as for LXMERT / VisualBERT: the distance between the reference's
+    # OWN fp32 and fp64 passes is the yardstick of the GPU tests for every tensor that went through safe_divide
+    torch.set_default_dtype(torch.float64)
+    try:
+        body.double()
+        body.pos = body.pos.double()
+        arrays.update({"f64__" + k: v for k, v in record(feats.double()).items() if k != "target_class"})
+    finally:
+        torch.set_default_dtype(torch.float32)
     save("detr_transformer_lrp", **arrays)
 
 

@@ -37,20 +37,22 @@ def note(label, value, bound=None, scale=None, relmax=None):
 RELMAX = 1e-4
 
 
-def close(a, b, atol=1e-5, rtol=0.0, what="", relmax=RELMAX):
+def close(a, b, atol=1e-5, rtol=0.0, what="", relmax=RELMAX, rel_always=False):
     """|a - b| <= atol + rtol |b| elementwise; ``rtol`` defaults to ZERO (relevancy maps are judged on the absolute 1e-5) and
     then the largest error must ALSO stay below ``relmax`` x the largest |reference| entry.  ``relmax=None`` switches the second
     bound off: only for comparisons whose tolerance is stated in another currency (a storage precision such as bf16 slabs, or the
-    reference's own fp32-vs-fp64 distance for the LRP passes) -- the call site says which."""
+    reference's own fp32-vs-fp64 distance for the LRP passes) -- the call site says which.  ``rel_always``: apply (and record) the
+    ``relmax`` bound also when an elementwise ``rtol`` is in use (the kernel-level suite: ``tests/test_gpu_ops.py``)."""
     a, b = _np(a), _np(b)
     assert a.shape == b.shape, (a.shape, b.shape)
     assert np.array_equal(np.isnan(a), np.isnan(b))
-    fin = ~np.isnan(b)
+    fin = np.isfinite(b) & np.isfinite(a)      # +-inf entries are compared by assert_allclose below, not by the error record
     err = float(np.abs(a[fin] - b[fin]).max()) if fin.any() else 0.0
     scale = float(np.abs(b[fin]).max()) if fin.any() else None
-    note(what, err, atol if rtol == 0.0 else None, scale, relmax if rtol == 0.0 else None)
+    rel_on = rtol == 0.0 or rel_always
+    note(what, err, atol if rel_on else None, scale, relmax if rel_on else None)
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
-    if rtol == 0.0 and relmax is not None and scale:
+    if rel_on and relmax is not None and scale and np.isfinite(scale):
         assert err <= relmax * scale, "%s: max |err| %.3e > %.0e x max |ref| (%.3e)" % (what or "map", err, relmax, scale)
 
 

@@ -175,6 +175,12 @@ def test_visualbert_generate_ours(golden):
     inp = {"input_mask": cu(g["input_mask"])}
     close(vb.SelfAttentionGenerator(model).generate_ours(inp), g["out"])
     close(vb.SelfAttentionGenerator(model).generate_rollout(inp), g["rollout_out"])
+    # save_visualization=True: the reference calls an undefined ``save_visual_results`` after computing the scores (NameError,
+    # VisualBERT/mmf/models/transformers/backends/ExplanationGenerator.py:99-100, :182-183); the flag is not silently ignored here
+    with pytest.raises(NameError, match="save_visual_results"):
+        vb.SelfAttentionGenerator(model).generate_ours(inp, save_visualization=True)
+    with pytest.raises(NameError, match="save_visual_results"):
+        vb.SelfAttentionGenerator(model).generate_rollout(inp, save_visualization=True)
 
 
 def test_detr_mha_module(golden):

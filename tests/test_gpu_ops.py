@@ -3,11 +3,17 @@
 Tolerance: 1e-5 absolute on relevancy values (BASELINE.json north_star: "within 1e-5 (fp32)"); both sides
 are fp32 and differ only in summation order.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import relevancy_np as onp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import parity  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 ATOL = 1e-5
@@ -35,12 +41,13 @@ def make_layers(seed, L, B, H, N, causal=False, gscale=0.05):
     return attn, grad
 
 
-def close(a, b, atol=ATOL):
-    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-    b = np.asarray(b)
-    assert a.shape == b.shape, (a.shape, b.shape)
-    assert np.array_equal(np.isnan(a), np.isnan(b))
-    np.testing.assert_allclose(a, b, rtol=1e-5, atol=atol, equal_nan=True)
+def close(a, b, atol=ATOL, relmax=parity.RELMAX):
+    """``tests/parity.close`` with this suite's elementwise bound (``atol + 1e-5 |ref|``) PLUS the suite-wide relative bound on the
+    largest error (``relmax`` x max |ref|) and the error record (``profiles/rNN_parity.json``); the record key carries the call
+    site's line and the compared shape, so every distinct comparison of this file is in it."""
+    line = sys._getframe(1).f_lineno
+    shape = "x".join(str(d) for d in np.shape(b)) or "scalar"
+    parity.close(a, b, atol=atol, rtol=1e-5, what="L%d[%s]" % (line, shape), relmax=relmax, rel_always=True)
 
 
 def test_mfma_matmul_asymmetric(ops):

@@ -51,17 +51,25 @@ def test_cfg3_detr_r50_k10_rows_hipgraph_vs_oracle_body():
     ne, nd = len(enc), len(dself)
     a_enc, a_self, a_cross = dt._np(enc), dt._np(dself), dt._np(dcross)
     from oracle import relevancy_np as rn
-    rows = []
+    rows, rows64 = [], []
     for t, c in zip(targets.cpu().tolist(), classes.tolist()):
         assert _is_argmax(logits[0, t, :-1].detach(), c), "device arg-max is not an arg-max of the oracle's logits"
         grads = torch.autograd.grad(logits[0, t, c], enc + dself + dcross, retain_graph=True)
         rows.append(rn.detr_generate_ours_chain(a_enc, dt._np(grads[:ne]), a_self, dt._np(grads[ne:ne + nd]), a_cross,
                                                 dt._np(grads[ne + nd:]), np.array([t]))[0, 0, 0])
-    want = np.stack(rows)
+        rows64.append(rn.detr_generate_ours_rows(a_enc, dt._np(grads[:ne]), a_self, dt._np(grads[ne:ne + nd]), a_cross,
+                                                 dt._np(grads[ne + nd:]), np.array([t]))[0, 0, 0])
+    want, ref64 = np.stack(rows), np.stack(rows64)
     assert out.shape == (1, 1, K, 950)
-    # relative bound: measured 1.4e-4 of the largest entry (7.0e-8 on 5.1e-4, profiles/r04_parity.json) -- two fp32 evaluations that
-    # sum 950-term dot products in different orders through 6 + 6 layers; 3e-4 keeps a 1 % regression out (the old bar let 2 % in)
+    # relative bound vs the fp32 ORACLE: measured 1.4e-4 of the largest entry (7.0e-8 on 5.1e-4, profiles/r04_parity.json).  Who owns
+    # it: the fp64 evaluation of the same schedule on the ORACLE'S OWN slabs (``detr_generate_ours_rows``: float64
+    # inside) is the referee -- the oracle's fp32 matrix route (R_i_i 950 x 950 through 6 layers, then diag(R_ii) - 1) sits ~1e-4 of
+    # the largest entry away from it, the device rows ~2e-5 (both recorded below: profiles/rNN_parity.json).  So the oracle side owns
+    # the error; the device result is held to the suite's 1e-4 against the REFEREE and to 3e-4 against the fp32 oracle.
     parity.close(out[0, 0], want, atol=1e-5, rtol=0.0, what="R_q_i rows (K=10, Ni=950)", relmax=3e-4)
+    parity.close(out[0, 0], ref64, atol=1e-5, rtol=0.0, what="R_q_i rows (K=10, Ni=950) vs the fp64 referee", relmax=1e-4)
+    top = float(np.abs(ref64).max())
+    parity.note("fp32 oracle (matrix route) vs the fp64 referee, same slabs", float(np.abs(want - ref64).max()), None, top)
 
 
 def test_cfg4_lxmert_base_b32_tape_hipgraph_vs_oracle_body():

@@ -55,14 +55,14 @@ def main():
         ("fused kernel G=4 no combine (debug 1)", {"self_chain_algo": 1, "self_chain_groups": 4, "debug_flags": 1}),
         ("cols auto (C=1: the default for one group)", {"self_chain_algo": 5}),
         ("cols C=4", {"self_chain_algo": 5, "self_chain_cols_c": 4}),
-        ("cols C=4 no rotation (debug 2)", {"self_chain_algo": 5, "self_chain_cols_c": 4, "debug_flags": 2}),
+        ("cols C=4 no rotation (debug 16)", {"self_chain_algo": 5, "self_chain_cols_c": 4, "debug_flags": 16}),
         ("cols C=2", {"self_chain_algo": 5, "self_chain_cols_c": 2}),
         ("cols C=3", {"self_chain_algo": 5, "self_chain_cols_c": 3}),
         ("cols C=1", {"self_chain_algo": 5, "self_chain_cols_c": 1}),
         ("cols NB=2", {"self_chain_algo": 5, "self_chain_cols_nb": 2}),
         ("cols NB=3", {"self_chain_algo": 5, "self_chain_cols_nb": 3}),
-        ("cols C=4 stream only (debug 1)", {"self_chain_algo": 5, "self_chain_cols_c": 4, "debug_flags": 1}),
-        ("cols C=4 stream only, no rotation (debug 3)", {"self_chain_algo": 5, "self_chain_cols_c": 4, "debug_flags": 3}),
+        ("cols C=4 stream only (debug 4)", {"self_chain_algo": 5, "self_chain_cols_c": 4, "debug_flags": 4}),
+        ("cols C=4 stream only, no rotation (debug 20)", {"self_chain_algo": 5, "self_chain_cols_c": 4, "debug_flags": 20}),
     ]
     for (L, H, N, name, sets) in [(12, 8, 77, "txt", 3), (12, 12, 50, "img", 4)]:
         slabs = []

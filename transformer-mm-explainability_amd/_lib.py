@@ -9,9 +9,12 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmmx_hip.so")
+# MMX_LIB_PATH: load another build of the SAME library (the host-AddressSanitizer build csrc/asan/libmmx_hip_asan.so in
+# tests/test_abi.py); never a fallback -- the file must exist and pass the ABI-version check like the default one
+LIB_PATH = os.environ.get("MMX_LIB_PATH") or os.path.join(_HERE, "csrc", "libmmx_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mmx_relevancy.h")
 
+ABI_VERSION = 2                 # == MMX_ABI_VERSION of include/mmx_relevancy.h (2: the round-5 schedule signature)
 MMX_F32, MMX_F16, MMX_BF16 = 0, 1, 2
 MMX_ENOTSUP = -95               # shape / view outside what the kernels support (include/mmx_relevancy.h)
 MMX_ATTN_IO_BF16 = 0x200        # backward: bf16 dO in, bf16 dq / dk / dv out (with MMX_ATTN_MMA_BF16)
@@ -120,8 +123,9 @@ def lib():
         for name, (res, args) in _PROTOTYPES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.mmx_abi_version() != 1:
-            raise MMXError("libmmx_hip.so ABI version %d != 1" % handle.mmx_abi_version())
+        if handle.mmx_abi_version() != ABI_VERSION:
+            raise MMXError("libmmx_hip.so ABI version %d != %d (stale build? `make -C transformer-mm-explainability_amd/csrc`)"
+                           % (handle.mmx_abi_version(), ABI_VERSION))
         _lib = handle
     return _lib
 

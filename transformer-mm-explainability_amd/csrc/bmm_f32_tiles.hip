@@ -200,6 +200,10 @@ bool bmm_f32_tiles_try(const float* A, const float* B, const float* Cin, float* 
     if (wgs < device_cu_count()) return false;
     bmm_f32_tiles_kernel<64, 64, 3><<<dim3(static_cast<unsigned>(wgs)), 256, 0, s>>>(A, B, Cin, C, M, N, K, sa, sb, sc, nan_to_zero,
                                                                                     cin_is_row);
+    // a failed launch is reported, not swallowed: the error stays pending (peek) for the caller's MMX_LAUNCH_CHECK, which turns it
+    // into the entry point's return code; the message names this kernel
+    const hipError_t e = hipPeekAtLastError();
+    if (e != hipSuccess) hip_fail(e, "bmm_f32_tiles_kernel");
     return true;
 }
 

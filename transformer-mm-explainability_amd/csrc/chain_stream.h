@@ -71,10 +71,12 @@ __device__ __forceinline__ void chain_stream_wave(const ChainStreamGeom& gm, int
         const int i = k / HB, hb = k - i * HB;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float w = (live && hb * 4 + u < H) ? 1.f : 0.f;      // heads in ascending order: the sequential sum
+            // heads in ascending order: the sequential sum.  A padding head (H % 4 != 0) or the dead tail batch re-loads the clamped
+            // head H - 1: it is SELECTED away, not multiplied by 0 (inf * 0 would plant a NaN where the reference has +inf)
+            const bool on = live && hb * 4 + u < H;
             const f32x4 x = __builtin_bit_cast(f32x4, gv[u]) * __builtin_bit_cast(f32x4, av[u]);
-            s[0] += relu_nan(x[0]) * w; s[1] += relu_nan(x[1]) * w;
-            s[2] += relu_nan(x[2]) * w; s[3] += relu_nan(x[3]) * w;
+            s[0] += on ? relu_nan(x[0]) : 0.f; s[1] += on ? relu_nan(x[1]) : 0.f;
+            s[2] += on ? relu_nan(x[2]) : 0.f; s[3] += on ? relu_nan(x[3]) : 0.f;
         }
         if (live && hb == HB - 1) {
             sink(item_layer(i), item_chunk(i), f32x4{s[0] / fH, s[1] / fH, s[2] / fH, s[3] / fH});
@@ -112,6 +114,9 @@ __device__ __forceinline__ void chain_stream_deliver(float* img, int S, unsigned
             if (++cc == N) { cc = 0; ++row; }
         }
     }
+    // the image stores above must be ISSUED before the count that announces them: the LDS executes a wave's operations in issue
+    // order, this fence (no instruction, no waitcnt) keeps the compiler from moving a store below the atomic
+    __atomic_signal_fence(__ATOMIC_RELEASE);
     if (lane == 0) {
         const int p0 = (cidx - lane) * 4, p1 = min(NN, p0 + 256);
         const int t0 = static_cast<int>(__umulhi(static_cast<unsigned>(p0), row_magic)) >> 4;

@@ -977,7 +977,12 @@ extern "C" int mmx_rollout_chain(const void* const* layers, int n_layers, int B,
 
 // ----------------------------------------------------------------------------------------- self chain
 static int nt_for(int N) { return (N + 15) / 16; }
+// option "debug_flags" (profiling only), ONE meaning per bit whatever kernel the dispatcher picks:
+//   1  return before the hand-off / combine (fused + groups kernels; the cols kernel has neither and ignores it)
+//   4  matrix waves skip the MFMAs (all three kernels)          8  groups kernel: take the ticket, skip the combine
+//   16 cols kernel: no block rotation
 static int g_debug_flags = 0;
+static int cols_debug_flags(int g) { return ((g & 4) ? 1 : 0) | ((g & 16) ? 2 : 0); }   // -> relevancy_chain_cols.hip's own bits
 static int g_chain_pipe = 4;     // option "self_chain_pipe": software-pipelined stream waves of the fused chain (fp32 slabs)
 static int g_chain_nt = 1;       // option "self_chain_nt": nt cache policy on the read-once slab loads of the pipelined stream waves
                                  // (default since round 4: text tower 85.8 -> 82.0 us, image 65.5 -> 63.8 us inside the replayed step)
@@ -1147,7 +1152,7 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
 
     if (use_cols(n_layers, B, H, N, M, dtype))
         return self_chain_cols_launch(attn_layers, grad_layers, n_layers, B, H, N, attn_batch_stride, R_init_dev, R_out_dev, g_chain_nt,
-                                      g_debug_flags, s);
+                                      cols_debug_flags(g_debug_flags), s);
     if (nt <= 8 && M == 0) {
         ChainArgs args;
         memset(&args, 0, sizeof(args));

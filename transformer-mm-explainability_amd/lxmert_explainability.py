@@ -62,6 +62,9 @@ def _backward_on_answer(model_usage, input, index, use_lrp=False, backward=True)
 
 class GeneratorOurs:
     def __init__(self, model_usage, save_visualization=False):
+        """``save_visualization`` is STORED and never read, exactly as in the reference (lxmert/lxmert/src/ExplanationGenerator.py:57-59,
+        :216-218, :369-371 assign it; no method of that file tests it or writes an image) -- the images of the LXMERT notebook are drawn
+        by the notebook itself from the returned ``R_t_i``.  (VisualBERT's generators DO act on their flag: ``visualbert_explainability``.)"""
         self.model_usage = model_usage
         self.save_visualization = save_visualization
         self.fused = True   # one-launch schedule kernel when T, I <= 48; False forces the per-rule kernels

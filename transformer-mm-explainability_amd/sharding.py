@@ -78,7 +78,7 @@ def length_buckets(lengths, max_batch):
     return out
 
 
-def gather_per_sample(local, total, fill=float("nan")):
+def gather_per_sample(local, total, fill=float("nan"), collective_at_world_one=False):
     """All-gather per-sample rows back into the ORIGINAL (unsharded) order.
 
     ``local``: ``[n_local, ...]`` results of this rank's ``shard_indices`` slice, in that order.  ``total``: number of
@@ -86,8 +86,8 @@ def gather_per_sample(local, total, fill=float("nan")):
     ``ceil(total / world)`` rows with ``fill`` and the padding is dropped after the gather.
     """
     rank, world_size = world()
-    if world_size == 1:
-        return local
+    if world_size == 1 and not (collective_at_world_one and dist.is_available() and dist.is_initialized()):
+        return local          # (``collective_at_world_one``: the RCCL smoke test runs the padded all-gather in a world-size-1 group)
     per = (total + world_size - 1) // world_size
     pad = torch.full((per,) + tuple(local.shape[1:]), fill, dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local

@@ -70,21 +70,24 @@ def scope(workload):
             finally:
                 _DEPTH[0] -= 1
             return
+        # the state capture and `enable` (a file read) run INSIDE the try whose finally resets the depth: an exception in the
+        # prologue must not leave _DEPTH at 1 (every later scope would take the nested branch and never restore anything)
         _DEPTH[0] = 1
-        was = tun.is_enabled()
-        was_tuning = _flag(tun, "tuning_is_enabled")
-        was_record = _flag(tun, "record_untuned_is_enabled")
-        if workload not in _LOADED:
-            _LOADED[workload] = enable(workload)
-        else:
-            tun.enable(True)
-            tun.tuning_enable(False)
+        saved = None
         try:
+            saved = (tun.is_enabled(), _flag(tun, "tuning_is_enabled"), _flag(tun, "record_untuned_is_enabled"))
+            if workload not in _LOADED:
+                _LOADED[workload] = enable(workload)
+            else:
+                tun.enable(True)
+                tun.tuning_enable(False)
             yield _LOADED[workload]
         finally:
             _DEPTH[0] = 0
-            if was_tuning is not None:
-                tun.tuning_enable(was_tuning)
-            if was_record is not None and hasattr(tun, "record_untuned_enable"):
-                tun.record_untuned_enable(was_record)
-            tun.enable(was)
+            if saved is not None:
+                was, was_tuning, was_record = saved
+                if was_tuning is not None:
+                    tun.tuning_enable(was_tuning)
+                if was_record is not None and hasattr(tun, "record_untuned_enable"):
+                    tun.record_untuned_enable(was_record)
+                tun.enable(was)

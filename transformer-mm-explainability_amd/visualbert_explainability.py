@@ -37,6 +37,17 @@ def _backward_on_answer(model, input, index, use_lrp=False, backward=True):
         model.relprop(one_hot.detach().clone(), alpha=1)
 
 
+def save_visual_results(*_args, **_kwargs):
+    """``save_visualization=True`` / ``save_visualization_per_token=True``: the reference calls ``save_visual_results(input, scores,
+    method_name=...)`` here (VisualBERT/mmf/models/transformers/backends/ExplanationGenerator.py:58-66, :99-107, :129-131, :164-166,
+    :182-184, :213-215) -- a function that file neither defines nor imports, so the reference itself raises ``NameError`` at this
+    point, after the scores are computed.  This package writes no images either (cv2 is not a dependency); it fails the same way,
+    loudly, instead of accepting the flag and doing nothing."""
+    raise NameError("name 'save_visual_results' is not defined -- the reference's ExplanationGenerator.py calls it without defining "
+                    "it; call the generator with save_visualization=False and render the returned scores yourself "
+                    "(transformer_mm_explainability_amd.postprocess)")
+
+
 class SelfAttentionGenerator:
     def __init__(self, model):
         self.model = model
@@ -55,6 +66,8 @@ class SelfAttentionGenerator:
         cls_index = input["input_mask"].sum(1) - 2
         cls_per_token_score = ops.relevancy_chain_row(attn, grad, 1, cls_index)          # R[cls_index], [1, N]
         cls_per_token_score[:, cls_index] = 0
+        if save_visualization or save_visualization_per_token:
+            save_visual_results(input, cls_per_token_score, method_name='generate_ours')
         return cls_per_token_score
 
     def generate_ours_batch(self, input, index=None, _n_text=None):
@@ -109,6 +122,8 @@ class SelfAttentionGenerator:
         cls_index = input["input_mask"].sum(1) - 2
         cls_per_token_score = rollout[0, cls_index]
         cls_per_token_score[:, cls_index] = 0
+        if save_visualization:
+            save_visual_results(input, cls_per_token_score, method_name='generate_rollout')
         return cls_per_token_score
 
     def generate_raw_attn(self, input, save_visualization=False):
@@ -118,6 +133,8 @@ class SelfAttentionGenerator:
         cls_index = input["input_mask"].sum(1) - 2
         cls_per_token_score = cam[0, cls_index]
         cls_per_token_score[:, cls_index] = 0
+        if save_visualization:
+            save_visual_results(input, cls_per_token_score, method_name='generate_raw_attn')
         return cls_per_token_score
 
     def generate_attn_gradcam(self, input, index=None, save_visualization=False):
@@ -129,6 +146,8 @@ class SelfAttentionGenerator:
         cls_index = input["input_mask"].sum(1) - 2
         cls_per_token_score = cam[0, cls_index]
         cls_per_token_score[:, cls_index] = 0
+        if save_visualization:
+            save_visual_results(input, cls_per_token_score, method_name='generate_attn_gradcam')
         return cls_per_token_score
 
     def generate_transformer_att(self, input, index=None, start_layer=0, save_visualization=False,
@@ -143,6 +162,8 @@ class SelfAttentionGenerator:
         cls_index = input["input_mask"].sum(1) - 2
         cls_per_token_score = rollout[0, cls_index]
         cls_per_token_score[:, cls_index] = 0
+        if save_visualization or save_visualization_per_token:
+            save_visual_results(input, cls_per_token_score, method_name='generate_transformer_att')
         return cls_per_token_score
 
     def generate_partial_lrp(self, input, index=None, save_visualization=False):
@@ -153,6 +174,8 @@ class SelfAttentionGenerator:
         cls_index = input["input_mask"].sum(1) - 2
         cls_per_token_score = cam[0, cls_index]
         cls_per_token_score[:, cls_index] = 0
+        if save_visualization:
+            save_visual_results(input, cls_per_token_score, method_name='generate_partial_lrp')
         return cls_per_token_score
 
 
