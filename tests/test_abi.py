@@ -115,18 +115,18 @@ print("ASAN_SWEEP_OK", swept)
 
 
 def test_argument_validation_under_host_asan():
-    """The host side of the C-ABI under AddressSanitizer (``make -C csrc asan-host``: host code instrumented, gfx950 code objects as
+    """The host side of the C-ABI under AddressSanitizer (``make -C csrc -f Makefile.asan asan-host``: host code instrumented, gfx950 code objects as
     in the product build): every entry point with null / zero arguments, option parsing, the workspace queries over the shape
     space, and -- where no GPU is visible -- full calls on made-up device addresses, which exercise the pointer tables, ``ChainArgs``
     and the dispatcher up to the (failing) launch.  Any heap / stack / global overflow or use-after-free in the wrappers aborts the
-    child with a report.  GPU-side ASAN (xnack+ code objects, ``HSA_XNACK=1``) is refused by the GPU pool: tests/test_gpu_stress.py
+    child with a report.  GPU-side ASAN (XNACK-on code objects and runtime mode) is refused by the GPU pool: tests/test_gpu_stress.py
     covers the device side from the outside."""
     import subprocess
     import sys
     csrc = os.path.join(ROOT, "transformer-mm-explainability_amd", "csrc")
     so, rt = os.path.join(csrc, "asan", "libmmx_hip_asan.so"), os.path.join(csrc, "asan", "runtime_path.txt")
     if not os.path.exists(so):
-        build = subprocess.run(["make", "-C", csrc, "-j4", "asan-host"], capture_output=True, text=True)
+        build = subprocess.run(["make", "-C", csrc, "-f", "Makefile.asan", "-j4", "asan-host"], capture_output=True, text=True)
         assert build.returncode == 0, build.stderr[-2000:]
     runtime = open(rt).read().strip()
     assert os.path.exists(runtime), runtime

@@ -257,7 +257,7 @@ def test_bmm_tiles_kernel(chain_options, B, M, N, K, cin, nan):
 def attn_options(ops):
     """Options of the attention kernels are process-global: whatever a test sets is put back, also when it fails."""
     yield ops
-    for key, value in (("attn_head", 1), ("attn_stream", 1), ("attn_fwd_split", 1), ("attn_bf16_v3", 2)):
+    for key, value in (("attn_head", 1), ("attn_stream", 1), ("attn_fwd_split", 1), ("attn_bf16_v3", 3)):
         ops.set_option(key, value)
 
 

@@ -381,7 +381,8 @@ def test_bf16_backward_third_generation_equals_second(N, B, need):
     the shared operands prepared once per call, padded / transposed probability images, 4 waves per SIMD) runs the SAME
     tile arithmetic in the SAME order as the second generation (``attention_bf16.hip``, pinned on the oracle above), so dq /
     dk / dv (bf16) agree up to isolated last-place flips and the carried relevancy row to 1e-6 (``attn_bf16_v3`` = 0 is the
-    second generation, 2 the default)."""
+    second generation, 2 the third-generation pair, 3 -- the default since round 6 -- the third-generation query side with the
+    fourth-generation key side ``attn_bwd_kv_v4_kernel``)."""
     from transformer_mm_explainability_amd import ops
     H, D = 4, 64
     g = torch.Generator().manual_seed(N * 7 + B)
@@ -393,7 +394,7 @@ def test_bf16_backward_third_generation_equals_second(N, B, need):
     rel = torch.rand(B, N, generator=g).cuda()
     results = {}
     try:
-        for mode in (0, 2):
+        for mode in (0, 2, 3):
             ops.set_option("attn_bf16_v3", mode)
             out = torch.full((B, N, 3, H, D), float("nan"), device="cuda", dtype=torch.bfloat16) if need else None
             res = ops.attn_capture_bwd(q, k, v, probs, d_o, None, D ** -0.5, batch=B, o=o, need_dqkv=need, mma_bf16=True,
@@ -401,10 +402,10 @@ def test_bf16_backward_third_generation_equals_second(N, B, need):
             torch.cuda.synchronize()
             results[mode] = (out, res[3])
     finally:
-        ops.set_option("attn_bf16_v3", 2)
+        ops.set_option("attn_bf16_v3", 3)
     want_out, want_rel = results[0]
     assert torch.isfinite(want_rel).all()
-    for mode in (2,):
+    for mode in (2, 3):
         got_out, got_rel = results[mode]
         if need:
             assert torch.isfinite(got_out.float()).all()
@@ -413,6 +414,8 @@ def test_bf16_backward_third_generation_equals_second(N, B, need):
             diff = (got_out.float() - want_out.float()).abs()
             top = float(want_out.float().abs().max())
             assert float(diff.max()) <= 2.0 ** -7 * top, (mode, float(diff.max()), top)        # <= one bf16 ulp of the largest entries
-            assert float((diff > 0).float().mean()) < 0.01, (mode, float((diff > 0).float().mean()))
+            # mode 3 (round 6: key side on v_mfma_f32_32x32x16_bf16, 16 query rows per instruction instead of 32): the SAME bf16
+            # products, fp32-accumulated in another grouping -> more last-place flips of the bf16 results, never more than one ulp
+            assert float((diff > 0).float().mean()) < (0.01 if mode == 2 else 0.05), (mode, float((diff > 0).float().mean()))
         # (the relevancy sum is fp32 VALU work: same terms, but the compiler may contract / order the fmas differently)
-        assert float((got_rel - want_rel).abs().max()) <= 1e-6 * float(want_rel.abs().max()), mode
+        assert float((got_rel - want_rel).abs().max()) <= (1e-6 if mode == 2 else 3e-6) * float(want_rel.abs().max()), mode

@@ -1,7 +1,7 @@
 """-m gpu: randomised stress + replay bit-stability of the hand-synchronised kernels.
 
-GPU AddressSanitizer and XNACK builds are refused on the pool this suite runs on (``gpurun`` turns ``xnack+`` code objects and
-``HSA_XNACK=1`` down), so what a sanitizer pass would look for is approached from the outside instead:
+GPU AddressSanitizer and XNACK builds are refused on the pool this suite runs on (``gpurun`` turns XNACK-on code objects and the
+XNACK runtime mode down), so what a sanitizer pass would look for is approached from the outside instead:
   * seeded random shapes (>= 50 per kernel family) through every dispatch route of the chain kernels and the tiled product --
     strict-order routes bit-identical to each other, re-associated (layer-group) routes within 1e-5, the product vs fp64;
   * the same launches under UNEVEN load (a copy stream hammering HBM on a side stream while the chain runs), the regime in which a
@@ -10,7 +10,7 @@ GPU AddressSanitizer and XNACK builds are refused on the pool this suite runs on
     every replay bit-identical to the first;
   * guard bands: outputs live inside larger NaN-filled allocations and the bands must come back untouched (a store past the end),
     inputs are followed by NaN poison that must not reach the result (a load past the end that is used).
-The C-ABI argument checks run under the host AddressSanitizer on the CPU (``make -C csrc asan-host``, tests/test_abi.py)."""
+The C-ABI argument checks run under the host AddressSanitizer on the CPU (``make -C csrc -f Makefile.asan asan-host``, tests/test_abi.py)."""
 import numpy as np
 import pytest
 import torch

@@ -265,10 +265,12 @@ def leg_cfg5(kernel_time_us, reps=3, batch=128):
     us = kernel_time_us(attn_layer, 5, torch.cuda.current_stream())
     fl, fl_exec = cfg5_step_flops(batch), cfg5_step_flops(batch, executed=True)
     step_tf = fl["total"] / (ms * 1e-3) / 1e12
-    kernel = _mfma("attn_bwd_q_v3_kernel + attn_bwd_kv_v3_kernel (+ the two prep kernels; one image-tower layer, B = 128, "
+    kernel = _mfma("attn_bwd_q_v3_kernel + attn_bwd_kv_v4_kernel (+ the two prep kernels; one image-tower layer, B = 128, "
                    "row-relevancy mode, attention_bf16_v3.hip)", attn_flops["algorithmic"], us, BF16_MFMA_PEAK_TFLOPS,
-                   "numerator = ALGORITHMIC FLOPs (4 products); the pair executes 5 (dP in both kernels): executed_* beside it.  Bound by "
-                   "L2 -> CU movement of the shared operands and of dO, not by the matrix cores: profiles/r04_cfg5_counters_mem.txt")
+                   "numerator = ALGORITHMIC FLOPs (4 products); the pair executes 5 (dP in both kernels: the deterministic two-kernel "
+                   "split, no atomics on dQ): executed_* beside it.  Bound by VALU issue of the elementwise work between the products "
+                   "(relevancy partial, dS, bf16 packing: ~12 VALU instructions per 32-cycle MFMA), not by the matrix cores: "
+                   "profiles/r06_cfg5_probe.txt")
     kernel["executed_flop_per_launch"] = int(attn_flops["executed"])
     kernel["executed_achieved"] = round(attn_flops["executed"] / us / 1e6, 1)
     kernel["executed_frac"] = round(attn_flops["executed"] / us / 1e6 / BF16_MFMA_PEAK_TFLOPS, 4)

@@ -39,7 +39,9 @@ typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;
 
-int g_attn_bf16_v3 = 2;       // 0: off (the call falls through to the second generation, attention_bf16.hip: the A / B arm of
+int g_attn_bf16_v3 = 3;       // 3 (default, round 6): query side as below, key side attn_bwd_kv_v4_kernel (32 keys per wave, 32x32x16 MFMA,
+                              // transpose reads) | 2: the third-generation pair |
+                              // 0: off (the call falls through to the second generation, attention_bf16.hip: the A / B arm of
                               // test_bf16_backward_third_generation_equals_second), non-zero: 8-wave workgroups, 4 waves / SIMD on both kernels
                               // (measured and removed in round 5: 4-wave workgroups; a fourth-generation key side with several key
                               // blocks per wave -- 882-980 us vs 780 us per layer pair, profiles/r04_cfg5_probe.txt)
@@ -47,6 +49,7 @@ int g_attn_bf16_v3 = 2;       // 0: off (the call falls through to the second ge
 struct V3Images {
     const bf16_t *Vb, *KbT, *QbT, *Pq, *PT;
     int Np;
+    const bf16_t *Qb, *PT32;      // fourth-generation key side: (scale q) rows, row-major like Vb; P^T blocked for 32-key waves
 };
 
 __device__ __forceinline__ unsigned pk2(float lo, float hi) {      // two fp32 -> packed bf16 pair, round to nearest even
@@ -74,12 +77,12 @@ __device__ __forceinline__ u32x2v column_of(const u32x2v (&rows)[4], int dd) {
 // ======================================================================================================= prep kernels
 // which = 0: Vb (row-major), 1: KbT, 2: QbT (times scale).  One workgroup per (64-row tile, head, which); fp32 in, 16-byte
 // aligned rows (checked by the caller), rows >= N are written as zeros.
-__global__ __launch_bounds__(256) void prep_qkv_kernel(const AttnBwdArgs a, bf16_t* Vb, bf16_t* KbT, bf16_t* QbT, int Np) {
+__global__ __launch_bounds__(256) void prep_qkv_kernel(const AttnBwdArgs a, bf16_t* Vb, bf16_t* KbT, bf16_t* QbT, bf16_t* Qb, int Np) {
     const int tid = threadIdx.x, row0 = blockIdx.x * kT, h = blockIdx.y, which = blockIdx.z;
     const int r4 = 4 * (tid >> 4), c = 4 * (tid & 15);
     const float* base = which == 0 ? a.v + h * a.vs.sh : which == 1 ? a.k + h * a.ks.sh : a.q + h * a.qs.sh;
     const int64_t sn = which == 0 ? a.vs.sn : which == 1 ? a.ks.sn : a.qs.sn;
-    const float mul = which == 2 ? a.scale : 1.f;
+    const float mul = which >= 2 ? a.scale : 1.f;                      // which == 3: (scale q) rows, row-major (4th-generation key side)
     u32x2v rows[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -90,10 +93,11 @@ __global__ __launch_bounds__(256) void prep_qkv_kernel(const AttnBwdArgs a, bf16
             rows[e] = u32x2v{pk2(x[0] * mul, x[1] * mul), pk2(x[2] * mul, x[3] * mul)};
         }
     }
-    if (which == 0) {
+    if (which == 0 || which == 3) {
+        bf16_t* dst = which == 0 ? Vb : Qb;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            *reinterpret_cast<u32x2v*>(Vb + (static_cast<int64_t>(h) * Np + row0 + r4 + e) * kD + c) = rows[e];
+            *reinterpret_cast<u32x2v*>(dst + (static_cast<int64_t>(h) * Np + row0 + r4 + e) * kD + c) = rows[e];
     } else {
         bf16_t* out = which == 1 ? KbT : QbT;
         // transposed images, staging-blocked: the 4 (d) x 4 (rows) block a staging thread moves per tile is 32 contiguous bytes
@@ -112,9 +116,17 @@ __host__ __device__ __forceinline__ int64_t p_block_offset(int h, int rb, int ct
     return ((static_cast<int64_t>(h) * (Np / 16) + rb) * (Np / kT) + ct) * (2 * 64 * 8);
 }
 
-// P slab [H][N][N] (16-bit elements, any alignment) -> Pq (blocked image of P, zero padded) and PT (blocked image of P^T)
+// Fourth-generation key side (32 keys per wave, v_mfma_f32_32x32x16_bf16): block (kb = key / 32, qt = query / 64, pp) holds, for
+// lane = 32 hi + i, the 16 elements P[64 qt + 32 pp + (r & 3) + 8 (r >> 2) + 4 hi][32 kb + i], r = 0 .. 15 -- the lane's entries of
+// the 32 x 32 accumulator tile dP[query][key], and at the same time (r = 8 m + j) the two bf16x8 A operands of dV = P^T . dO.
+__host__ __device__ __forceinline__ int64_t p32_block_offset(int h, int kb, int qt, int Np) {
+    return ((static_cast<int64_t>(h) * (Np / 32) + kb) * (Np / kT) + qt) * (2 * 64 * 16);
+}
+
+// P slab [H][N][N] (16-bit elements, any alignment) -> Pq (blocked image of P, zero padded) and PT (blocked image of P^T; `wide`:
+// in the 32-key form p32_block_offset describes)
 __global__ __launch_bounds__(256) void prep_p_kernel(const bf16_t* __restrict__ P, bf16_t* __restrict__ Pq, bf16_t* __restrict__ PT,
-                                                     int N, int Np) {
+                                                     int N, int Np, int wide) {
     __shared__ bf16_t tile[kT][kT + 2];
     const int tid = threadIdx.x, k0 = blockIdx.x * kT, q0 = blockIdx.y * kT, h = blockIdx.z;
     const bf16_t* src = P + static_cast<int64_t>(h) * N * N;
@@ -141,7 +153,16 @@ __global__ __launch_bounds__(256) void prep_p_kernel(const bf16_t* __restrict__ 
         const int64_t oq = p_block_offset(h, q0 / 16 + rbl, k0 / kT, Np) + (pp * 64 + lane) * 8;
         const int64_t ot = p_block_offset(h, k0 / 16 + rbl, q0 / kT, Np) + (pp * 64 + lane) * 8;
         *reinterpret_cast<u32x4v*>(Pq + oq) = *reinterpret_cast<const u32x4v*>(wq);
-        *reinterpret_cast<u32x4v*>(PT + ot) = *reinterpret_cast<const u32x4v*>(wt);
+        if (!wide) *reinterpret_cast<u32x4v*>(PT + ot) = *reinterpret_cast<const u32x4v*>(wt);
+    }
+    if (wide) {                                                    // 2 key blocks x 2 halves x 64 lanes: one 32-byte record per thread
+        const int kbl = tid >> 7, pp = (tid >> 6) & 1, lane = tid & 63, i = lane & 31, hi = lane >> 5;
+        bf16_t w[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[r] = tile[32 * pp + (r & 3) + 8 * (r >> 2) + 4 * hi][32 * kbl + i];
+        u32x4v* dst = reinterpret_cast<u32x4v*>(PT + p32_block_offset(h, k0 / 32 + kbl, q0 / kT, Np) + (pp * 64 + lane) * 16);
+        dst[0] = *reinterpret_cast<const u32x4v*>(w);
+        dst[1] = *reinterpret_cast<const u32x4v*>(w + 8);
     }
 }
 
@@ -267,7 +288,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_q_v3_kernel
 
     // NW == 4: every thread stages a block of V and one of K; NW == 8: waves 0-3 stage V, waves 4-7 K (ONE block per set)
     RawBlock rs[2][NOP];
-    u32x4v ps[2][2];                                                  // [set][half pp]: the words of sub-tiles 2 pp, 2 pp + 1
+    // [half pp]: the words of sub-tiles 2 pp, 2 pp + 1.  The products read p_cur, which is only ever COPIED (top of `body`) out of
+    // p_nxt, the destination of the loads: with the words loaded straight into the registers the MFMAs read (rounds 3-5: two sets,
+    // two tiles ahead) hipcc's wait-count pass -- which merges the pending-load state of the prologue, the early exits and the
+    // exec-masked staging branches -- put s_waitcnt vmcnt(1) / vmcnt(0) INSIDE the product block, i.e. every tile waited for the
+    // operand fetch it had just issued (round 6, found in the ISA: the query side's 48 % SQ_WAIT_ANY of profiles/r05_cfg5_probe.txt)
+    u32x4v p_cur[2], p_nxt[2];
     auto fetch = [&](int kt, auto set) {
         constexpr int S = decltype(set)::value;
         if constexpr (NW == 4) {
@@ -295,6 +321,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_q_v3_kernel
     // tile kt: LDS buffer / register set / probability set kt & 1 (= PAR)
     auto body = [&](int kt, auto par) {
         constexpr int PAR = decltype(par)::value;
+        p_cur[0] = p_nxt[0];
+        p_cur[1] = p_nxt[1];
+        if (kt + 1 < ntiles) p_issue(p_nxt, kt + 1);                   // consumed one iteration from now
         if (ABL != 2 && ABL != 6 && kt + 2 < ntiles) fetch(kt + 2, par);   // this set's tile kt went to LDS one iteration ago
         if (ABL != 2 && ABL != 6 && kt + 1 < ntiles) stage(1 - PAR, std::integral_constant<int, 1 - PAR>{});   // waits for THAT set only
         const bf16_t* Vcur = Vt + PAR * kT * kLR;
@@ -316,8 +345,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_q_v3_kernel
                         dpT[hh] = mfma16x16x32_bf16(op, dob[s][pr], dpT[hh]);
                     }
                 // dS[q][key] = P * (dP - delta) for keys 16 t + 4 g + r, t = 2 pp + hh (scale_mode Q_FIRST: no further factor)
-                dsb[s] = pack8(unpack4(u32x2v{ps[PAR][pp][0], ps[PAR][pp][1]}) * (dpT[0] - delta[s]),
-                               unpack4(u32x2v{ps[PAR][pp][2], ps[PAR][pp][3]}) * (dpT[1] - delta[s]));
+                dsb[s] = pack8(unpack4(u32x2v{p_cur[pp][0], p_cur[pp][1]}) * (dpT[0] - delta[s]),
+                               unpack4(u32x2v{p_cur[pp][2], p_cur[pp][3]}) * (dpT[1] - delta[s]));
                 // the V operands are RE-READ from LDS for the next sample (16 registers the budget of 4 waves / SIMD does not
                 // have): the clobber keeps the compiler from carrying them over
                 asm volatile("" ::: "memory");
@@ -330,14 +359,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_q_v3_kernel
             }
             __builtin_amdgcn_sched_barrier(0);                        // keep the two halves apart: bounds the live registers
         }
-        if (kt + 2 < ntiles) p_issue(ps[PAR], kt + 2);                 // consumed two iterations from now
         lds_barrier();
     };
 
     fetch(0, std::integral_constant<int, 0>{});
     if (ntiles > 1) fetch(1, std::integral_constant<int, 1>{});
-    p_issue(ps[0], 0);
-    if (ntiles > 1) p_issue(ps[1], 1);
+    p_issue(p_nxt, 0);
     stage(0, std::integral_constant<int, 0>{});
     __syncthreads();
     for (int kt = 0; kt < ntiles; kt += 2) {
@@ -537,6 +564,204 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_bwd_kv_v3_kerne
     }
 }
 
+// ===================================================================================================== key side, 4th generation
+// The same three products per query tile (dP recomputed, dV = P^T . dO, dK = dS^T . Q) on v_mfma_f32_32x32x16_bf16 with 32 keys
+// per wave: an LDS operand (a [32 x 16] slice of the dO / Q tile) now feeds a 32 x 32 accumulator tile instead of 16 x 16, i.e.
+// HALF the LDS operand bytes per FLOP -- the third generation's key side spent more LDS-array cycles per tile (16 waves x 160) than
+// matrix-pipe cycles (profiles/r05_cfg5_probe.txt: 30 % of the wave cycles issuing, 38 % waiting on an instruction pipe).  The
+// "contract over the query index" operands are read with ds_read_b64_tr_b16 straight from the ROW-MAJOR dO / Q tiles (a 16-lane
+// group reads a 4-row x 16-column block and lane c gets column c's four rows): no transposed LDS images (the third generation
+// staged dO twice and Q pre-transposed), no v_perm transposes in the staging waves.  Lane maps (tools/hip/tr16_probe.hip checks
+// them on the hardware): A[i = l & 31][k = 8 (l >> 5) + j], B[k = 8 (l >> 5) + j][n = l & 31], C[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
+// 4 waves = 128 keys per workgroup, <= 256 registers: two workgroups per CU.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 mfma32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+// What was measured around this kernel in round 6 and NOT kept (in-process A / B on one MI355X, rocprofv3 kernel trace of
+// tools/probe_attn_v3.py, profiles/r06_cfg5_probe.txt): unpadded 128-byte rows with XOR-swizzled 16-byte slots (conflict-free for both
+// read patterns: SQ_LDS_BANK_CONFLICT 10.5 % -> 2.5 % of the wave cycles, time +/- 0), clamp(x, 0) as (x + |x|) / 2, dS as
+// fma(-p, delta, p dP), and a half-tile software pipeline over three LDS buffers (dP of the next half issued ahead of the VALU work of
+// the current one, the barrier between the halves): 487-540 us against this form's 455 us and the third generation's 500 us -- the
+// kernel is bound by VALU issue (~12 VALU instructions per 32-cycle MFMA: SQ_ACTIVE_INST_VALU 29 % of the wave cycles at two waves
+// per SIMD), not by the matrix pipe or the LDS, and none of those moves VALU instructions off the critical path.
+// B operand "rows of the tile are the contraction index" for k-slots (hi, j) <-> tile row 32 pp + 16 m + 8 (j >> 2) + 4 hi + (j & 3),
+// column n = 32 db + (l & 31): two transpose reads of 4 rows x 16 columns per 16-lane group
+__device__ __forceinline__ int tr_lane_base(int lane) {
+    const int a = lane & 15, gq = lane >> 4;
+    return (4 * (gq >> 1) + (a >> 2)) * kLR + 16 * (gq & 1) + 4 * (a & 3);
+}
+__device__ __forceinline__ bf16x8 tr_operand(const bf16_t* tile_lane, int pp, int m, int db) {
+    typedef __attribute__((address_space(3))) bf16x4v* lds_tr_ptr;
+    const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr_ptr)(tile_lane + (32 * pp + 16 * m) * kLR + 32 * db));
+    const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_tr_ptr)(tile_lane + (32 * pp + 16 * m + 8) * kLR + 32 * db));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+template <bool DKV>
+__global__ __launch_bounds__(256, 2) void attn_bwd_kv_v4_kernel(const AttnBwdArgs a, const V3Images im) {
+    constexpr int R = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* dOr = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* Qr = dOr + 2 * kT * kLR;
+    float* dl = reinterpret_cast<float*>(Qr + 2 * kT * kLR);
+    float* vl = dl + 2 * kT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, hi = lane >> 5;
+    const int nkt = (a.Nk + R - 1) / R;
+    const int wg = xcd_contiguous_id(blockIdx.x, gridDim.x);
+    const int b = (wg / nkt) % a.B, h = wg / (nkt * a.B);
+    const int kw = (wg % nkt) * R + wave * 32;
+    const int key = kw + i;
+    const bool key_ok = key < a.Nk;
+    const bool wave_live = __builtin_amdgcn_readfirstlane(kw) < a.Nk;
+    const int64_t head = static_cast<int64_t>(b) * a.H + h;
+    const bf16_t* pcol = im.PT32 + p32_block_offset(h, min(kw / 32, im.Np / 32 - 1), 0, im.Np) + 16 * lane;
+    const bf16_t* qimg = im.Qb + static_cast<int64_t>(h) * im.Np * kD;
+    const bf16_t* dobase = reinterpret_cast<const bf16_t*>(a.dout) + b * a.os.sb + h * a.os.sh;
+    bf16x8 vop[kD / 16];
+    {
+        const bf16_t* vrow = im.Vb + (static_cast<int64_t>(h) * im.Np + min(key, im.Np - 1)) * kD + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < kD / 16; ++ks) vop[ks] = as_bf16x8(*reinterpret_cast<const u32x4v*>(vrow + 16 * ks));
+    }
+    f32x16 kacc[2], vacc[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kacc[db][r] = vacc[db][r] = 0.f;
+    const int ntiles = (a.Nq + kT - 1) / kT;
+    const int srow = tid >> 2, sseg = 16 * (tid & 3);
+    u32x4v doreg[2], qreg[2];
+    bool do_ok = false;
+    float dlreg = 0.f, vlreg = 0.f, racc = 0.f;
+    auto fetch = [&](int qt) {
+        const int row = qt * kT + srow;
+        do_ok = row < a.Nq;
+        const u32x4v* src = reinterpret_cast<const u32x4v*>(dobase + static_cast<int64_t>(min(row, a.Nq - 1)) * a.os.sn + sseg);
+        doreg[0] = src[0];
+        doreg[1] = src[1];
+        if constexpr (DKV) {
+            const u32x4v* qs = reinterpret_cast<const u32x4v*>(qimg + static_cast<int64_t>(row) * kD + sseg);   // padded image: row < Np
+            qreg[0] = qs[0];
+            qreg[1] = qs[1];
+        }
+        if (tid < kT) {
+            const int r = min(qt * kT + tid, a.Nq - 1);
+            if constexpr (DKV) dlreg = a.delta[head * a.Nq + r];
+            vlreg = a.rel_v[static_cast<int64_t>(b) * a.Nq + r];
+        }
+    };
+    auto stage = [&](int buf) {
+        const u32x4v z = {0u, 0u, 0u, 0u};
+        u32x4v* dd = reinterpret_cast<u32x4v*>(dOr + buf * kT * kLR + srow * kLR + sseg);
+        dd[0] = do_ok ? doreg[0] : z;
+        dd[1] = do_ok ? doreg[1] : z;
+        if constexpr (DKV) {
+            u32x4v* qd = reinterpret_cast<u32x4v*>(Qr + buf * kT * kLR + srow * kLR + sseg);
+            qd[0] = qreg[0];
+            qd[1] = qreg[1];
+        }
+        if (tid < kT) {
+            if constexpr (DKV) dl[buf * kT + tid] = dlreg;
+            vl[buf * kT + tid] = vlreg;
+        }
+    };
+    u32x4v p_cur[2][2], p_nxt[2][2];
+    auto p_issue = [&](u32x4v (&raw)[2][2], int qt) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const u32x4v* src = reinterpret_cast<const u32x4v*>(pcol + qt * 2048 + pp * 1024);
+            raw[pp][0] = src[0];
+            raw[pp][1] = src[1];
+        }
+    };
+    const int trl = tr_lane_base(lane);
+    fetch(0);
+    stage(0);
+    p_issue(p_nxt, 0);
+    if (ntiles > 1) fetch(1);
+    __syncthreads();
+    for (int qt = 0; qt < ntiles; ++qt) {
+        const int cur = qt & 1;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            p_cur[pp][0] = p_nxt[pp][0];
+            p_cur[pp][1] = p_nxt[pp][1];
+        }
+        if (qt + 1 < ntiles) {
+            stage(cur ^ 1);
+            p_issue(p_nxt, qt + 1);
+            if (qt + 2 < ntiles) fetch(qt + 2);
+        }
+        const bf16_t* dOrc = dOr + cur * kT * kLR;
+        const bf16_t* Qrc = Qr + cur * kT * kLR;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            if ((pp == 1 && qt * kT + 32 >= a.Nq) || !wave_live) break;
+            f32x16 dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < kD / 16; ++ks) {
+                const bf16x8 op = *reinterpret_cast<const bf16x8*>(dOrc + (32 * pp + i) * kLR + 16 * ks + 8 * hi);
+                dp = mfma32x32x16_bf16(op, vop[ks], dp);
+            }
+            f32x4 ds[4];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const u32x4v w = p_cur[pp][rg >> 1];
+                const f32x4 p = unpack4(u32x2v{w[2 * (rg & 1)], w[2 * (rg & 1) + 1]});
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(vl + cur * kT + 32 * pp + 8 * rg + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) racc += vv[e] * relu_nan(p[e] * dp[4 * rg + e]);
+                if constexpr (DKV) {
+                    const f32x4 dlv = *reinterpret_cast<const f32x4*>(dl + cur * kT + 32 * pp + 8 * rg + 4 * hi);
+                    ds[rg] = p * (f32x4{dp[4 * rg], dp[4 * rg + 1], dp[4 * rg + 2], dp[4 * rg + 3]} - dlv);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < (DKV ? 2 : 0); ++m) {
+                const bf16x8 p_op = as_bf16x8(p_cur[pp][m]);
+                const bf16x8 ds_op = pack8(ds[2 * m], ds[2 * m + 1]);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    vacc[db] = mfma32x32x16_bf16(p_op, tr_operand(dOrc + trl, pp, m, db), vacc[db]);
+                    kacc[db] = mfma32x32x16_bf16(ds_op, tr_operand(Qrc + trl, pp, m, db), kacc[db]);
+                }
+            }
+            asm volatile("" : "+v"(racc));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_barrier();
+    }
+    racc += __shfl_xor(racc, 32);
+    if (hi == 0 && key_ok) a.rel_part[head * a.Nk + key] = racc;
+    if constexpr (!DKV) return;
+    const int64_t dk0 = b * a.dks.sb + h * a.dks.sh, dv0 = b * a.dvs.sb + h * a.dvs.sh;
+    const bool odd = i & 1;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        const int d = 32 * db + i;
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+            const int r = 2 * rp + (odd ? 1 : 0);
+            const int j = kw + (r & 3) + 8 * (r >> 2) + 4 * hi, c0 = d - (odd ? 1 : 0);
+            const float km = odd ? kacc[db][2 * rp + 1] : kacc[db][2 * rp];
+            const float vm = odd ? vacc[db][2 * rp + 1] : vacc[db][2 * rp];
+            const float ko = __int_as_float(__builtin_amdgcn_update_dpp(
+                0, __float_as_int(odd ? kacc[db][2 * rp] : kacc[db][2 * rp + 1]), 0xB1, 0xF, 0xF, false));
+            const float vo = __int_as_float(__builtin_amdgcn_update_dpp(
+                0, __float_as_int(odd ? vacc[db][2 * rp] : vacc[db][2 * rp + 1]), 0xB1, 0xF, 0xF, false));
+            if (j < a.Nk) {
+                bf16_t* dk = reinterpret_cast<bf16_t*>(a.dk) + dk0 + static_cast<int64_t>(j) * a.dks.sn + c0;
+                bf16_t* dv = reinterpret_cast<bf16_t*>(a.dv) + dv0 + static_cast<int64_t>(j) * a.dvs.sn + c0;
+                *reinterpret_cast<unsigned*>(dk) = odd ? pk2(ko, km) : pk2(km, ko);
+                *reinterpret_cast<unsigned*>(dv) = odd ? pk2(vo, vm) : pk2(vm, vo);
+            }
+        }
+    }
+}
+
 constexpr size_t kQLds = sizeof(bf16_t) * (2 * kT * kLR + 2 * kD * kLT);
 constexpr size_t kKvLds = sizeof(bf16_t) * (2 * kT * kLR + 4 * kD * kLT) + sizeof(float) * 4 * kT;
 
@@ -559,6 +784,20 @@ int run_v3(const AttnBwdArgs& a, const V3Images& im, hipStream_t s) {
     constexpr int NS = 2;                                                // samples per query-side workgroup
     dim3 gq(((a.Nq + R - 1) / R) * a.H * ((a.B + NS - 1) / NS)), gk(((a.Nk + R - 1) / R) * a.H * a.B);
     int rc = MMX_OK;
+    const bool wide = g_attn_bf16_v3 >= 3;                              // fourth-generation key side (32 keys per wave)
+    const dim3 gk4(((a.Nk + 127) / 128) * a.H * a.B);
+    if (wide) {
+        constexpr size_t lds4 = sizeof(bf16_t) * 4 * kT * kLR + sizeof(float) * 4 * kT;
+        if (a.need_dqkv) {
+            rc = launch_v3(attn_bwd_q_v3_kernel<NW, NS>, a, im, gq, 64 * NW, kQLds, s, "attn_bwd_q_v3_kernel");
+            if (rc) return rc;
+            rc = launch_v3(attn_bwd_kv_v4_kernel<true>, a, im, gk4, 256, lds4, s, "attn_bwd_kv_v4_kernel");
+        } else {
+            rc = launch_v3(attn_bwd_kv_v4_kernel<false>, a, im, gk4, 256, lds4, s, "attn_bwd_kv_v4_kernel<rel only>");
+        }
+        if (rc) return rc;
+        return rel_row_update(a.rel_v, a.rel_part, a.rel_out, a.B, a.H, a.Nk, 1.0f / a.H, s);
+    }
     if (a.need_dqkv) {
 #ifdef MMX_ATTN_ABLATE
         static const int abl = getenv("MMX_ATTN_ABLATE") ? atoi(getenv("MMX_ATTN_ABLATE")) : 0;
@@ -594,7 +833,7 @@ void attn_bf16_v3_enable(int mode) { g_attn_bf16_v3 = mode; }
 // bytes of the prep images (independent of the batch): appended to the row-relevancy workspace
 size_t attn_bwd_bf16_v3_prep_bytes(int H, int N) {
     const size_t Np = (static_cast<size_t>(N) + kT - 1) / kT * kT;
-    return sizeof(bf16_t) * (3 * H * Np * kD + 2 * H * Np * Np) + 256;
+    return sizeof(bf16_t) * (4 * H * Np * kD + 2 * H * Np * Np) + 256;       // Vb, KbT, QbT, Qb + Pq, PT (or PT32: the same size)
 }
 
 // returns 1 if the third-generation kernels were launched (rc in *rc_out), 0 if the call is not eligible (see the header
@@ -617,15 +856,17 @@ int attn_bwd_bf16_v3_try(const AttnBwdArgs& a, void* prep, size_t prep_bytes, hi
     bf16_t* Vb = base;
     bf16_t* KbT = Vb + static_cast<size_t>(a.H) * Np * kD;
     bf16_t* QbT = KbT + static_cast<size_t>(a.H) * Np * kD;
-    bf16_t* Pq = QbT + static_cast<size_t>(a.H) * Np * kD;
+    bf16_t* Qb = QbT + static_cast<size_t>(a.H) * Np * kD;
+    bf16_t* Pq = Qb + static_cast<size_t>(a.H) * Np * kD;
     bf16_t* PT = Pq + static_cast<size_t>(a.H) * Np * Np;
-    prep_qkv_kernel<<<dim3(Np / kT, a.H, a.need_dqkv ? 3 : 1), 256, 0, s>>>(a, Vb, KbT, QbT, Np);
+    const int wide = g_attn_bf16_v3 >= 3 ? 1 : 0;
+    prep_qkv_kernel<<<dim3(Np / kT, a.H, a.need_dqkv ? 4 : 1), 256, 0, s>>>(a, Vb, KbT, QbT, Qb, Np);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { *rc_out = hip_fail(e, "prep_qkv_kernel"); return 1; }
-    prep_p_kernel<<<dim3(Np / kT, Np / kT, a.H), 256, 0, s>>>(reinterpret_cast<const bf16_t*>(a.probs), Pq, PT, a.Nk, Np);
+    prep_p_kernel<<<dim3(Np / kT, Np / kT, a.H), 256, 0, s>>>(reinterpret_cast<const bf16_t*>(a.probs), Pq, PT, a.Nk, Np, wide);
     e = hipGetLastError();
     if (e != hipSuccess) { *rc_out = hip_fail(e, "prep_p_kernel"); return 1; }
-    const V3Images im{Vb, KbT, QbT, Pq, PT, Np};
+    const V3Images im{Vb, KbT, QbT, Pq, PT, Np, Qb, PT};
     *rc_out = run_v3<8>(a, im, s);
     return 1;
 }

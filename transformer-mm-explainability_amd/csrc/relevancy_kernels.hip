@@ -1023,7 +1023,7 @@ extern "C" int mmx_set_option(const char* key, int value) {
         attn_head_enable(value);
         return MMX_OK;
     }
-    if (key && strcmp(key, "attn_bf16_v3") == 0 && value >= 0 && value <= 2) {
+    if (key && strcmp(key, "attn_bf16_v3") == 0 && value >= 0 && value <= 3) {
         attn_bf16_v3_enable(value);
         return MMX_OK;
     }
