@@ -86,6 +86,10 @@ def main():
     ap.add_argument("--text", dest="is_text_pert", action="store_true", help="alias of --is-text-pert True")
     ap.add_argument("--positive", dest="is_positive_pert", action="store_true", help="alias of --is-positive-pert True")
     ap.add_argument("--resume-dir", default=None, help="per-rank partial score files; finished samples are skipped on restart")
+    ap.add_argument("--eager-perturbation", action="store_true",
+                    help="round-5 path: the 9-step image test as eager PyTorch launches instead of one hipGraph replay")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="round-5 host path: batch assembly and blocking host-to-device copies on the launching thread")
     ap.add_argument("--bucket-by-length", action="store_true",
                     help="round-1 behaviour: group items by question length, eager explain pass per group")
     args = ap.parse_args()
@@ -117,7 +121,7 @@ def main():
     T_PAD = 20                                 # the synthetic questions have 6..20 tokens
     graphed = {}
 
-    def process_batch(ids):                    # explain + perturb one batch -> [len(ids), 9] accuracies
+    def load_batch(ids):                       # HOST half of a batch (sharding.BatchPrefetcher runs it on a worker thread, ahead)
         items = [cache.pop(k, None) or synthetic_item(k, 36, cfg.visual_feat_dim, cfg.vocab_size, cfg.num_qa_labels) for k in ids]
         n = len(items)
         if args.bucket_by_length:
@@ -131,10 +135,16 @@ def main():
             t = it["input_ids"].numel()
             input_ids[b, :t] = it["input_ids"]
             mask[b, :t] = 1
-        batch = dict(input_ids=input_ids.to(dev), attention_mask=mask.to(dev),
-                     token_type_ids=torch.zeros(B, T, dtype=torch.long, device=dev),
-                     visual_feats=torch.stack([it["visual_feats"] for it in items]).to(dev),
-                     visual_pos=torch.stack([it["visual_pos"] for it in items]).to(dev))
+        # lists of per-item tensors are stacked by the prefetcher straight into its pinned staging buffers
+        return dict(input_ids=input_ids, attention_mask=mask, token_type_ids=torch.zeros(B, T, dtype=torch.long),
+                    visual_feats=[it["visual_feats"] for it in items], visual_pos=[it["visual_pos"] for it in items],
+                    labels=[it["label"] for it in items])
+
+    def process_batch(ids, batch=None):        # explain + perturb one batch -> [len(ids), 9] accuracies
+        if batch is None:                      # --no-prefetch: the round-5 path (host assembly + blocking copies on this thread)
+            batch = {k: (torch.stack(v) if isinstance(v, list) else v).to(dev) for k, v in load_batch(ids).items()}
+        n = len(ids)
+        labels = batch.pop("labels")
         if per_item:
             if "explain" not in graphed:
                 graphed["explain"] = per_item_method(args.method, le, ItemUsage(model))
@@ -146,17 +156,22 @@ def main():
             if "run" not in graphed:           # captured once; serves every later batch whatever its question lengths
                 graphed["run"] = le.GraphedGenerateOursBatch(model, batch, **rule_flags)
             R_t_t, R_t_i = graphed["run"](batch)
+        if not args.text and not per_item and not args.bucket_by_length and not args.eager_perturbation:
+            if "pert" not in graphed:          # the image test of a fixed-shape batch: one more hipGraph (see GraphedImagePerturbation)
+                graphed["pert"] = lp.GraphedImagePerturbation(pert, batch, R_t_t, R_t_i, labels, args.positive)
+            return graphed["pert"](batch, R_t_t, R_t_i, labels)[:n].clone()
         cam_image, cam_text = lp.normalize_cams_batch(R_t_t, R_t_i, batch["attention_mask"])
         scores = pert.perturbation_text(batch, cam_text, args.positive) if args.text else \
             pert.perturbation_image(batch, cam_image, args.positive)
-        labels = torch.stack([it["label"] for it in items]).to(dev)
         return lp.LxmertPerturbation.accuracy(scores, labels)[:n]
 
     torch.cuda.synchronize()
+    stats = {}
     t0 = time.perf_counter()
     length_of = (lambda k: item(k)["input_ids"].numel()) if args.bucket_by_length else (lambda k: 0)   # 0: one bucket
     per_sample = sharding.evaluate_sharded(indices, length_of, process_batch,
-                                           len(lp.PERT_STEPS), max_batch=args.max_batch, store=store, device=gather_dev)
+                                           len(lp.PERT_STEPS), max_batch=args.max_batch, store=store, device=gather_dev,
+                                           load_batch=None if args.no_prefetch else load_batch, prefetch_device=dev, stats=stats)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -167,7 +182,12 @@ def main():
     if rank == 0:
         print(json.dumps({"samples": len(indices), "n_gpus": world, "seconds": round(elapsed, 3),
                           "samples_per_s": round(len(indices) / elapsed, 1), "test": "text" if args.text else "image",
-                          "method": args.method, "positive": bool(args.positive),
+                          "method": args.method, "positive": bool(args.positive), "host_path": "inline" if args.no_prefetch else "prefetch thread + side-stream copies",
+                          # the first batch holds the hipGraph capture and the library warm-up: the rate of the remaining batches
+                          "samples_per_s_after_first_batch": round((len(indices) - min(args.max_batch, len(indices))) / max(elapsed - (stats.get("first_batch_s") or 0.0), 1e-9) / world, 1) * world
+                          if stats.get("batches", 0) > 1 else None,
+                          "first_batch_s": round(stats.get("first_batch_s") or 0.0, 3),
+                          "starved_for_host_s": None if stats.get("starved_s") is None else round(stats["starved_s"], 3),
                           "step_accuracy_percent": [round(float(a), 2) for a in acc]}))
     if world > 1:
         dist.barrier()

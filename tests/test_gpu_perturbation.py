@@ -366,6 +366,18 @@ def test_graphed_generate_ours_batch_replays_any_lengths():
         torch.testing.assert_close(img[b], pert.perturbation_image(one, cam_image[b]), rtol=1e-4, atol=1e-5)
     with pytest.raises(ValueError, match="captured"):
         run(_ragged_batch(g, [5, 5, 5]))
+    # round 6: the 9-step image test of a fixed-shape batch as ONE hipGraph (GraphedImagePerturbation) == the eager calls
+    labels = torch.rand(4, 31, device="cuda")
+    graphed = None
+    for lens in ([12, 12, 12, 12], [6, 11, 9, 7], [12, 5, 12, 8]):
+        batch = _ragged_batch(g, lens)
+        tt, ti = (t.clone() for t in run(batch))
+        cam_image, _ = lp.normalize_cams_batch(tt, ti, batch["attention_mask"])
+        want = lp.LxmertPerturbation.accuracy(lp.LxmertPerturbation(model, tuned=False).perturbation_image(batch, cam_image), labels)
+        if graphed is None:
+            graphed = lp.GraphedImagePerturbation(lp.LxmertPerturbation(model), batch, tt, ti, labels)
+        got = graphed(batch, tt, ti, labels)
+        assert got.shape == (4, 9) and torch.equal(got, want), (got, want)
 
 
 def test_lxmert_tape_path_equals_autograd_path():

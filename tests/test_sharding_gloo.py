@@ -129,3 +129,33 @@ def test_partial_scores_torn_first_line_still_gets_a_header(tmp_path):
     again.close()
     with pytest.raises(ValueError):
         PartialScores(str(tmp_path), 0, {"method": "rollout", "steps": 9})
+
+
+def test_batch_prefetcher_feeds_evaluate_sharded_in_order(tmp_path):
+    """``load_batch`` path of ``evaluate_sharded`` (the evaluators' host pipeline: a worker thread assembles batches ahead, the main
+    thread consumes them): same table as the inline path, every batch's prepared tensors belong to ITS ids, the store lags one batch
+    and ends complete, and an exception in the worker surfaces on the caller."""
+    sys.path.insert(0, ROOT)
+    from transformer_mm_explainability_amd import sharding
+    ids = sharding.perturbation_sample_indices(100, 37)
+    loaded = []
+
+    def load(batch_ids):
+        loaded.append(list(batch_ids))
+        return {"x": torch.tensor([[float(k), float(k % 7)] for k in batch_ids]), "tag": "host-object"}
+
+    def process(batch_ids, batch):
+        assert batch["tag"] == "host-object" and batch["x"][:, 0].tolist() == [float(k) for k in batch_ids]
+        return torch.cat([batch["x"], batch["x"].sum(1, keepdim=True)], dim=1)
+
+    want = torch.tensor([[float(k), float(k % 7), float(k + k % 7)] for k in ids])
+    got = sharding.evaluate_sharded(ids, lambda k: k % 3, process, 3, max_batch=5, load_batch=load, prefetch_device="cpu")
+    assert torch.equal(got, want) and sorted(k for b in loaded for k in b) == sorted(ids)
+    store = sharding.PartialScores(str(tmp_path), 0)
+    got = sharding.evaluate_sharded(ids, lambda k: k % 3, process, 3, max_batch=5, store=store, load_batch=load, prefetch_device="cpu")
+    assert torch.equal(got, want) and store.done() == set(ids)
+
+    def broken(batch_ids):
+        raise RuntimeError("dataset went away")
+    with pytest.raises(RuntimeError, match="dataset went away"):
+        sharding.evaluate_sharded(ids, lambda k: 0, process, 3, max_batch=5, load_batch=broken, prefetch_device="cpu")

@@ -69,13 +69,15 @@ def _ranks(order):
     return torch.empty_like(order).scatter_(-1, order, pos)
 
 
-def image_keep_masks(cam_image, steps=PERT_STEPS, is_positive_pert=False):
+def image_keep_masks(cam_image, steps=PERT_STEPS, is_positive_pert=False, counts=None):
     """``[S, I]`` float 0/1 (``[B, S, I]`` for ``cam_image [B, I]``): row s keeps the ``int((1 - step_s) * I)`` top-scoring
     regions (``perturbation.py:114-117``).  Every step keeps a prefix of ONE ranking, so region i stays in step s iff its rank
-    is below that step's count: a handful of launches for the whole batch."""
+    is below that step's count: a handful of launches for the whole batch.  ``counts``: the per-step counts already on the device
+    (a captured pass must not build tensors from host lists)."""
     cam = -cam_image if is_positive_pert else cam_image
     n = cam.shape[-1]
-    counts = torch.tensor([int((1 - step) * n) for step in steps], device=cam.device)          # host arithmetic, as the reference
+    if counts is None:
+        counts = torch.tensor([int((1 - step) * n) for step in steps], device=cam.device)      # host arithmetic, as the reference
     rank = _ranks(ranking(cam))                                                                 # [..., I]
     return (rank.unsqueeze(-2) < counts.unsqueeze(-1)).to(torch.float32)                        # [..., S, I]
 
@@ -133,6 +135,19 @@ class LxmertPerturbation:
         self.model = model
         self.steps = tuple(steps)
         self.tuned = tuned
+        self._const = {}
+
+    def _image_constants(self, I, device):
+        """Per (region count, device): the steps' keep counts, the live / region-free step indices -- built ONCE from host
+        arithmetic (as the reference does per call), so that a call creates no tensor from a host list (hipGraph-capturable)."""
+        key = (I, str(device))
+        if key not in self._const:
+            counts = [int((1 - step) * I) for step in self.steps]
+            live = [s for s, c in enumerate(counts) if c > 0]
+            dead = [s for s in range(len(self.steps)) if s not in live]
+            self._const[key] = (torch.tensor(counts, device=device), live, torch.tensor(live, device=device, dtype=torch.long),
+                                torch.tensor(dead, device=device, dtype=torch.long))
+        return self._const[key]
 
     def _scores(self, **kw):
         """Answer scores of one batched re-run: the body's grad-free fast forward when it has one."""
@@ -157,12 +172,10 @@ class LxmertPerturbation:
         cams = cam_image.reshape(-1, cam_image.shape[-1])
         B, I = cams.shape
         S = len(self.steps)
-        keep = image_keep_masks(cams, self.steps, is_positive_pert)                                 # [B, S, I]
-        counts = [int((1 - step) * I) for step in self.steps]                                       # host arithmetic only
-        live = [s for s, c in enumerate(counts) if c > 0]
+        counts_dev, live, rows, dead = self._image_constants(I, cams.device)                        # host arithmetic only, cached
+        keep = image_keep_masks(cams, self.steps, is_positive_pert, counts=counts_dev)              # [B, S, I]
         scores = None
         if live:
-            rows = torch.tensor(live, device=keep.device)
             n = len(live)
             vis = dict(visual_feats=self._rep(inputs["visual_feats"], n), visual_pos=self._rep(inputs["visual_pos"], n),
                        visual_attention_mask=keep[:, rows].reshape(B * n, I))
@@ -182,7 +195,6 @@ class LxmertPerturbation:
                                visual_pos=inputs["visual_pos"][:, :0])
             if scores is None:
                 scores = out.new_empty(B, S, out.shape[-1])
-            dead = torch.tensor([s for s in range(S) if s not in live], device=keep.device)
             scores[:, dead] = out[:, None, :]
         return scores[0] if single else scores
 
@@ -212,3 +224,49 @@ class LxmertPerturbation:
         answer id (0 where absent) -> ``[S]`` (``[B, S]``)."""
         best = scores.argmax(dim=-1)
         return label_scores[best] if label_scores.dim() == 1 else torch.gather(label_scores, 1, best)
+
+
+
+class GraphedImagePerturbation:
+    """``normalize_cams_batch`` + ``LxmertPerturbation.perturbation_image`` + ``accuracy`` of a fixed-shape batch captured ONCE into
+    a hipGraph and replayed: the 9-step test of a batch is ~700 launches of eager PyTorch (two grad-free forwards at 8x and 1x the
+    batch), i.e. ~20 ms of HOST time per batch on the thread that also has to replay the explain graph -- with one process per GPU
+    that, not the device work, bounded the evaluator (round 5: 465-507 samples / s end to end against 1170 for the device legs).
+
+        run = GraphedImagePerturbation(pert, batch, R_t_t, R_t_i, labels)       # example tensors of the shapes to come
+        acc = run(batch, R_t_t, R_t_i, labels)                                    # [B, S] per-step soft accuracies (graph output)
+
+    The library GEMMs inside run with the DEFAULT selection (a tuned selection is not switched under a capture, ``tuned_gemms.scope``).
+    Image test only: the text test reads the question lengths on the host (``perturbation_text``)."""
+
+    def __init__(self, pert, batch, R_t_t, R_t_i, labels, is_positive_pert=False, warmup=2):
+        from . import ops
+        self.pert, self.positive = pert, bool(is_positive_pert)
+        self.static = {k: v.clone() for k, v in batch.items()}
+        self.R_t_t, self.R_t_i, self.labels = R_t_t.clone(), R_t_i.clone(), labels.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._call()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with ops.graph_capture(self.graph):
+            self.out = self._call()
+        self._pinned = ops.pinned_state(pert.model)
+
+    def _call(self):
+        cam_image, _ = normalize_cams_batch(self.R_t_t, self.R_t_i, self.static["attention_mask"])
+        scores = self.pert._perturbation_image(self.static, cam_image, self.positive)
+        return LxmertPerturbation.accuracy(scores, self.labels)
+
+    def __call__(self, batch, R_t_t, R_t_i, labels):
+        for k, v in batch.items():
+            if v.shape != self.static[k].shape:
+                raise ValueError("%s: %s, but the graph was captured for %s" % (k, tuple(v.shape), tuple(self.static[k].shape)))
+            self.static[k].copy_(v)
+        self.R_t_t.copy_(R_t_t)
+        self.R_t_i.copy_(R_t_i)
+        self.labels.copy_(labels)
+        self.graph.replay()
+        return self.out
