@@ -88,6 +88,10 @@ const char* mmx_last_error(void);
  *                        probability slab shared by the batch keeps the default policy) | 0: default policy everywhere.  Same results
  *   "self_chain_groups"  0 auto (the fewest groups that put a workgroup on ~70 % of the CUs, at most 4, never more workgroups than
  *                        CUs; 1 below 1 MB per sample) | 1..8 layer groups per sample (1 = strict sequential order)
+ *   "self_chain_rows"    0 (default) N > 128: avg_heads_kernel + the tiled product, two launches per layer with A_bar through memory |
+ *                        1: no second right-hand side: a layer of the chain is ONE launch -- the head reduction of a 16-row block into
+ *                        LDS, then that block row of A_bar . R on the exact-fp32 MFMA (csrc/relevancy_chain_rows.hip; same results to
+ *                        summation order, measured 0.87x the speed of the default at 577 tokens: profiles/r06_chain_rows_probe.txt)
  *   "attn_head"          1 (default) register-resident whole-head attention kernels (Nk <= 128, Nq <= 256) | 0 never
  *   "attn_stream"        1 (default) long-sequence streaming attention kernels | 0 only the general tiled kernels (any head_dim, any
  *                        alignment: what every shape the other families turn down runs on)

@@ -266,7 +266,7 @@ def chain_options(ops):
     """Options of the chain kernels are process-global: whatever a test sets is put back, also when it fails."""
     yield ops
     for key, value in (("self_chain_algo", 0), ("self_chain_groups", 0), ("self_chain_pipe", 4), ("self_chain_nt", 1),
-                       ("self_chain_cols_c", 0), ("self_chain_cols_nb", 0),
+                       ("self_chain_cols_c", 0), ("self_chain_cols_nb", 0), ("self_chain_rows", 0),
                        ("debug_flags", 0), ("bmm_tiles", 1)):
         ops.set_option(key, value)
 
@@ -944,3 +944,35 @@ def test_bf16_outputs_of_layernorm_and_gelu_forward(ops):
         assert torch.equal(s16, s32) and torch.equal(m16, m32) and torch.equal(r16, r32)
         a32, a16 = ops.quick_gelu_fwd(x), ops.quick_gelu_fwd(x, torch.bfloat16)
         assert a16.dtype == torch.bfloat16 and torch.equal(a16, a32.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("L,B,H,N,dt,shared,init", [
+    (3, 2, 3, 197, torch.float32, False, False), (2, 3, 4, 577, torch.bfloat16, True, False), (2, 2, 2, 129, torch.float16, False, True),
+    (3, 1, 5, 255, torch.float32, True, True), (2, 2, 2, 636, torch.float32, False, False), (2, 1, 3, 950, torch.float32, False, False),
+    (1, 2, 2, 300, torch.bfloat16, False, False), (2, 1, 2, 1050, torch.bfloat16, False, True), (2, 2, 3, 639, torch.float32, False, False)])
+def test_long_chain_one_launch_per_layer(chain_options, L, B, H, N, dt, shared, init):
+    """``relevancy_chain_rows.hip`` (round 6: head reduction of a 16-row block into LDS + that block row of ``A_bar . R`` in one launch,
+    ``self_chain_rows`` = 1; an opt-in: measured slower than the default two launches) == the numpy oracle's chain on the same (rounded) slabs and == the two-launch form
+    (``avg_heads_kernel`` + tiled product) to summation order: fp32 / fp16 / bf16 slabs, shared probabilities, a given ``R_init``, odd
+    sizes on both sides of every instantiation's limits (636 / 639: the second falls back to two launches by design)."""
+    ops = chain_options
+    g = torch.Generator().manual_seed(N + L)
+    attn = [torch.rand((1 if shared else B) * H, N, N, generator=g).softmax(-1).to(dt) for _ in range(L)]
+    grad = [(torch.randn(B * H, N, N, generator=g) * 0.05).to(dt) for _ in range(L)]
+    r0 = (torch.eye(N) + torch.rand(B, N, N, generator=g) * 0.01) if init else None
+    run = lambda: ops.relevancy_self_chain([a.cuda() for a in attn], [x.cuda() for x in grad], B,   # noqa: E731
+                                           R_init=None if r0 is None else r0.cuda(), shared_attn=shared).cpu()
+    ops.set_option("self_chain_rows", 1)
+    got = run()
+    ops.set_option("self_chain_rows", 0)
+    two = run()
+    a32 = [a.float().numpy().reshape(-1, H, N, N) for a in attn]
+    g32 = [x.float().numpy().reshape(B, H, N, N) for x in grad]
+    for b in range(B):
+        R = np.eye(N, dtype=np.float32) if r0 is None else r0[b].numpy()
+        for a, x in zip(a32, g32):
+            cam = onp.avg_heads(a[0 if shared else b], x[b])
+            R = R + cam @ R
+        close(got[b], R)
+        close(two[b], R)
+    assert float((got - two).abs().max()) <= 2e-6 * float(two.abs().max())

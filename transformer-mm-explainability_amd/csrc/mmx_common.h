@@ -224,6 +224,10 @@ int hip_fail(hipError_t e, const char* what);
 // kernel nodes carry their arguments by value and do not have that problem.  ``bytes`` must be a multiple of 4.
 int zero_async(void* dst, size_t bytes, hipStream_t s);
 // bmm_f32_tiles.hip: the large exact-fp32 products (32 x 32 x 2 MFMA, 64 x 64 tiles); false = not its shape
+// relevancy_chain_rows.hip: one layer R_out = R_in + mean_h clamp(G * A, 0) . R_in of the long-sequence chain in ONE launch
+bool chain_rows_layer_applies(int N);
+int chain_rows_layer_launch(const void* attn, const void* grad, const float* R_in, float* R_out, int B, int H, int N, int dtype,
+                            int64_t attn_bstride, hipStream_t s, int debug = 0);
 bool bmm_f32_tiles_try(const float* A, const float* B, const float* Cin, float* C, int batch, int M, int N, int K, int trans_a,
                        int64_t sa, int64_t sb, int64_t sc, int nan_to_zero, int cin_is_row, hipStream_t s);
 int device_cu_count();   // compute units of the current device, cached

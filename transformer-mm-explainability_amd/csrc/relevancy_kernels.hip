@@ -981,12 +981,17 @@ static int nt_for(int N) { return (N + 15) / 16; }
 //   1  return before the hand-off / combine (fused + groups kernels; the cols kernel has neither and ignores it)
 //   4  matrix waves skip the MFMAs (all three kernels)          8  groups kernel: take the ticket, skip the combine
 //   16 cols kernel: no block rotation
+//   32 / 64  long-sequence layer kernel (relevancy_chain_rows.hip): no head reduction / return after the head reduction
 static int g_debug_flags = 0;
 static int cols_debug_flags(int g) { return ((g & 4) ? 1 : 0) | ((g & 16) ? 2 : 0); }   // -> relevancy_chain_cols.hip's own bits
 static int g_chain_pipe = 4;     // option "self_chain_pipe": software-pipelined stream waves of the fused chain (fp32 slabs)
 static int g_chain_nt = 1;       // option "self_chain_nt": nt cache policy on the read-once slab loads of the pipelined stream waves
                                  // (default since round 4: text tower 85.8 -> 82.0 us, image 65.5 -> 63.8 us inside the replayed step)
 static int g_chain_groups = 0;  // layer groups per sample of the per-sample kernel: 0 auto, 1 = strict sequential order
+static int g_chain_rows = 0;    // option "self_chain_rows": 0 (default) avg_heads_kernel + the tiled product, two launches per layer | 1: N > 128, one
+                                // right-hand side: a layer is ONE launch (relevancy_chain_rows.hip: head reduction of a 16-row block into LDS +
+                                // that block row of the product).  Built in round 6, parity-green, and NOT faster: 27.6 vs 24.0 ms for the 24
+                                // layers of cfg 5's slab variant (profiles/r06_chain_rows_probe.txt has the phase split and why)
 static int g_chain_algo = 0;  // 0 auto = 4: layer groups with barrier-free stream waves where they apply (fp32 slabs, G > 1), else this file's
                               // per-sample kernel | 1: this file's kernel everywhere | 5: relevancy_chain_cols.hip wherever it applies
 
@@ -1005,6 +1010,10 @@ extern "C" int mmx_set_option(const char* key, int value) {
     }
     if (key && strcmp(key, "self_chain_pipe") == 0 && value >= 0 && value <= 4) {
         g_chain_pipe = value;            // 0 off | 1 one chunk per lane and head | 2 / 4: up to that many contiguous chunks
+        return MMX_OK;
+    }
+    if (key && strcmp(key, "self_chain_rows") == 0 && value >= 0 && value <= 1) {
+        g_chain_rows = value;
         return MMX_OK;
     }
     if (key && strcmp(key, "bmm_tiles") == 0 && value >= 0 && value <= 1) {
@@ -1209,12 +1218,25 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
     float* Rcur = (n_layers % 2 == 0) ? Rout : Rpong;
     float* SQcur = (n_layers % 2 == 0) ? SQout : SQpong;
     hipError_t e;
+    const bool rows_path = g_chain_rows && M == 0 && chain_rows_layer_applies(N);
     if (R_init_dev) {
         e = hipMemcpyAsync(Rcur, R_init_dev, sizeof(float) * B * nn, hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(R_init)");
-    } else {
+    } else if (!rows_path || n_layers == 0) {
         int rc = identity_async(Rcur, B, N, s);
         if (rc) return rc;
+    }
+    if (rows_path) {
+        // one launch per layer: the head reduction lands in LDS and is multiplied from there (relevancy_chain_rows.hip); the first
+        // layer of a chain that starts at the identity is R = I + A_bar (no product, the identity is never materialised)
+        for (int l = 0; l < n_layers; ++l) {
+            float* Rnxt = (Rcur == Rout) ? Rpong : Rout;
+            const float* Rin = (l == 0 && !R_init_dev) ? nullptr : Rcur;
+            int rc = chain_rows_layer_launch(attn_layers[l], grad_layers[l], Rin, Rnxt, B, H, N, dtype, attn_batch_stride, s, g_debug_flags);
+            if (rc) return rc;
+            Rcur = Rnxt;
+        }
+        return MMX_OK;
     }
     if (M > 0) {
         if (Rsq_init_dev) {
