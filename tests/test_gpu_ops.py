@@ -949,7 +949,8 @@ def test_bf16_outputs_of_layernorm_and_gelu_forward(ops):
 @pytest.mark.parametrize("L,B,H,N,dt,shared,init", [
     (3, 2, 3, 197, torch.float32, False, False), (2, 3, 4, 577, torch.bfloat16, True, False), (2, 2, 2, 129, torch.float16, False, True),
     (3, 1, 5, 255, torch.float32, True, True), (2, 2, 2, 636, torch.float32, False, False), (2, 1, 3, 950, torch.float32, False, False),
-    (1, 2, 2, 300, torch.bfloat16, False, False), (2, 1, 2, 1050, torch.bfloat16, False, True), (2, 2, 3, 639, torch.float32, False, False)])
+    (1, 2, 2, 300, torch.bfloat16, False, False), (2, 1, 2, 1050, torch.bfloat16, False, True), (2, 2, 3, 639, torch.float32, False, False),
+    (2, 90, 2, 197, torch.bfloat16, True, False), (2, 75, 1, 130, torch.float32, False, True)])    # > 256 blocks: several rounds of the persistent grid
 def test_long_chain_one_launch_per_layer(chain_options, L, B, H, N, dt, shared, init):
     """``relevancy_chain_rows.hip`` (round 6: head reduction of a 16-row block into LDS + that block row of ``A_bar . R`` in one launch,
     ``self_chain_rows`` = 1; an opt-in: measured slower than the default two launches) == the numpy oracle's chain on the same (rounded) slabs and == the two-launch form

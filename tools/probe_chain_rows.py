@@ -51,6 +51,15 @@ for ci, (name, L, B, H, N, dt, shared) in enumerate(CASES):
     ops.set_option("debug_flags", 0)
     ops.set_option("self_chain_rows", 0)
     print("    phases of the one-launch form alone: product only %.3f ms | head reduction only %.3f ms" % (phase[32], phase[64]))
+    # fp64 referee on the LAST sample (its blocks run in the last rounds of the persistent kernel)
+    bl = B - 1
+    R64 = torch.eye(N, dtype=torch.float64, device="cuda")
+    for l in range(L):
+        a_ = al[l].reshape(-1, H, N, N)[0 if shared else bl].double()
+        g_ = gl[l].reshape(B, H, N, N)[bl].double()
+        R64 = R64 + (a_ * g_).clamp(min=0).mean(0) @ R64
+    e64 = [float((res[m][bl].double() - R64).abs().max()) for m in (0, 1)]
+    print("    last sample vs fp64: two launches %.2e | one launch %.2e" % (e64[0], e64[1]))
     err = float((res[1] - res[0]).abs().max())
     top = float(res[0].abs().max())
     t0, t1 = sorted(times[0])[1], sorted(times[1])[1]
