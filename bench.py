@@ -346,13 +346,24 @@ def synthetic_text_slabs(batch, device, seed=3, layers=12, heads=8, n=77):
     return attn, grad
 
 
+def causal_requested_bytes(layers, batch, heads, n):
+    """Bytes the chain launch asks for under MMX_CHAIN_CAUSAL: the 16-byte chunks of the row-major n x n slabs that are NOT entirely
+    above the diagonal (csrc/chain_stream.h: first element above it and the chunk does not wrap into the next row), both slabs, every
+    head and layer, plus the R write.  (The memory system still moves whole 128-byte lines: `traffic` is the measured figure.)"""
+    live = 0
+    for c in range((n * n + 3) // 4):
+        row, col = divmod(4 * c, n)
+        live += not (col > row and col + 3 < n)
+    return 2 * layers * batch * heads * live * 16 + batch * n * n * 4
+
+
 def chain_worker(batch, launches):
     """Child process run UNDER rocprofv3 (``measure_chain_counters``): nothing but ``launches`` stand-alone launches of the text
     tower's chain kernel at ``batch`` (the kernel ``roofline`` is quoted on), so that the per-dispatch PMC values are that kernel's."""
     from transformer_mm_explainability_amd import ops
     dev = torch.device("cuda", 0)
     attn, grad = synthetic_text_slabs(batch, dev)
-    plan = ops.ChainPlan(attn, grad, batch)
+    plan = ops.ChainPlan(attn, grad, batch, causal=True)      # the text tower's launch as `interpret` makes it (causal mask)
     for _ in range(launches):
         plan.launch()
     torch.cuda.synchronize()
@@ -617,9 +628,14 @@ def main():
 
         ce.interpret(image, texts, model, device, 0, 0, share_image_forward=False)   # per-sample slabs for both towers
 
-        def chain(tr):
+        # The text tower is causally masked: `interpret` launches its chain with MMX_CHAIN_CAUSAL (four-element chunks entirely above
+        # the diagonal, where the probabilities are exact zeros, are not requested; same bits) -- that launch is the one timed; the
+        # full read of the same slabs is timed beside it ("full_read").  `bytes_per_launch` stays SURVEY 8(d)'s algorithmic figure
+        # (the whole slabs), `traffic` is what the counters saw.
+        def chain(tr, causal=None):
             b = tr.buffers   # prepared launch: the timed loop is one C call per launch, not Python tensor plumbing
-            return ops.ChainPlan([b.probs[l] for l in range(tr.layers)], [b.grads[l] for l in range(tr.layers)], BATCH).launch
+            return ops.ChainPlan([b.probs[l] for l in range(tr.layers)], [b.grads[l] for l in range(tr.layers)], BATCH,
+                                 causal=(tr is txt) if causal is None else causal).launch
 
         def chain_bytes(tr, n):
             return 2 * tr.layers * BATCH * tr.heads * n * n * 4 + BATCH * n * n * 4
@@ -628,14 +644,15 @@ def main():
         # Each tower's launch is timed over ROTATING slab sets (text 3 x 293 MB, image 4 x 185 MB: more than the 256 MiB
         # Infinity Cache between two uses of a set), i.e. every byte comes from HBM as it does for slabs a backward pass has
         # just written; "same_buffers" (back-to-back launches over ONE set, what rounds 1-3 reported) is kept beside it.
-        def rotating(tr, sets):
+        def rotating(tr, sets, keep=None, causal=None):
             b = tr.buffers
-            plans = [chain(tr)]
-            keep = []
-            for _ in range(sets - 1):
-                pr, gr = [b.probs[l].clone() for l in range(tr.layers)], [b.grads[l].clone() for l in range(tr.layers)]
-                keep.append((pr, gr))
-                plans.append(ops.ChainPlan(pr, gr, BATCH).launch)
+            causal = (tr is txt) if causal is None else causal
+            plans = [chain(tr, causal)]
+            if keep is None:
+                keep = [([b.probs[l].clone() for l in range(tr.layers)], [b.grads[l].clone() for l in range(tr.layers)])
+                        for _ in range(sets - 1)]
+            for pr, gr in keep:
+                plans.append(ops.ChainPlan(pr, gr, BATCH, causal=causal).launch)
             state = {"i": 0}
 
             def fn():
@@ -645,7 +662,9 @@ def main():
 
         rot_txt, keep_txt = rotating(txt, 3)
         rot_img, keep_img = rotating(vis, 4)
+        rot_txt_full, _ = rotating(txt, 3, keep_txt, causal=False)
         us_txt = kernel_time_us(rot_txt, 21, stream)
+        us_txt_full = kernel_time_us(rot_txt_full, 21, stream)
         us_img = kernel_time_us(rot_img, 20, stream)
         us_txt_same = kernel_time_us(chain(txt), 20, stream)
         us_img_same = kernel_time_us(chain(vis), 20, stream)
@@ -658,17 +677,22 @@ def main():
         for bb in (64, 128, 256):
             sets = 3 if bb == 64 else 2
             keep = [synthetic_text_slabs(bb, device, seed=10 + k) for k in range(sets)]
-            plans = [ops.ChainPlan(a_, g_, bb).launch for a_, g_ in keep]
-            state = {"i": 0}
-
-            def rot_fn():
-                plans[state["i"] % sets]()
-                state["i"] += 1
-            us_b = kernel_time_us(rot_fn, 4 * sets + 1, stream)
             bytes_b = 2 * 12 * bb * 8 * 77 * 77 * 4 + bb * 77 * 77 * 4
+            us_by = {}
+            for causal in (True, False):
+                plans = [ops.ChainPlan(a_, g_, bb, causal=causal).launch for a_, g_ in keep]
+                state = {"i": 0}
+
+                def rot_fn():
+                    plans[state["i"] % sets]()
+                    state["i"] += 1
+                us_by[causal] = kernel_time_us(rot_fn, 4 * sets + 1, stream)
+            us_b = us_by[True]
             by_batch[str(bb)] = {"us_per_launch": round(us_b, 2), "achieved": round(bytes_b / us_b / 1e3, 1),
                                  "frac": round(bytes_b / us_b / 1e3 / HBM_PEAK_GBS, 4), "bytes_per_launch": bytes_b,
-                                 "slab_sets": sets}
+                                 "slab_sets": sets,
+                                 "full_read": {"us_per_launch": round(us_by[False], 2),
+                                               "frac": round(bytes_b / us_by[False] / 1e3 / HBM_PEAK_GBS, 4)}}
             del keep, plans
         torch.cuda.empty_cache()
         # HBM traffic of the same launch: measured in this run by two rocprofv3 --pmc child processes when rocprofv3 is on the box
@@ -721,6 +745,14 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_source, "traffic_split": traffic_split,
                     "by_batch": by_batch,
                     "bytes_per_launch": by_txt, "us_per_launch": round(us_txt, 2),
+                    "causal_skip": {"what": "the text tower is causally masked (probabilities exactly 0 above the diagonal): the launch "
+                                            "is made with MMX_CHAIN_CAUSAL and does not request the 16-byte chunks that lie entirely above "
+                                            "the diagonal -- same bits as the full read (tests/test_gpu_ops.py).  `achieved` / `frac` price "
+                                            "the launch on SURVEY 8(d)'s algorithmic bytes (the whole slabs); `traffic` is what the HBM "
+                                            "counters saw for it; `full_read` is the same kernel over the same slabs without the flag",
+                                    "requested_bytes_per_launch": causal_requested_bytes(txt.layers, BATCH, txt.heads, 77),
+                                    "full_read": {"us_per_launch": round(us_txt_full, 2), "achieved": round(by_txt / us_txt_full / 1e3, 1),
+                                                  "frac": round(by_txt / us_txt_full / 1e3 / HBM_PEAK_GBS, 4)}},
                     "same_buffers": {"us_per_launch": round(us_txt_same, 2), "achieved": round(by_txt / us_txt_same / 1e3, 1),
                                      "note": "20 back-to-back launches over ONE slab set: partly served by the Infinity Cache"},
                     "in_step": in_step,

@@ -151,6 +151,21 @@ int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const void* cons
                                 const void* Rsq_init_dev, void* Rsq_out_dev, int M,
                                 void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Same, with flags (ABI 2, added in round 6).
+ *   MMX_CHAIN_CAUSAL  the probability slabs come out of CAUSALLY MASKED attention (CLIP's text tower: CLIP/clip/model.py:334-340
+ *                     `build_attention_mask`, applied in CLIP/clip/auxilary.py:232-236): every entry above the diagonal is an exact 0,
+ *                     hence clamp(grad * attn, 0) is 0 there for any finite gradient, and the fp32 chain kernels do not READ the
+ *                     4-element chunks that lie entirely above the diagonal (of either slab) -- about half the bytes of the launch.
+ *                     Results are bit-identical to flags = 0 on such slabs.  The caller vouches for the mask: the kernels do not
+ *                     look at the skipped entries (a non-finite gradient above the diagonal, which the reference would turn into a
+ *                     NaN, goes unseen).  Ignored by the paths that have no use for it (16-bit slabs, N > 128, a second right-hand side). */
+#define MMX_CHAIN_CAUSAL 1u
+int mmx_relevancy_self_chain_flags(const void* const* attn_layers, const void* const* grad_layers, int n_layers,
+                                   int B, int H, int N, int dtype, int64_t attn_batch_stride,
+                                   const void* R_init_dev, void* R_out_dev,
+                                   const void* Rsq_init_dev, void* Rsq_out_dev, int M, unsigned flags,
+                                   void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* The same chain in the reference's HALF-PRECISION mode.  On a GPU the reference runs the CLIP model after
  * `convert_weights` (CLIP/clip/model.py:381-402, 440) and creates R in the dtype of the fp16 attention probabilities
  * (CLIP_explainability.ipynb cell 6:20,43), so `grad * cam`, `.clamp(min=0).mean(dim=1)`, `torch.bmm(cam, R)` and

@@ -125,9 +125,9 @@ def test_argument_validation_under_host_asan():
     import sys
     csrc = os.path.join(ROOT, "transformer-mm-explainability_amd", "csrc")
     so, rt = os.path.join(csrc, "asan", "libmmx_hip_asan.so"), os.path.join(csrc, "asan", "runtime_path.txt")
-    if not os.path.exists(so):
-        build = subprocess.run(["make", "-C", csrc, "-f", "Makefile.asan", "-j4", "asan-host"], capture_output=True, text=True)
-        assert build.returncode == 0, build.stderr[-2000:]
+    # (make is incremental: a no-op when the sanitizer build is current, a rebuild of what changed otherwise)
+    build = subprocess.run(["make", "-C", csrc, "-f", "Makefile.asan", "-j4", "asan-host"], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
     runtime = open(rt).read().strip()
     assert os.path.exists(runtime), runtime
     try:

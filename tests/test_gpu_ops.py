@@ -977,3 +977,39 @@ def test_long_chain_one_launch_per_layer(chain_options, L, B, H, N, dt, shared, 
         close(got[b], R)
         close(two[b], R)
     assert float((got - two).abs().max()) <= 2e-6 * float(two.abs().max())
+
+
+@pytest.mark.parametrize("L,B,H,N,groups", [(12, 64, 8, 77, 0), (12, 160, 8, 77, 0), (5, 3, 3, 77, 2), (4, 2, 5, 128, 1), (3, 70, 2, 33, 0),
+                                            (6, 9, 4, 50, 3), (2, 1, 1, 17, 1)])
+def test_causal_flag_skips_the_upper_triangle_with_the_same_bits(chain_options, L, B, H, N, groups):
+    """``MMX_CHAIN_CAUSAL`` (round 6): on the slabs of a causally masked tower (probabilities exactly 0 above the diagonal, gradients
+    ANYTHING finite there) the chain kernels that stream fp32 slabs do not request the 4-element chunks that lie entirely above the
+    diagonal -- and return the SAME BITS as the full read, for the layer-group kernel, the column kernel and every group count; the
+    oracle on the same slabs agrees to 1e-5.  Non-causal slabs with the flag set would be wrong by design (the caller vouches)."""
+    ops = chain_options
+    attn, grad = make_layers(N * 3 + L, L, B, H, N, causal=True)
+    attn, grad = [a.cuda() for a in attn], [g.cuda() for g in grad]
+    for a in attn:
+        assert float(a.triu(1).abs().max()) == 0.0
+    ops.set_option("self_chain_groups", groups)
+    full = ops.relevancy_self_chain(attn, grad, B).clone()
+    skip = ops.relevancy_self_chain(attn, grad, B, causal=True).clone()
+    assert torch.equal(full, skip)
+    plan = ops.ChainPlan(attn, grad, B, causal=True)
+    assert torch.equal(plan.launch(), full)
+    close(full, onp.self_chain([a.cpu().numpy() for a in attn], [g.cpu().numpy() for g in grad], B))
+    # the flag is honoured, not ignored: probabilities planted in chunks that lie ENTIRELY above the diagonal (16-byte aligned in the
+    # flat slab, inside one row) change the full read and do not reach the causal one
+    if N >= 33:
+        bad = [a.clone() for a in attn]
+        hot = [g.clone() for g in grad]
+        for row in (2, 5):
+            c0 = next(c for c in range(row + 1, N) if (row * N + c) % 4 == 0)
+            assert c0 + 7 < N
+            for t in (bad[0], hot[0]):
+                t.reshape(B, H, N, N)[0, :, row, c0:c0 + 8] = 0.25       # two whole chunks, every head, gradient positive there too
+        dirty, clean = ops.relevancy_self_chain(bad, hot, B).clone(), ops.relevancy_self_chain(attn, hot, B).clone()
+        assert not torch.equal(dirty, clean)
+        got = ops.relevancy_self_chain(bad, hot, B, causal=True)
+        # (the flag is a licence, not an order: a route that does not stream fp32 slabs through chain_stream.h reads everything)
+        assert torch.equal(got, clean) or (N < 50 and torch.equal(got, dirty))

@@ -20,6 +20,7 @@ MMX_ENOTSUP = -95               # shape / view outside what the kernels support 
 MMX_ATTN_IO_BF16 = 0x200        # backward: bf16 dO in, bf16 dq / dk / dv out (with MMX_ATTN_MMA_BF16)
 MMX_ATTN_MMA_BF16 = 0x100       # OR-ed into slab_dtype of the attention *_ex entry points (bf16 matrix cores)
 MM_NORMALIZE, MM_SELF_IN_RULE10, MM_NAN_TO_ZERO = 1, 2, 4
+CHAIN_CAUSAL = 1                # mmx_relevancy_self_chain_flags: probabilities of a causally masked tower (zeros above the diagonal)
 SCALE_Q_FIRST, SCALE_SCORES = 0, 1
 LRP_VALUES, LRP_SCORES = 1, 2        # phases of mmx_attn_relprop_phase
 MAX_LAYERS = 48
@@ -36,6 +37,7 @@ _PROTOTYPES = {
     "mmx_self_chain_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mmx_relevancy_self_chain": (_i, [_vpp, _vpp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "mmx_relevancy_self_chain_ex": (_i, [_vpp, _vpp, _i, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "mmx_relevancy_self_chain_flags": (_i, [_vpp, _vpp, _i, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _i, _u, _vp, _sz, _vp]),
     "mmx_relevancy_self_chain_half": (_i, [_vpp, _vpp, _i, _i, _i, _i, _i, _i64, _vp, _vp, _sz, _vp]),
     "mmx_bmm_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i, _vp]),
     "mmx_handle_residual": (_i, [_vp, _vp, _i, _i, _vp, _vp]),

@@ -21,16 +21,39 @@ import torch
 from . import ops
 from .rules import frozen_parameters as _Frozen
 
-def _plan(buffers, first, last, batch_size, shared, half_chain=False):
+def _plan(buffers, first, last, batch_size, shared, half_chain=False, causal=False):
     """Prepared chain launch, cached on the slab object (the slabs keep their addresses from call to call).  ``half_chain``:
-    the reference's fp16 chain (a model after ``set_body_dtype(torch.float16)``; ``ops.ChainPlan``)."""
+    the reference's fp16 chain (a model after ``set_body_dtype(torch.float16)``; ``ops.ChainPlan``).  ``causal``: the tower's
+    attention carries CLIP's causal mask (the text tower, CLIP/clip/model.py:334-340): its probabilities are exact zeros above the
+    diagonal and the chain kernel does not read that half of either slab (``MMX_CHAIN_CAUSAL``)."""
     cache = buffers.__dict__.setdefault("_chain_plans", {})
-    key = (first, last, batch_size, shared, bool(half_chain))
+    key = (first, last, batch_size, shared, bool(half_chain), bool(causal))
     if key not in cache:
         cache[key] = ops.ChainPlan([buffers.probs[l] for l in range(first, last)],
                                    [buffers.grads[l] for l in range(first, last)], batch_size, shared_attn=shared,
-                                   half_chain=half_chain)
+                                   half_chain=half_chain, causal=causal)
     return cache[key]
+
+
+def _is_causal_tower(tower):
+    """True iff every block of ``tower`` runs under an additive mask that is -inf strictly above the diagonal (CLIP's
+    ``build_attention_mask``, CLIP/clip/model.py:334-340): its probabilities are then exact zeros there and the chain may skip that
+    half (``_plan(causal=True)``).  Checked on the mask tensors themselves, once per mask object (one device -> host read, made during
+    the warm-up call that precedes any hipGraph capture); anything else -- no mask, another mask -- is not causal."""
+    blocks = list(tower.resblocks)
+    masks = [getattr(blk, "attn_mask", None) for blk in blocks]
+    if not masks or any(m is None for m in masks):
+        return False
+    key = tuple(id(m) for m in masks)
+    cached = tower.__dict__.get("_causal_mask_check")
+    if cached is None or cached[0] != key:
+        ok = True
+        for m in {id(m): m for m in masks}.values():
+            n = m.shape[-1]
+            upper = torch.ones(n, n, dtype=torch.bool, device=m.device).triu_(1)
+            ok = ok and m.dim() == 2 and m.shape[0] == n and bool(torch.isneginf(m[upper]).all())
+        tower.__dict__["_causal_mask_check"] = cached = (key, ok)
+    return cached[1]
 
 
 def _side_stream(device):
@@ -105,7 +128,8 @@ def interpret(image, texts, model, device, start_layer=-1, start_layer_text=-1, 
                 image_relevance = R[:, 0, 1:]
     model.backward_text_tape(txt_state, text_features.grad, slt)
     txt = model.transformer
-    R_text = _plan(txt.buffers, slt, txt.layers, batch_size, False, getattr(txt, "half_chain", False)).launch()
+    R_text = _plan(txt.buffers, slt, txt.layers, batch_size, False, getattr(txt, "half_chain", False),
+                   causal=_is_causal_tower(txt)).launch()
     main.wait_stream(side)
     if image_chain_on_main and not row_mode:
         R = _plan(vis.buffers, sl, vis.layers, batch_size, vis.buffers.shared_probs and batch_size > 1,

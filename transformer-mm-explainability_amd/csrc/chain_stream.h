@@ -28,6 +28,13 @@ struct ChainStreamGeom {
     int b, B;                  // sample, batch
     int64_t attn_bstride;      // H * N * N, or 0: one probability slab shared by the batch
     int nt;                    // nt cache policy on the read-once slabs
+    // MMX_CHAIN_CAUSAL (round 6): the probabilities come out of causally masked attention -- exact zeros above the diagonal, so
+    // clamp(G * A, 0) is 0 there whatever G holds (finite) -- and a 4-element chunk that lies ENTIRELY above the diagonal is not
+    // requested at all: its lanes present an out-of-range buffer offset, which the hardware answers with zeros without touching
+    // memory.  Same bits as the full read (0 * g = +-0, and +0 + -0 = +0); about half the bytes of a causal tower.
+    int causal = 0;
+    int N = 0;                 // tokens (causal only)
+    unsigned row_magic = 0;    // ceil(2^32 / N): row of flat element p = umulhi(p, row_magic) for p < N * N (causal only)
 };
 
 // sink(layer_in_list, chunk_index, mean) is called once per item by all 64 lanes (chunk_index may be >= nchunks in the last block)
@@ -58,10 +65,17 @@ __device__ __forceinline__ void chain_stream_wave(const ChainStreamGeom& gm, int
             const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(gm.attn[lu]) + sampleA)), 0, bytesA, kRawBufferFlags);
         const auto rG = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(gm.grad[lu]) + sampleG)), 0, bytesG, kRawBufferFlags);
-        const unsigned voff = static_cast<unsigned>(min(item_chunk(i), gm.nchunks - 1)) * 16u;
+        const int cidx = min(item_chunk(i), gm.nchunks - 1);
+        unsigned voff = static_cast<unsigned>(cidx) * 16u;
+        unsigned skip = 0u;
+        if (gm.causal) {                                // elements p .. p + 3 all above the diagonal: first one is, and the chunk does not wrap
+            const unsigned p = static_cast<unsigned>(cidx) * 4u;
+            const unsigned row = __umulhi(p, gm.row_magic), col = p - row * static_cast<unsigned>(gm.N);
+            skip = (col > row && col + 3u < static_cast<unsigned>(gm.N)) ? 0xC0000000u : 0u;   // + 3 GB: past any resource bound (<= 2^31 - 1)
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const unsigned off = voff + static_cast<unsigned>(min(hb * 4 + u, H - 1) * hstride);
+            const unsigned off = (voff + static_cast<unsigned>(min(hb * 4 + u, H - 1) * hstride)) | skip;
             av[u] = __builtin_amdgcn_raw_buffer_load_b128(rA, off, 0, AUXA);
             gv[u] = __builtin_amdgcn_raw_buffer_load_b128(rG, off, 0, AUXG);
         }

@@ -41,6 +41,7 @@ struct ColsArgs {
     float* R_out;
     int64_t attn_bstride;
     int nt;
+    int causal;          // MMX_CHAIN_CAUSAL: chunks entirely above the diagonal are not requested (chain_stream.h)
     int debug;           // profiling only: bit0 = matrix waves skip the MFMAs, bit1 = no block rotation
 };
 
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(kColsThreads) void self_chain_cols_kernel(const Col
 
     if (wave >= nown) {
         // =============================================================================================== stream waves (chain_stream.h)
-        const ChainStreamGeom gm{a.attn, a.grad, 0, NBLK, rot, a.nchunks, H, NN, b, a.B, a.attn_bstride, (a.nt && C == 1) ? 1 : 0};
+        const ChainStreamGeom gm{a.attn, a.grad, 0, NBLK, rot, a.nchunks, H, NN, b, a.B, a.attn_bstride, (a.nt && C == 1) ? 1 : 0, a.causal, N, a.row_magic};
         // (with several workgroups per sample the partners re-read every line from L2: default cache policy)
         chain_stream_wave(gm, wave - nown, kColsWaves - nown, L * NBLK, lane, [&](int l, int cidx, f32x4 mean) {
             const int slot = l % NB;
@@ -217,7 +218,8 @@ int self_chain_cols_launch(const void* const* attn_layers, const void* const* gr
     r.R_init = static_cast<const float*>(R_init);
     r.R_out = static_cast<float*>(R_out);
     r.attn_bstride = attn_bstride;
-    r.nt = nt_policy;
+    r.nt = nt_policy & 1;              // `nt_policy`: bit 0 = nt loads on the read-once slabs, bit 1 = MMX_CHAIN_CAUSAL
+    r.causal = (nt_policy >> 1) & 1;
     r.debug = debug;
     switch ((N + 15) / 16) {
         case 1: return cols_launch<1>(r, s);

@@ -37,6 +37,7 @@ struct GroupsArgs {
     unsigned* counters;  // [B] arrival tickets
     int64_t attn_bstride;
     int nt;
+    int causal;          // MMX_CHAIN_CAUSAL: chunks entirely above the diagonal are not requested (chain_stream.h)
     int debug;           // profiling only: bit0 = return before the hand-off / combine, bit2 = matrix waves skip the MFMAs,
                          // bit3 = return after the ticket (no combine)
 };
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(kGroupsThreads) void self_chain_groups_kernel(const
     if (wave >= NT) {
         // =============================================================================================== stream waves (chain_stream.h)
         const int NBLK = (a.nchunks + 63) >> 6;            // 64-chunk blocks per layer
-        const ChainStreamGeom gm{a.attn, a.grad, l0, NBLK, 0, a.nchunks, H, NN, b, a.B, a.attn_bstride, a.nt};
+        const ChainStreamGeom gm{a.attn, a.grad, l0, NBLK, 0, a.nchunks, H, NN, b, a.B, a.attn_bstride, a.nt, a.causal, N, a.row_magic};
         chain_stream_wave(gm, wave - NT, kGroupsWaves - NT, L * NBLK, lane, [&](int lg, int cidx, f32x4 mean) {
             chain_stream_deliver(smem + lg * NP * S, S, lds_cnt + lg * NT, cidx, lane, a.nchunks, N, NN, a.row_magic, mean);
         });
@@ -266,7 +267,8 @@ int self_chain_groups_launch(const void* const* attn_layers, const void* const* 
     r.parts = parts;
     r.counters = counters;
     r.attn_bstride = attn_bstride;
-    r.nt = nt_policy;
+    r.nt = nt_policy & 1;              // `nt_policy`: bit 0 = nt loads on the read-once slabs, bit 1 = MMX_CHAIN_CAUSAL
+    r.causal = (nt_policy >> 1) & 1;
     r.debug = debug;
     int zrc = zero_async(counters, sizeof(unsigned) * B, s);
     if (zrc) return zrc;

@@ -1144,6 +1144,17 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
                                            const void* R_init_dev, void* R_out_dev, const void* Rsq_init_dev,
                                            void* Rsq_out_dev, int M, void* workspace_dev, size_t workspace_bytes,
                                            void* stream) {
+    return mmx_relevancy_self_chain_flags(attn_layers, grad_layers, n_layers, B, H, N, dtype, attn_batch_stride, R_init_dev, R_out_dev,
+                                          Rsq_init_dev, Rsq_out_dev, M, 0u, workspace_dev, workspace_bytes, stream);
+}
+
+extern "C" int mmx_relevancy_self_chain_flags(const void* const* attn_layers, const void* const* grad_layers, int n_layers,
+                                              int B, int H, int N, int dtype, int64_t attn_batch_stride,
+                                              const void* R_init_dev, void* R_out_dev, const void* Rsq_init_dev,
+                                              void* Rsq_out_dev, int M, unsigned flags, void* workspace_dev, size_t workspace_bytes,
+                                              void* stream) {
+    MMX_CHECK_ARG((flags & ~MMX_CHAIN_CAUSAL) == 0u, "mmx_relevancy_self_chain_flags: unknown flag bits %#x", flags);
+    const int stream_policy = g_chain_nt | ((flags & MMX_CHAIN_CAUSAL) ? 2 : 0);   // -> the stream waves of the fp32 chain kernels
     const int64_t full_stride = static_cast<int64_t>(H) * N * N;
     if (attn_batch_stride < 0) attn_batch_stride = full_stride;
     MMX_CHECK_ARG(attn_batch_stride == 0 || attn_batch_stride == full_stride,
@@ -1160,7 +1171,7 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
     const int nt = nt_for(N);
 
     if (use_cols(n_layers, B, H, N, M, dtype))
-        return self_chain_cols_launch(attn_layers, grad_layers, n_layers, B, H, N, attn_batch_stride, R_init_dev, R_out_dev, g_chain_nt,
+        return self_chain_cols_launch(attn_layers, grad_layers, n_layers, B, H, N, attn_batch_stride, R_init_dev, R_out_dev, stream_policy,
                                       cols_debug_flags(g_debug_flags), s);
     if (nt <= 8 && M == 0) {
         ChainArgs args;
@@ -1185,7 +1196,7 @@ extern "C" int mmx_relevancy_self_chain_ex(const void* const* attn_layers, const
             // fp32 slabs: the kernel with barrier-free stream waves (relevancy_chain_groups.hip) unless algo 1 asks for this file's
             if (g_chain_algo != 1 && dtype == MMX_F32 && self_chain_groups_applies(n_layers, args.G, H, N))
                 return self_chain_groups_launch(attn_layers, grad_layers, n_layers, B, H, N, args.G, attn_batch_stride, R_init_dev,
-                                                R_out_dev, args.counters, args.parts, g_chain_nt, g_debug_flags, s);
+                                                R_out_dev, args.counters, args.parts, stream_policy, g_debug_flags, s);
         }
         switch (nt) {
             case 1: return launch_fused<1>(args, dtype, s);

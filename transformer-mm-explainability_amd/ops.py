@@ -159,12 +159,14 @@ def avg_heads(cam, grad, batch_size=1, shared_attn=False):
 
 
 # ------------------------------------------------------------------------------------------- fused chain
-def relevancy_self_chain(attn_layers, grad_layers, batch_size, R_init=None, R_sq_init=None, shared_attn=False):
+def relevancy_self_chain(attn_layers, grad_layers, batch_size, R_init=None, R_sq_init=None, shared_attn=False, causal=False):
     """All-layer chain ``R <- R + A_bar_l @ R`` (``R_0 = I`` or ``R_init``) [and ``R_sq`` likewise] in one call.
 
     ``attn_layers[l]`` / ``grad_layers[l]``: ``[B*H, N, N]`` or ``[B, H, N, N]`` (fp32/fp16/bf16).
     ``shared_attn=True``: ``attn_layers[l]`` holds ONE sample's heads (``[H, N, N]``) shared by all ``batch_size``
     samples of ``grad_layers[l]`` (shared-forward mode; read with batch stride 0).
+    ``causal=True``: the probabilities come from causally masked attention (exact zeros above the diagonal, CLIP's text tower):
+    the kernels do not read what lies above the diagonal (``MMX_CHAIN_CAUSAL``); same bits, about half the bytes.
     Returns ``R [B, N, N]`` (and ``R_sq [B, N, M]`` when ``R_sq_init`` is given).
     """
     if len(attn_layers) != len(grad_layers):
@@ -204,9 +206,10 @@ def relevancy_self_chain(attn_layers, grad_layers, batch_size, R_init=None, R_sq
     ws = _workspace(need, device)
     at, _k1 = _lib.ptr_table([a.data_ptr() for a in attn])
     gt, _k2 = _lib.ptr_table([g.data_ptr() for g in grad])
-    check(lib().mmx_relevancy_self_chain_ex(at, gt, len(attn), batch_size, heads, n, dt, 0 if shared_attn else -1,
-                                            _p(R_init), _p(R_out), _p(R_sq_init), _p(sq_out), m, _p(ws), need,
-                                            _stream()), "mmx_relevancy_self_chain_ex")
+    check(lib().mmx_relevancy_self_chain_flags(at, gt, len(attn), batch_size, heads, n, dt, 0 if shared_attn else -1,
+                                               _p(R_init), _p(R_out), _p(R_sq_init), _p(sq_out), m,
+                                               _lib.CHAIN_CAUSAL if causal else 0, _p(ws), need,
+                                               _stream()), "mmx_relevancy_self_chain_flags")
     return (R_out, sq_out) if sq_out is not None else R_out
 
 
@@ -523,11 +526,12 @@ class ChainPlan:
     built once; ``launch()`` is a single C call (no per-call Python tensor plumbing).  The captured slabs of a tower
     keep their addresses from step to step, so the plan stays valid as long as the tensors it references are alive."""
 
-    def __init__(self, attn_layers, grad_layers, batch_size, shared_attn=False, half_chain=False):
+    def __init__(self, attn_layers, grad_layers, batch_size, shared_attn=False, half_chain=False, causal=False):
         """``half_chain``: the reference's fp16 chain (``mmx_relevancy_self_chain_half``: every tensor-level result of the rule
         rounded to fp16, like the notebook's R on a model after ``convert_weights``); ``launch`` then returns an fp16 tensor."""
         _dev(*attn_layers, *grad_layers)
         self.half_chain = bool(half_chain)
+        self.flags = _lib.CHAIN_CAUSAL if causal else 0     # ``causal``: see ``relevancy_self_chain``
         self.attn = [_capture(a) for a in attn_layers]
         self.grad = [_capture(g) for g in grad_layers]
         if not self.attn or len(self.attn) != len(self.grad) or len(self.attn) > _lib.MAX_LAYERS:
@@ -561,9 +565,9 @@ class ChainPlan:
                                                       self.shared, _p(out), _p(self.ws), self.need, _stream()),
                   "mmx_relevancy_self_chain_half")
             return out.to(torch.float16)                   # lossless: the kernel rounds every result to fp16
-        check(lib().mmx_relevancy_self_chain_ex(self.at, self.gt, len(self.attn), self.batch, self.heads, self.n, self.dt,
-                                                self.shared, None, _p(out), None, None, 0, _p(self.ws), self.need,
-                                                _stream()), "mmx_relevancy_self_chain_ex")
+        check(lib().mmx_relevancy_self_chain_flags(self.at, self.gt, len(self.attn), self.batch, self.heads, self.n, self.dt,
+                                                   self.shared, None, _p(out), None, None, 0, self.flags, _p(self.ws), self.need,
+                                                   _stream()), "mmx_relevancy_self_chain_flags")
         return out
 
 
