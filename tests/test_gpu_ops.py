@@ -997,6 +997,9 @@ def test_causal_flag_skips_the_upper_triangle_with_the_same_bits(chain_options, 
     assert torch.equal(full, skip)
     plan = ops.ChainPlan(attn, grad, B, causal=True)
     assert torch.equal(plan.launch(), full)
+    # a caller-supplied start is not triangular: the tile shortcut of the causal form (lower-triangular R) must stay off
+    R0 = torch.randn(B, N, N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(N))
+    assert torch.equal(ops.relevancy_self_chain(attn, grad, B, R_init=R0, causal=True), ops.relevancy_self_chain(attn, grad, B, R_init=R0))
     close(full, onp.self_chain([a.cpu().numpy() for a in attn], [g.cpu().numpy() for g in grad], B))
     # the flag is honoured, not ignored: probabilities planted in chunks that lie ENTIRELY above the diagonal (16-byte aligned in the
     # flat slab, inside one row) change the full read and do not reach the causal one

@@ -24,4 +24,17 @@ for bb in (64, 128, 256):
     for c in (False, True):
         m = statistics.median(res[c])
         print("B=%d causal=%d  median %.2f us  min %.2f  max %.2f  alg GB/s %.0f" % (bb, c, m, min(res[c]), max(res[c]), by / m / 1e3))
+    if bb <= 128:      # explicit group counts under the causal form (0 = the auto rule)
+        res = {}
+        for rnd in range(3):
+            for G in ((0, 2, 3, 4) if bb == 64 else (0, 2)):
+                ops.set_option("self_chain_groups", G)
+                pl = [ops.ChainPlan(a, g, bb, causal=True) for a, g in keep]
+                st = {"i": 0}
+                def fn():
+                    pl[st["i"] % sets].launch(); st["i"] += 1
+                res.setdefault(G, []).append(bench.kernel_time_us(fn, 4 * sets + 1, stream))
+        ops.set_option("self_chain_groups", 0)
+        for G, v in res.items():
+            print("B=%d causal G=%d  median %.2f us" % (bb, G, statistics.median(v)))
     del keep, plans

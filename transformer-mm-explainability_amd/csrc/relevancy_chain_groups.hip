@@ -82,6 +82,10 @@ __global__ __launch_bounds__(kGroupsThreads) void self_chain_groups_kernel(const
     const int col = wave * 16 + (lane & 15);
     const int rq = (lane >> 4) * 4;
     f32x4 Rold[NT], Rnew[NT];
+    // MMX_CHAIN_CAUSAL and R starts as the identity: every A_bar_l, every R and every partial product is LOWER TRIANGULAR, so the
+    // 16 x 16 tile (ti, tj) of a product is sum over tj <= t <= ti only -- 35 of the 125 tile products at 77 tokens.  The skipped
+    // ones multiply exact zeros (finite operands): same bits up to the sign of a zero.
+    const bool tri = a.causal && !a.R_init;
 
     if (wave >= NT) {
         // =============================================================================================== stream waves (chain_stream.h)
@@ -121,6 +125,7 @@ __global__ __launch_bounds__(kGroupsThreads) void self_chain_groups_kernel(const
                 if (!(a.debug & 4)) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
+                        if (tri && (t > ti || t < wave)) continue;      // (wave = this wave's column slab tj; wave-uniform)
                         const f32x4 av = *reinterpret_cast<const f32x4*>(Ab + ti * 16 * S + t * 16);
                         acc = mfma16x16x4(av[0], Rold[t][0], acc);
                         acc = mfma16x16x4(av[1], Rold[t][1], acc);
@@ -206,6 +211,7 @@ __global__ __launch_bounds__(kGroupsThreads) void self_chain_groups_kernel(const
             const float* bp = Xc + rq * S + tj * 16 + li;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
+                if (tri && (t > ti || t < tj)) continue;                // (tiles above the diagonal come out as the zeros they are)
                 const f32x4 av = *reinterpret_cast<const f32x4*>(ap + t * 16);
                 acc = mfma16x16x4(av[0], bp[(t * 16 + 0) * S], acc);
                 acc = mfma16x16x4(av[1], bp[(t * 16 + 1) * S], acc);
