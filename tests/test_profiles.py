@@ -29,8 +29,9 @@ def test_pmc_chain_json_regenerates_from_the_summaries(tag):
     text = doc.get("self_chain_groups_kernel<5>") or doc["self_chain_fused_kernel<5, 0>"]
     assert text["algorithmic_bytes"] == 2 * 12 * 64 * 8 * 77 * 77 * 4 + 64 * 77 * 77 * 4
     # the kernel reads every slab once: measured traffic within 15 % above the algorithmic bytes, never below them
+    # (round 6 on the launch skips the chunks above the diagonal of the causal text tower: the floor is what it asks for)
     measured = text["fetch_bytes"] + text["write_bytes"]
-    assert text["algorithmic_bytes"] <= measured <= 1.15 * text["algorithmic_bytes"]
+    assert text.get("causal_requested_bytes", text["algorithmic_bytes"]) <= measured <= 1.15 * text["algorithmic_bytes"]
 
 
 @pytest.mark.parametrize("tag", _rounds())

@@ -1,13 +1,13 @@
 #!/bin/bash
 # One GPU-box round: gpu tests, smoke, bench (JSON line), rocprofv3 kernel trace + PMC passes. Outputs under gpurun_out/$TAG.
 #   $2 = "notest" skips the pytest / smoke legs (profiles only); "lite" keeps them and skips the cfg-5 / DETR side traces at the end
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 nproc > $OUT/nproc.txt
 if [ "$2" != "notest" ]; then
-timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -12 | tee $OUT/pytest_gpu.txt
+timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -12 | tee $OUT/pytest_gpu.txt
 cp gpurun_out/parity_errors.json $OUT/parity.json 2>/dev/null
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/smoke.txt
 fi
@@ -32,12 +32,12 @@ timeout 200 python tools/probe_lrp.py both 5 2>&1 | grep -v amdgpu.ids > $OUT/lr
 rocprofv3 --list-avail > $OUT/counters_avail.txt 2>&1
 fi
 if [ "$2" == "lite" ]; then rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/trace $OUT/trace_full; exit 0; fi
-# cfg 5: the step's kernel split, the attention backward pair alone (v2 vs v3), SQ counters of the v3 kernels
+# cfg 5: the step's kernel split, the attention backward pair alone (generations 0 / 2 / 3 of the option attn_bf16_v3), SQ counters of the default pair
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/trace_cfg5 -o cfg5 -- python tools/probe_cfg5_trace.py 128 3 > /dev/null 2> $OUT/trace_cfg5.log
 python tools/prof_summary.py $OUT/trace_cfg5/cfg5_results.db "" 2>&1 | head -30 | cut -c1-190 > $OUT/cfg5_step_kernels.txt
-timeout 300 python tools/probe_attn_v3.py 128 0,2 2>&1 | grep -v amdgpu.ids > $OUT/attn_v3_probe.txt; cat $OUT/attn_v3_probe.txt
-timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/pmc_v3 -o v3 -- python tools/probe_attn_v3.py 16 2 > /dev/null 2> $OUT/pmc_v3.log
-python tools/pmc_sq.py $OUT/pmc_v3/v3_counter_collection.csv _v3_ > $OUT/attn_v3_sq.txt 2>&1; cat $OUT/attn_v3_sq.txt
+timeout 300 python tools/probe_attn_v3.py 128 0,2,3 3 2>&1 | grep -v amdgpu.ids > $OUT/attn_v3_probe.txt; cat $OUT/attn_v3_probe.txt
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/pmc_v3 -o v3 -- python tools/probe_attn_v3.py 16 3 > /dev/null 2> $OUT/pmc_v3.log
+python tools/pmc_sq.py $OUT/pmc_v3/v3_counter_collection.csv attn_bwd_ > $OUT/attn_v3_sq.txt 2>&1; cat $OUT/attn_v3_sq.txt
 if [ -z "$SKIP_PROBES" ]; then
 # cfg 3: DETR K = 10 pass with the three-launch decoder rules (rows of R_q_i only)
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_detr -o detr -- python tools/probe_detr_trace.py 5 10 rows > /dev/null 2> $OUT/trace_detr.log

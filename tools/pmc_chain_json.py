@@ -46,6 +46,11 @@ def build(tag):
         if m.group(2) in TOWERS and m.group(1) in ("self_chain_fused_kernel", "self_chain_groups_kernel"):
             _, L, H, N = TOWERS[m.group(2)]
             entry["algorithmic_bytes"] = 2 * L * BATCH * H * N * N * 4 + BATCH * N * N * 4
+            if m.group(2) == "5" and int(re.sub(r"\D", "", tag) or 0) >= 6:
+                # round 6 on: the text tower's launch carries MMX_CHAIN_CAUSAL (csrc/chain_stream.h) -- 16-byte chunks entirely above
+                # the diagonal are not requested, so the counters may read BELOW the algorithmic bytes, never below the requested ones
+                live = sum(1 for c in range((N * N + 3) // 4) if not ((4 * c) % N > (4 * c) // N and (4 * c) % N + 3 < N))
+                entry["causal_requested_bytes"] = 2 * L * BATCH * H * live * 16 + BATCH * N * N * 4
         doc[key] = entry
     return doc
 
