@@ -77,7 +77,7 @@ def leg_cfg1(kernel_time_us, reps=20):
             "multi_target": {"targets": 8, "ms": round(ms8, 3), "rate": round(8e3 / ms8, 1)},
             "kernel": _hbm("avg_heads_kernel<f32> (one layer, B = 1: 12 heads x 197^2)", 2 * H * N * N * 4 + N * N * 4, us,
                            "latency-bound at batch 1 (3.7 MB per launch); the pass itself is ~700 body launches"),
-            "source": "profiles/r05_cfg_legs.txt"}
+            "source": "measured in this run (HIP events); rocprofv3 kernel table of the same legs: profiles/r06_cfg_legs.txt"}
 
 
 def leg_cfg3(kernel_time_us, reps=10):
@@ -151,7 +151,7 @@ def leg_cfg3(kernel_time_us, reps=10):
             "lrp": {"ours_no_lrp_ms": round(lrp_no, 3), "ours_lrp_ms": round(lrp_yes, 3), "ratio": round(lrp_yes / lrp_no, 2),
                     "what": "Generator.generate_ours(img, [q]) per kept query, eager, per-query route (autograd backward): "
                             "use_lrp=False vs the default use_lrp=True (body relprop: closed-form rules + HIP attention-core kernels)"},
-            "kernel": kern, "source": "profiles/r05_cfg_legs.txt"}
+            "kernel": kern, "source": "measured in this run (HIP events); rocprofv3 kernel table of the same legs: profiles/r06_cfg_legs.txt"}
 
 
 def leg_cfg4(kernel_time_us, reps=10):
@@ -199,7 +199,7 @@ def leg_cfg4(kernel_time_us, reps=10):
                     "what": "GeneratorOurs.generate_ours(item) per item, eager: use_lrp=False vs the default use_lrp=True"},
             "kernel": _hbm("lxmert_schedule_v2_kernel = mmx_lxmert_schedule (38 rule applications: chip-wide rule 5 + last-arriver schedule on the MFMA, "
                            "B = 32)", nbytes, us, "2 MB of slabs per sample; the serial 38-step schedule of a sample is the floor"),
-            "source": "profiles/r05_cfg_legs.txt"}
+            "source": "measured in this run (HIP events); rocprofv3 kernel table of the same legs: profiles/r06_cfg_legs.txt"}
 
 
 def cfg5_step_flops(batch, executed=False):
@@ -289,7 +289,7 @@ def leg_cfg5(kernel_time_us, reps=3, batch=128):
             "variant_slab_chain": slab,
             "variant_trim_text_padding": {"ms": round(ms_trim, 3), "rate": round(batch / ms_trim * 1e3, 1),
                                           "note": "same maps (exact); NOT the headline of this leg: the reference runs all 77 positions"},
-            "source": "profiles/r05_cfg_legs.txt"}
+            "source": "measured in this run (HIP events); rocprofv3 kernel table of the same legs: profiles/r06_cfg_legs.txt"}
 
 
 def _cfg5_slab_chain_variant(model, image, texts, batch, kernel_time_us):
