@@ -28,6 +28,9 @@ import sys
 import tempfile
 import time
 
+# multi-process GPU work on this driver stack needs dmabuf IPC (the task environment exports it; a bare shell may not)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

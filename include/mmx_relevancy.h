@@ -401,7 +401,7 @@ int mmx_attn_capture_bwd_rowrel(const void* q_dev, const void* k_dev, const void
 /* ---------------------------------------------------------------------------------------------
  * K2-DETR: the decoder half of DETR's rule schedule for ROWS of R_q_i -- rules 5, 6, 7 and 10 with
  * eq. 8-9 and the NaN policy of DETR/modules/ExplanationGenerator.py:19-53 (rule functions), :120-140 (handle_co_attn_*) --
- * in three launches for all decoder layers.  For sample k and explained query t_k = targets[k]:
+ * in four launches for all decoder layers.  For sample k and explained query t_k = targets[k]:
  *     s[k][:] = sum_l clean_l ? u_l . N(R_qq^(l))^T . C_l : 0,     u_l = e_t^T (I + B_L) ... (I + B_(l+1)),
  * B_l / C_l = mean_h clamp(grad * attn, 0) of decoder layer l's self- / cross-attention, R_qq^(l) = (I + B_l) ... (I + B_1),
  * N = handle_residual; clean_l = no NaN in N(R_qq^(l)) nor in C_l (the reference zeroes the NaNs of the rule-10 addition,

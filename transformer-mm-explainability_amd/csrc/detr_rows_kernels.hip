@@ -5,9 +5,10 @@
 //     sum_l  u_l . N(R_qq^(l))^T . C_l . N(R_ii)           u_l = e_t^T (I + B_L) ... (I + B_(l+1))
 // with B_l / C_l the head-averaged decoder self- / cross-attention maps (rule 5), R_qq^(l) = (I + B_l) ... (I + B_1) and
 // N(.) eq. 8-9.  Everything left of C_l lives in the 100-query space; C_l is the [Q x Ni] map whose slabs are the bytes of
-// this step (K x H x Q x Ni x 4 per layer and operand: 30 MB at K = 10, Ni = 950).  Three launches for ALL decoder layers
+// this step (K x H x Q x Ni x 4 per layer and operand: 30 MB at K = 10, Ni = 950).  Four launches for ALL decoder layers
 // replace, per layer, avg_heads (self) + baddbmm + row_normalise + bmm + avg_heads (cross) + bmm + isnan / any / where / add +
 // baddbmm (torch launches in the round-2 rows-only route):
+//   0. detr_self_heads_kernel        B_l = rule 5 of every decoder self-attention map, chip-wide (round 6)
 //   1. detr_decoder_vectors_kernel   one workgroup per sample, R_qq and B_l in LDS (products on the exact-fp32 MFMA): bottom-up B_l, R_qq^(l), N(R_qq^(l)) (+ the
 //                                    diag >= 0 word of handle_residual and the NaN flag of the DETR policy), then top-down
 //                                    w_l = u_l . N(R_qq^(l))^T and u_(l-1) = u_l (I + B_l)
@@ -46,6 +47,36 @@ struct DetrRowsArgs {
 // word the Python wrapper reads (``NaN >= 0`` is false) -- ops.handle_residual's atomic_min_float keeps NaN bits the same way.
 __device__ __forceinline__ float min_keep_nan(float m, float v) { return (m != m || v != v) ? __builtin_nanf("") : fminf(m, v); }
 
+// Rule 5 of the decoder SELF-attention maps, every (sample, layer) at once: B_l = mean_h clamp(G_l * A_l, 0) into the Bq scratch.  The maps do not
+// depend on the chain, so they are reduced chip-wide here (K x L x ceil(Q^2 / 1024) workgroups, heads in ascending order: the same sums as
+// avg_heads_kernel) instead of inside the one-workgroup-per-sample chain below, where the 2 H dependent slab reads per element were 50 of its
+// 64 us per layer (round 6).
+__global__ __launch_bounds__(256) void detr_self_heads_kernel(const DetrRowsArgs a) {
+    const int l = blockIdx.y, k = blockIdx.z, QQ = a.Q * a.Q;
+    const int e0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e0 >= QQ) return;
+    const float* A = a.self_a[l] + static_cast<int64_t>(k) * a.self_a_bs;
+    const float* G = a.self_g[l] + static_cast<int64_t>(k) * a.H * QQ;
+    float* Bg = a.Bq + (static_cast<int64_t>(k) * a.L + l) * QQ;
+    const float fH = static_cast<float>(a.H);
+    if (e0 + 3 < QQ) {
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < a.H; ++h) {
+            const f32x4 av = ldg4_u(A + static_cast<int64_t>(h) * QQ + e0), gv = ldg4_u(G + static_cast<int64_t>(h) * QQ + e0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum[r] += relu_nan(gv[r] * av[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Bg[e0 + r] = sum[r] / fH;
+    } else {
+        for (int e = e0; e < QQ; ++e) {
+            float sum = 0.f;
+            for (int h = 0; h < a.H; ++h) sum += relu_nan(G[static_cast<int64_t>(h) * QQ + e] * A[static_cast<int64_t>(h) * QQ + e]);
+            Bg[e] = sum / fH;
+        }
+    }
+}
+
 __global__ __launch_bounds__(kVecThreads) void detr_decoder_vectors_kernel(const DetrRowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Q = a.Q, NTQ = (Q + 15) / 16, QP = NTQ * 16, LD = QP + 1, QQ = Q * Q;
@@ -65,16 +96,8 @@ __global__ __launch_bounds__(kVecThreads) void detr_decoder_vectors_kernel(const
     __syncthreads();
     // ---- bottom-up: B_l (rule 5), R_qq <- R_qq + B_l R_qq (rule 6), N(R_qq) (eq. 8-9)
     for (int l = 0; l < a.L; ++l) {
-        const float* A = a.self_a[l] + static_cast<int64_t>(k) * a.self_a_bs;
-        const float* G = a.self_g[l] + static_cast<int64_t>(k) * a.H * QQ;
-        float* Bg = a.Bq + (static_cast<int64_t>(k) * a.L + l) * QQ;
-        for (int e = tid; e < QQ; e += kVecThreads) {
-            float sum = 0.f;
-            for (int h = 0; h < a.H; ++h) sum += relu_nan(G[static_cast<int64_t>(h) * QQ + e] * A[static_cast<int64_t>(h) * QQ + e]);
-            sum = sum / static_cast<float>(a.H);
-            Bm[(e / Q) * LD + e % Q] = sum;
-            Bg[e] = sum;
-        }
+        const float* Bg = a.Bq + (static_cast<int64_t>(k) * a.L + l) * QQ;          // B_l: detr_self_heads_kernel
+        for (int e = tid; e < QQ; e += kVecThreads) Bm[(e / Q) * LD + e % Q] = Bg[e];
         __syncthreads();
         // R_new = R + B R on the exact-fp32 MFMA: 16 x 16 output tiles dealt round-robin to the 16 waves, both operands in LDS
         // (A = B_l [i][c], B = R [c][j], zero padded); the new tiles stay in registers until every wave has read the old R
@@ -183,10 +206,23 @@ __global__ __launch_bounds__(256) void detr_cross_rows_kernel(const DetrRowsArgs
         const int64_t off = static_cast<int64_t>(q) * Ni + n0;
         f32x4 cam = {0.f, 0.f, 0.f, 0.f};
         if (full) {
-            for (int h = 0; h < a.H; ++h) {
-                const f32x4 av = ldg4_u(A + h * hs + off), gv = ldg4_u(G + h * hs + off);
+            // heads in ascending order (the reference's sum), four at a time: the eight 16-byte loads of a batch are requested before
+            // the first is used (one load pair per dependent iteration left the slabs at 1.4 TB/s); a padding head re-reads head H - 1
+            // and is selected away
+            for (int h0 = 0; h0 < a.H; h0 += 4) {
+                f32x4 av[4], gv[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cam[r] += relu_nan(gv[r] * av[r]);
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t ho = static_cast<int64_t>(min(h0 + u, a.H - 1)) * hs + off;
+                    av[u] = ldg4_u(A + ho);
+                    gv[u] = ldg4_u(G + ho);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool on = h0 + u < a.H;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cam[r] += on ? relu_nan(gv[u][r] * av[u][r]) : 0.f;
+                }
             }
         } else if (any) {
             for (int h = 0; h < a.H; ++h)
@@ -286,6 +322,8 @@ extern "C" int mmx_detr_decoder_rows(const void* const* self_attn, const void* c
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     }
+    detr_self_heads_kernel<<<dim3((Q * Q + 1023) / 1024, n_layers, K), 256, 0, s>>>(a);
+    MMX_LAUNCH_CHECK("detr_self_heads_kernel");
     detr_decoder_vectors_kernel<<<dim3(K), kVecThreads, lds, s>>>(a);
     MMX_LAUNCH_CHECK("detr_decoder_vectors_kernel");
     detr_cross_rows_kernel<<<dim3((Ni + kCrossCols - 1) / kCrossCols, n_layers, K), 256, 0, s>>>(a);

@@ -992,7 +992,7 @@ def attn_relprop(q, k, v, probs, o, cam_o, scale, scale_mode=_lib.SCALE_Q_FIRST,
 
 
 def detr_decoder_rows(self_pairs, cross_pairs, targets, shared_attn=False):
-    """K2-DETR (``mmx_detr_decoder_rows``): the decoder half of DETR's rules for ROWS of ``R_q_i`` in three launches.
+    """K2-DETR (``mmx_detr_decoder_rows``): the decoder half of DETR's rules for ROWS of ``R_q_i`` in four launches.
     ``self_pairs[l]`` / ``cross_pairs[l]``: ``(attn, grad)`` of decoder layer l's self- / cross-attention, fp32, gradient
     slabs ``[K*H, Q, *]``, probability slabs the same or ``[H, Q, *]`` when ``shared_attn`` (one forward for the K samples).
     ``targets``: ``[K]`` long.  Returns ``(s [K, Ni], diag_min [1])`` -- see include/mmx_relevancy.h."""

@@ -14,6 +14,8 @@ import json
 import os
 import random
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL between processes (before the HIP runtime starts)
+
 import torch
 import torch.distributed as dist
 
