@@ -107,8 +107,14 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # The reference gathers variable-length per-rank pieces instead (pickled ``evalImgs`` + image ids: DETR/util/misc.py:88-128,
+    # DETR/datasets/coco_eval.py:170-189).  Same pieces through that route -- this rank's image ids and its rows as an
+    # ``[..., n_local_images]`` array -- must give the same table (outside the timed region; pycocotools' own content is out of reach here).
+    mine = sharding.shard_indices(ids)
+    merged_ids, merged = sharding.merge_eval_images(mine, table[mine].T.reshape(STAT_COLS, 1, len(mine)).cpu().numpy(), device=gather_dev)
+    merge_ok = merged_ids.tolist() == ids and bool((torch.from_numpy(merged[:, 0, :].T.copy()) == table.cpu()).all())
     if rank == 0:
-        print(json.dumps({"images": len(ids), "n_gpus": world, "seconds": round(elapsed, 3), "warmup_images": args.warmup_images,
+        print(json.dumps({"images": len(ids), "n_gpus": world, "eval_imgs_merge_matches": merge_ok, "seconds": round(elapsed, 3), "warmup_images": args.warmup_images,
                           "images_per_s": round(len(ids) / elapsed, 1),
                           "queries_per_s_this_rank": round(queries[0] / elapsed, 1), "method": args.method,
                           "mean_kept": round(float(table[:, 0].mean()), 2),

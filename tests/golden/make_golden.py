@@ -941,6 +941,30 @@ def reference_function(rel_path, class_name, func_name, namespace):
     raise KeyError((class_name, func_name))
 
 
+def gen_detr_eval_merge():
+    """``merge`` of ``DETR/datasets/coco_eval.py:170-189`` -- the module cannot be imported (pycocotools), so the function's source is cut
+    out of the file and exec'd unchanged -- on the per-rank pieces of a two-rank run: image-id lists of different lengths with the
+    repeated images a distributed sampler pads the last shard with, and ``evalImgs``-shaped object arrays ``[categories, areas, images]``.
+    ``all_gather`` (``DETR/util/misc.py:88-128``) is a stand-in that returns the two ranks' pieces in rank order, which is its contract."""
+    import ast
+    import textwrap
+    rel = "DETR/datasets/coco_eval.py"
+    src = open(os.path.join(REF, rel)).read()
+    node = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "merge")
+    rng = np.random.RandomState(77)
+    ids = [[17, 3, 42, 8, 23], [5, 42, 11, 3]]                       # ranks 0 / 1; 42 and 3 appear on both (sampler padding)
+    evals = [rng.rand(4, 3, len(i)).astype(np.float64) for i in ids]
+    pieces = {"ids": ids, "evals": evals}
+
+    def all_gather(data):
+        return pieces["ids"] if isinstance(data, list) else pieces["evals"]
+    ns = {"np": np, "all_gather": all_gather}
+    exec(textwrap.dedent(ast.get_source_segment(src, node)), ns)
+    merged_ids, merged_evals = ns["merge"](ids[0], evals[0])
+    save("detr_eval_merge", ids_rank0=np.array(ids[0]), ids_rank1=np.array(ids[1]), evals_rank0=evals[0], evals_rank1=evals[1],
+         merged_ids=np.asarray(merged_ids), merged_evals=np.asarray(merged_evals))
+
+
 def gen_lxmert_perturbation():
     """``ModelPert.perturbation_image`` / ``perturbation_text`` (lxmert/lxmert/perturbation.py:85-194) -- the reference's
     own method bodies, exec'd from the file -- driving the REAL reference LXMERT body of ``gen_lxmert_model`` (same
@@ -1196,6 +1220,8 @@ def main(which):
         "lxmert_model_lrp": gen_lxmert_model_lrp, "visualbert_model_lrp": gen_visualbert_model_lrp,
         # round 4
         "clip_tiny_fp16": gen_clip_tiny_fp16, "clip_vitb32_fp16": gen_clip_vitb32_fp16,
+        # round 6
+        "detr_eval_merge": gen_detr_eval_merge,
     }
     for name in (which or list(todo)):
         todo[name]()

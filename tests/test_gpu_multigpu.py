@@ -66,6 +66,8 @@ def test_evaluators_two_ranks_on_one_gpu_equal_one_rank(script, args, same):
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     for key in same:
         assert one[key] == two[key], (key, one[key], two[key])
+    if script == "detr_masks_eval.py":      # the reference's pickled-pieces gather + merge (sharding.merge_eval_images) gives the same table
+        assert one["eval_imgs_merge_matches"] is True and two["eval_imgs_merge_matches"] is True
 
 
 def test_lxmert_evaluator_two_ranks_equal_one_rank():

@@ -159,3 +159,38 @@ def test_batch_prefetcher_feeds_evaluate_sharded_in_order(tmp_path):
         raise RuntimeError("dataset went away")
     with pytest.raises(RuntimeError, match="dataset went away"):
         sharding.evaluate_sharded(ids, lambda k: 0, process, 3, max_batch=5, load_batch=broken, prefetch_device="cpu")
+
+
+def _merge_worker(rank, world_size, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from transformer_mm_explainability_amd import sharding
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "detr_eval_merge.npz"))
+    # ragged objects first: rank 0 a long record, rank 1 an empty one
+    mine = {"rank": rank, "ids": list(range(1000)) if rank == 0 else [], "note": "x" * (3 if rank else 70000)}
+    everyone = sharding.all_gather_objects(mine)
+    ok = [e["rank"] for e in everyone] == [0, 1] and len(everyone[0]["ids"]) == 1000 and everyone[1]["ids"] == [] \
+        and len(everyone[0]["note"]) == 70000 and everyone[1]["note"] == "xxx"
+    ids, evals = sharding.merge_eval_images(list(gold["ids_rank%d" % rank]), gold["evals_rank%d" % rank])
+    ok = ok and np.array_equal(ids, gold["merged_ids"]) and ids.dtype == gold["merged_ids"].dtype \
+        and np.array_equal(evals, gold["merged_evals"])
+    torch.save({"ok": bool(ok)}, os.path.join(tmpdir, "m%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_object_gather_and_eval_image_merge_world2(tmp_path):
+    """``sharding.all_gather_objects`` / ``merge_eval_images`` = ``DETR/util/misc.py:88-128`` ``all_gather`` and
+    ``DETR/datasets/coco_eval.py:170-189`` ``merge``: two gloo ranks with ragged pieces reproduce, on BOTH ranks, what the reference's own
+    ``merge`` source returned for the same pieces (``tests/golden/detr_eval_merge.npz``, made by ``make_golden.py gen_detr_eval_merge``);
+    without a process group the gather is ``[data]`` and the merge just sorts and de-duplicates."""
+    import numpy as np
+    from transformer_mm_explainability_amd import sharding
+    port = 29500 + (os.getpid() + 911) % 2000
+    mp.spawn(_merge_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert torch.load(tmp_path / "m0.pt")["ok"] and torch.load(tmp_path / "m1.pt")["ok"]
+    assert sharding.all_gather_objects({"a": 1}) == [{"a": 1}]
+    ids, evals = sharding.merge_eval_images([9, 2, 9, 4], np.arange(8.0).reshape(1, 2, 4))
+    assert ids.tolist() == [2, 4, 9] and evals[0, :, :].tolist() == [[1.0, 3.0, 0.0], [5.0, 7.0, 4.0]]

@@ -100,6 +100,45 @@ def gather_per_sample(local, total, fill=float("nan"), collective_at_world_one=F
     return out.transpose(0, 1).reshape((per * world_size,) + tuple(local.shape[1:]))[:total]
 
 
+def all_gather_objects(data, device=None):
+    """Every rank's picklable ``data`` as a list in rank order, on every rank -- what ``DETR/util/misc.py:88-128`` ``all_gather`` gives the
+    reference's evaluators (COCO ``evalImgs`` / image-id lists of different lengths per rank, ``DETR/datasets/coco_eval.py:170-189``).  World
+    size 1 returns ``[data]`` without touching a process group, like the reference.  Two fixed-shape collectives: the byte counts (one int64
+    per rank), then ONE flat ``all_gather_into_tensor`` of the payloads zero-padded to the longest (RCCL wants equal shapes; the reference
+    pads too).  ``device``: where the byte tensors live -- defaults to the current CUDA device under the ``nccl`` backend, the host otherwise."""
+    import pickle
+    rank, world_size = world()
+    if world_size == 1:
+        return [data]
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    payload = torch.frombuffer(bytearray(pickle.dumps(data)), dtype=torch.uint8).to(device)
+    sizes = torch.empty(world_size, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(sizes, torch.tensor([payload.numel()], dtype=torch.int64, device=device))
+    sizes = [int(n) for n in sizes.tolist()]
+    longest = max(max(sizes), 1)
+    padded = torch.zeros(longest, dtype=torch.uint8, device=device)
+    padded[: payload.numel()] = payload
+    flat = torch.empty(world_size * longest, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(flat, padded)
+    flat = flat.cpu().numpy()
+    return [pickle.loads(flat[r * longest: r * longest + sizes[r]].tobytes()) for r in range(world_size)]
+
+
+def merge_eval_images(img_ids, eval_imgs, device=None):
+    """``DETR/datasets/coco_eval.py:170-189`` ``merge``: gather every rank's image ids (a list) and its per-image evaluation array
+    (``[..., n_local_images]``, images on the LAST axis), concatenate in rank order and keep each image ONCE, in sorted id order (a
+    distributed sampler pads the last shard with repeated images: the first occurrence wins, as ``np.unique(return_index=True)`` picks it).
+    Returns ``(merged_img_ids, merged_eval_imgs)`` as numpy arrays, identical on every rank."""
+    import numpy as np
+    all_ids = all_gather_objects(list(img_ids), device)
+    all_imgs = all_gather_objects(np.asarray(eval_imgs), device)
+    merged_ids = np.array([i for part in all_ids for i in part])
+    merged_imgs = np.concatenate(all_imgs, axis=-1)
+    merged_ids, first = np.unique(merged_ids, return_index=True)
+    return merged_ids, merged_imgs[..., first]
+
+
 class BatchPrefetcher:
     """Host side of an evaluator loop off the critical path: a worker thread assembles batch i + 1, i + 2 (``load(ids)`` -> a dict of
     CPU tensors: dataset access, padding, stacking), stages them in REUSED pinned buffers and issues the host-to-device copies on a
