@@ -93,6 +93,8 @@ const char* mmx_last_error(void);
  *                        LDS, then that block row of A_bar . R on the exact-fp32 MFMA (csrc/relevancy_chain_rows.hip; same results to
  *                        summation order, measured 0.87x the speed of the default at 577 tokens: profiles/r06_chain_rows_probe.txt)
  *   "attn_head"          1 (default) register-resident whole-head attention kernels (Nk <= 128, Nq <= 256) | 0 never
+ *   "attn_head_tile_skip" 1 (default) the whole-head kernels skip the products of 16-key tiles whose probabilities are exact zeros for a
+ *                        whole 16-row strip (causal / padding masks; same bits, dP stays dense) | 0 never (A / B runs)
  *   "attn_stream"        1 (default) long-sequence streaming attention kernels | 0 only the general tiled kernels (any head_dim, any
  *                        alignment: what every shape the other families turn down runs on)
  *   "attn_bf16_v3"       non-zero (default): third-generation bf16 backward of the shared-forward row-relevancy mode | 0: second generation

@@ -257,7 +257,7 @@ def test_bmm_tiles_kernel(chain_options, B, M, N, K, cin, nan):
 def attn_options(ops):
     """Options of the attention kernels are process-global: whatever a test sets is put back, also when it fails."""
     yield ops
-    for key, value in (("attn_head", 1), ("attn_stream", 1), ("attn_fwd_split", 1), ("attn_bf16_v3", 3)):
+    for key, value in (("attn_head", 1), ("attn_stream", 1), ("attn_fwd_split", 1), ("attn_bf16_v3", 3), ("attn_head_tile_skip", 1)):
         ops.set_option(key, value)
 
 
@@ -1016,3 +1016,54 @@ def test_causal_flag_skips_the_upper_triangle_with_the_same_bits(chain_options, 
         got = ops.relevancy_self_chain(bad, hot, B, causal=True)
         # (the flag is a licence, not an order: a route that does not stream fp32 slabs through chain_stream.h reads everything)
         assert torch.equal(got, clean) or (N < 50 and torch.equal(got, dirty))
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D,mask_kind", [
+    (4, 8, 77, 77, 64, "causal"), (2, 12, 50, 50, 64, "none"), (3, 4, 128, 128, 32, "causal"), (2, 3, 33, 33, 16, "causal"),
+    (2, 12, 14, 36, 64, "padding"), (3, 2, 100, 100, 64, "padding"), (2, 4, 77, 77, 64, "band"), (1, 2, 17, 120, 48, "padding"),
+    (2, 2, 77, 77, 64, "dead_rows"),
+])
+def test_whole_head_masked_tile_skip_same_bits(attn_options, B, H, Nq, Nk, D, mask_kind):
+    """``attention_head.hip`` skips the products of 16-key tiles that are masked out for a whole 16-row strip (causal towers: 10 of 25
+    tiles at 77 tokens; padded batches; any additive -inf mask): P, O, dP, dq, dk, dv must be BIT-identical to the kernels with the skip
+    switched off (option ``attn_head_tile_skip``), the results of the forward must still match the torch reference, and dP stays dense
+    (the reference exposes it as ``attn_grad``: dO.V^T above the diagonal too).  ``band``: live tiles that are neither a prefix nor a
+    suffix for some strips; ``dead_rows``: whole query rows masked (NaN rows in the reference too) must come out the same either way."""
+    ops = attn_options
+    g = torch.Generator().manual_seed(Nq * 11 + Nk)
+    q, k, v, d_o = (torch.randn(B, n, H, D, generator=g).cuda() for n in (Nq, Nk, Nk, Nq))
+    ninf = float("-inf")
+    mask = None
+    if mask_kind == "causal":
+        mask = torch.full((Nq, Nk), ninf).triu_(1)
+    elif mask_kind == "padding":
+        lens = torch.randint(1, Nk + 1, (B,), generator=g)
+        mask = torch.zeros(B, 1, Nk)
+        for b in range(B):
+            mask[b, 0, int(lens[b]):] = ninf
+    elif mask_kind == "band":
+        i, j = torch.arange(Nq)[:, None], torch.arange(Nk)[None, :]
+        mask = torch.where((j > i) | (j < i - 20), torch.tensor(ninf), torch.tensor(0.0))
+    elif mask_kind == "dead_rows":
+        mask = torch.full((Nq, Nk), ninf).triu_(1)
+        mask[5] = ninf
+        mask[40:44] = ninf
+    mc = mask.cuda() if mask is not None else None
+    scale = D ** -0.5
+    outs = {}
+    for skip in (0, 1):
+        ops.set_option("attn_head_tile_skip", skip)
+        probs, dprobs = torch.full((B, H, Nq, Nk), 7.0, device="cuda"), torch.full((B, H, Nq, Nk), 7.0, device="cuda")
+        o = ops.attn_capture_fwd(q, k, v, probs, scale, 0, mc)
+        dq, dk, dv = ops.attn_capture_bwd(q, k, v, probs, d_o, dprobs, scale, 0)
+        outs[skip] = [t.clone() for t in (probs, o, dprobs, dq, dk, dv)]
+    for name, a, b in zip(("P", "O", "dP", "dq", "dk", "dv"), outs[0], outs[1]):
+        assert torch.equal(a.nan_to_num(nan=123.0), b.nan_to_num(nan=123.0)) and torch.equal(a.isnan(), b.isnan()), name
+    if mask_kind != "dead_rows":
+        mref = mask if mask is None or mask.dim() == 2 else mask[:, None]
+        qr, kr, vr = (t.cpu().permute(0, 2, 1, 3) for t in (q, k, v))
+        p_ref, o_ref = torch_attention(qr, kr, vr, scale, 0, mref)
+        close(outs[1][0], p_ref.float().numpy(), atol=2e-6)
+        close(outs[1][1].permute(0, 2, 1, 3), o_ref.float().numpy(), atol=1e-5)
+    if mask_kind == "causal":       # dP is dense: the gradient of the probabilities above the diagonal is dO.V^T, not zero
+        assert float(outs[1][2][:, :, 0, Nk - 1].abs().min()) > 0.0

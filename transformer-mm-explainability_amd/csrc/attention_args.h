@@ -16,6 +16,7 @@ struct AttnFwdArgs {
     int debug;  // profiling only (attention_small.hip)
     int slab_dt;  // MMX_F32 | MMX_F16 | MMX_BF16: element type behind `probs` (non-fp32: streaming kernels only)
     int mma_bf16; // 1: products on v_mfma_f32_16x16x32_bf16 (operands rounded to bf16, fp32 accumulate, fp32 softmax)
+    int tile_skip = 0;  // whole-head kernels: skip the products of key tiles that are masked out for a whole wave (attention_head.hip)
 };
 
 struct AttnBwdArgs {
@@ -42,6 +43,7 @@ struct AttnBwdArgs {
     // MMX_ATTN_IO_BF16 (bf16-MFMA streaming kernels only): `dout` is bf16 and dq / dk / dv are written as bf16 (the
     // gradient stream between the bf16 GEMMs of a bf16 body); strides stay in elements.  q / k / v / o / delta: fp32.
     int io_bf16;
+    int tile_skip = 0;  // whole-head kernels: skip the products of all-zero probability tiles (attention_head.hip, with_tile_count)
 };
 
 int attn_fwd_head_try(const AttnFwdArgs& a, hipStream_t s, int* rc_out);    // attention_head.hip (register-resident)

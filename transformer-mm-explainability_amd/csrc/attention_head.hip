@@ -27,6 +27,8 @@
 #include "mmx_common.h"
 #include "attention_args.h"
 
+#include <type_traits>
+
 namespace mmx {
 
 namespace {
@@ -168,28 +170,29 @@ __device__ __forceinline__ void store_chunk(float* row, int k0, int n, bool row_
 // acc[t] += X[16t + c16][.] . breg[.] over the head dimension: the A operand tiles (one ds_read_b128 per (kk, t)) are
 // fetched ONE kk-step ahead of the MFMAs that consume them, and consecutive MFMAs go to different accumulators
 // (the 16x16x4 fp32 MFMA has 40 cycles of dependent latency against 32 of issue).
-template <int DP, int NTK, int LS>
+// NA <= NTK: only the FIRST NA tiles are computed (the others are known to be masked out / multiplied by exact zeros: see live_tiles)
+template <int DP, int NTK, int LS, int NA = NTK>
 __device__ __forceinline__ void tiles_kd(f32x4 (&acc)[NTK], const float* Xs, const f32x4 (&breg)[DP / 16], int c16, int g) {
     constexpr int KK = DP / 16;
-    f32x4 cur[NTK], nxt[NTK];
+    f32x4 cur[NA], nxt[NA];
 #pragma unroll
-    for (int t = 0; t < NTK; ++t) cur[t] = *reinterpret_cast<const f32x4*>(Xs + (t * 16 + c16) * LS + 4 * g);
+    for (int t = 0; t < NA; ++t) cur[t] = *reinterpret_cast<const f32x4*>(Xs + (t * 16 + c16) * LS + 4 * g);
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
         if (kk + 1 < KK) {
 #pragma unroll
-            for (int t = 0; t < NTK; ++t)
+            for (int t = 0; t < NA; ++t)
                 nxt[t] = *reinterpret_cast<const f32x4*>(Xs + (t * 16 + c16) * LS + (kk + 1) * 16 + 4 * g);
         }
         __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE the MFMAs (hipcc sinks LDS reads to their use)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int t = 0; t < NTK; ++t) acc[t] = mfma16x16x4(cur[t][i], breg[kk][i], acc[t]);
+            for (int t = 0; t < NA; ++t) acc[t] = mfma16x16x4(cur[t][i], breg[kk][i], acc[t]);
         __builtin_amdgcn_sched_barrier(0);
         if (kk + 1 < KK) {
 #pragma unroll
-            for (int t = 0; t < NTK; ++t) cur[t] = nxt[t];
+            for (int t = 0; t < NA; ++t) cur[t] = nxt[t];
         }
     }
 }
@@ -199,7 +202,7 @@ __device__ __forceinline__ void tiles_kd(f32x4 (&acc)[NTK], const float* Xs, con
 // The registers go in as the MFMA's B operand and Y as its A operand, i.e. the tile comes out TRANSPOSED: lane (c16, g) holds
 // columns 16td + 4g .. + 3 of ITS OWN row c16 -- four consecutive floats of one output row, one 16-byte store
 // (store_rows16) instead of four 4-byte stores to four rows.  Same products, same contraction order.
-template <int DP, int NTK, int LS>
+template <int DP, int NTK, int LS, int NA = NTK>
 __device__ __forceinline__ void tiles_from_regs(f32x4 (&out)[DP / 16], const f32x4 (&areg)[NTK], const float* Ys, int c16, int g) {
     constexpr int KK = DP / 16;
     float cur[KK], nxt[KK];
@@ -207,8 +210,8 @@ __device__ __forceinline__ void tiles_from_regs(f32x4 (&out)[DP / 16], const f32
 #pragma unroll
     for (int td = 0; td < KK; ++td) cur[td] = y0[td * 16];
 #pragma unroll
-    for (int s = 0; s < NTK * 4; ++s) {
-        if (s + 1 < NTK * 4) {
+    for (int s = 0; s < NA * 4; ++s) {
+        if (s + 1 < NA * 4) {
             const float* yn = y0 + (((s + 1) >> 2) * 16 + ((s + 1) & 3)) * LS;
 #pragma unroll
             for (int td = 0; td < KK; ++td) nxt[td] = yn[td * 16];
@@ -217,10 +220,26 @@ __device__ __forceinline__ void tiles_from_regs(f32x4 (&out)[DP / 16], const f32
 #pragma unroll
         for (int td = 0; td < KK; ++td) out[td] = mfma16x16x4(cur[td], areg[s >> 2][s & 3], out[td]);
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < NTK * 4) {
+        if (s + 1 < NA * 4) {
 #pragma unroll
             for (int td = 0; td < KK; ++td) cur[td] = nxt[td];
         }
+    }
+}
+
+// Masked-tile skip (round 6).  A 16-key tile whose probabilities are exact zeros for all 16 query rows of a wave -- the keys above the
+// diagonal of a causally masked tower (CLIP's text tower: 10 of 25 tiles at 77 tokens), the padding keys of a padded batch -- contributes
+// exact zeros to O = P.V, dQ = dS.K, dK = dS^T.Q and dV = P^T.dO (finite operands), and its scores end at -inf whatever K.Q^T says.  A wave
+// finds its LAST tile that is not like that (from the mask chunks in the forward, from the P chunks in the backward; wave-uniform) and runs
+// the products of the tiles up to it only; the instantiation for that count is picked by a wave-uniform switch.  Same bits as the full
+// products; dP = dO.V^T, which the reference exposes as `attn_grad`, stays dense.  a.tile_skip = 0 switches it off (A / B runs).
+template <int NTK, typename F>
+__device__ __forceinline__ void with_tile_count(int na, F&& f) {
+    switch (na) {
+#define MMX_NA_CASE(K) case K: if constexpr (K < NTK) { f(std::integral_constant<int, K>{}); break; }
+        MMX_NA_CASE(1) MMX_NA_CASE(2) MMX_NA_CASE(3) MMX_NA_CASE(4) MMX_NA_CASE(5) MMX_NA_CASE(6) MMX_NA_CASE(7)
+#undef MMX_NA_CASE
+        default: f(std::integral_constant<int, NTK>{});
     }
 }
 
@@ -329,7 +348,20 @@ __global__ __launch_bounds__(1024) void attn_fwd_head_kernel(const AttnFwdArgs a
     f32x4 acc[NTK];
 #pragma unroll
     for (int t = 0; t < NTK; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!(skip & 2)) tiles_kd<DP, NTK, LSK>(acc, Ks, qreg, c16, g);
+    // tiles beyond `na` are masked with -inf for every valid row of this wave (with_tile_count): their scores are -inf without the MFMAs
+    int na = NTK;
+    if (a.mask && a.tile_skip) {
+        na = 1;
+#pragma unroll
+        for (int t = 1; t < NTK; ++t) {
+            bool dead = true;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dead = dead && (mk[t][r] == -__builtin_inff() || t * 16 + 4 * g + r >= a.Nk);
+            if (!__all(dead || !qv)) na = t + 1;
+        }
+    }
+    if (!(skip & 2))
+        with_tile_count<NTK>(na, [&](auto n) { tiles_kd<DP, NTK, LSK, decltype(n)::value>(acc, Ks, qreg, c16, g); });
 
     // scale / mask / softmax, all in registers (the mask chunks were requested before the S MFMAs)
     float m = -__builtin_inff();
@@ -370,7 +402,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_head_kernel(const AttnFwdArgs a
     f32x4 oacc[KK];
 #pragma unroll
     for (int td = 0; td < KK; ++td) oacc[td] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!(skip & 8)) tiles_from_regs<DP, NTK, LSV>(oacc, acc, Vs, c16, g);
+    if (!(skip & 8))
+        with_tile_count<NTK>(na, [&](auto n) { tiles_from_regs<DP, NTK, LSV, decltype(n)::value>(oacc, acc, Vs, c16, g); });
     store_rows16<DP>(a.o + b * a.os.sb + h * a.os.sh, a.os.sn, q, qv && (!(skip & 16) || oacc[0][0] == 12345.f), a.D, g, oacc, 1.f);
 }
 
@@ -386,6 +419,10 @@ __global__ __launch_bounds__(NTK >= 7 ? 512 : 1024) void attn_bwd_head_kernel(co
     float* Ks = Vs + NPk * LSA;       // [NPk][LSB]   phase B: B operand of dQ = dS.K
     float* Ts = smem;                 // [NPq][SS]    phase C: dS (pass 1) / P (pass 2), row-major [q][key]
     float* Bs = Ts + NPq * SS;        // [NPq][LSB]   phase C: Q' (pass 1) / dO (pass 2)
+    // [NTQ] bit t set: P tile (this strip, key tile t) is not all zero -- behind whichever of the two layouts above is the longer one
+    constexpr int kAB = NPk * (LSA + LSB);
+    const int kC = NPq * (SS + LSB);
+    unsigned* live_tab = reinterpret_cast<unsigned*>(smem + (kAB > kC ? kAB : kC));
 
     const int h = blockIdx.x, b = blockIdx.y;
     const int c16 = lane & 15, g = lane >> 4;
@@ -434,6 +471,19 @@ __global__ __launch_bounds__(NTK >= 7 ? 512 : 1024) void attn_bwd_head_kernel(co
         for (int r = 0; r < 4; ++r) dot += acc[t][r] * preg[t][r];
     }
     if (!a.need_dqkv) return;
+    // key tiles whose probabilities are exact zeros for every row of this strip (with_tile_count): bit t of `live`, wave-uniform; published
+    // for phase C (the barriers in front of its first read order the store)
+    unsigned live = (1u << NTK) - 1u;
+    if (a.tile_skip) {
+        live = 0u;
+#pragma unroll
+        for (int t = 0; t < NTK; ++t) {
+            const bool zero = preg[t][0] == 0.f && preg[t][1] == 0.f && preg[t][2] == 0.f && preg[t][3] == 0.f;
+            if (!__all(zero)) live |= 1u << t;
+        }
+    }
+    if (lane == 0) live_tab[wave] = live;
+    const int na = live ? 32 - __builtin_clz(live) : 1;
     dot = rows4_allreduce<false>(dot);
 #pragma unroll
     for (int t = 0; t < NTK; ++t)
@@ -450,7 +500,7 @@ __global__ __launch_bounds__(NTK >= 7 ? 512 : 1024) void attn_bwd_head_kernel(co
         f32x4 dq[KK];
 #pragma unroll
         for (int td = 0; td < KK; ++td) dq[td] = f32x4{0.f, 0.f, 0.f, 0.f};
-        tiles_from_regs<DP, NTK, LSB>(dq, acc, Ks, c16, g);
+        with_tile_count<NTK>(na, [&](auto n) { tiles_from_regs<DP, NTK, LSB, decltype(n)::value>(dq, acc, Ks, c16, g); });
         if constexpr (IOH)
             store_rows16_bf16<DP>(reinterpret_cast<unsigned short*>(a.dq) + b * a.dqs.sb + h * a.dqs.sh, a.dqs.sn, q, qv, a.D, g, dq,
                                   q_first ? a.scale : 1.f);
@@ -483,12 +533,20 @@ __global__ __launch_bounds__(NTK >= 7 ? 512 : 1024) void attn_bwd_head_kernel(co
             for (int td = 0; td < KK; ++td) o[td] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* t0 = Ts + 4 * g * SS + kt * 16 + c16;
             const float* b0 = Bs + 4 * g * LSB + c16;
-            const int steps = NTQ * 4;
-            float a_cur = t0[0], a_nxt, b_cur[KK], b_nxt[KK];
+            // query strips whose P tile at this key tile is all zero contribute exact zeros (dS = P (dP - delta) is zero with it): run from
+            // the first live strip to the last one (a causal tower: strips kt ... NTQ - 1)
+            int tq0 = NTQ, tq1 = 0;
+            for (int tq = 0; tq < NTQ; ++tq)
+                if ((live_tab[tq] >> kt) & 1u) { tq0 = min(tq0, tq); tq1 = tq + 1; }
+            tq0 = __builtin_amdgcn_readfirstlane(min(tq0, tq1));
+            tq1 = __builtin_amdgcn_readfirstlane(tq1);
+            const int s0 = tq0 * 4, steps = tq1 * 4;
+            const int row0 = tq0 * 16;
+            float a_cur = t0[row0 * SS], a_nxt, b_cur[KK], b_nxt[KK];
 #pragma unroll
-            for (int td = 0; td < KK; ++td) b_cur[td] = b0[td * 16];
+            for (int td = 0; td < KK; ++td) b_cur[td] = b0[row0 * LSB + td * 16];
 #pragma unroll 4
-            for (int s = 0; s < steps; ++s) {
+            for (int s = s0; s < steps; ++s) {
                 const int sn = s + 1 < steps ? s + 1 : s;
                 const int rown = (sn >> 2) * 16 + (sn & 3);
                 a_nxt = t0[rown * SS];
@@ -530,6 +588,8 @@ static bool aligned16(const void* p, int64_t s0, int64_t s1, int64_t s2) {
 }
 
 static int g_attn_head = 1;   // 0: skip these kernels (tests / A-B profiling run the older paths)
+static int g_attn_head_tile_skip = 1;   // option "attn_head_tile_skip": masked-tile skip (with_tile_count); 0 for A / B runs
+void attn_head_tile_skip(int on) { g_attn_head_tile_skip = on ? 1 : 0; }
 static int g_attn_head_stagger = 0;
 void attn_head_enable(int on) { g_attn_head = on & 1; g_attn_head_stagger = on >> 8; }   // bits 8..15 fwd phase skips, 16.. stagger
 
@@ -538,7 +598,7 @@ static size_t fwd_head_lds(int DP, int NTK) { return sizeof(float) * NTK * 16 * 
 static size_t bwd_head_lds(int DP, int NTK, int NTQ) {
     const size_t ab = static_cast<size_t>(NTK) * 16 * (2 * DP + 12);
     const size_t c = static_cast<size_t>(NTQ) * 16 * (NTK * 16 + 4 + DP + 4);
-    return sizeof(float) * (ab > c ? ab : c);
+    return sizeof(float) * ((ab > c ? ab : c) + static_cast<size_t>(NTQ));      // + the strips' live-tile words
 }
 
 template <typename K, typename A>
@@ -596,6 +656,7 @@ static int bwd_head_dispatch(const AttnBwdArgs& a, int NTK, int threads, size_t 
 int attn_fwd_head_try(const AttnFwdArgs& a_in, hipStream_t s, int* rc_out) {
     AttnFwdArgs a = a_in;
     a.debug = g_attn_head_stagger;
+    a.tile_skip = g_attn_head_tile_skip;
     if (!g_attn_head || a.slab_dt != MMX_F32 || a.D % 4 || a.D > 64 || a.Nk > 128 || a.Nq > 256 || a.Nq < 1 || a.Nk < 1)
         return 0;
     if (!aligned16(a.q, a.qs.sb, a.qs.sh, a.qs.sn) || !aligned16(a.k, a.ks.sb, a.ks.sh, a.ks.sn) ||
@@ -610,6 +671,7 @@ int attn_fwd_head_try(const AttnFwdArgs& a_in, hipStream_t s, int* rc_out) {
 int attn_bwd_head_try(const AttnBwdArgs& a_in, hipStream_t s, int* rc_out) {
     AttnBwdArgs a = a_in;
     a.debug = g_attn_head_stagger;
+    a.tile_skip = g_attn_head_tile_skip;
     if (!g_attn_head || a.slab_dt != MMX_F32 || a.D % 4 || a.D > 64 || a.Nk > 128 || a.Nq > 256 || a.Nq < 1 || a.Nk < 1)
         return 0;
     // (bf16 gradient I/O: 4-element chunks are 8 bytes -- aligned16 on half the byte strides is the 8-byte test)

@@ -204,6 +204,7 @@ inline size_t dtype_size(int dt) { return dt == MMX_F32 ? 4 : 2; }
 
 void set_error(const char* fmt, ...);
 void attn_head_enable(int on);
+void attn_head_tile_skip(int on);
 // relevancy_chain_cols.hip: the chain split by columns of R over the workgroups of a sample, strict layer order (K1c)
 bool self_chain_cols_applies(int n_layers, int B, int H, int N);
 int self_chain_cols_launch(const void* const* attn_layers, const void* const* grad_layers, int n_layers, int B, int H, int N,

@@ -1028,6 +1028,11 @@ extern "C" int mmx_set_option(const char* key, int value) {
         g_chain_groups = value;
         return MMX_OK;
     }
+    if (key && strcmp(key, "attn_head_tile_skip") == 0) {
+        if (value != 0 && value != 1) { set_error("mmx_set_option(attn_head_tile_skip): 0 or 1"); return MMX_EINVAL; }
+        attn_head_tile_skip(value);
+        return MMX_OK;
+    }
     if (key && strcmp(key, "attn_head") == 0) {
         attn_head_enable(value);
         return MMX_OK;
