@@ -253,3 +253,55 @@ def test_avg_heads_and_product_outputs_leave_guard_bands_alone(ops):
         assert rc == 0
         torch.cuda.synchronize()
         assert torch.equal(outp, wantp) and _bands_intact(wholep, bandp, B * nn)
+
+
+def test_whole_head_attention_random_shapes_and_masks(ops):
+    """40 seeded random (batch, heads, Nq, Nk <= 128, head_dim, mask) through the whole-head attention kernels (attention_head.hip): the
+    masked-tile skip (a wave-uniform switch over per-tile-count instantiations, live-strip words in LDS) on vs off must be BIT-identical
+    for P, O, dP, dq, dk, dv -- every tile count 1..8 and every strip count gets exercised -- and both must agree with the general tiled
+    kernels (another code path: attention_kernels.hip) to rounding level."""
+    rng = np.random.default_rng(11)
+    ninf = float("-inf")
+    worst = 0.0
+    try:
+        for case in range(40):
+            B, H = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+            Nq, Nk = int(rng.integers(1, 200)), int(rng.integers(1, 129))
+            D = int(rng.choice([8, 16, 20, 32, 48, 64]))
+            kind = ["none", "causal", "padding", "random_rows"][case % 4]
+            if kind == "causal":
+                Nq = Nk = min(Nq, Nk)
+            g = torch.Generator(device="cuda").manual_seed(1000 + case)
+            q, k, v, d_o = (torch.randn(B, n, H, D, device="cuda", generator=g) for n in (Nq, Nk, Nk, Nq))
+            mask = None
+            if kind == "causal":
+                mask = torch.full((Nq, Nk), ninf, device="cuda").triu_(1)
+            elif kind == "padding":
+                mask = torch.zeros(B, 1, Nk, device="cuda")
+                for b in range(B):
+                    mask[b, 0, int(rng.integers(1, Nk + 1)):] = ninf
+            elif kind == "random_rows":      # per-row visible window [lo, hi): live tiles anywhere, never an empty row
+                lo = torch.from_numpy(rng.integers(0, Nk, Nq)).cuda()
+                hi = torch.minimum(lo + torch.from_numpy(rng.integers(1, Nk + 1, Nq)).cuda(), torch.tensor(Nk, device="cuda"))
+                j = torch.arange(Nk, device="cuda")[None, :]
+                mask = torch.where((j >= lo[:, None]) & (j < hi[:, None]), 0.0, ninf).float()
+            scale = D ** -0.5
+            outs = {}
+            for mode in ("skip", "noskip", "tiled"):
+                ops.set_option("attn_head", int(mode != "tiled"))
+                ops.set_option("attn_stream", int(mode != "tiled"))
+                ops.set_option("attn_head_tile_skip", int(mode == "skip"))
+                probs, dprobs = torch.empty(B, H, Nq, Nk, device="cuda"), torch.empty(B, H, Nq, Nk, device="cuda")
+                o = ops.attn_capture_fwd(q, k, v, probs, scale, 0, mask)
+                dq, dk, dv = ops.attn_capture_bwd(q, k, v, probs, d_o, dprobs, scale, 0)
+                outs[mode] = [t.clone() for t in (probs, o, dprobs, dq, dk, dv)]
+            for name, a, b, c in zip(("P", "O", "dP", "dq", "dk", "dv"), outs["skip"], outs["noskip"], outs["tiled"]):
+                assert torch.equal(a, b), (case, kind, (B, H, Nq, Nk, D), name)
+                err = float((a - c).abs().max()) / max(float(c.abs().max()), 1e-6)
+                worst = max(worst, err)
+                assert err <= 2e-5, (case, kind, (B, H, Nq, Nk, D), name, err)
+    finally:
+        for key in ("attn_head", "attn_stream", "attn_head_tile_skip"):
+            ops.set_option(key, 1)
+    from parity import note
+    note("whole-head attention (skip on) vs the general tiled kernels, worst of 40 random shapes (relative to max |ref|)", worst, 2e-5, 1.0)
