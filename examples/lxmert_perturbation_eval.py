@@ -155,7 +155,7 @@ def main():
         else:
             if "run" not in graphed:           # captured once; serves every later batch whatever its question lengths
                 graphed["run"] = le.GraphedGenerateOursBatch(model, batch, **rule_flags)
-            R_t_t, R_t_i = graphed["run"](batch)
+            R_t_t, R_t_i = graphed["run"](batch, check="deferred")      # (the diag >= 0 word is asserted one batch later: no stall)
         if not args.text and not per_item and not args.bucket_by_length and not args.eager_perturbation:
             if "pert" not in graphed:          # the image test of a fixed-shape batch: one more hipGraph (see GraphedImagePerturbation)
                 graphed["pert"] = lp.GraphedImagePerturbation(pert, batch, R_t_t, R_t_i, labels, args.positive)
@@ -172,6 +172,8 @@ def main():
     per_sample = sharding.evaluate_sharded(indices, length_of, process_batch,
                                            len(lp.PERT_STEPS), max_batch=args.max_batch, store=store, device=gather_dev,
                                            load_batch=None if args.no_prefetch else load_batch, prefetch_device=dev, stats=stats)
+    if "run" in graphed:
+        graphed["run"].finish()                # the last batch's handle_residual word
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -359,7 +359,8 @@ class GraphedGenerateOursBatch:
     per-sample question lengths, ONE graph captured at a padded length ``T`` serves every batch whose questions are at
     most ``T`` tokens long -- no grouping by length, no re-capture.  Nothing in the captured pass synchronises: the
     reference's ``handle_residual`` assert becomes the device word ``diag_min``, checked by ``__call__`` when it hands out
-    the results (``check=True``, one device->host read per batch instead of one per rule).
+    the results (``check=True``, one device->host read per batch instead of one per rule; ``check="deferred"``: read behind the
+    replay, asserted at the next call or ``finish()`` -- no stall between this graph and whatever the caller launches next).
 
         run = GraphedGenerateOursBatch(model, example_inputs)          # example: padded [B, T] ids, [B, I, F] features ...
         R_t_t, R_t_i = run(inputs)                                      # same shapes; returns the graph's output buffers
@@ -398,6 +399,29 @@ class GraphedGenerateOursBatch:
                 raise ValueError("the graph was captured with index=None (arg-max answers)")
             self.static_index.copy_(torch.as_tensor(index))
         self.graph.replay()
-        if check and self.diag_min is not None:
+        if check == "deferred":
+            # the same assert WITHOUT stalling this thread on the replay it has just launched (an evaluator wants to launch the next
+            # graph now): the word is copied to pinned host memory behind the replay and checked at the NEXT call / ``finish()``
+            self.finish()
+            if self.diag_min is not None:
+                if self._diag_host is None:
+                    self._diag_host = [torch.empty(1, dtype=self.diag_min.dtype).pin_memory() for _ in range(2)]
+                slot = self._diag_host[self._diag_turn]
+                self._diag_turn ^= 1
+                slot.copy_(self.diag_min.reshape(1), non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
+                self._diag_pending = (slot, done)
+        elif check and self.diag_min is not None:
             assert self.diag_min.item() >= 0        # the reference's handle_residual assert, once per batch
         return self.outputs
+
+    _diag_host, _diag_turn, _diag_pending = None, 0, None
+
+    def finish(self):
+        """Check the ``handle_residual`` word of the last ``check="deferred"`` call (a no-op when nothing is pending)."""
+        if self._diag_pending is not None:
+            slot, done = self._diag_pending
+            self._diag_pending = None
+            done.synchronize()
+            assert float(slot[0]) >= 0

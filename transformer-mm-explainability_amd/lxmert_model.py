@@ -303,7 +303,7 @@ class LxmertEncoder(nn.Module):                                        # lxmert_
     # ---- tape path of the explainability pass (bert_tape.py): no autograd graph, no weight gradients
     overlap_modalities = True     # tape path: the image chain of every layer group on a side stream beside the text chain
 
-    def forward_tape(self, lang, lang_mask, visual_feats, visual_pos, visn_mask=None, lang_repeat=1, visn_repeat=1):
+    def forward_tape(self, lang, lang_mask, visual_feats, visual_pos, visn_mask=None, lang_repeat=1, visn_repeat=1, lang_encoded=False):
         """``lang_repeat`` / ``visn_repeat`` (forward-only callers): the single-modality layers run on the batch as given and
         their output (and mask) is repeated that many times, sample-major, before the cross-modality layers -- the perturbation
         evaluator re-runs a sample 9 times with only ONE modality changed, so the other modality's own layers (9 language / 5
@@ -323,9 +323,10 @@ class LxmertEncoder(nn.Module):                                        # lxmert_
             for blk in self.r_layers:
                 visn, t = bt.layer_fwd(blk, visn, visn_mask)
                 tapes["r"].append(t)
-        for blk in self.layer:
-            lang, t = bt.layer_fwd(blk, lang, lang_mask)
-            tapes["l"].append(t)
+        if not lang_encoded:      # (``lang_encoded``: ``lang`` already IS the output of the language layers -- ``encode_language``)
+            for blk in self.layer:
+                lang, t = bt.layer_fwd(blk, lang, lang_mask)
+                tapes["l"].append(t)
         if lang_repeat > 1:
             lang = lang.repeat_interleave(lang_repeat, dim=0)
             lang_mask = None if lang_mask is None else lang_mask.repeat_interleave(lang_repeat, dim=0)
@@ -479,25 +480,40 @@ class LxmertForQuestionAnswering(nn.Module):                           # lxmert_
         return scores, (tapes, cls, scores, lang.shape)
 
     @torch.no_grad()
+    def encode_language(self, input_ids, attention_mask=None, token_type_ids=None):
+        """Output of the embeddings + the 9 language-only layers, grad-free (tape forward): what ``scores_no_grad(lang_encoded=...)``
+        takes when SEVERAL region sets are scored against the same questions (the perturbation evaluator's step groups)."""
+        m = self.lxmert
+        emb = m.embeddings(input_ids, token_type_ids, None)
+        if attention_mask is None:
+            attention_mask = torch.ones(emb.shape[:2], device=emb.device)
+        lang_mask = _extended_mask(attention_mask, emb.dtype)
+        for blk in m.encoder.layer:
+            emb, _ = bt.layer_fwd(blk, emb, lang_mask)
+        return emb
+
+    @torch.no_grad()
     def scores_no_grad(self, input_ids=None, visual_feats=None, visual_pos=None, attention_mask=None,
                        visual_attention_mask=None, token_type_ids=None, inputs_embeds=None, lang_repeat=1, visn_repeat=1,
-                       **unused):
+                       lang_encoded=None, **unused):
         """``forward(...).question_answering_score`` through the tape forward (packed q / k / v GEMMs, fused bias / add /
         LayerNorm, the two modalities side by side) without keeping anything for a backward -- what the perturbation evaluator's
         re-runs need (lxmert/lxmert/perturbation.py:119-131).  An empty region set takes the module forward.
         ``lang_repeat`` / ``visn_repeat``: the text (visual) inputs are given ONCE per sample and their own layers' output is
-        repeated for the cross-modality layers (``LxmertEncoder.forward_tape``); the other modality comes already repeated."""
-        if visual_feats.shape[1] == 0 or input_ids is None:
-            if lang_repeat != 1 or visn_repeat != 1:
+        repeated for the cross-modality layers (``LxmertEncoder.forward_tape``); the other modality comes already repeated.
+        ``lang_encoded``: the output of ``encode_language`` for these questions -- the embeddings and language layers are skipped."""
+        if visual_feats.shape[1] == 0 or (input_ids is None and lang_encoded is None):
+            if lang_repeat != 1 or visn_repeat != 1 or lang_encoded is not None:
                 raise ValueError("scores_no_grad: the repeat hints need a non-empty region set and token ids")
             return self.forward(input_ids, visual_feats, visual_pos, attention_mask, visual_attention_mask, token_type_ids,
                                 inputs_embeds).question_answering_score
         m = self.lxmert
-        emb = m.embeddings(input_ids, token_type_ids, inputs_embeds)
+        emb = lang_encoded if lang_encoded is not None else m.embeddings(input_ids, token_type_ids, inputs_embeds)
         if attention_mask is None:
             attention_mask = torch.ones(emb.shape[:2], device=emb.device)
         lang, _, _ = m.encoder.forward_tape(emb, _extended_mask(attention_mask, emb.dtype), visual_feats, visual_pos,
-                                            _extended_mask(visual_attention_mask, emb.dtype), lang_repeat, visn_repeat)
+                                            _extended_mask(visual_attention_mask, emb.dtype), lang_repeat, visn_repeat,
+                                            lang_encoded=lang_encoded is not None)
         return self.answer_head(m.pooler(lang))
 
     @torch.no_grad()

@@ -7,9 +7,12 @@ Here the 9 perturbed inputs of one sample are ONE batch:
 
   * image test: a region that is masked as an attention key everywhere (-10000 additive mask -> exp underflows to an
     exact 0) is indistinguishable from a removed region for every other token -- LXMERT's visual stream has no
-    index-dependent position term, and the answer is read from the [CLS] text token.  So the 9 steps are 9 rows of a
-    ``visual_attention_mask``; the features are shared.  The step that keeps ZERO regions is the one exception (a
-    uniform -10000 shift is no mask at all): it runs as a second, region-free forward.
+    index-dependent position term, and the answer is read from the [CLS] text token.  Every step keeps a PREFIX of one ranking of
+    the regions, so the live steps run as (at most) two GROUPS: a group is one batch over the gathered ``kmax`` top-ranked regions
+    of every sample (what the reference's ``topk`` + index does per step) with a ``visual_attention_mask`` row per step for the
+    steps that keep fewer -- (36, 27, 18 | 9, 7, 5, 3, 1) at 36 regions: 153 region rows per sample where one masked batch over
+    all regions (rounds 1-5) ran 288; the questions' own 9 layers run once for both groups.  The step that keeps ZERO regions is
+    the one exception (a uniform -10000 shift is no mask at all): it runs as a region-free forward.
   * text test: removing tokens re-indexes the position embeddings (``perturbation.py:170``: "text tokens must be
     sorted for positional embedding to work"), so the kept ids are gathered, left-aligned and padded; padding is masked.
 
@@ -128,13 +131,14 @@ class LxmertPerturbation:
     soft accuracies (``label_scores[argmax]``, ``perturbation.py:134-136``).
     """
 
-    def __init__(self, model, steps=PERT_STEPS, tuned=True):
-        """``tuned``: run the re-runs' library GEMMs (8-9x the batch: thousands of rows) with the pre-tuned hipBLASLt / rocBLAS
-        selection of ``tuned_gemms`` ("lxmert_pert"; on for the duration of a call only, ignored when the file does not match
-        the box)."""
+    def __init__(self, model, steps=PERT_STEPS, tuned=False, grouped=True):
+        """``tuned`` (default OFF since round 6): run the re-runs' library GEMMs with a TunableOp selection ``tuned_gemms`` holds
+        under "lxmert_pert" (on for the duration of a call only; a no-op without such a file -- the one of rounds 3-5 was removed: one
+        of its solutions hung the GPU at the text test's 5760-row shapes)."""
         self.model = model
         self.steps = tuple(steps)
         self.tuned = tuned
+        self.grouped = grouped      # False: all live steps as ONE masked batch over the largest keep count (rounds 1-5; A / B runs)
         self._const = {}
 
     def _image_constants(self, I, device):
@@ -146,8 +150,31 @@ class LxmertPerturbation:
             live = [s for s, c in enumerate(counts) if c > 0]
             dead = [s for s in range(len(self.steps)) if s not in live]
             self._const[key] = (torch.tensor(counts, device=device), live, torch.tensor(live, device=device, dtype=torch.long),
-                                torch.tensor(dead, device=device, dtype=torch.long))
+                                torch.tensor(dead, device=device, dtype=torch.long), self._step_groups(counts, live, device, self.grouped))
         return self._const[key]
+
+    @staticmethod
+    def _step_groups(counts, live, device, split=True):
+        """The live steps in at most two GROUPS, each scored as one batch over the ``kmax`` top-ranked regions of every sample (the
+        reference gathers the kept regions, ``perturbation.py:114-121``; a group's steps that keep fewer mask the tail): the split that
+        needs the fewest region rows -- (36, 27, 18 | 9, 7, 5, 3, 1) for 36 regions: 153 rows against 288 for one masked batch.
+        -> ``[(step index tensor, kmax, keep mask [n, kmax])]``, device constants built once (nothing from host lists under a capture)."""
+        by_count = sorted(live, key=lambda s: -counts[s])
+        n = len(by_count)
+        if n == 0:
+            return []
+        best, cut = n * counts[by_count[0]], n
+        for p in range(1, n if split else 1):
+            rows = p * counts[by_count[0]] + (n - p) * counts[by_count[p]]
+            if rows < best:
+                best, cut = rows, p
+        groups = []
+        for part in (by_count[:cut], by_count[cut:]):
+            if part:
+                kmax = counts[part[0]]
+                keep = (torch.arange(kmax, device=device)[None, :] < torch.tensor([counts[s] for s in part], device=device)[:, None])
+                groups.append((torch.tensor(part, device=device, dtype=torch.long), kmax, keep.to(torch.float32)))
+        return groups
 
     def _scores(self, **kw):
         """Answer scores of one batched re-run: the body's grad-free fast forward when it has one."""
@@ -172,23 +199,35 @@ class LxmertPerturbation:
         cams = cam_image.reshape(-1, cam_image.shape[-1])
         B, I = cams.shape
         S = len(self.steps)
-        counts_dev, live, rows, dead = self._image_constants(I, cams.device)                        # host arithmetic only, cached
-        keep = image_keep_masks(cams, self.steps, is_positive_pert, counts=counts_dev)              # [B, S, I]
+        _, live, _, dead, groups = self._image_constants(I, cams.device)                            # host arithmetic only, cached
         scores = None
         if live:
-            n = len(live)
-            vis = dict(visual_feats=self._rep(inputs["visual_feats"], n), visual_pos=self._rep(inputs["visual_pos"], n),
-                       visual_attention_mask=keep[:, rows].reshape(B * n, I))
-            if hasattr(self.model, "scores_no_grad"):
-                # the text is the same in all n re-runs of a sample: its own 9 layers run once per sample (lang_repeat)
-                out = self.model.scores_no_grad(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
-                                                token_type_ids=inputs["token_type_ids"], lang_repeat=n, **vis)
-            else:
-                out = self._scores(input_ids=self._rep(inputs["input_ids"], n),
-                                   attention_mask=self._rep(inputs["attention_mask"], n),
-                                   token_type_ids=self._rep(inputs["token_type_ids"], n), **vis)
-            scores = out.new_empty(B, S, out.shape[-1])
-            scores[:, rows] = out.reshape(B, n, -1)
+            # ONE stable ranking per sample (module docstring: tie policy); every step keeps a prefix of it, so a group of steps is the
+            # gather of the group's kmax top-ranked regions (in rank order, as the reference's ``topk`` hands them over -- the visual
+            # stream has no index-dependent term) plus a mask for the steps that keep fewer.  Round 6: before, all live steps ran as
+            # ONE batch over all I regions with masks -- 288 region rows per sample instead of 153 for the same answers.
+            order = ranking(-cams if is_positive_pert else cams)                                    # [B, I]
+            fast = hasattr(self.model, "scores_no_grad")
+            lang = self.model.encode_language(inputs["input_ids"], inputs["attention_mask"], inputs["token_type_ids"]) \
+                if fast and hasattr(self.model, "encode_language") and len(groups) > 1 else None
+            for steps_g, kmax, keep_g in groups:
+                n = steps_g.numel()
+                top = order[:, :kmax]
+                feats = torch.gather(inputs["visual_feats"], 1, top.unsqueeze(-1).expand(-1, -1, inputs["visual_feats"].shape[-1]))
+                pos = torch.gather(inputs["visual_pos"], 1, top.unsqueeze(-1).expand(-1, -1, inputs["visual_pos"].shape[-1]))
+                vis = dict(visual_feats=self._rep(feats, n), visual_pos=self._rep(pos, n), visual_attention_mask=keep_g.repeat(B, 1))
+                if fast:
+                    # the text is the same in all n re-runs of a sample: its own 9 layers run once per sample (lang_repeat), and
+                    # once for all groups (lang_encoded)
+                    out = self.model.scores_no_grad(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
+                                                    token_type_ids=inputs["token_type_ids"], lang_repeat=n, lang_encoded=lang, **vis)
+                else:
+                    out = self._scores(input_ids=self._rep(inputs["input_ids"], n),
+                                       attention_mask=self._rep(inputs["attention_mask"], n),
+                                       token_type_ids=self._rep(inputs["token_type_ids"], n), **vis)
+                if scores is None:
+                    scores = out.new_empty(B, S, out.shape[-1])
+                scores[:, steps_g] = out.reshape(B, n, -1)
         if len(live) < S:                                    # steps that keep no region at all: region-free forward
             out = self._scores(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
                                token_type_ids=inputs["token_type_ids"], visual_feats=inputs["visual_feats"][:, :0],

@@ -149,11 +149,15 @@ class BatchPrefetcher:
     also launches the kernels, from pageable memory with blocking copies -- 465-507 samples / s end to end against 1170 samples / s
     for the device work alone, i.e. with one process per GPU the host, not the GPUs or xGMI, set the rate."""
 
-    def __init__(self, batches, load, device, depth=2):
+    def __init__(self, batches, load, device, depth=2, loaders=2):
+        """``loaders``: threads that run ``load`` (the host assembly of a batch) for the batches ahead; ONE staging thread takes their
+        results in order, copies them into the pinned sets and starts the device copies.  With a launching thread that no longer
+        stalls per batch, a single loader thread sharing the interpreter with it was the bottleneck (round 6: ``starved_s``)."""
         import queue
         import threading
         self.device = torch.device(device)
         self.load = load
+        self.loaders = max(1, int(loaders))
         self.batches = list(batches)
         self.q = queue.Queue(maxsize=depth)
         self.cuda = self.device.type == "cuda"
@@ -185,9 +189,22 @@ class BatchPrefetcher:
         return torch.is_tensor(v) or (isinstance(v, (list, tuple)) and len(v) > 0 and all(torch.is_tensor(x) for x in v))
 
     def _work(self):
+        import collections
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=self.loaders)
         try:
-            for ids in self.batches:
-                host = self.load(ids)
+            ahead, todo = collections.deque(), iter(self.batches)
+
+            def submit():
+                ids = next(todo, None)
+                if ids is not None:
+                    ahead.append((ids, pool.submit(self.load, ids)))
+            for _ in range(self.loaders + 1):
+                submit()
+            while ahead:
+                ids, loaded = ahead.popleft()
+                host = loaded.result()
+                submit()
                 if self.cuda:
                     with torch.cuda.stream(self.stream):
                         dev = {k: (self._pinned(k, v).to(self.device, non_blocking=True) if self._is_data(v) else v)
@@ -200,6 +217,8 @@ class BatchPrefetcher:
                 self.q.put((ids, dev, done))
         except BaseException as exc:                      # surfaced on the consumer's thread
             self.error = exc
+        finally:
+            pool.shutdown(wait=False, cancel_futures=True)
         self.q.put(None)
 
     def __iter__(self):
@@ -259,13 +278,13 @@ def evaluate_sharded(sample_ids, length_of, process_batch, n_cols, max_batch=128
                 store.add(ids, rows)
             else:                                               # write the PREVIOUS batch: its rows are ready, this one's are in flight
                 if pending is not None:
-                    store.add(*pending)
-                pending = (ids, rows)
+                    store.add(pending[0], _landed(pending[1]))
+                pending = (ids, _to_host_async(rows))
         else:
             for k, row in zip(ids, rows):
                 fresh[k] = row
     if pending is not None:
-        store.add(*pending)
+        store.add(pending[0], _landed(pending[1]))
     if stats is not None:
         stats.update(batches=len(id_batches), first_batch_s=first_s, starved_s=getattr(feeder, "starved_s", None))
     if store is not None and mine:
@@ -275,6 +294,35 @@ def evaluate_sharded(sample_ids, length_of, process_batch, n_cols, max_batch=128
     else:
         local = torch.zeros(0, n_cols, dtype=torch.float32, device=device)
     return gather_per_sample(local, len(sample_ids))
+
+
+_D2H_STREAMS = {}
+
+
+def _to_host_async(rows):
+    """Start the device -> host copy of a batch's result rows on a side stream (pinned destination, behind an event recorded where
+    the rows were produced) -> ``(host rows, event)``; a blocking ``.cpu()`` on the launching stream would be queued behind the NEXT
+    batch's launches and stall the thread for a whole batch.  CPU rows pass through."""
+    if not rows.is_cuda:
+        return rows, None
+    ready = torch.cuda.Event()
+    ready.record()
+    side = _D2H_STREAMS.setdefault(rows.device, torch.cuda.Stream(rows.device))
+    side.wait_event(ready)
+    host = torch.empty(rows.shape, dtype=rows.dtype).pin_memory()
+    with torch.cuda.stream(side):
+        host.copy_(rows, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(side)
+    rows.record_stream(side)
+    return host, done
+
+
+def _landed(pair):
+    host, done = pair
+    if done is not None:
+        done.synchronize()
+    return host
 
 
 def mean_step_accuracy(per_sample_scores):
