@@ -22,7 +22,7 @@ def _need_two_gpus():
 def _launch(script_args, nproc, port, **env):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
            "127.0.0.1", "--master-port", str(port)] + script_args
-    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900,
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300,
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -53,6 +53,7 @@ SHARED = dict(MMX_EVAL_SHARE_DEVICE="1", MMX_EVAL_BACKEND="gloo")
 
 @pytest.mark.parametrize("script, args, same", [
     ("lxmert_perturbation_eval.py", ["--num-samples", "40", "--max-batch", "8", "--method", "ours_no_lrp"], ("samples", "step_accuracy_percent")),
+    ("lxmert_perturbation_eval.py", ["--num-samples", "40", "--max-batch", "8", "--method", "ours_no_lrp", "--text"], ("samples", "step_accuracy_percent")),
     ("visualbert_pert_eval.py", ["--num-samples", "12"], ("samples", "step_accuracy_percent")),
     ("detr_masks_eval.py", ["--num-images", "6", "--graph-slots", "8", "--warmup-images", "1"], ("images", "mean_kept", "mean_mask_area")),
 ])
