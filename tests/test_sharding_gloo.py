@@ -155,6 +155,16 @@ def test_batch_prefetcher_feeds_evaluate_sharded_in_order(tmp_path):
     got = sharding.evaluate_sharded(ids, lambda k: k % 3, process, 3, max_batch=5, store=store, load_batch=load, prefetch_device="cpu")
     assert torch.equal(got, want) and store.done() == set(ids)
 
+    # several loader threads finishing OUT of order (the later batch's load returns first): batches still arrive in list order
+    import time
+    batches = [[i, i + 100] for i in range(12)]
+
+    def jittery(batch_ids):
+        time.sleep(0.02 if batch_ids[0] % 3 == 0 else 0.001)
+        return {"x": torch.tensor([float(k) for k in batch_ids])}
+    seen = [(b, d["x"].tolist()) for b, d in sharding.BatchPrefetcher(batches, jittery, "cpu", depth=2, loaders=3)]
+    assert [b for b, _ in seen] == batches and all(x == [float(k) for k in b] for b, x in seen)
+
     def broken(batch_ids):
         raise RuntimeError("dataset went away")
     with pytest.raises(RuntimeError, match="dataset went away"):
