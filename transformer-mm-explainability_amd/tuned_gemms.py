@@ -22,7 +22,7 @@ _DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning")
 #  evaluator's ``--text`` run was exercised at full size -- and since the re-runs are replayed from a hipGraph (default selection) or
 #  are host-bound when eager, it bought nothing any more.  ``scope("lxmert_pert")`` is now a no-op unless a file is regenerated.)
 WORKLOADS = {"clip_vitb32_b64": "tunableop_gfx950_clip_vitb32_b64.csv", "detr": "tunableop_gfx950_detr_r50.csv",
-             "clip_vitl14_336_bf16": "tunableop_gfx950_clip_vitl14_336_bf16.csv", "lxmert_pert": "tunableop_gfx950_lxmert_pert.csv"}      # (the last: not shipped, see above)
+             "clip_vitl14_336_bf16": "tunableop_gfx950_clip_vitl14_336_bf16.csv"}      # ("lxmert_pert": not shipped any more, see above)
 _LOADED = {}
 
 
